@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark of the voicemap hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one ``train_on_batch`` of the siamese script at cfg-A (experiments/train_siamese.py:20-25: filters 128,
+embedding 64, dropout 0; contrastive loss per BASELINE.json config 2), 128 pairs (256 windows) of 3 s @ 16 kHz per
+GPU, bf16 storage / fp32 accumulate: decimate x4 + whiten on the GPU, twin forward, loss, backward, (gradient
+all-reduce), global-norm clip + Adam, GEMM-layout weight refresh.  Raw windows are synthetic and resident
+in HBM before the timed region.  value = audio-seconds embedded per second = N * 256 windows * 3 s * K / wall time,
+wall time = max over ranks between barrier+synchronize brackets.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP events on the launch stream inside the timed
+region) and "cpu_baseline" (the CPU oracle's fp32 training step on a bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+TRAIN_BYTES_PER_WINDOW = 44.02e6   # algorithmic HBM bytes per 3 s window, training, S4k, bf16
+TRAIN_FLOPS_PER_WINDOW = 7.373e9
+
+
+def conv_launch_work(name, args, esize):
+    """Algorithmic bytes and FLOPs of one conv entry-point launch (layer-granular compulsory traffic of SURVEY 8d:
+    each operand tensor is read once and each result written once; weights excluded)."""
+    base = {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[name]
+    n, L, cin, cout = args[base:base + 4]
+    shape = {"n_windows": n, "L": L, "c_in": cin, "c_out": cout}
+    return (n * L * (cin + cout)) * esize, 2.0 * n * L * 3 * cin * cout, shape
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (cfg: 128)")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--loss", default="contrastive")
+    ap.add_argument("--dominant", default="vm_conv_wgrad", help="entry point timed with HIP events for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
+    a = ap.parse_args()
+
+    from voicemap_amd import parallel
+    from voicemap_amd.engine import HipEncoderEngine
+    rank, world, local = parallel.init_distributed()
+    assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    n_gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    F, E = 128, 64
+    blocks = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
+    eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
+    parallel.attach(eng, n_gpus)
+    parallel.broadcast_state(eng)
+
+    # synthetic raw windows, a different shard per rank, resident in HBM
+    pairs = a.pairs
+    rng = np.random.default_rng(1234 + rank)
+
+    def raw():
+        x = rng.normal(0.0, 0.05, size=(pairs, 48000)).astype(np.float32)
+        return torch.from_numpy(x + rng.uniform(-0.01, 0.01, size=(pairs, 1)).astype(np.float32)).to(dev)
+    x1, x2 = raw(), raw()
+    y = torch.cat([torch.zeros(pairs // 2), torch.ones(pairs - pairs // 2)]).to(dev)
+    xcat = torch.cat([x1, x2], 0).contiguous()
+    l0 = 12000
+    pl = eng.plan(2 * pairs, l0, True)
+
+    def step():
+        eng.preprocess(pl, xcat, 4, True, pairs)
+        eng.forward(pl, pairs, None)
+        eng.siamese_head(pl, y, a.loss)
+        eng.backward(pl)
+        eng.optimizer_step()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    eng.timed = {a.dominant: []}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    recs = eng.timed[a.dominant]
+    eng.timed = {}
+    loss = float(pl["loss_acc"][0].item())
+    assert np.isfinite(loss), "training diverged"
+
+    windows = 2 * pairs * n_gpus * a.steps
+    value = windows * 3.0 / dt
+    ms = dt / a.steps * 1e3
+
+    # ---- roofline of the dominant kernel: slowest launch family of that entry point ----------------------------
+    esize = 2 if a.dtype == "bf16" else 4
+    by_shape = {}
+    for e0, e1, args in recs:
+        key = tuple(conv_launch_work(a.dominant, args, esize)[2].values())
+        by_shape.setdefault(key, []).append((e0.elapsed_time(e1) * 1e-3, args))
+    worst = max(by_shape.values(), key=lambda v: sum(t for t, _ in v))
+    t_avg = sum(t for t, _ in worst) / len(worst)
+    nbytes, nflops, shape = conv_launch_work(a.dominant, worst[0][1], esize)
+    ai = nflops / nbytes
+    ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if ai < ridge:
+        roof = {"bound": "hbm", "achieved": nbytes / t_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": nflops / t_avg / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof["kernel"] = a.dominant
+    roof["launch_ms"] = t_avg * 1e3
+    roof["launch_shape"] = shape
+    roof["step_hbm_frac"] = TRAIN_BYTES_PER_WINDOW * (2 * pairs * a.steps / dt) / (HBM_PEAK_GBS * 1e9)
+    roof["step_mfma_frac"] = TRAIN_FLOPS_PER_WINDOW * (2 * pairs * a.steps / dt) / (MFMA_BF16_PEAK_TF * 1e12)
+
+    out = {"metric": "audio-sec/s embedded, 3s@16kHz siamese batch (training step)", "value": value, "unit": "audio-s/s",
+           "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "siamese cfg-A train step (filters 128, embed 64, %s loss), %d pairs/GPU of 3 s @ 16 kHz "
+                                  "decimated x4 (L=12000), Adam(clipnorm 1)" % (a.loss, pairs),
+                      "global_pairs": pairs * n_gpus, "parallelism": "dp%d" % n_gpus, "final_loss": loss},
+           "roofline": roof}
+
+    if a.breakdown and rank == 0:
+        names = ["vm_decimate_whiten", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd",
+                 "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
+                 "vm_bn_pool_bwd_reduce", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply", "vm_colsum", "vm_conv_wgrad",
+                 "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]
+        eng.timed = {nm: [] for nm in names}
+        reps = 3
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        rows = []
+        for nm in names:
+            r_ = eng.timed[nm]
+            tot = sum(e0.elapsed_time(e1) for e0, e1, _ in r_) / reps
+            rows.append((nm, len(r_) // reps, tot))
+        eng.timed = {}
+        with open(a.breakdown, "w") as f:
+            f.write("entry_point,launches_per_step,ms_per_step\n")
+            for nm, cnt, tot in sorted(rows, key=lambda r: -r[2]):
+                f.write("%s,%d,%.4f\n" % (nm, cnt, tot))
+            f.write("TOTAL_EVENT_MS,,%.4f\nWALL_MS_PER_STEP,,%.4f\n" % (sum(r[2] for r in rows), ms))
+
+    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
+        from oracle import voicemap_oracle as O
+        arch = O.EncoderArch.baseline(F, E, dropout=0.0)
+        cores = os.cpu_count() or 1
+        cpu_pairs, cpu_steps = 8, 4
+        sec, threads = O.time_cpu_train_steps(arch, cpu_pairs, cpu_steps, loss=a.loss, threads=cores)
+        out["cpu_baseline"] = {"value": 2 * cpu_pairs * 3.0 / sec, "unit": "audio-s/s", "cores": threads, "kind": "port",
+                               "sample": "%d steps of %d pairs (same step definition, fp32 torch-CPU oracle, %.0f ms/step)"
+                                         % (cpu_steps, cpu_pairs, sec * 1e3)}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

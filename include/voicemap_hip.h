@@ -1,0 +1,183 @@
+/*
+ * voicemap_hip.h -- C ABI of libvoicemap_hip.so (gfx950 / MI355X).
+ *
+ * The reference (oscarknagg/voicemap) has no FFI of its own: its hot path is Keras-2.2.2 layer calls
+ * that TensorFlow lowers to cuDNN/Eigen kernels.  Each entry point below replaces one such implicit
+ * device op (or a fusion of several); the reference line that *creates* the op is cited.  Host code
+ * (voicemap_amd/ *.py, the mirror of voicemap/{models,utils,librispeech}.py) binds these with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions (every function):
+ *   - plain pointers are DEVICE pointers unless named host_*; sizes are explicit; no torch types.
+ *   - `dtype` selects the storage type of activations / GEMM operands: VM_F32 or VM_BF16.  Accumulation,
+ *     batch statistics, the tail (global max -> dense -> head -> loss) and the optimizer are always fp32.
+ *   - enqueue-only on `stream` (a hipStream_t passed as void*); no host sync, no allocation, no global
+ *     mutable state; re-entrant per stream.
+ *   - returns 0 on success, <0 on error (VM_ERR_*); vm_last_error() gives a thread-local message.
+ *   - activation layout is Keras' channels-last.  "padded" tensors are (N, L+2, C) with one zero halo
+ *     row before and after each window so that a k=3 SAME convolution reads rows t..t+2 with no branch;
+ *     the halo rows are zeroed once by the owner (vm_fill_zero) and never written.
+ *   - "towers": BatchNorm statistics are taken per encoder call (voicemap/models.py:52-53 calls the
+ *     shared encoder twice), so windows [0,wpt) are tower 0, [wpt,2*wpt) tower 1, ... with
+ *     wpt = windows_per_tower.
+ */
+#ifndef VOICEMAP_HIP_H
+#define VOICEMAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VM_F32 = 0, VM_BF16 = 1 };
+enum { VM_OK = 0, VM_ERR_ARG = -1, VM_ERR_LAUNCH = -2, VM_ERR_UNSUPPORTED = -3 };
+enum { VM_LOSS_CONTRASTIVE = 0, VM_LOSS_BCE = 1 };
+enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
+enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
+
+const char* vm_last_error(void);
+int vm_abi_version(void);
+/* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
+int vm_check_device(void);
+
+int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
+
+/* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------
+ * raw: (n_windows, raw_len) fp32 (or int16 if raw_is_i16, scaled by 1/32768).  Takes every
+ * `downsampling`-th sample (utils.py:29), subtracts the per-window mean (utils.py:94-95) and multiplies
+ * by ONE scalar per tower rms/sqrt(mean(batch^2)) of the un-centred decimated batch (utils.py:98).
+ * out: (n_windows, L0 + 31) fp32 = the conv-1 input with its SAME halo (15 zeros left, 16 right).
+ * ws: >= vm_decimate_whiten_workspace_bytes(n_windows).  whitening=0 skips utils.py:30-31. */
+int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows);
+int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_windows, int64_t raw_len, int downsampling,
+                       int whitening, float rms, int64_t windows_per_tower, float* out, void* ws, void* stream);
+
+/* ---- a1 block 1: Conv1D(filters, 32, padding='same', activation='relu')  (voicemap/models.py:13-16) --
+ * x: (n_windows, L + 31) fp32 from vm_decimate_whiten; w: (32, 1, F) fp32 Keras layout; bias (F).
+ * z: (n_windows, L, F) `dtype`, = relu(conv + bias).  If stat_sum != NULL also writes per-(window, tile)
+ * partial sums of z and z^2 (fp32) for the BatchNorm that follows: stat_sum/stat_sq are
+ * (n_windows * vm_conv1_stat_rows(L), F). */
+int64_t vm_conv1_stat_rows(int64_t L);
+int vm_conv1_fwd(const float* x, const float* w, const float* bias, int64_t n_windows, int64_t L, int F,
+                 int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
+/* wgrad of block 1: dW[k][c] = sum_{n,t} x[n][t+k] * du[n][t][c] over all windows.
+ * du: (n_windows, L+2, F) padded `dtype`.  ws: (n_windows, 32, F) fp32 partials; grad_w (32,1,F) is
+ * overwritten with the fixed-order sum (deterministic). */
+int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L, int F, int dtype,
+                   float* ws, float* grad_w, void* stream);
+
+/* ---- a1 blocks 2-4: Conv1D(c_out, 3, padding='same', activation='relu')  (voicemap/models.py:22,27,32)
+ * implicit GEMM on MFMA.  in: padded (n_windows, L+2, c_in) `dtype`; wf: (c_out, 3*c_in) `dtype` from
+ * vm_prep_conv_weights; z: (n_windows, L, c_out) `dtype`.  stat_* as for vm_conv1_fwd with
+ * vm_conv_stat_rows(L) rows per window (NULL in inference). */
+int64_t vm_conv_stat_rows(int64_t L);
+int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in,
+                int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
+/* dgrad: dx[n][t][ci] = sum_{k,co} du[n][t+1-k][co] * W[k][ci][co].  du padded (n_windows, L+2, c_out);
+ * wd: (c_in, 3*c_out) `dtype` tap-flipped copy from vm_prep_conv_weights; dx: (n_windows, L, c_in). */
+int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                  void* dx, void* stream);
+/* wgrad: dW[k][ci][co] = sum_{n,t} in[n][t+k][ci] * du[n][t+1][co] (both padded).  Split over windows into
+ * vm_conv_wgrad_splits() slabs in ws (fp32), then summed in fixed order into grad_w (3, c_in, c_out). */
+int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out);
+int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out);
+int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                  void* ws, float* grad_w, void* stream);
+/* fp32 Keras kernel (3, c_in, c_out) -> wf (c_out, 3*c_in) and wd (c_in, 3*c_out) in `dtype`. */
+int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream);
+
+/* ---- a1-BN: BatchNormalization()  (voicemap/models.py:17,23,28,33; Keras defaults eps 1e-3, momentum .99)
+ * Reduces the conv partials per tower in a fixed order (fp64), producing per-tower
+ *   mean, invstd = rsqrt(var_biased + eps), scale = gamma*invstd, shift = beta - mean*scale     (each (n_towers, C))
+ * and applies the moving-average updates tower by tower:  moving -= (moving - batch) * (1 - momentum), with the
+ * batch variance multiplied by n/(n-(1+eps)) first when unbiased_moving_var != 0 (Keras 2.2.x). */
+int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
+                   double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
+                   int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
+                   float* scale, float* shift, void* stream);
+/* inference affine from moving statistics (one "tower"). */
+int vm_bn_infer_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                       float eps, int C, float* scale, float* shift, void* stream);
+
+/* BN apply + SpatialDropout1D + MaxPool1D(pool)  (voicemap/models.py:17-19 etc.)
+ * y = (z*scale[tower] + shift[tower]) * drop[n][c];  out[n][1+q][c] = max_{j<pool} y[n][q*pool+j][c], q < L/pool.
+ * z: (n_windows, L, C); drop: (n_windows, C) fp32 keep-mask/(1-rate) or NULL; out: padded (n_windows, L/pool + 2, C). */
+int vm_bn_drop_pool_fwd(const void* z, const float* scale, const float* shift, const float* drop,
+                        int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                        void* out, void* stream);
+/* backward, pass 1: partials of sum(dy) and sum(dy*zhat) over the pooled positions, where dy is dp routed to
+ * the first maximum of each pool window.  dp: (n_windows, L/pool, C).
+ * part_*: (n_windows * vm_bn_part_rows(), C) fp32 (a fixed number of segments per window). */
+int vm_bn_part_rows(void);
+int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
+                          int64_t L, int C, int pool, int dtype, float* part_dy, float* part_dyz, void* stream);
+/* reduce those partials per tower: c1 = sum(dy)/count, c2 = sum(dy*zhat)/count (each (n_towers, C)); and add the
+ * parameter gradients over all towers: grad_gamma = sum(dy*zhat), grad_beta = sum(dy)  (overwritten). */
+int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
+                       int C, double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta,
+                       void* stream);
+/* backward, pass 2: du[n][1+t][c] = [z>0] * scale * (dy - c1 - zhat*c2)  (padded (n_windows, L+2, C) out), plus
+ * partial column sums of du -> part_du (n_windows * vm_bn_part_rows(), C) for the conv bias gradient. */
+int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, const float* drop, const float* c1, const float* c2,
+                         int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                         void* du, float* part_du, void* stream);
+/* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
+int vm_colsum(const float* part, int64_t rows, int C, float* out, void* stream);
+
+/* ---- a1 tail: GlobalMaxPool1D + Dense(E)  (voicemap/models.py:37-39) ------------------------------------
+ * act: padded (n_windows, L+2, C) `dtype`; gmax (n_windows, C) fp32; gidx (n_windows, C) int32 = first argmax. */
+int vm_global_maxpool_fwd(const void* act, int64_t n_windows, int64_t L, int C, int dtype, float* gmax,
+                          int32_t* gidx, void* stream);
+/* dp: (n_windows, L, C) `dtype`, zero except dp[n][gidx[n][c]][c] = dg[n][c]. */
+int vm_global_maxpool_bwd(const float* dg, const int32_t* gidx, int64_t n_windows, int64_t L, int C, int dtype,
+                          void* dp, void* stream);
+/* out[r][o] = sum_i in[r][i]*w[i][o] + b[o]   (w: (n_in, n_out) Keras Dense kernel; all fp32). */
+int vm_dense_fwd(const float* in, const float* w, const float* b, int64_t rows, int n_in, int n_out, float* out,
+                 void* stream);
+/* grad_w[i][o] = sum_r in[r][i]*dout[r][o]; grad_b[o] = sum_r dout[r][o]; din[r][i] = sum_o dout[r][o]*w[i][o]
+ * (din may be NULL).  Fixed summation order. */
+int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t rows, int n_in, int n_out,
+                 float* grad_w, float* grad_b, float* din, void* stream);
+
+/* ---- a2 + a3/a4: siamese head + loss, forward and backward in one launch ----------------------------------
+ * (voicemap/models.py:55-69; voicemap/utils.py:77-85; 'binary_crossentropy' experiments/train_siamese.py:57)
+ * emb: (2*pairs, E) fp32, rows [0,pairs) = tower 0, [pairs, 2*pairs) = tower 1.
+ * head_kind UNIFORM_EUCLIDEAN: d = sqrt(sum (e1-e2)^2), p = sigmoid(w[0]*d + b);  WEIGHTED_L1: p = sigmoid(sum w[j]|e1-e2|_j + b).
+ * y: (pairs) fp32 labels, 0 = same speaker (voicemap/librispeech.py:194).  y may be NULL for predict-only
+ * (then loss/backward outputs are not touched).
+ * pred (pairs); loss_acc[0] = loss, [1] = binary accuracy; demb (2*pairs, E); grad_hw (1 or E); grad_hb (1).
+ * loss_scale multiplies the backward seed (1/world_size for data-parallel averaging is applied later, keep 1). */
+int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
+                         int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
+                         float* grad_hw, float* grad_hb, void* stream);
+
+/* ---- a9: classifier head Dense(num_classes, softmax) + categorical CE  (experiments/train_classifier.py:112,115)
+ * logits (rows, n_classes) fp32 -> prob; labels int32 (rows); loss_acc[0] = mean CE (Keras clip 1e-7), [1] = accuracy;
+ * dlogits = d loss / d logits (may be NULL).  labels may be NULL for predict-only.  ws: 2*rows floats. */
+int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float* prob,
+                   float* loss_acc, float* dlogits, float* ws, void* stream);
+
+/* ---- a5: Adam(clipnorm=1.)  (experiments/train_siamese.py:56; Keras 2.2.2 optimizers.py) -------------------
+ * sqnorm: 1 fp32 on device <- sum(g^2) over the flat gradient buffer (fixed order; ws >= vm_sqnorm_workspace_bytes). */
+int64_t vm_sqnorm_workspace_bytes(int64_t n);
+int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm, void* stream);
+/* g *= grad_prescale (e.g. 1/world after an all-reduce sum); norm = grad_prescale*sqrt(*sqnorm);
+ * if clipnorm > 0 and norm >= clipnorm: g *= clipnorm/norm;  m,v,p updated with lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+ * (computed on the host, passed in), p -= lr_t*m/(sqrt(v)+eps). */
+int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                      float eps, float clipnorm, float grad_prescale, const float* sqnorm, void* stream);
+
+/* ---- a8: n-shot evaluation distances  (voicemap/utils.py:159-206) ------------------------------------------
+ * For each task: query embedding (E) vs k class prototypes built from n support embeddings each
+ * (support: (tasks, k*n, E), query: (tasks, E), fp32); writes pred (tasks, k) as float64-accumulated distances
+ * and argmin (tasks) int32.  dist_kind per VM_DIST_*. */
+int vm_nshot_distances(const float* query, const float* support, int64_t tasks, int k, int n, int E, int dist_kind,
+                       float* pred, int32_t* argmin, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOICEMAP_HIP_H */

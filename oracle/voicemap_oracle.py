@@ -1,0 +1,540 @@
+"""CPU oracle for the voicemap siamese hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a *restatement* (PyTorch CPU, float64 or float32) of the arithmetic of
+oscarknagg/voicemap's 1-D CNN siamese encoder + loss step.  It is the checker that the HIP path is
+compared against.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it; nothing under ``voicemap_amd/`` does.
+
+Why a restatement and not the reference itself: the reference is Python-2-only code on
+Keras 2.2.2 / tensorflow-gpu 1.10.1 (requirements.txt:30,69); neither runs in this toolchain
+(SURVEY.md section 8c).  The arithmetic below therefore follows
+
+* the reference's own files (cited per function as ``file:line`` relative to the reference root), and
+* the published semantics of the pinned third-party layers it delegates to, marked **[3P]**:
+  Keras==2.2.2 (layers, losses, optimizers) and tensorflow==1.10.1 (SAME padding, moments, pooling).
+
+PARITY PIN STATUS: the reference's tests (tests/tests.py) pin only ``whiten`` and the sampling
+invariants of the pair/task API; for the encoder / heads / losses / gradients / optimizer the
+reference holds NO golden vectors, so those are "parity unpinned by reference tests".  The oracle is
+anchored instead on the data the reference tree does hold (tests/golden/, see
+tests/golden/extract_reference_fixtures.py): the shipped Keras checkpoint and the known-answer
+5-way 1-shot task recorded in notebooks/Human_Evaluation.ipynb cell 8 ("The correct answer was 5"),
+plus float64 finite-difference gradient checks of every hand-derived formula.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------------------------
+# architecture description
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class EncoderArch:
+    """Geometry of get_baseline_convolutional_encoder (voicemap/models.py:6-41).
+
+    blocks: (kernel_size, out_channels, pool) per conv block.  The current reference source uses
+    kernel sizes 32,3,3,3, channels F,2F,3F,4F and pools 4,2,2,2 (models.py:13-35; MaxPool1D()
+    defaults to pool 2 [3P]).  The shipped checkpoint (cfg-CK) was produced by an older revision with
+    first pool 2 (tests/golden/ckpt_cfgCK_meta.json).
+    """
+
+    blocks: List[Tuple[int, int, int]]
+    embedding_dimension: int
+    dropout: float = 0.05
+    bn_eps: float = 1e-3          # Keras BatchNormalization default epsilon [3P]
+    bn_momentum: float = 0.99     # Keras BatchNormalization default momentum [3P]
+
+    @staticmethod
+    def baseline(filters: int, embedding_dimension: int, dropout: float = 0.05, first_pool: int = 4) -> "EncoderArch":
+        f = filters
+        return EncoderArch(blocks=[(32, f, first_pool), (3, 2 * f, 2), (3, 3 * f, 2), (3, 4 * f, 2)],
+                           embedding_dimension=embedding_dimension, dropout=dropout)
+
+    def in_channels(self, i: int) -> int:
+        return 1 if i == 0 else self.blocks[i - 1][1]
+
+    def lengths(self, l0: int) -> List[int]:
+        out = [l0]
+        for (_, _, p) in self.blocks:
+            out.append(out[-1] // p)
+        return out
+
+
+def param_names(arch: EncoderArch, head: Optional[str] = "uniform_euclidean", num_classes: int = 0) -> List[str]:
+    """Trainable tensors in Keras ``model.trainable_weights`` order [3P] (conv kernel, conv bias,
+    BN gamma, BN beta per block; dense kernel/bias; head kernel/bias)."""
+    names = []
+    for i in range(len(arch.blocks)):
+        names += [f"conv{i+1}.kernel", f"conv{i+1}.bias", f"bn{i+1}.gamma", f"bn{i+1}.beta"]
+    names += ["dense.kernel", "dense.bias"]
+    if head is not None:
+        names += ["head.kernel", "head.bias"]
+    return names
+
+
+def init_params(arch: EncoderArch, head: Optional[str] = "uniform_euclidean", num_classes: int = 0,
+                seed: int = 1234, dtype=torch.float64) -> "OrderedDict[str, torch.Tensor]":
+    """Keras default initialisers [3P]: glorot_uniform kernels (limit sqrt(6/(fan_in+fan_out)),
+    conv fan = K*C), zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving variance 1 -- all
+    confirmed by the checkpoint's model_config (tests/golden/ckpt_cfgCK_meta.json)."""
+    g = torch.Generator().manual_seed(seed)
+    p: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def glorot(shape, fan_in, fan_out):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(dtype)
+
+    for i, (k, c, _) in enumerate(arch.blocks):
+        cin = arch.in_channels(i)
+        p[f"conv{i+1}.kernel"] = glorot((k, cin, c), k * cin, k * c)
+        p[f"conv{i+1}.bias"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.gamma"] = torch.ones(c, dtype=dtype)
+        p[f"bn{i+1}.beta"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.moving_mean"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.moving_variance"] = torch.ones(c, dtype=dtype)
+    cl = arch.blocks[-1][1]
+    e = arch.embedding_dimension
+    p["dense.kernel"] = glorot((cl, e), cl, e)
+    p["dense.bias"] = torch.zeros(e, dtype=dtype)
+    if head == "uniform_euclidean":
+        p["head.kernel"] = glorot((1, 1), 1, 1)
+        p["head.bias"] = torch.zeros(1, dtype=dtype)
+    elif head == "weighted_l1":
+        p["head.kernel"] = glorot((e, 1), e, 1)
+        p["head.bias"] = torch.zeros(1, dtype=dtype)
+    elif head == "classifier":
+        p["head.kernel"] = glorot((e, num_classes), e, num_classes)
+        p["head.bias"] = torch.zeros(num_classes, dtype=dtype)
+    elif head is not None:
+        raise ValueError(head)
+    return p
+
+
+def params_from_checkpoint(npz: Dict[str, np.ndarray], dtype=torch.float64):
+    """Map the cfg-CK checkpoint arrays (tests/golden/ckpt_cfgCK_weights.npz) onto oracle names."""
+    p: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for i in range(1, 5):
+        p[f"conv{i}.kernel"] = torch.tensor(npz[f"conv1d_{i}/kernel"], dtype=dtype)
+        p[f"conv{i}.bias"] = torch.tensor(npz[f"conv1d_{i}/bias"], dtype=dtype)
+        p[f"bn{i}.gamma"] = torch.tensor(npz[f"batch_normalization_{i}/gamma"], dtype=dtype)
+        p[f"bn{i}.beta"] = torch.tensor(npz[f"batch_normalization_{i}/beta"], dtype=dtype)
+        p[f"bn{i}.moving_mean"] = torch.tensor(npz[f"batch_normalization_{i}/moving_mean"], dtype=dtype)
+        p[f"bn{i}.moving_variance"] = torch.tensor(npz[f"batch_normalization_{i}/moving_variance"], dtype=dtype)
+    p["dense.kernel"] = torch.tensor(npz["dense_1/kernel"], dtype=dtype)
+    p["dense.bias"] = torch.tensor(npz["dense_1/bias"], dtype=dtype)
+    p["head.kernel"] = torch.tensor(npz["dense_2/kernel"], dtype=dtype)
+    p["head.bias"] = torch.tensor(npz["dense_2/bias"], dtype=dtype)
+    f = p["conv1.kernel"].shape[2]
+    arch = EncoderArch.baseline(f, p["dense.kernel"].shape[1], dropout=0.05, first_pool=2)
+    return arch, p
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocessing  (voicemap/utils.py:22-34, 88-101)
+# ---------------------------------------------------------------------------------------------
+
+
+def whiten(batch: np.ndarray, rms: float = 0.038021) -> np.ndarray:
+    """voicemap/utils.py:88-101, closed form.
+
+    The reference subtracts the per-sample mean over the time axis (utils.py:94-95) and multiplies by
+    ONE scalar for the whole batch, ``rms / sqrt(mean(batch**2))`` taken over the *un-centred* batch
+    (utils.py:98): ``np.power(batch, 2).mean()`` has no axis argument.  The tile/transpose dance at
+    :95 and :99 is a broadcast.  Raises on non-3-D input like :90-91.
+    """
+    if batch.ndim != 3:
+        raise ValueError("Input must be a 3D array of shape (n_segments, n_timesteps, 1).")
+    mean = batch.mean(axis=1, keepdims=True)
+    scale = rms / np.sqrt(np.power(batch, 2).mean())
+    return (batch - mean) * scale
+
+
+def whiten_reference_literal(batch: np.ndarray, rms: float = 0.038021) -> np.ndarray:
+    """The same function written with the reference's literal tile/transpose steps (utils.py:94-99),
+    kept only so a test can show the closed form above is exact."""
+    sample_wise_mean = batch.mean(axis=1)
+    w = batch - np.tile(sample_wise_mean, (1, 1, batch.shape[1])).transpose((1, 2, 0))
+    resc = rms / np.sqrt(np.power(batch, 2).mean())
+    return w * np.tile(resc, (1, 1, batch.shape[1])).transpose((1, 2, 0))
+
+
+def preprocess_instances(downsampling: int, whitening: bool = True):
+    """voicemap/utils.py:22-34: ``instances[:, ::downsampling, :]`` (no anti-alias filter) then whiten."""
+    def fn(instances):
+        instances = instances[:, ::downsampling, :]
+        if whitening:
+            instances = whiten(instances)
+        return instances
+    return fn
+
+
+# ---------------------------------------------------------------------------------------------
+# layers [3P semantics], channels-last (N, L, C) like Keras
+# ---------------------------------------------------------------------------------------------
+
+
+def same_padding(k: int) -> Tuple[int, int]:
+    """TensorFlow SAME padding for stride 1 [3P]: total K-1, left = floor((K-1)/2), right = rest
+    (15/16 for K=32, 1/1 for K=3)."""
+    tot = k - 1
+    left = tot // 2
+    return left, tot - left
+
+
+def conv1d_same_relu(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """Keras Conv1D(padding='same', activation='relu') [3P] as used at voicemap/models.py:13-32.
+    x (N,L,Cin); kernel (K,Cin,Cout) in Keras layout; cross-correlation."""
+    k = kernel.shape[0]
+    pl, pr = same_padding(k)
+    xt = F.pad(x.transpose(1, 2), (pl, pr))
+    w = kernel.permute(2, 1, 0)  # (Cout, Cin, K)
+    y = F.conv1d(xt, w, bias)
+    return torch.relu(y).transpose(1, 2)
+
+
+def batchnorm_train(z: torch.Tensor, gamma, beta, eps: float):
+    """Keras BatchNormalization(axis=-1) in training mode on a 3-D input [3P]: tf.nn.moments over
+    axes (0,1) (biased variance) then tf.nn.batch_normalization: inv = gamma*rsqrt(var+eps);
+    y = z*inv + (beta - mean*inv)."""
+    mean = z.mean(dim=(0, 1))
+    var = z.var(dim=(0, 1), unbiased=False)
+    inv = gamma * torch.rsqrt(var + eps)
+    return z * inv + (beta - mean * inv), mean, var
+
+
+def batchnorm_infer(z, gamma, beta, moving_mean, moving_variance, eps: float):
+    inv = gamma * torch.rsqrt(moving_variance + eps)
+    return z * inv + (beta - moving_mean * inv)
+
+
+def moving_update(moving, batch_value, momentum: float):
+    """K.moving_average_update [3P]: moving -= (moving - value) * (1 - momentum)."""
+    return moving - (moving - batch_value) * (1.0 - momentum)
+
+
+def bn_unbiased_variance(var, n: int, eps: float):
+    """Keras 2.2.x multiplies the batch variance by n / (n - (1 + eps)) before the moving update
+    (normalization.py, 'sample variance - unbiased estimator of population variance') [3P].  Not
+    pinned by any reference fixture; the product exposes it as a switch (default on)."""
+    return var * (n / (n - (1.0 + eps)))
+
+
+def spatial_dropout(y: torch.Tensor, mask: Optional[torch.Tensor], rate: float):
+    """Keras SpatialDropout1D [3P]: Bernoulli keep-mask of shape (N,1,C) scaled by 1/(1-rate).
+    The TF RNG stream cannot be reproduced, so callers inject the keep-mask (0/1)."""
+    if mask is None or rate == 0.0:
+        return y
+    return y * (mask.to(y.dtype) / (1.0 - rate))
+
+
+def maxpool1d(y: torch.Tensor, pool: int) -> torch.Tensor:
+    """Keras MaxPool1D(pool, pool) VALID [3P]: L_out = floor(L/pool); gradient goes to the first
+    maximum of a window (torch's CPU kernel has the same tie rule)."""
+    return F.max_pool1d(y.transpose(1, 2), pool, pool).transpose(1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# encoder / heads  (voicemap/models.py)
+# ---------------------------------------------------------------------------------------------
+
+
+def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
+                    drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                    collect: Optional[dict] = None) -> torch.Tensor:
+    """get_baseline_convolutional_encoder (voicemap/models.py:6-41): 4 x [Conv1D SAME + bias -> ReLU
+    -> BatchNorm -> SpatialDropout1D -> MaxPool1D] -> GlobalMaxPool1D (:37) -> Dense(E) linear (:39).
+    x is (N, L0, 1).  ``collect`` (optional dict) receives per-block batch statistics and
+    activations."""
+    h = x
+    for i, (k, c, pool) in enumerate(arch.blocks):
+        z = conv1d_same_relu(h, p[f"conv{i+1}.kernel"], p[f"conv{i+1}.bias"])
+        if training:
+            y, mean, var = batchnorm_train(z, p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"], arch.bn_eps)
+            if collect is not None:
+                collect.setdefault("bn_mean", []).append(mean.detach())
+                collect.setdefault("bn_var", []).append(var.detach())
+                collect.setdefault("bn_count", []).append(z.shape[0] * z.shape[1])
+            m = drop_masks[i] if drop_masks is not None else None
+            y = spatial_dropout(y, m, arch.dropout)
+        else:
+            y = batchnorm_infer(z, p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"], p[f"bn{i+1}.moving_mean"],
+                                p[f"bn{i+1}.moving_variance"], arch.bn_eps)
+        h = maxpool1d(y, pool)
+        if collect is not None:
+            collect.setdefault("z", []).append(z.detach())
+            collect.setdefault("pooled", []).append(h.detach())
+    g = h.max(dim=1).values  # GlobalMaxPool1D
+    if collect is not None:
+        collect["global_max"] = g.detach()
+    return g @ p["dense.kernel"] + p["dense.bias"]
+
+
+SIAMESE_METRICS = ("uniform_euclidean", "weighted_euclidean", "uniform_l1", "weighted_l1", "dot_product",
+                   "cosine_distance")
+
+
+def siamese_head(p, e1: torch.Tensor, e2: torch.Tensor, distance_metric: str = "uniform_euclidean") -> torch.Tensor:
+    """build_siamese_net head (voicemap/models.py:55-77).  uniform_euclidean: sqrt(sum((e1-e2)^2))
+    keepdims -> Dense(1, sigmoid) (:61-69); weighted_l1: |e1-e2| -> Dense(1, sigmoid) (:55-60);
+    the other allowed names raise NotImplementedError (:70-77); unknown names fail the assert (:45-47).
+    No epsilon under the sqrt: identical embeddings give an infinite derivative like the reference."""
+    assert distance_metric in SIAMESE_METRICS
+    if distance_metric == "weighted_l1":
+        d = (e1 - e2).abs()
+    elif distance_metric == "uniform_euclidean":
+        d = torch.sqrt(((e1 - e2) ** 2).sum(dim=-1, keepdim=True))
+    else:
+        raise NotImplementedError
+    return torch.sigmoid(d @ p["head.kernel"] + p["head.bias"])
+
+
+def siamese_forward(arch, p, x1, x2, training: bool, distance_metric="uniform_euclidean",
+                    drop_masks1=None, drop_masks2=None, collect1=None, collect2=None):
+    """One shared encoder called on each input (voicemap/models.py:52-53): in training mode each call
+    normalises with its OWN batch statistics."""
+    e1 = encoder_forward(arch, p, x1, training, drop_masks1, collect1)
+    e2 = encoder_forward(arch, p, x2, training, drop_masks2, collect2)
+    return siamese_head(p, e1, e2, distance_metric), e1, e2
+
+
+def classifier_forward(arch, p, x, training: bool, drop_masks=None, collect=None):
+    """experiments/train_classifier.py:110-112: encoder + Dense(num_classes, softmax)."""
+    e = encoder_forward(arch, p, x, training, drop_masks, collect)
+    return torch.softmax(e @ p["head.kernel"] + p["head.bias"], dim=-1), e
+
+
+# ---------------------------------------------------------------------------------------------
+# losses / metrics
+# ---------------------------------------------------------------------------------------------
+
+KERAS_EPSILON = 1e-7  # K.epsilon() [3P]
+
+
+def contrastive_loss(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    """voicemap/utils.py:77-85: mean((1-y)*p^2 + y*max(margin-p,0)^2), margin 1 (:81), mean over all
+    elements.  Labels: 0 = same speaker, 1 = different (voicemap/librispeech.py:194)."""
+    margin = 1.0
+    return ((1 - y_true) * y_pred ** 2 + y_true * torch.clamp(margin - y_pred, min=0) ** 2).mean()
+
+
+def binary_crossentropy(y_true, y_pred):
+    """Keras 'binary_crossentropy' on a sigmoid output with the TF backend [3P]: clip p to
+    [eps, 1-eps], logit = log(p/(1-p)), sigmoid_cross_entropy_with_logits, mean
+    (experiments/train_siamese.py:57)."""
+    pc = torch.clamp(y_pred, KERAS_EPSILON, 1 - KERAS_EPSILON)
+    logit = torch.log(pc / (1 - pc))
+    return (torch.clamp(logit, min=0) - logit * y_true + torch.log1p(torch.exp(-logit.abs()))).mean()
+
+
+def categorical_crossentropy(y_true_onehot, y_pred):
+    """Keras 'categorical_crossentropy' on a softmax output [3P]: renormalise, clip to [eps, 1-eps],
+    -sum(t*log(p)) per sample, mean (experiments/train_classifier.py:115)."""
+    q = y_pred / y_pred.sum(dim=-1, keepdim=True)
+    q = torch.clamp(q, KERAS_EPSILON, 1 - KERAS_EPSILON)
+    return (-(y_true_onehot * torch.log(q)).sum(dim=-1)).mean()
+
+
+def binary_accuracy(y_true, y_pred):
+    """Keras metrics=['accuracy'] with a 1-unit output -> binary_accuracy: mean(round(p) == y) [3P]."""
+    return (torch.round(y_pred) == y_true).to(y_pred.dtype).mean()
+
+
+def categorical_accuracy(y_true_onehot, y_pred):
+    return (y_pred.argmax(-1) == y_true_onehot.argmax(-1)).to(y_pred.dtype).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer: Keras Adam(clipnorm=1.) [3P]  (experiments/train_siamese.py:56)
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class AdamState:
+    lr: float = 1e-3
+    beta_1: float = 0.9
+    beta_2: float = 0.999
+    epsilon: float = KERAS_EPSILON
+    decay: float = 0.0
+    clipnorm: Optional[float] = 1.0
+    iterations: int = 0
+    m: Dict[str, torch.Tensor] = field(default_factory=dict)
+    v: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+
+def global_norm(grads: Dict[str, torch.Tensor]) -> torch.Tensor:
+    return torch.sqrt(sum((g ** 2).sum() for g in grads.values()))
+
+
+def adam_step(state: AdamState, params, grads: Dict[str, torch.Tensor]):
+    """Standalone-Keras 2.2.2 Adam.get_updates + Optimizer.get_gradients [3P]:
+    norm = sqrt(sum_g sum(g^2)) over ALL gradients; g <- g*clip/norm if norm >= clip;
+    lr <- lr/(1+decay*iter) if decay; t = iter+1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    m = b1*m+(1-b1)g; v = b2*v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps)."""
+    names = list(grads.keys())
+    if state.clipnorm is not None and state.clipnorm > 0:
+        n = global_norm(grads)
+        if float(n) >= state.clipnorm:
+            grads = {k: g * (state.clipnorm / n) for k, g in grads.items()}
+    lr = state.lr
+    if state.decay > 0:
+        lr = lr * (1.0 / (1.0 + state.decay * state.iterations))
+    t = state.iterations + 1
+    lr_t = lr * math.sqrt(1.0 - state.beta_2 ** t) / (1.0 - state.beta_1 ** t)
+    for k in names:
+        g = grads[k]
+        m = state.m.get(k, torch.zeros_like(g))
+        v = state.v.get(k, torch.zeros_like(g))
+        m = state.beta_1 * m + (1 - state.beta_1) * g
+        v = state.beta_2 * v + (1 - state.beta_2) * g * g
+        params[k] = params[k] - lr_t * m / (torch.sqrt(v) + state.epsilon)
+        state.m[k], state.v[k] = m, v
+    state.iterations = t
+    return params
+
+
+# ---------------------------------------------------------------------------------------------
+# one training step of either siamese script
+# ---------------------------------------------------------------------------------------------
+
+
+def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str = "contrastive",
+                       distance_metric: str = "uniform_euclidean", drop_masks1=None, drop_masks2=None,
+                       unbiased_moving_variance: bool = True):
+    """train_on_batch of experiments/siamese_contrastive_loss.py:70 (loss='contrastive') or
+    experiments/train_siamese.py:57 (loss='bce'): forward both towers in training mode, loss, grads
+    wrt the 20 trainable tensors, global-norm clip + Adam, two sequential BN moving-stat updates
+    (tower 1 then tower 2).  Returns a dict with everything a parity test needs."""
+    head = "head.kernel" in p
+    names = param_names(arch)
+    leaf = OrderedDict((k, (v.detach().clone().requires_grad_(k in names))) for k, v in p.items())
+    c1, c2 = {}, {}
+    pred, e1, e2 = siamese_forward(arch, leaf, x1, x2, True, distance_metric, drop_masks1, drop_masks2, c1, c2)
+    if loss == "contrastive":
+        l = contrastive_loss(y, pred)
+    elif loss in ("bce", "binary_crossentropy"):
+        l = binary_crossentropy(y, pred)
+    else:
+        raise ValueError(loss)
+    acc = binary_accuracy(y, pred)
+    gl = torch.autograd.grad(l, [leaf[k] for k in names])
+    grads = OrderedDict((k, g.detach()) for k, g in zip(names, gl))
+    new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
+    for c in (c1, c2):
+        for i in range(len(arch.blocks)):
+            var = c["bn_var"][i]
+            if unbiased_moving_variance:
+                var = bn_unbiased_variance(var, c["bn_count"][i], arch.bn_eps)
+            new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
+            new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    gnorm = global_norm(grads)
+    if state is not None:
+        tr = OrderedDict((k, new_p[k]) for k in names)
+        tr = adam_step(state, tr, grads)
+        for k in names:
+            new_p[k] = tr[k]
+    return {"loss": l.detach(), "acc": acc.detach(), "pred": pred.detach(), "e1": e1.detach(), "e2": e2.detach(),
+            "grads": grads, "grad_norm": gnorm, "params": new_p, "collect1": c1, "collect2": c2}
+
+
+def classifier_train_step(arch, p, state: Optional[AdamState], x, y_onehot, drop_masks=None,
+                          unbiased_moving_variance: bool = True):
+    """train_on_batch of experiments/train_classifier.py:110-115 (categorical CE + Adam(clipnorm 1))."""
+    names = param_names(arch)
+    leaf = OrderedDict((k, (v.detach().clone().requires_grad_(k in names))) for k, v in p.items())
+    c = {}
+    prob, e = classifier_forward(arch, leaf, x, True, drop_masks, c)
+    l = categorical_crossentropy(y_onehot, prob)
+    acc = categorical_accuracy(y_onehot, prob)
+    gl = torch.autograd.grad(l, [leaf[k] for k in names])
+    grads = OrderedDict((k, g.detach()) for k, g in zip(names, gl))
+    new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
+    for i in range(len(arch.blocks)):
+        var = c["bn_var"][i]
+        if unbiased_moving_variance:
+            var = bn_unbiased_variance(var, c["bn_count"][i], arch.bn_eps)
+        new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
+        new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    if state is not None:
+        tr = adam_step(state, OrderedDict((k, new_p[k]) for k in names), grads)
+        for k in names:
+            new_p[k] = tr[k]
+    return {"loss": l.detach(), "acc": acc.detach(), "prob": prob.detach(), "e": e.detach(), "grads": grads,
+            "grad_norm": global_norm(grads), "params": new_p, "collect": c}
+
+
+# ---------------------------------------------------------------------------------------------
+# n-shot k-way evaluation distances  (voicemap/utils.py:104-216)
+# ---------------------------------------------------------------------------------------------
+
+
+def n_shot_prediction(query_embedding: np.ndarray, support_set_embeddings: np.ndarray, n: int, k: int,
+                      distance: str = "euclidean") -> np.ndarray:
+    """The ``pred`` vector of utils.py:159-206 for one task (float64 numpy like the reference):
+    euclidean: per-class mean of support embeddings then L2 (:159-170); cosine: per-class mean of unit
+    vectors then scipy cdist 'cosine' (:171-184); dot_product: mean magnitude x mean unit vector, then
+    negative dot product (:185-206).  Correct iff argmin == 0 (:208-210)."""
+    q = np.asarray(query_embedding, dtype=np.float64).reshape(1, -1)
+    s = np.asarray(support_set_embeddings, dtype=np.float64)
+    if distance == "euclidean":
+        means = np.stack([s[i:i + n].mean(axis=0) for i in range(0, n * k, n)])
+        return np.sqrt(np.power(np.concatenate([q] * k) - means, 2).sum(axis=1))
+    mag = np.linalg.norm(s, axis=1, keepdims=True)
+    unit = s / mag
+    mean_unit = np.stack([unit[i:i + n].mean(axis=0) for i in range(0, n * k, n)])
+    if distance == "cosine":
+        qn = q / np.linalg.norm(q)
+        mu = mean_unit / np.linalg.norm(mean_unit, axis=1, keepdims=True)
+        return (1.0 - qn @ mu.T)[0]
+    if distance == "dot_product":
+        mean_mag = np.vstack([mag[i:i + n].sum() / n for i in range(0, n * k, n)])
+        return (-(q @ (mean_mag * mean_unit).T))[0]
+    raise ValueError("Distance must be in (euclidean, cosine, dot_product)")
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic workload of SURVEY section 8(d) + the timed CPU baseline leg of bench.py
+# ---------------------------------------------------------------------------------------------
+
+
+def synthetic_pairs(batch_pairs: int, seed: int = 1234, samples: int = 48000):
+    """raw windows N(0, 0.05^2) + per-window DC offset U(-0.01, 0.01); labels zeros for
+    the first half, ones for the rest (voicemap/librispeech.py:194 layout)."""
+    rng = np.random.default_rng(seed)
+    def one():
+        x = rng.normal(0.0, 0.05, size=(batch_pairs, samples, 1))
+        return (x + rng.uniform(-0.01, 0.01, size=(batch_pairs, 1, 1))).astype(np.float32)
+    x1, x2 = one(), one()
+    y = np.concatenate([np.zeros(batch_pairs // 2), np.ones(batch_pairs - batch_pairs // 2)])[:, None].astype(np.float32)
+    return x1, x2, y
+
+
+def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contrastive", threads: Optional[int] = None,
+                         seed: int = 1234, downsampling: int = 4):
+    """bench.py cpu_baseline leg: the oracle's fp32 training step (preprocess + twin forward + loss +
+    backward + clip + Adam) on a bounded sample, on the host cores.  Returns (seconds_per_step, threads)."""
+    import time
+    if threads:
+        torch.set_num_threads(threads)
+    x1, x2, y = synthetic_pairs(batch_pairs, seed)
+    pre = preprocess_instances(downsampling)
+    p = init_params(arch, seed=seed, dtype=torch.float32)
+    st = AdamState()
+    yt = torch.tensor(y)
+    ts = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        a = torch.tensor(pre(x1.astype(np.float64)).astype(np.float32))
+        b = torch.tensor(pre(x2.astype(np.float64)).astype(np.float32))
+        out = siamese_train_step(arch, p, st, a, b, yt, loss=loss)
+        p = out["params"]
+        ts.append(time.perf_counter() - t0)
+    return float(np.mean(ts[1:])), torch.get_num_threads()

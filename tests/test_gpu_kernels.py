@@ -1,0 +1,367 @@
+"""-m gpu parity tests, one per C-ABI entry point: HIP kernel vs the CPU oracle (oracle/voicemap_oracle.py) on the
+same seeded inputs.  Tolerances: fp32 storage -> 2e-5 relative (L2) unless stated; bf16 storage -> the oracle is fed
+the bf16-rounded inputs and outputs are compared at 1e-2 relative (bf16 has 8 mantissa bits: 2^-8 = 3.9e-3 per
+rounding)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voicemap_oracle as O
+from tests.gpu_util import DTYPES, L, dev, max_err, p, padded, quant, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-5, "bf16": 1e-2}
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,l,f", [(3, 700, 16), (2, 256, 128), (1, 37, 8)])
+def test_conv1_fwd(dt, n, l, f):
+    vm, tdt = DTYPES[dt]
+    r = rng(1)
+    x = r.normal(0, 0.05, (n, l)).astype(np.float32)
+    w = r.normal(0, 0.2, (32, 1, f)).astype(np.float32)
+    b = r.normal(0, 0.05, (f,)).astype(np.float32)
+    xp = np.zeros((n, l + 31), np.float32)
+    xp[:, 15:15 + l] = x
+    rows = L().query("vm_conv1_stat_rows", l)
+    z = torch.empty(n, l, f, dtype=tdt, device="cuda")
+    ss = torch.zeros(n * rows, f, device="cuda")
+    sq = torch.zeros(n * rows, f, device="cuda")
+    L().call("vm_conv1_fwd", p(dev(xp)), p(dev(w)), p(dev(b)), n, l, f, vm, p(z), p(ss), p(sq), stream())
+    ref = O.conv1d_same_relu(torch.tensor(x, dtype=torch.float64)[:, :, None], torch.tensor(w, dtype=torch.float64),
+                             torch.tensor(b, dtype=torch.float64)).numpy()
+    zz = z.float().cpu().numpy()
+    assert rel_err(zz, ref) < TOL[dt]
+    # statistics are taken over the stored (rounded) values
+    assert rel_err(ss.cpu().numpy().reshape(n, rows, f).sum(1), zz.astype(np.float64).sum(1)) < 1e-5
+    assert rel_err(sq.cpu().numpy().reshape(n, rows, f).sum(1), (zz.astype(np.float64) ** 2).sum(1)) < 1e-5
+
+
+def _conv_ref(x, w, b):
+    return O.conv1d_same_relu(x, w, b)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8)])
+def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
+    vm, tdt = DTYPES[dt]
+    r = rng(2)
+    x = quant(r.normal(0, 1.0, (n, l, cin)), dt)
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt)
+    b = torch.tensor(r.normal(0, 0.3, (cout,)).astype(np.float32), dtype=torch.float64)
+    wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
+    wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
+    xp = padded(x, tdt)
+    rows = L().query("vm_conv_stat_rows", l)
+    z = torch.empty(n, l, cout, dtype=tdt, device="cuda")
+    ss = torch.zeros(n * rows, cout, device="cuda")
+    sq = torch.zeros(n * rows, cout, device="cuda")
+    L().call("vm_conv_fwd", p(xp), p(wf), p(dev(b)), n, l, cin, cout, vm, p(z), p(ss), p(sq), stream())
+    ref = _conv_ref(x, w, b).numpy()
+    zz = z.float().cpu().numpy()
+    assert rel_err(zz, ref) < TOL[dt]
+    assert rel_err(ss.cpu().numpy().reshape(n, rows, cout).sum(1), zz.astype(np.float64).sum(1)) < 1e-5
+    assert rel_err(sq.cpu().numpy().reshape(n, rows, cout).sum(1), (zz.astype(np.float64) ** 2).sum(1)) < 1e-5
+    # inference launch (no statistics) gives the same z
+    z2 = torch.empty_like(z)
+    L().call("vm_conv_fwd", p(xp), p(wf), p(dev(b)), n, l, cin, cout, vm, p(z2), None, None, stream())
+    assert torch.equal(z, z2)
+
+    # dgrad / wgrad against autograd of the linear conv (du given)
+    du = quant(r.normal(0, 1.0, (n, l, cout)), dt)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    pl_, pr_ = O.same_padding(3)
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(xr.transpose(1, 2), (pl_, pr_)), wr.permute(2, 1, 0)).transpose(1, 2)
+    gx, gw = torch.autograd.grad((y * du).sum(), [xr, wr])
+    dup = padded(du, tdt)
+    dx = torch.empty(n, l, cin, dtype=tdt, device="cuda")
+    L().call("vm_conv_dgrad", p(dup), p(wd), n, l, cin, cout, vm, p(dx), stream())
+    assert rel_err(dx.float().cpu().numpy(), gx.numpy()) < TOL[dt]
+    ws = torch.empty(L().query("vm_conv_wgrad_workspace_bytes", n, l, cin, cout) // 4, device="cuda")
+    gwd = torch.empty(3, cin, cout, device="cuda")
+    L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gwd), stream())
+    # fp32 accumulation of exact products of the (rounded) operands: tight in both modes
+    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv1_wgrad(dt):
+    vm, tdt = DTYPES[dt]
+    r = rng(3)
+    n, l, f = 3, 1500, 24
+    x = r.normal(0, 0.05, (n, l)).astype(np.float32)
+    du = quant(r.normal(0, 1, (n, l, f)), dt)
+    xp = np.zeros((n, l + 31), np.float32)
+    xp[:, 15:15 + l] = x
+    ws = torch.empty(n * 32 * f, device="cuda")
+    gw = torch.empty(32, 1, f, device="cuda")
+    L().call("vm_conv1_wgrad", p(dev(xp)), p(padded(du, tdt)), n, l, f, vm, p(ws), p(gw), stream())
+    xt = torch.tensor(xp, dtype=torch.float64)
+    ref = torch.stack([(xt[:, k:k + l, None] * du).sum((0, 1)) for k in range(32)])[:, None, :]
+    assert rel_err(gw.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------------------
+def _bn_block_oracle(z, gamma, beta, drop, pool, wpt, eps=1e-3):
+    """BN(train, per tower) -> dropout -> maxpool on float64 tensors with autograd."""
+    outs = []
+    stats = []
+    for t0 in range(0, z.shape[0], wpt):
+        zt = z[t0:t0 + wpt]
+        y, mean, var = O.batchnorm_train(zt, gamma, beta, eps)
+        if drop is not None:
+            y = y * drop[t0:t0 + wpt, None, :]
+        outs.append(O.maxpool1d(y, pool))
+        stats.append((mean, var))
+    return torch.cat(outs, 0), stats
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 50, 16, 2, True), (2, 1, 64, 136, 4, False), (4, 4, 31, 8, 2, True),
+                                                     (2, 2, 9, 24, 4, False)])
+def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
+    vm, tdt = DTYPES[dt]
+    r = rng(4)
+    z = quant(np.maximum(r.normal(0.2, 1.0, (n, l, c)), 0.0), dt)  # post-ReLU activations, many exact zeros
+    gamma = torch.tensor(r.normal(1.0, 0.3, c) * np.where(r.random(c) < 0.2, -1, 1), dtype=torch.float64)
+    beta = torch.tensor(r.normal(0, 0.3, c), dtype=torch.float64)
+    drop = None
+    if use_drop:
+        drop = torch.tensor((r.random((n, c)) > 0.3) / 0.7, dtype=torch.float64)
+    lq = l // pool
+    towers = n // wpt
+    # forward statistics straight from z (as the conv epilogue would produce them: one partial row per window)
+    zd = z.to("cuda", tdt).contiguous()
+    ssum = z.sum(1).to("cuda", torch.float32).contiguous()
+    ssq = (z * z).sum(1).to("cuda", torch.float32).contiguous()
+    f32 = dict(dtype=torch.float32, device="cuda")
+    mean, invstd, scale, shift = (torch.empty(towers, c, **f32) for _ in range(4))
+    mm = torch.zeros(c, **f32)
+    mv = torch.ones(c, **f32)
+    L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
+             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), stream())
+    zr = z.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    out_ref, stats = _bn_block_oracle(zr, gr, br, drop, pool, wpt)
+    for t, (m_, v_) in enumerate(stats):
+        assert max_err(mean[t].cpu().numpy(), m_.detach().numpy()) < 1e-5
+        assert rel_err(invstd[t].cpu().numpy(), (1 / torch.sqrt(v_ + 1e-3)).detach().numpy()) < 1e-5
+    # moving statistics: sequential update per tower, Keras unbiased-variance factor
+    mm_ref, mv_ref = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    for (m_, v_) in stats:
+        mm_ref = O.moving_update(mm_ref, m_.detach(), 0.99)
+        mv_ref = O.moving_update(mv_ref, O.bn_unbiased_variance(v_.detach(), wpt * l, 1e-3), 0.99)
+    assert max_err(mm.cpu().numpy(), mm_ref.numpy()) < 1e-6
+    assert max_err(mv.cpu().numpy(), mv_ref.numpy()) < 1e-6
+
+    dropd = dev(drop) if drop is not None else None
+    out = torch.zeros(n, lq + 2, c, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(zd), p(scale), p(shift), p(dropd), n, wpt, l, c, pool, vm, p(out), stream())
+    o = out.float().cpu().numpy()
+    assert np.all(o[:, 0] == 0) and np.all(o[:, -1] == 0)
+    assert rel_err(o[:, 1:-1], out_ref.detach().numpy()) < (2e-5 if dt == "f32" else 6e-3)
+
+    # backward
+    dp = quant(r.normal(0, 1, (n, lq, c)), dt)
+    gz, gg, gb = torch.autograd.grad((out_ref * dp).sum(), [zr, gr, br])
+    gz = gz * (z > 0)  # ReLU of the producing conv is fused into this backward
+    rows = L().query("vm_bn_part_rows")
+    pa, pb, pdu = (torch.zeros(n * rows, c, **f32) for _ in range(3))
+    c1, c2 = torch.empty(towers, c, **f32), torch.empty(towers, c, **f32)
+    ggam, gbet = torch.empty(c, **f32), torch.empty(c, **f32)
+    dpd = dp.to("cuda", tdt).contiguous()
+    common = (p(zd), p(dpd), p(scale), p(shift), p(mean), p(invstd), p(dropd))
+    L().call("vm_bn_pool_bwd_reduce", *common, n, wpt, l, c, pool, vm, p(pa), p(pb), stream())
+    L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, c, float(wpt * l), p(c1), p(c2), p(ggam), p(gbet), stream())
+    du = torch.zeros(n, l + 2, c, dtype=tdt, device="cuda")
+    L().call("vm_bn_pool_bwd_apply", *common, p(c1), p(c2), n, wpt, l, c, pool, vm, p(du), p(pdu), stream())
+    gbias = torch.empty(c, **f32)
+    L().call("vm_colsum", p(pdu), n * rows, c, p(gbias), stream())
+    tol = 5e-5 if dt == "f32" else 1e-2
+    assert rel_err(ggam.cpu().numpy(), gg.numpy()) < tol
+    assert rel_err(gbet.cpu().numpy(), gb.numpy()) < tol
+    d = du.float().cpu().numpy()
+    assert np.all(d[:, 0] == 0) and np.all(d[:, -1] == 0)
+    assert rel_err(d[:, 1:-1], gz.numpy()) < tol
+    assert rel_err(gbias.cpu().numpy(), d[:, 1:-1].astype(np.float64).sum((0, 1))) < 1e-5
+
+
+def test_bn_infer_affine():
+    r = rng(5)
+    c = 40
+    g, b, mm = (r.normal(0, 1, c).astype(np.float32) for _ in range(3))
+    mv = r.random(c).astype(np.float32)
+    sc, sh = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    L().call("vm_bn_infer_affine", p(dev(g)), p(dev(b)), p(dev(mm)), p(dev(mv)), 1e-3, c, p(sc), p(sh), stream())
+    z = torch.tensor(r.normal(0, 1, (2, 5, c)))
+    ref = O.batchnorm_infer(z, torch.tensor(g, dtype=torch.float64), torch.tensor(b, dtype=torch.float64),
+                            torch.tensor(mm, dtype=torch.float64), torch.tensor(mv, dtype=torch.float64), 1e-3)
+    got = z * sc.cpu().double() + sh.cpu().double()
+    assert rel_err(got.numpy(), ref.numpy()) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,l,c", [(3, 375, 64), (2, 7, 136), (1, 1, 8)])
+def test_global_maxpool(dt, n, l, c):
+    vm, tdt = DTYPES[dt]
+    r = rng(6)
+    a = quant(np.round(r.normal(0, 1, (n, l, c)) * 4) / 4, dt)  # coarse grid -> ties, first max must win
+    gmax = torch.empty(n, c, device="cuda")
+    gidx = torch.empty(n, c, dtype=torch.int32, device="cuda")
+    L().call("vm_global_maxpool_fwd", p(padded(a, tdt)), n, l, c, vm, p(gmax), p(gidx), stream())
+    assert np.array_equal(gmax.cpu().numpy(), a.max(1).values.float().numpy())
+    assert np.array_equal(gidx.cpu().numpy(), a.numpy().argmax(1).astype(np.int32))
+    dg = r.normal(0, 1, (n, c)).astype(np.float32)
+    dp = torch.empty(n, l, c, dtype=tdt, device="cuda")
+    L().call("vm_global_maxpool_bwd", p(dev(dg)), p(gidx), n, l, c, vm, p(dp), stream())
+    ref = np.zeros((n, l, c))
+    ii, jj = np.meshgrid(np.arange(n), np.arange(c), indexing="ij")
+    ref[ii, a.numpy().argmax(1), jj] = quant(dg, dt).numpy()
+    assert np.array_equal(dp.float().cpu().numpy().astype(np.float64), ref)
+
+
+def test_dense_fwd_bwd():
+    r = rng(7)
+    rows, ni, no = 10, 72, 33
+    x, w, b, dout = (r.normal(0, 1, s).astype(np.float32) for s in [(rows, ni), (ni, no), (no,), (rows, no)])
+    out = torch.empty(rows, no, device="cuda")
+    L().call("vm_dense_fwd", p(dev(x)), p(dev(w)), p(dev(b)), rows, ni, no, p(out), stream())
+    assert rel_err(out.cpu().numpy(), x.astype(np.float64) @ w + b) < 1e-6
+    gw, gb, din = torch.empty(ni, no, device="cuda"), torch.empty(no, device="cuda"), torch.empty(rows, ni, device="cuda")
+    L().call("vm_dense_bwd", p(dev(x)), p(dev(w)), p(dev(dout)), rows, ni, no, p(gw), p(gb), p(din), stream())
+    assert rel_err(gw.cpu().numpy(), x.astype(np.float64).T @ dout) < 1e-6
+    assert rel_err(gb.cpu().numpy(), dout.astype(np.float64).sum(0)) < 1e-6
+    assert rel_err(din.cpu().numpy(), dout.astype(np.float64) @ w.T) < 1e-6
+
+
+@pytest.mark.parametrize("head", ["uniform_euclidean", "weighted_l1"])
+@pytest.mark.parametrize("loss", ["contrastive", "bce"])
+@pytest.mark.parametrize("pairs,e", [(6, 32), (300, 8)])
+def test_siamese_head_loss(head, loss, pairs, e):
+    from voicemap_amd.engine import HEADS, LOSSES
+    r = rng(8)
+    emb = r.normal(0, 0.4, (2 * pairs, e)).astype(np.float32)
+    hw = r.normal(0.5, 0.3, (1, 1) if head == "uniform_euclidean" else (e, 1)).astype(np.float32)
+    hb = r.normal(-0.5, 0.1, (1,)).astype(np.float32)
+    y = (r.random(pairs) > 0.5).astype(np.float32)
+    pred, la = torch.empty(pairs, device="cuda"), torch.empty(2, device="cuda")
+    demb = torch.empty(2 * pairs, e, device="cuda")
+    ghw, ghb = torch.empty(hw.size, device="cuda"), torch.empty(1, device="cuda")
+    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), p(dev(y)), pairs, e, HEADS[head], LOSSES[loss],
+             p(pred), p(la), p(demb), p(ghw), p(ghb), stream())
+    et = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
+    prm = {"head.kernel": torch.tensor(hw, dtype=torch.float64, requires_grad=True),
+           "head.bias": torch.tensor(hb, dtype=torch.float64, requires_grad=True)}
+    pr = O.siamese_head(prm, et[:pairs], et[pairs:], head)
+    yt = torch.tensor(y, dtype=torch.float64)[:, None]
+    lo = O.contrastive_loss(yt, pr) if loss == "contrastive" else O.binary_crossentropy(yt, pr)
+    ge, gw, gb = torch.autograd.grad(lo, [et, prm["head.kernel"], prm["head.bias"]])
+    assert rel_err(pred.cpu().numpy(), pr.detach().numpy()[:, 0]) < 1e-5
+    assert abs(la[0].item() - lo.item()) < 2e-5 * max(1.0, abs(lo.item()))
+    assert abs(la[1].item() - O.binary_accuracy(yt, pr).item()) < 1e-6
+    assert rel_err(demb.cpu().numpy(), ge.numpy()) < 1e-4
+    assert rel_err(ghw.cpu().numpy(), gw.numpy().ravel()) < 1e-4
+    assert rel_err(ghb.cpu().numpy(), gb.numpy()) < 1e-4
+    # predict-only launch leaves the training outputs alone and gives the same pred
+    pred2 = torch.empty(pairs, device="cuda")
+    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), None, pairs, e, HEADS[head], LOSSES[loss],
+             p(pred2), None, None, None, None, stream())
+    assert torch.equal(pred, pred2)
+
+
+def test_siamese_head_rejects_unimplemented_metric():
+    from voicemap_amd._lib import VoicemapHipError
+    d = torch.zeros(8, device="cuda")
+    with pytest.raises(VoicemapHipError):
+        L().call("vm_siamese_head_loss", p(d), p(d), p(d), None, 2, 2, 5, 0, p(d), None, None, None, None, stream())
+
+
+@pytest.mark.parametrize("rows,nc", [(5, 40), (3, 1172)])
+def test_softmax_cce(rows, nc):
+    r = rng(9)
+    logits = r.normal(0, 2, (rows, nc)).astype(np.float32)
+    labels = r.integers(0, nc, rows).astype(np.int32)
+    prob, dl = torch.empty(rows, nc, device="cuda"), torch.empty(rows, nc, device="cuda")
+    la, ws = torch.empty(2, device="cuda"), torch.empty(2 * rows, device="cuda")
+    L().call("vm_softmax_cce", p(dev(logits)), p(dev(labels, torch.int32)), rows, nc, p(prob), p(la), p(dl), p(ws), stream())
+    lt = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    pr = torch.softmax(lt, -1)
+    oh = torch.nn.functional.one_hot(torch.tensor(labels, dtype=torch.int64), nc).double()
+    lo = O.categorical_crossentropy(oh, pr)
+    (g,) = torch.autograd.grad(lo, [lt])
+    assert rel_err(prob.cpu().numpy(), pr.detach().numpy()) < 1e-5
+    assert abs(la[0].item() - lo.item()) < 1e-5 * max(1, abs(lo.item()))
+    assert abs(la[1].item() - O.categorical_accuracy(oh, pr).item()) < 1e-6
+    assert rel_err(dl.cpu().numpy(), g.numpy()) < 1e-4
+
+
+def test_adam_clip_step():
+    r = rng(10)
+    n = 5000
+    for gscale in (0.001, 3.0):  # below and above the clip threshold
+        pv, g = r.normal(0, 1, n).astype(np.float32), (r.normal(0, 1, n) * gscale).astype(np.float32)
+        m0, v0 = r.normal(0, 0.01, n).astype(np.float32), (r.random(n) * 1e-3).astype(np.float32)
+        P_, G_, M_, V_ = dev(pv), dev(g), dev(m0), dev(v0)
+        ws = torch.empty(L().query("vm_sqnorm_workspace_bytes", n) // 8, dtype=torch.float64, device="cuda")
+        sq = torch.empty(1, device="cuda")
+        L().call("vm_grad_sqnorm", p(G_), n, p(ws), p(sq), stream())
+        assert abs(sq.item() - float((g.astype(np.float64) ** 2).sum())) < 1e-5 * float((g.astype(np.float64) ** 2).sum())
+        st = O.AdamState(iterations=6)
+        st.m["w"], st.v["w"] = torch.tensor(m0, dtype=torch.float64), torch.tensor(v0, dtype=torch.float64)
+        ref = O.adam_step(st, {"w": torch.tensor(pv, dtype=torch.float64)}, {"w": torch.tensor(g, dtype=torch.float64)})["w"]
+        t = 7
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        L().call("vm_adam_clip_step", p(P_), p(G_), p(M_), p(V_), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq), stream())
+        assert max_err(P_.cpu().numpy(), ref.numpy()) < 2e-6
+        assert rel_err(M_.cpu().numpy(), st.m["w"].numpy()) < 1e-5
+        assert rel_err(V_.cpu().numpy(), st.v["w"].numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("i16", [False, True])
+def test_decimate_whiten(i16):
+    r = rng(11)
+    n, wpt, raw_len, ds = 6, 3, 4801, 4
+    raw = (r.normal(0, 0.05, (n, raw_len)) + r.uniform(-0.01, 0.01, (n, 1)))
+    if i16:
+        raw_i = np.clip(np.round(raw * 32768), -32768, 32767).astype(np.int16)
+        raw = raw_i.astype(np.float64) / 32768.0
+        rd = dev(raw_i, torch.int16)
+    else:
+        raw = raw.astype(np.float32)
+        rd = dev(raw)
+    l0 = (raw_len + ds - 1) // ds
+    out = torch.zeros(n, l0 + 31, device="cuda")
+    ws = torch.empty(2 * n, dtype=torch.float64, device="cuda")
+    L().call("vm_decimate_whiten", p(rd), int(i16), n, raw_len, ds, 1, 0.038021, wpt, p(out), p(ws), stream())
+    pre = O.preprocess_instances(ds)
+    ref = np.concatenate([pre(raw.astype(np.float64)[t:t + wpt, :, None]) for t in range(0, n, wpt)])[:, :, 0]
+    o = out.cpu().numpy()
+    assert np.all(o[:, :15] == 0) and np.all(o[:, 15 + l0:] == 0)
+    assert max_err(o[:, 15:15 + l0], ref) < 1e-7
+    L().call("vm_decimate_whiten", p(rd), int(i16), n, raw_len, ds, 0, 0.038021, wpt, p(out), p(ws), stream())
+    assert max_err(out.cpu().numpy()[:, 15:15 + l0], raw[:, ::ds]) < 1e-7
+
+
+@pytest.mark.parametrize("dist", ["euclidean", "cosine", "dot_product"])
+@pytest.mark.parametrize("k,n", [(5, 1), (20, 5), (70, 2)])
+def test_nshot_distances(dist, k, n):
+    kinds = {"euclidean": 0, "cosine": 1, "dot_product": 2}
+    r = rng(12)
+    tasks, e = 7, 24
+    q = r.normal(0, 1, (tasks, e)).astype(np.float32)
+    s = r.normal(0, 1, (tasks, k * n, e)).astype(np.float32)
+    pred = torch.empty(tasks, k, device="cuda")
+    am = torch.empty(tasks, dtype=torch.int32, device="cuda")
+    L().call("vm_nshot_distances", p(dev(q)), p(dev(s)), tasks, k, n, e, kinds[dist], p(pred), p(am), stream())
+    ref = np.stack([O.n_shot_prediction(q[t], s[t], n, k, dist) for t in range(tasks)])
+    assert rel_err(pred.cpu().numpy(), ref) < 1e-5
+    assert np.array_equal(am.cpu().numpy(), ref.argmin(1).astype(np.int32))

@@ -1,0 +1,126 @@
+"""Pins the CPU oracle (oracle/voicemap_oracle.py) on the data the reference tree holds (tests/golden/) and on
+finite-difference checks.  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voicemap_oracle as O
+
+
+def test_whiten_closed_form_equals_literal_reference_steps():
+    x = np.random.default_rng(0).normal(0.01, 0.1, (3, 1000, 1))
+    assert np.array_equal(O.whiten(x), O.whiten_reference_literal(x))
+    with pytest.raises(ValueError):
+        O.whiten(x[:, :, 0])
+
+
+def test_whitening_like_reference_test(golden_dir):
+    """tests/tests.py:71-90 restated on a clip the reference holds (its FLAC is absent here): two identical rows ->
+    whitened mean ~ 0, RMS ~ 0.038021 (np.isclose defaults)."""
+    c = np.load(f"{golden_dir}/clips_human_eval.npz")
+    clip = c["query"].astype(np.float64) / 32768.0
+    data = np.stack([clip] * 2)[:, :, None]
+    w = O.whiten(data, 0.038021)
+    assert np.isclose(w.mean().item(), 0)
+    # like the reference test this only holds because the clip is ~zero-mean
+    assert np.isclose(np.sqrt(np.power(w[0, :], 2).mean()).item(), 0.038021, rtol=1e-3)
+
+
+def test_known_answer_task(golden_dir):
+    """notebooks/Human_Evaluation.ipynb cell 8: 'The correct answer was 5'."""
+    w = np.load(f"{golden_dir}/ckpt_cfgCK_weights.npz")
+    arch, p = O.params_from_checkpoint(w)
+    assert [b[2] for b in arch.blocks] == [2, 2, 2, 2] and arch.embedding_dimension == 128
+    c = np.load(f"{golden_dir}/clips_human_eval.npz")
+    q = c["query"].astype(np.float64) / 32768.0
+    s = c["support"].astype(np.float64) / 32768.0
+    pre = O.preprocess_instances(4)
+    i1, i2 = pre(np.stack([q] * 5)[:, :, None]), pre(s[:, :, None])
+    assert i1.shape == (5, 12000, 1)
+    pred, e1, e2 = O.siamese_forward(arch, p, torch.tensor(i1), torch.tensor(i2), False, "weighted_l1")
+    assert int(pred[:, 0].argmin()) + 1 == int(c["correct_answer_1based"]) == 5
+    # the current models.py geometry (first pool 4) does NOT solve the task with these weights: the fixture
+    # discriminates architecture errors
+    arch4 = O.EncoderArch.baseline(32, 128, 0.05, first_pool=4)
+    pred4, _, _ = O.siamese_forward(arch4, p, torch.tensor(i1), torch.tensor(i2), False, "weighted_l1")
+    assert int(pred4[:, 0].argmin()) + 1 != 5
+    g = np.load(f"{golden_dir}/oracle_vectors_cfgCK.npz")
+    assert np.allclose(pred[:, 0].numpy(), g["pred"], rtol=1e-9)
+    assert np.allclose(e1.numpy(), g["e1"], rtol=1e-9, atol=1e-12)
+
+
+def test_layer_shapes_match_notebook_svg():
+    """Embedding_Space_Visualisation.ipynb cell 12 SVG: 12000 -> 6000 -> 3000 -> 1500 -> 750 for cfg-CK."""
+    arch = O.EncoderArch.baseline(32, 128, first_pool=2)
+    assert arch.lengths(12000) == [12000, 6000, 3000, 1500, 750]
+    assert O.EncoderArch.baseline(128, 64).lengths(12000) == [12000, 3000, 1500, 750, 375]
+    assert O.EncoderArch.baseline(128, 64).lengths(6000) == [6000, 1500, 750, 375, 187]
+
+
+def test_param_count_cfgA():
+    arch = O.EncoderArch.baseline(128, 64, dropout=0.0)
+    p = O.init_params(arch)
+    assert sum(p[k].numel() for k in O.param_names(arch)) == 1023810
+
+
+def test_same_padding_is_tensorflow_same():
+    assert O.same_padding(32) == (15, 16) and O.same_padding(3) == (1, 1)
+    x = torch.zeros(1, 40, 1, dtype=torch.float64)
+    x[0, 20, 0] = 1.0
+    k = torch.arange(32, dtype=torch.float64).reshape(32, 1, 1) + 1
+    y = O.conv1d_same_relu(x, k, torch.zeros(1, dtype=torch.float64))
+    # y[t] = sum_k x[t + k - 15] w[k]  ->  impulse at 20 puts w[k] at t = 35 - k
+    assert y[0, 35 - 0, 0] == 1 and y[0, 35 - 31, 0] == 32
+
+
+def test_losses_and_metrics():
+    y = torch.tensor([[0.0], [0.0], [1.0], [1.0]], dtype=torch.float64)
+    p = torch.tensor([[0.1], [0.9], [0.4], [1.0]], dtype=torch.float64)
+    assert np.isclose(O.contrastive_loss(y, p).item(), (0.01 + 0.81 + 0.36 + 0.0) / 4)
+    ref = -(np.log(0.9) + np.log(0.1) + np.log(0.4) + np.log(1 - 1e-7)) / 4
+    assert np.isclose(O.binary_crossentropy(y, p).item(), ref, rtol=1e-6)
+    assert O.binary_accuracy(y, p).item() == 0.5
+    assert O.binary_accuracy(torch.tensor([[0.0]]), torch.tensor([[0.5]])).item() == 1.0  # round-half-even
+
+
+def test_adam_matches_hand_computation():
+    st = O.AdamState()
+    p = {"w": torch.tensor([1.0, -2.0], dtype=torch.float64)}
+    g = {"w": torch.tensor([3.0, 4.0], dtype=torch.float64)}  # norm 5 -> clipped to 1
+    out = O.adam_step(st, p, g)["w"]
+    gc = np.array([0.6, 0.8])
+    m, v = 0.1 * gc, 0.001 * gc ** 2
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert np.allclose(out.numpy(), np.array([1.0, -2.0]) - lr_t * m / (np.sqrt(v) + 1e-7))
+
+
+def test_training_step_gradients_against_finite_differences():
+    arch = O.EncoderArch.baseline(8, 8, dropout=0.0)
+    p = O.init_params(arch, seed=1)
+    r = np.random.default_rng(1)
+    x1 = torch.tensor(O.whiten(r.normal(0, 0.05, (2, 160, 1))))
+    x2 = torch.tensor(O.whiten(r.normal(0, 0.05, (2, 160, 1))))
+    y = torch.tensor([[0.0], [1.0]], dtype=torch.float64)
+    out = O.siamese_train_step(arch, p, None, x1, x2, y, loss="contrastive")
+    for name, idx in [("conv2.kernel", (1, 3, 5)), ("bn3.gamma", (2,)), ("dense.kernel", (4, 1)), ("conv1.bias", (3,))]:
+        eps = 1e-6
+        vals = []
+        for s in (+1, -1):
+            q = {k: v.clone() for k, v in p.items()}
+            q[name][idx] += s * eps
+            pr, _, _ = O.siamese_forward(arch, q, x1, x2, True)
+            vals.append(O.contrastive_loss(y, pr).item())
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert np.isclose(out["grads"][name][idx].item(), fd, rtol=1e-4, atol=1e-9), name
+
+
+def test_n_shot_prediction_modes():
+    from scipy.spatial.distance import cdist
+    r = np.random.default_rng(2)
+    q, s = r.normal(0, 1, 16), r.normal(0, 1, (15, 16))
+    n, k = 3, 5
+    unit = s / np.linalg.norm(s, axis=1, keepdims=True)
+    mu = np.stack([unit[i:i + n].mean(0) for i in range(0, n * k, n)])
+    assert np.allclose(O.n_shot_prediction(q, s, n, k, "cosine"), cdist(q[None], mu, "cosine")[0])
+    with pytest.raises(ValueError):
+        O.n_shot_prediction(q, s, n, k, "manhattan")

@@ -1,0 +1,102 @@
+"""ctypes binding of libvoicemap_hip.so (the C ABI declared in include/voicemap_hip.h).
+
+There is NO fallback: if the shared library is missing (and cannot be built because hipcc is absent) the
+import of the product path fails loudly.  The oracle under ``oracle/`` is never imported from here.
+"""
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvoicemap_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
+
+VM_F32, VM_BF16 = 0, 1
+VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
+VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
+VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
+
+P, I, L, F, D = c_void_p, c_int, c_int64, c_float, c_double
+
+# name -> (restype, argtypes); must list every function the header declares (tests/test_abi.py checks).
+SIGNATURES = {
+    "vm_last_error": (c_char_p, []),
+    "vm_abi_version": (I, []),
+    "vm_check_device": (I, []),
+    "vm_fill_zero": (I, [P, L, P]),
+    "vm_decimate_whiten_workspace_bytes": (L, [L]),
+    "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
+    "vm_conv1_stat_rows": (L, [L]),
+    "vm_conv1_fwd": (I, [P, P, P, L, L, I, I, P, P, P, P]),
+    "vm_conv1_wgrad": (I, [P, P, L, L, I, I, P, P, P]),
+    "vm_conv_stat_rows": (L, [L]),
+    "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
+    "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
+    "vm_conv_wgrad_splits": (I, [L, L, I, I]),
+    "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),
+    "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),
+    "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
+    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P]),
+    "vm_bn_infer_affine": (I, [P, P, P, P, F, I, P, P, P]),
+    "vm_bn_drop_pool_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P]),
+    "vm_bn_part_rows": (I, []),
+    "vm_bn_pool_bwd_reduce": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P]),
+    "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_colsum": (I, [P, L, I, P, P]),
+    "vm_global_maxpool_fwd": (I, [P, L, L, I, I, P, P, P]),
+    "vm_global_maxpool_bwd": (I, [P, P, L, L, I, I, P, P]),
+    "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),
+    "vm_dense_bwd": (I, [P, P, P, L, I, I, P, P, P, P]),
+    "vm_siamese_head_loss": (I, [P, P, P, P, L, I, I, I, P, P, P, P, P, P]),
+    "vm_softmax_cce": (I, [P, P, L, I, P, P, P, P, P]),
+    "vm_sqnorm_workspace_bytes": (L, [L]),
+    "vm_grad_sqnorm": (I, [P, L, P, P, P]),
+    "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P]),
+    "vm_nshot_distances": (I, [P, P, L, I, I, I, I, P, P, P]),
+}
+
+
+def header_functions(path=HEADER_PATH):
+    """Names of all functions declared in include/voicemap_hip.h."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vm_[a-z0-9_]+)\s*\(", src)))
+
+
+class VoicemapHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            _build.build(verbose=False)  # raises if hipcc is missing too
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        self.abi = self.cdll.vm_abi_version()
+
+    def call(self, name, *args):
+        """Call an int-returning entry point; raise with vm_last_error() on failure."""
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            msg = self.cdll.vm_last_error()
+            raise VoicemapHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else ""))
+
+    def query(self, name, *args):
+        return getattr(self.cdll, name)(*args)
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

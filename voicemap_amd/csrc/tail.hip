@@ -1,0 +1,406 @@
+// Tail of the encoder and the siamese / classifier heads: GlobalMaxPool1D -> Dense(E) (voicemap/models.py:37-39),
+// twin distance -> Dense(1, sigmoid) (models.py:55-69), contrastive / binary-cross-entropy loss
+// (voicemap/utils.py:77-85, experiments/train_siamese.py:57) and softmax + categorical CE
+// (experiments/train_classifier.py:112-115).  A few hundred KB of fp32 work per step: small kernels, fixed
+// summation order, everything in fp32.
+#include "common.hpp"
+
+namespace vm {
+
+// ---- GlobalMaxPool1D ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void global_maxpool_fwd_kernel(const T* __restrict__ act, int64_t L, int C, int P,
+                                                                 float* __restrict__ gmax, int32_t* __restrict__ gidx) {
+    constexpr int VEC = Elem<T>::kVec;
+    __shared__ float rv[256][VEC];
+    __shared__ int ri[256][VEC];
+    const int tid = threadIdx.x, RP = 256 / P, pl = tid % P, rl = tid / P;
+    const int CV = C / VEC;
+    const int64_t n = blockIdx.x;
+    for (int cvb = 0; cvb < CV; cvb += P) {
+        const int cv = cvb + pl;
+        const bool cok = cv < CV;
+        const int c0 = cv * VEC;
+        float best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            best[i] = -INFINITY;
+            bi[i] = 0x7fffffff;
+        }
+        if (cok) {
+            for (int64_t t = rl; t < L; t += RP) {
+                const Vec16<T> v = load16<T>(act + (n * (L + 2) + 1 + t) * C + c0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float y = v.get(i);
+                    if (y > best[i] || bi[i] == 0x7fffffff) {
+                        best[i] = y;
+                        bi[i] = (int)t;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            rv[tid][i] = best[i];
+            ri[tid][i] = bi[i];
+        }
+        __syncthreads();
+        if (rl == 0 && cok) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float b = rv[pl][i];
+                int k = ri[pl][i];
+                for (int r = 1; r < RP; ++r) {
+                    const float y = rv[r * P + pl][i];
+                    const int kk = ri[r * P + pl][i];
+                    if (kk != 0x7fffffff && (k == 0x7fffffff || y > b || (y == b && kk < k))) {
+                        b = y;
+                        k = kk;
+                    }
+                }
+                gmax[n * C + c0 + i] = b;
+                gidx[n * C + c0 + i] = k;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __restrict__ dg, const int32_t* __restrict__ gidx,
+                                                                 int64_t total, int64_t L, int C, T* __restrict__ dp) {
+    constexpr int VEC = Elem<T>::kVec;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int CV = C / VEC;
+    const int cv = (int)(idx % CV);
+    const int64_t r = idx / CV;
+    const int64_t t = r % L, n = r / L;
+    const int c0 = cv * VEC;
+    Vec16<T> o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o.set(i, gidx[n * C + c0 + i] == (int)t ? dg[n * C + c0 + i] : 0.f);
+    store16<T>(dp + (n * L + t) * C + c0, o);
+}
+
+// ---- Dense ------------------------------------------------------------------------------------------
+__global__ void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                 int64_t rows, int n_in, int n_out, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * n_out) return;
+    const int o = (int)(idx % n_out);
+    const int64_t r = idx / n_out;
+    float acc = b ? b[o] : 0.f;
+    const float* ir = in + r * n_in;
+    for (int i = 0; i < n_in; ++i) acc = fmaf(ir[i], w[(int64_t)i * n_out + o], acc);
+    out[idx] = acc;
+}
+
+__global__ void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout, int64_t rows, int n_in,
+                                   int n_out, float* __restrict__ grad_w, float* __restrict__ grad_b) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (int64_t)n_in * n_out;
+    if (idx < nw) {
+        const int o = (int)(idx % n_out);
+        const int i = (int)(idx / n_out);
+        float acc = 0.f;
+        for (int64_t r = 0; r < rows; ++r) acc = fmaf(in[r * n_in + i], dout[r * n_out + o], acc);
+        grad_w[idx] = acc;
+    } else if (idx < nw + n_out) {
+        const int o = (int)(idx - nw);
+        float acc = 0.f;
+        for (int64_t r = 0; r < rows; ++r) acc += dout[r * n_out + o];
+        grad_b[o] = acc;
+    }
+}
+
+__global__ void dense_bwd_in_kernel(const float* __restrict__ w, const float* __restrict__ dout, int64_t rows, int n_in,
+                                    int n_out, float* __restrict__ din) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * n_in) return;
+    const int i = (int)(idx % n_in);
+    const int64_t r = idx / n_in;
+    float acc = 0.f;
+    const float* wr = w + (int64_t)i * n_out;
+    const float* dr = dout + r * n_out;
+    for (int o = 0; o < n_out; ++o) acc = fmaf(dr[o], wr[o], acc);
+    din[idx] = acc;
+}
+
+// ---- siamese head + loss, forward and backward ----------------------------------------------------------
+constexpr float KERAS_EPS = 1e-7f;
+
+__device__ inline float dloss_dpred(float p, float y, int loss_kind) {
+    if (loss_kind == VM_LOSS_CONTRASTIVE) {
+        const float m = fmaxf(1.0f - p, 0.f);
+        return 2.f * (1.f - y) * p - 2.f * y * m;
+    }
+    if (p < KERAS_EPS || p > 1.0f - KERAS_EPS) return 0.f;  // clip_by_value passes no gradient outside
+    return (p - y) / (p * (1.0f - p));
+}
+
+__device__ inline float loss_value(float p, float y, int loss_kind) {
+    if (loss_kind == VM_LOSS_CONTRASTIVE) {
+        const float m = fmaxf(1.0f - p, 0.f);
+        return (1.f - y) * p * p + y * m * m;
+    }
+    const float pc = fminf(fmaxf(p, KERAS_EPS), 1.0f - KERAS_EPS);
+    const float x = logf(pc / (1.0f - pc));
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+__device__ inline float block_sum_256(float v, float* red) {
+    const int tid = threadIdx.x;
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void siamese_head_loss_kernel(const float* __restrict__ emb, const float* __restrict__ hw,
+                                                                const float* __restrict__ hb, const float* __restrict__ y,
+                                                                int64_t pairs, int E, int head_kind, int loss_kind,
+                                                                float* __restrict__ pred, float* __restrict__ loss_acc,
+                                                                float* __restrict__ demb, float* __restrict__ grad_hw,
+                                                                float* __restrict__ grad_hb) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const float bias = hb[0];
+    float lsum = 0.f, asum = 0.f, gb = 0.f, gw0 = 0.f;
+    for (int64_t b = tid; b < pairs; b += 256) {
+        const float* e1 = emb + b * E;
+        const float* e2 = emb + (pairs + b) * E;
+        float a = bias, d = 0.f;
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+            float s = 0.f;
+            for (int j = 0; j < E; ++j) {
+                const float df = e1[j] - e2[j];
+                s = fmaf(df, df, s);
+            }
+            d = sqrtf(s);
+            a = fmaf(hw[0], d, a);
+        } else {
+            for (int j = 0; j < E; ++j) a = fmaf(hw[j], fabsf(e1[j] - e2[j]), a);
+        }
+        const float p = 1.0f / (1.0f + expf(-a));
+        pred[b] = p;
+        if (y == nullptr) continue;
+        const float yy = y[b];
+        lsum += loss_value(p, yy, loss_kind);
+        asum += (rintf(p) == yy) ? 1.f : 0.f;
+        const float dlda = dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs;
+        gb += dlda;
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+            gw0 += dlda * d;
+            const float k = dlda * hw[0] / d;  // d == 0 -> inf/NaN, exactly like sqrt'(0) in the reference graph
+            for (int j = 0; j < E; ++j) {
+                const float g = k * (e1[j] - e2[j]);
+                demb[b * E + j] = g;
+                demb[(pairs + b) * E + j] = -g;
+            }
+        } else {
+            for (int j = 0; j < E; ++j) {
+                const float df = e1[j] - e2[j];
+                const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                const float g = dlda * hw[j] * sg;
+                demb[b * E + j] = g;
+                demb[(pairs + b) * E + j] = -g;
+            }
+        }
+    }
+    if (y == nullptr) return;
+    const float ls = block_sum_256(lsum, red);
+    const float as = block_sum_256(asum, red);
+    const float gbs = block_sum_256(gb, red);
+    const float gws = block_sum_256(gw0, red);
+    if (tid == 0) {
+        loss_acc[0] = ls / (float)pairs;
+        loss_acc[1] = as / (float)pairs;
+        grad_hb[0] = gbs;
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) grad_hw[0] = gws;
+    }
+    if (head_kind == VM_HEAD_WEIGHTED_L1) {
+        // grad_hw[j] = sum_b dlda_b * |e1-e2|_j  (pred was written by this block; make it visible first)
+        __syncthreads();
+        for (int j = tid; j < E; j += 256) {
+            float acc = 0.f;
+            for (int64_t b = 0; b < pairs; ++b) {
+                const float p = pred[b];
+                const float dlda = dloss_dpred(p, y[b], loss_kind) * p * (1.0f - p) / (float)pairs;
+                acc = fmaf(dlda, fabsf(emb[b * E + j] - emb[(pairs + b) * E + j]), acc);
+            }
+            grad_hw[j] = acc;
+        }
+    }
+}
+
+// ---- softmax + categorical cross-entropy ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                          int64_t rows, int n_classes, float* __restrict__ prob,
+                                                          float* __restrict__ row_loss, float* __restrict__ row_hit,
+                                                          float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    __shared__ float redm[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float* x = logits + r * n_classes;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = tid; c < n_classes; c += 256) {
+        if (x[c] > m) {
+            m = x[c];
+            mi = c;
+        }
+    }
+    // block argmax (first maximum)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) {
+            m = om;
+            mi = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        redm[tid >> 6] = m;
+        redi[tid >> 6] = mi;
+    }
+    __syncthreads();
+    m = redm[0];
+    mi = redi[0];
+    for (int i = 1; i < 4; ++i)
+        if (redm[i] > m || (redm[i] == m && redi[i] < mi)) {
+            m = redm[i];
+            mi = redi[i];
+        }
+    float s = 0.f;
+    for (int c = tid; c < n_classes; c += 256) s += expf(x[c] - m);
+    const float S = block_sum_256(s, red);
+    float psum = 0.f;
+    for (int c = tid; c < n_classes; c += 256) {
+        const float p = expf(x[c] - m) / S;
+        prob[r * n_classes + c] = p;
+        psum += p;
+    }
+    const float PS = block_sum_256(psum, red);  // Keras renormalises the softmax output before the clip
+    if (labels == nullptr) return;
+    const int lab = labels[r];
+    const float ql_raw = (expf(x[lab] - m) / S) / PS;
+    const bool in_range = ql_raw >= KERAS_EPS && ql_raw <= 1.0f - KERAS_EPS;
+    if (tid == 0) {
+        const float ql = fminf(fmaxf(ql_raw, KERAS_EPS), 1.0f - KERAS_EPS);
+        row_loss[r] = -logf(ql);
+        row_hit[r] = (mi == lab) ? 1.f : 0.f;
+    }
+    if (dlogits != nullptr) {
+        for (int c = tid; c < n_classes; c += 256) {
+            const float q = (expf(x[c] - m) / S) / PS;
+            float g = in_range ? (q - (c == lab ? 1.f : 0.f)) : 0.f;
+            dlogits[r * n_classes + c] = g / (float)rows;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mean2_kernel(const float* a, const float* b, int64_t n, float* out) {
+    __shared__ float red[4];
+    float sa = 0.f, sb = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        sa += a[i];
+        sb += b[i];
+    }
+    const float A = block_sum_256(sa, red);
+    const float B = block_sum_256(sb, red);
+    if (threadIdx.x == 0) {
+        out[0] = A / (float)n;
+        out[1] = B / (float)n;
+    }
+}
+
+static int lanes_for_t(int cv) {
+    int p = 1;
+    while (p < cv && p < 256) p <<= 1;
+    return p;
+}
+
+}  // namespace vm
+
+using namespace vm;
+
+extern "C" int vm_global_maxpool_fwd(const void* act, int64_t n_windows, int64_t L, int C, int dtype, float* gmax,
+                                     int32_t* gidx, void* stream) {
+    VM_REQUIRE(act && gmax && gidx, "vm_global_maxpool_fwd: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0 && C % 8 == 0, "vm_global_maxpool_fwd: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, {
+        const int P = lanes_for_t(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((global_maxpool_fwd_kernel<T>), dim3((unsigned)n_windows), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)act, L, C, P, gmax, gidx);
+    });
+    return check_launch("vm_global_maxpool_fwd");
+}
+
+extern "C" int vm_global_maxpool_bwd(const float* dg, const int32_t* gidx, int64_t n_windows, int64_t L, int C, int dtype,
+                                     void* dp, void* stream) {
+    VM_REQUIRE(dg && gidx && dp, "vm_global_maxpool_bwd: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0 && C % 8 == 0, "vm_global_maxpool_bwd: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, {
+        const int64_t total = n_windows * L * (C / Elem<T>::kVec);
+        hipLaunchKernelGGL((global_maxpool_bwd_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dg, gidx, total, L, C, (T*)dp);
+    });
+    return check_launch("vm_global_maxpool_bwd");
+}
+
+extern "C" int vm_dense_fwd(const float* in, const float* w, const float* b, int64_t rows, int n_in, int n_out, float* out,
+                            void* stream) {
+    VM_REQUIRE(in && w && out && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_fwd: bad argument");
+    const int64_t total = rows * n_out;
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, rows,
+                       n_in, n_out, out);
+    return check_launch("vm_dense_fwd");
+}
+
+extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t rows, int n_in, int n_out,
+                            float* grad_w, float* grad_b, float* din, void* stream) {
+    VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
+    const int64_t tw = (int64_t)n_in * n_out + n_out;
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((unsigned)cdiv(tw, 256)), dim3(256), 0, (hipStream_t)stream, in, dout, rows,
+                       n_in, n_out, grad_w, grad_b);
+    int rc = check_launch("vm_dense_bwd(w)");
+    if (rc || din == nullptr) return rc;
+    const int64_t ti = rows * n_in;
+    hipLaunchKernelGGL(dense_bwd_in_kernel, dim3((unsigned)cdiv(ti, 256)), dim3(256), 0, (hipStream_t)stream, w, dout, rows,
+                       n_in, n_out, din);
+    return check_launch("vm_dense_bwd(in)");
+}
+
+extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
+                                    int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
+                                    float* grad_hw, float* grad_hb, void* stream) {
+    VM_REQUIRE(emb && head_w && head_b && pred, "vm_siamese_head_loss: null pointer");
+    VM_REQUIRE(pairs > 0 && E > 0, "vm_siamese_head_loss: bad sizes");
+    VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1,
+               "vm_siamese_head_loss: head_kind %d not implemented (the reference raises NotImplementedError too)", head_kind);
+    VM_REQUIRE(loss_kind == VM_LOSS_CONTRASTIVE || loss_kind == VM_LOSS_BCE, "vm_siamese_head_loss: unknown loss %d", loss_kind);
+    VM_REQUIRE(y == nullptr || (loss_acc && demb && grad_hw && grad_hb), "vm_siamese_head_loss: training outputs missing");
+    hipLaunchKernelGGL(siamese_head_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, head_w, head_b, y, pairs, E,
+                       head_kind, loss_kind, pred, loss_acc, demb, grad_hw, grad_hb);
+    return check_launch("vm_siamese_head_loss");
+}
+
+extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float* prob,
+                              float* loss_acc, float* dlogits, float* ws, void* stream) {
+    VM_REQUIRE(logits && prob && rows > 0 && n_classes > 0, "vm_softmax_cce: bad argument");
+    VM_REQUIRE(labels == nullptr || (loss_acc && ws), "vm_softmax_cce: loss_acc and ws (2*rows floats) required with labels");
+    hipLaunchKernelGGL(softmax_cce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, labels, rows,
+                       n_classes, prob, ws, ws ? ws + rows : nullptr, dlogits);
+    int rc = check_launch("vm_softmax_cce");
+    if (rc || labels == nullptr) return rc;
+    hipLaunchKernelGGL(mean2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (const float*)(ws + rows),
+                       rows, loss_acc);
+    return check_launch("vm_softmax_cce(mean)");
+}

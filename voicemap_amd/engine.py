@@ -1,0 +1,465 @@
+"""Host-side driver of the HIP hot path: owns the flat parameter / gradient / Adam buffers and the activation
+workspaces, and enqueues the libvoicemap_hip.so kernels for one encoder forward, backward and optimizer step.
+
+PyTorch is used for device memory, streams and (in parallel.py) torch.distributed -- plumbing only; every
+arithmetic op of the path is a call through the C ABI (include/voicemap_hip.h).  Mirrors, at the level of one
+``train_on_batch``, what Keras does for the reference scripts (experiments/train_siamese.py:54-57,65;
+experiments/siamese_contrastive_loss.py:67-70; experiments/train_classifier.py:110-115).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import VM_BF16, VM_F32
+
+_DT = {"f32": VM_F32, "fp32": VM_F32, "float32": VM_F32, "bf16": VM_BF16, "bfloat16": VM_BF16}
+_TORCH_DT = {VM_F32: torch.float32, VM_BF16: torch.bfloat16}
+HEADS = {"uniform_euclidean": _lib.VM_HEAD_UNIFORM_EUCLIDEAN, "weighted_l1": _lib.VM_HEAD_WEIGHTED_L1}
+LOSSES = {"contrastive": _lib.VM_LOSS_CONTRASTIVE, "contrastive_loss": _lib.VM_LOSS_CONTRASTIVE,
+          "bce": _lib.VM_LOSS_BCE, "binary_crossentropy": _lib.VM_LOSS_BCE}
+CONV1_HALO_L, CONV1_HALO = 15, 31  # TF SAME padding of the k=32 first conv: 15 left / 16 right
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class HipEncoderEngine:
+    """The voicemap encoder (voicemap/models.py:6-41) + optional head on one MI355X.
+
+    blocks: [(kernel_size, channels, pool)] -- first block must be (32, F, p) on a 1-channel waveform, the others
+    k=3 (the only geometries the reference builds).  head: None | 'uniform_euclidean' | 'weighted_l1' |
+    'classifier'.  dtype: storage type of activations / GEMM operands ('bf16' or 'f32').
+    """
+
+    def __init__(self, blocks: Sequence[Tuple[int, int, int]], embedding_dimension: int, dropout: float = 0.05,
+                 head: Optional[str] = None, num_classes: int = 0, dtype: str = "bf16", device="cuda",
+                 bn_eps: float = 1e-3, bn_momentum: float = 0.99, unbiased_moving_variance: bool = True,
+                 seed: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEncoderEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = _lib.lib()
+        self.timed = {}
+        self._call("vm_check_device")
+        self.blocks = [tuple(int(v) for v in b) for b in blocks]
+        assert self.blocks[0][0] == 32, "first block must be the k=32 waveform conv"
+        assert all(b[0] == 3 for b in self.blocks[1:]), "blocks 2.. must be k=3"
+        assert all(b[1] % 8 == 0 for b in self.blocks), "channel counts must be multiples of 8"
+        self.E = int(embedding_dimension)
+        self.dropout = float(dropout)
+        self.head = head
+        self.num_classes = int(num_classes)
+        self.dtype = _DT[dtype]
+        self.tdt = _TORCH_DT[self.dtype]
+        self.device = torch.device(device)
+        self.bn_eps, self.bn_momentum = float(bn_eps), float(bn_momentum)
+        self.unbiased = bool(unbiased_moving_variance)
+        self.nb = len(self.blocks)
+
+        # ---- flat parameter store, Keras trainable_weights order -------------------------------------
+        spec: List[Tuple[str, Tuple[int, ...]]] = []
+        for i, (k, c, _) in enumerate(self.blocks):
+            cin = 1 if i == 0 else self.blocks[i - 1][1]
+            spec += [(f"conv{i+1}.kernel", (k, cin, c)), (f"conv{i+1}.bias", (c,)),
+                     (f"bn{i+1}.gamma", (c,)), (f"bn{i+1}.beta", (c,))]
+        cl = self.blocks[-1][1]
+        spec += [("dense.kernel", (cl, self.E)), ("dense.bias", (self.E,))]
+        if head == "uniform_euclidean":
+            spec += [("head.kernel", (1, 1)), ("head.bias", (1,))]
+        elif head == "weighted_l1":
+            spec += [("head.kernel", (self.E, 1)), ("head.bias", (1,))]
+        elif head == "classifier":
+            assert num_classes > 0
+            spec += [("head.kernel", (self.E, num_classes)), ("head.bias", (num_classes,))]
+        elif head is not None:
+            raise NotImplementedError(head)
+        self.spec = spec
+        self.offsets: Dict[str, Tuple[int, int, Tuple[int, ...]]] = OrderedDict()
+        off = 0
+        for name, shape in spec:
+            n = int(np.prod(shape))
+            self.offsets[name] = (off, n, shape)
+            off += _align(n)
+        self.n_flat = off
+        self.n_params = sum(n for _, n, _ in self.offsets.values())
+        dev = self.device
+        self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.nt_off: Dict[str, Tuple[int, int]] = OrderedDict()
+        off = 0
+        for i, (_, c, _) in enumerate(self.blocks):
+            self.nt_off[f"bn{i+1}.moving_mean"] = (off, c)
+            off += _align(c)
+            self.nt_off[f"bn{i+1}.moving_variance"] = (off, c)
+            off += _align(c)
+        self.NT = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.wf: Dict[int, torch.Tensor] = {}
+        self.wd: Dict[int, torch.Tensor] = {}
+        for i in range(1, self.nb):
+            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            self.wf[i] = torch.empty(cout * 3 * cin, dtype=self.tdt, device=dev)
+            self.wd[i] = torch.empty(cin * 3 * cout, dtype=self.tdt, device=dev)
+        self._sq_ws = torch.empty(self.lib.query("vm_sqnorm_workspace_bytes", self.n_flat) // 8, dtype=torch.float64, device=dev)
+        self._sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # Adam(clipnorm=1.) defaults of the reference scripts
+        self.lr, self.beta_1, self.beta_2, self.adam_eps, self.decay, self.clipnorm = 1e-3, 0.9, 0.999, 1e-7, 0.0, 1.0
+        self.iterations = 0
+        self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
+        self.grad_prescale = 1.0
+        self._plans: Dict[Tuple, dict] = {}
+        self.init_params(seed)
+
+    # ------------------------------------------------------------------------------------------------
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _call(self, name, *args):
+        """Enqueue one C-ABI entry point; entry points listed in ``self.timed`` are bracketed by HIP events on the
+        launch stream (bench.py uses this for the per-kernel roofline figure)."""
+        rec = self.timed.get(name) if self.timed else None
+        if rec is None:
+            self.lib.call(name, *args)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.lib.call(name, *args)
+        e1.record()
+        rec.append((e0, e1, args))
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if name in self.nt_off:
+            o, n = self.nt_off[name]
+            return self.NT[o:o + n]
+        o, n, shape = self.offsets[name]
+        return (self.P if buf is None else buf)[o:o + n].view(shape)
+
+    def init_params(self, seed: Optional[int] = None):
+        """Keras default initialisers (glorot_uniform kernels, zero biases, gamma 1, beta 0, moving 0 / 1)."""
+        g = torch.Generator().manual_seed(0 if seed is None else int(seed))
+        self.P.zero_()
+        for name, (o, n, shape) in self.offsets.items():
+            if name.endswith(".kernel"):
+                if len(shape) == 3:
+                    fan_in, fan_out = shape[0] * shape[1], shape[0] * shape[2]
+                else:
+                    fan_in, fan_out = shape
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                w = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim
+                self.P[o:o + n] = w.flatten().to(torch.float32).to(self.device)
+            elif name.endswith(".gamma"):
+                self.P[o:o + n] = 1.0
+        for name, (o, n) in self.nt_off.items():
+            self.NT[o:o + n] = 1.0 if name.endswith("moving_variance") else 0.0
+        self.M.zero_()
+        self.V.zero_()
+        self.iterations = 0
+        self.refresh_weights()
+
+    def set_params(self, params: Dict[str, "np.ndarray"]):
+        for name, val in params.items():
+            t = torch.as_tensor(np.asarray(val, dtype=np.float32)).to(self.device)
+            v = self.view(name)
+            v.copy_(t.reshape(v.shape))
+        self.refresh_weights()
+
+    def get_params(self) -> "OrderedDict[str, np.ndarray]":
+        out = OrderedDict()
+        for name in list(self.offsets) + list(self.nt_off):
+            out[name] = self.view(name).detach().cpu().numpy().copy()
+        return out
+
+    def get_grads(self) -> "OrderedDict[str, np.ndarray]":
+        return OrderedDict((name, self.view(name, self.G).detach().cpu().numpy().copy()) for name in self.offsets)
+
+    def refresh_weights(self):
+        """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
+        for i in range(1, self.nb):
+            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            self._call("vm_prep_conv_weights", _p(self.view(f"conv{i+1}.kernel")), cin, cout, self.dtype,
+                          _p(self.wf[i]), _p(self.wd[i]), self.stream())
+
+    # ------------------------------------------------------------------------------------------------
+    def lengths(self, l0: int) -> List[int]:
+        out = [l0]
+        for (_, _, p) in self.blocks:
+            out.append(out[-1] // p)
+        return out
+
+    def plan(self, n_windows: int, l0: int, training: bool) -> dict:
+        key = (n_windows, l0, training)
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        dev, tdt = self.device, self.tdt
+        ls = self.lengths(l0)
+        assert ls[-1] >= 1, "window too short for this encoder"
+        pl = {"n": n_windows, "l0": l0, "L": ls, "training": training}
+        f32 = torch.float32
+        pl["x0"] = torch.zeros(n_windows, l0 + CONV1_HALO, dtype=f32, device=dev)
+        prow = self.lib.query("vm_bn_part_rows")
+        for i, (k, c, pool) in enumerate(self.blocks):
+            L = ls[i]
+            b = {}
+            b["z"] = torch.empty(n_windows, L, c, dtype=tdt, device=dev)
+            b["act"] = torch.zeros(n_windows, ls[i + 1] + 2, c, dtype=tdt, device=dev)  # halo rows stay zero
+            rows = self.lib.query("vm_conv1_stat_rows" if i == 0 else "vm_conv_stat_rows", L)
+            b["stat_rows"] = rows
+            for nm in ("mean", "invstd", "scale", "shift", "c1", "c2"):
+                b[nm] = torch.zeros(2, c, dtype=f32, device=dev)
+            if training:
+                b["ssum"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
+                b["ssq"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
+                b["dp"] = torch.empty(n_windows, ls[i + 1], c, dtype=tdt, device=dev)
+                b["du"] = torch.zeros(n_windows, L + 2, c, dtype=tdt, device=dev)
+                for nm in ("pa", "pb", "pdu"):
+                    b[nm] = torch.empty(n_windows * prow, c, dtype=f32, device=dev)
+            pl[i] = b
+        cl = self.blocks[-1][1]
+        pl["gmax"] = torch.empty(n_windows, cl, dtype=f32, device=dev)
+        pl["gidx"] = torch.empty(n_windows, cl, dtype=torch.int32, device=dev)
+        pl["emb"] = torch.empty(n_windows, self.E, dtype=f32, device=dev)
+        if training:
+            pl["demb"] = torch.zeros(n_windows, self.E, dtype=f32, device=dev)
+            pl["dgmax"] = torch.empty(n_windows, cl, dtype=f32, device=dev)
+            ws = 0
+            for i in range(1, self.nb):
+                ws = max(ws, self.lib.query("vm_conv_wgrad_workspace_bytes", n_windows, ls[i], self.blocks[i - 1][1],
+                                            self.blocks[i][1]))
+            ws = max(ws, n_windows * 32 * self.blocks[0][1] * 4)
+            pl["wgrad_ws"] = torch.empty(ws // 4 + 16, dtype=f32, device=dev)
+        pl["pred"] = torch.empty(max(n_windows // 2, 1), dtype=f32, device=dev)
+        pl["loss_acc"] = torch.zeros(2, dtype=f32, device=dev)
+        if self.head == "classifier":
+            pl["logits"] = torch.empty(n_windows, self.num_classes, dtype=f32, device=dev)
+            pl["prob"] = torch.empty_like(pl["logits"])
+            pl["dlogits"] = torch.empty_like(pl["logits"])
+            pl["cce_ws"] = torch.empty(2 * n_windows, dtype=f32, device=dev)
+        pl["pre_ws"] = torch.empty(2 * n_windows, dtype=torch.float64, device=dev)
+        self._plans[key] = pl
+        return pl
+
+    # ------------------------------------------------------------------------------------------------
+    def load_preprocessed(self, pl: dict, x: torch.Tensor):
+        """x: (n_windows, L0) or (n_windows, L0, 1) already decimated + whitened (host path of the reference)."""
+        x = x.reshape(pl["n"], pl["l0"]).to(self.device, torch.float32)
+        pl["x0"][:, CONV1_HALO_L:CONV1_HALO_L + pl["l0"]].copy_(x)
+
+    def preprocess(self, pl: dict, raw: torch.Tensor, downsampling: int, whitening: bool, windows_per_tower: int,
+                   rms: float = 0.038021):
+        """voicemap/utils.py:22-34 + 88-101 on the GPU: raw (n_windows, raw_len) fp32 or int16 -> pl['x0']."""
+        raw = raw.reshape(pl["n"], -1).contiguous()
+        is16 = raw.dtype == torch.int16
+        if not is16:
+            raw = raw.to(torch.float32)
+        assert (raw.shape[1] + downsampling - 1) // downsampling == pl["l0"]
+        self._call("vm_decimate_whiten", _p(raw), int(is16), pl["n"], raw.shape[1], downsampling, int(whitening), rms,
+                      windows_per_tower, _p(pl["x0"]), _p(pl["pre_ws"]), self.stream())
+
+    def forward(self, pl: dict, windows_per_tower: int, drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        """x0 -> embeddings (pl['emb']).  Training plans use batch statistics per tower and update the moving
+        statistics; inference plans use the moving statistics (Keras learning phase 0)."""
+        lib, st, n, dt = self.lib, self.stream(), pl["n"], self.dtype
+        training = pl["training"]
+        n_towers = n // windows_per_tower if training else 1
+        assert (not training) or n % windows_per_tower == 0
+        assert n_towers <= 2 or not training, "at most two towers per call"
+        wpt = windows_per_tower if training else n
+        pl["wpt"], pl["drop"] = wpt, drop_masks
+        for i, (k, c, pool) in enumerate(self.blocks):
+            b, L = pl[i], pl["L"][i]
+            ssum = _p(b["ssum"]) if training else None
+            ssq = _p(b["ssq"]) if training else None
+            bias = _p(self.view(f"conv{i+1}.bias"))
+            if i == 0:
+                self._call("vm_conv1_fwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), bias, n, L, c, dt, _p(b["z"]), ssum,
+                         ssq, st)
+            else:
+                cin = self.blocks[i - 1][1]
+                self._call("vm_conv_fwd", _p(pl[i - 1]["act"]), _p(self.wf[i]), bias, n, L, cin, c, dt, _p(b["z"]), ssum, ssq,
+                         st)
+            gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
+            mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
+            if training:
+                self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
+                         self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
+                         _p(b["scale"]), _p(b["shift"]), st)
+            else:
+                self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
+            dm = drop_masks[i] if (drop_masks is not None and training) else None
+            self._call("vm_bn_drop_pool_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt, L, c, pool, dt,
+                     _p(b["act"]), st)
+        cl, Ll = self.blocks[-1][1], pl["L"][-1]
+        self._call("vm_global_maxpool_fwd", _p(pl[self.nb - 1]["act"]), n, Ll, cl, dt, _p(pl["gmax"]), _p(pl["gidx"]), st)
+        self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
+                 _p(pl["emb"]), st)
+        return pl["emb"]
+
+    def backward(self, pl: dict):
+        """pl['demb'] -> gradients of every encoder tensor in self.G (fixed summation order throughout)."""
+        assert pl["training"]
+        lib, st, n, dt, wpt = self.lib, self.stream(), pl["n"], self.dtype, pl["wpt"]
+        drop = pl["drop"]
+        cl, Ll = self.blocks[-1][1], pl["L"][-1]
+        G = self.G
+        self._call("vm_dense_bwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E,
+                 _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), _p(pl["dgmax"]), st)
+        self._call("vm_global_maxpool_bwd", _p(pl["dgmax"]), _p(pl["gidx"]), n, Ll, cl, dt, _p(pl[self.nb - 1]["dp"]), st)
+        for i in range(self.nb - 1, -1, -1):
+            k, c, pool = self.blocks[i]
+            b, L = pl[i], pl["L"][i]
+            dm = _p(drop[i]) if drop is not None and drop[i] is not None else None
+            common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
+            self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
+            self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                     _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), st)
+            self._call("vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, pool, dt, _p(b["du"]),
+                     _p(b["pdu"]), st)
+            self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), st)
+            gw = _p(self.view(f"conv{i+1}.kernel", G))
+            if i == 0:
+                self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
+            else:
+                cin = self.blocks[i - 1][1]
+                self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(pl["wgrad_ws"]), gw, st)
+                self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(pl[i - 1]["dp"]), st)
+
+    # ------------------------------------------------------------------------------------------------
+    def siamese_head(self, pl: dict, y: Optional[torch.Tensor], loss: str = "contrastive"):
+        """Twin distance -> Dense(1, sigmoid) -> loss (+ backward into pl['demb'] and the head gradients)."""
+        assert self.head in HEADS, "engine was built without a siamese head"
+        pairs = pl["n"] // 2
+        G = self.G
+        train = y is not None
+        self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")),
+                      _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]),
+                      _p(pl["loss_acc"]) if train else None, _p(pl["demb"]) if train else None,
+                      _p(self.view("head.kernel", G)) if train else None, _p(self.view("head.bias", G)) if train else None,
+                      self.stream())
+        return pl["pred"][:pairs]
+
+    def classifier_head(self, pl: dict, labels: Optional[torch.Tensor]):
+        """Dense(num_classes, softmax) + categorical CE (+ backward into pl['demb'] and the head gradients)."""
+        assert self.head == "classifier"
+        lib, st, n = self.lib, self.stream(), pl["n"]
+        self._call("vm_dense_fwd", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), n, self.E,
+                 self.num_classes, _p(pl["logits"]), st)
+        train = labels is not None
+        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, _p(pl["prob"]),
+                 _p(pl["loss_acc"]) if train else None, _p(pl["dlogits"]) if train else None, _p(pl["cce_ws"]), st)
+        if train:
+            G = self.G
+            self._call("vm_dense_bwd", _p(pl["emb"]), _p(self.view("head.kernel")), _p(pl["dlogits"]), n, self.E,
+                     self.num_classes, _p(self.view("head.kernel", G)), _p(self.view("head.bias", G)), _p(pl["demb"]), st)
+        return pl["prob"]
+
+    def optimizer_step(self):
+        """Keras Adam(clipnorm) on the flat buffers (after the optional data-parallel gradient sum)."""
+        if self.grad_sync is not None:
+            self.grad_sync(self.G)
+        lib, st = self.lib, self.stream()
+        if self.clipnorm and self.clipnorm > 0:
+            self._call("vm_grad_sqnorm", _p(self.G), self.n_flat, _p(self._sq_ws), _p(self._sqnorm), st)
+        lr = self.lr
+        if self.decay > 0:
+            lr = lr * (1.0 / (1.0 + self.decay * self.iterations))
+        t = self.iterations + 1
+        lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        self._call("vm_adam_clip_step", _p(self.P), _p(self.G), _p(self.M), _p(self.V), self.n_flat, lr_t, self.beta_1,
+                 self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale), _p(self._sqnorm), st)
+        self.iterations = t
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------------------------------------
+    def make_drop_masks(self, n_windows: int, generator: Optional[torch.Generator] = None):
+        """SpatialDropout1D keep masks (n_windows, C) / (1 - rate) per block; None when rate == 0."""
+        if self.dropout <= 0.0:
+            return None
+        out = []
+        for (_, c, _) in self.blocks:
+            u = torch.rand(n_windows, c, device=self.device, generator=generator)
+            out.append((u >= self.dropout).to(torch.float32) / (1.0 - self.dropout))
+        return out
+
+    def siamese_train_step(self, x1, x2, y, loss: str = "contrastive", preprocessed: bool = True, downsampling: int = 4,
+                           whitening: bool = True, drop_masks="auto", apply_update: bool = True):
+        """One ``train_on_batch`` of the siamese scripts.  x1/x2: (pairs, L, 1) windows (already decimated+whitened if
+        ``preprocessed``, else raw fp32/int16 16 kHz windows that are decimated+whitened on the GPU, each tower
+        separately like voicemap/utils.py:59-60).  y: (pairs, 1) labels, 0 = same speaker."""
+        x1 = torch.as_tensor(x1)
+        x2 = torch.as_tensor(x2)
+        pairs = x1.shape[0]
+        x = torch.cat([x1.reshape(pairs, -1), x2.reshape(pairs, -1)], 0).to(self.device)
+        l0 = x.shape[1] if preprocessed else (x.shape[1] + downsampling - 1) // downsampling
+        pl = self.plan(2 * pairs, l0, True)
+        if preprocessed:
+            self.load_preprocessed(pl, x)
+        else:
+            self.preprocess(pl, x, downsampling, whitening, pairs)
+        if isinstance(drop_masks, str):
+            drop_masks = self.make_drop_masks(2 * pairs)
+        yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
+        self.forward(pl, pairs, drop_masks)
+        self.siamese_head(pl, yd, loss)
+        self.backward(pl)
+        if apply_update:
+            self.optimizer_step()
+        return pl
+
+    def classifier_train_step(self, x, labels, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True,
+                              drop_masks="auto", apply_update: bool = True):
+        """One ``train_on_batch`` of experiments/train_classifier.py (labels: int class ids)."""
+        x = torch.as_tensor(x)
+        n = x.shape[0]
+        x = x.reshape(n, -1).to(self.device)
+        l0 = x.shape[1] if preprocessed else (x.shape[1] + downsampling - 1) // downsampling
+        pl = self.plan(n, l0, True)
+        if preprocessed:
+            self.load_preprocessed(pl, x)
+        else:
+            self.preprocess(pl, x, downsampling, whitening, n)
+        if isinstance(drop_masks, str):
+            drop_masks = self.make_drop_masks(n)
+        lab = torch.as_tensor(labels).reshape(n).to(self.device, torch.int32).contiguous()
+        self.forward(pl, n, drop_masks)
+        self.classifier_head(pl, lab)
+        self.backward(pl)
+        if apply_update:
+            self.optimizer_step()
+        return pl
+
+    def embed(self, x, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True,
+              windows_per_tower: Optional[int] = None) -> torch.Tensor:
+        """Inference-mode embeddings (encoder.predict): x (n, L[, 1]) -> (n, E) fp32 device tensor."""
+        x = torch.as_tensor(x)
+        n = x.shape[0]
+        x = x.reshape(n, -1).to(self.device)
+        l0 = x.shape[1] if preprocessed else (x.shape[1] + downsampling - 1) // downsampling
+        pl = self.plan(n, l0, False)
+        if preprocessed:
+            self.load_preprocessed(pl, x)
+        else:
+            self.preprocess(pl, x, downsampling, whitening, windows_per_tower or n)
+        return self.forward(pl, n, None)
+
+    def siamese_predict(self, x1, x2, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True):
+        """siamese.predict([x1, x2]) -> (pairs, 1) probabilities (inference-mode BN)."""
+        x1 = torch.as_tensor(x1)
+        x2 = torch.as_tensor(x2)
+        pairs = x1.shape[0]
+        x = torch.cat([x1.reshape(pairs, -1), x2.reshape(pairs, -1)], 0)
+        self.embed(x, preprocessed, downsampling, whitening, windows_per_tower=pairs)
+        l0 = x.shape[1] if preprocessed else (x.shape[1] + downsampling - 1) // downsampling
+        pl = self.plan(2 * pairs, l0, False)
+        return self.siamese_head(pl, None).reshape(pairs, 1)
