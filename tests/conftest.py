@@ -32,3 +32,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    try:
+        from tests import gpu_util
+        gpu_util.release()
+    except Exception:
+        pass

@@ -6,6 +6,12 @@ import of the product path fails loudly.  The oracle under ``oracle/`` is never 
 import ctypes
 import os
 import re
+
+# torch must be imported BEFORE the shared library is loaded: the wheel bundles its own libamdhip64.so / HSA
+# runtime, and the process must end up with ONE HIP runtime (ours then binds to the copy torch already mapped,
+# so torch's streams and allocations are valid in our launches).  Loading ours first leaves two runtimes and
+# hipGetDevice fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
