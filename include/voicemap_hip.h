@@ -92,10 +92,13 @@ int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* w
  *   mean, invstd = rsqrt(var_biased + eps), scale = gamma*invstd, shift = beta - mean*scale     (each (n_towers, C))
  * and applies the moving-average updates tower by tower:  moving -= (moving - batch) * (1 - momentum), with the
  * batch variance multiplied by n/(n-(1+eps)) first when unbiased_moving_var != 0 (Keras 2.2.x). */
+/* ws (all three reducers below): >= vm_colreduce_workspace_bytes(n_segments, C) bytes of scratch for the first of the
+ * two deterministic reduction stages (n_segments = n_towers; 1 for vm_colsum). */
+int64_t vm_colreduce_workspace_bytes(int n_segments, int C);
 int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                    double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                    int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                   float* scale, float* shift, void* stream);
+                   float* scale, float* shift, void* ws, void* stream);
 /* inference affine from moving statistics (one "tower"). */
 int vm_bn_infer_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                        float eps, int C, float* scale, float* shift, void* stream);
@@ -117,7 +120,7 @@ int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, con
  * parameter gradients over all towers: grad_gamma = sum(dy*zhat), grad_beta = sum(dy)  (overwritten). */
 int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
                        int C, double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta,
-                       void* stream);
+                       void* ws, void* stream);
 /* backward, pass 2: du[n][1+t][c] = [z>0] * scale * (dy - c1 - zhat*c2)  (padded (n_windows, L+2, C) out), plus
  * partial column sums of du -> part_du (n_windows * vm_bn_part_rows(), C) for the conv bias gradient. */
 int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
@@ -125,7 +128,7 @@ int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, cons
                          int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
                          void* du, float* part_du, void* stream);
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
-int vm_colsum(const float* part, int64_t rows, int C, float* out, void* stream);
+int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
 
 /* ---- a1 tail: GlobalMaxPool1D + Dense(E)  (voicemap/models.py:37-39) ------------------------------------
  * act: padded (n_windows, L+2, C) `dtype`; gmax (n_windows, C) fp32; gidx (n_windows, C) int32 = first argmax. */

@@ -145,8 +145,9 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
     mean, invstd, scale, shift = (torch.empty(towers, c, **f32) for _ in range(4))
     mm = torch.zeros(c, **f32)
     mv = torch.ones(c, **f32)
+    crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, c) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
-             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), stream())
+             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), p(crws), stream())
     zr = z.clone().requires_grad_(True)
     gr = gamma.clone().requires_grad_(True)
     br = beta.clone().requires_grad_(True)
@@ -180,11 +181,11 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
     dpd = dp.to("cuda", tdt).contiguous()
     common = (p(zd), p(dpd), p(scale), p(shift), p(mean), p(invstd), p(dropd))
     L().call("vm_bn_pool_bwd_reduce", *common, n, wpt, l, c, pool, vm, p(pa), p(pb), stream())
-    L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, c, float(wpt * l), p(c1), p(c2), p(ggam), p(gbet), stream())
+    L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, c, float(wpt * l), p(c1), p(c2), p(ggam), p(gbet), p(crws), stream())
     du = torch.zeros(n, l + 2, c, dtype=tdt, device="cuda")
     L().call("vm_bn_pool_bwd_apply", *common, p(c1), p(c2), n, wpt, l, c, pool, vm, p(du), p(pdu), stream())
     gbias = torch.empty(c, **f32)
-    L().call("vm_colsum", p(pdu), n * rows, c, p(gbias), stream())
+    L().call("vm_colsum", p(pdu), n * rows, c, p(gbias), p(crws), stream())
     tol = 5e-5 if dt == "f32" else 1e-2
     assert rel_err(ggam.cpu().numpy(), gg.numpy()) < tol
     assert rel_err(gbet.cpu().numpy(), gb.numpy()) < tol

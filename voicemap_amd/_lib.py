@@ -43,14 +43,15 @@ SIGNATURES = {
     "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),
     "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),
     "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
-    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P]),
+    "vm_colreduce_workspace_bytes": (L, [I, I]),
+    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P]),
     "vm_bn_infer_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "vm_bn_drop_pool_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P]),
     "vm_bn_part_rows": (I, []),
     "vm_bn_pool_bwd_reduce": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
-    "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P]),
+    "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P, P]),
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
-    "vm_colsum": (I, [P, L, I, P, P]),
+    "vm_colsum": (I, [P, L, I, P, P, P]),
     "vm_global_maxpool_fwd": (I, [P, L, L, I, I, P, P, P]),
     "vm_global_maxpool_bwd": (I, [P, P, L, L, I, I, P, P]),
     "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),

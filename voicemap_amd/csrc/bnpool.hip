@@ -16,58 +16,87 @@ namespace vm {
 constexpr int BN_SEG = 8;  // partial-sum segments per window in the backward kernels
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stat_sum, const float* __restrict__ stat_sq,
-                                                            int64_t rows_per_tower, int n_towers, int C, double count,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float eps, float momentum, int unbiased, float* moving_mean,
-                                                            float* moving_var, float* mean, float* invstd, float* scale,
-                                                            float* shift) {
+// Column sums of (rows, C) fp32 partial matrices, two deterministic stages so that the long reduction over
+// rows is spread over many workgroups instead of C/64 of them:
+//   stage 1: grid (C/64, segments*CR_CHUNKS); a workgroup (64 channels x 16 row lanes) sums one row chunk of
+//            one segment (tower) in fp64 -> ws[(seg*CR_CHUNKS + chunk)][which][C]
+//   stage 2: the consumer kernel adds the CR_CHUNKS doubles per (segment, channel) in a fixed order.
+constexpr int CR_CHUNKS = 32;
+
+__global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 int64_t rows_per_seg, int C, double* __restrict__ ws) {
     __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    const bool cok = c < C;
+    const int seg = blockIdx.y / CR_CHUNKS, chunk = blockIdx.y % CR_CHUNKS;
+    const int64_t per = (rows_per_seg + CR_CHUNKS - 1) / CR_CHUNKS;
+    const int64_t r_lo = chunk * per;
+    int64_t r_hi = r_lo + per;
+    if (r_hi > rows_per_seg) r_hi = rows_per_seg;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int64_t base = (int64_t)seg * rows_per_seg;
+        for (int64_t r = r_lo + rg; r < r_hi; r += 16) {
+            s += (double)a[(base + r) * C + c];
+            if (b != nullptr) q += (double)b[(base + r) * C + c];
+        }
+    }
+    red[0][rg][cl] = s;
+    red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ss += red[0][i][cl];
+            qq += red[1][i][cl];
+        }
+        ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
+        ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+    }
+}
+
+__device__ inline void colreduce_stage2(const double* __restrict__ ws, int seg, int C, int c, double& s, double& q) {
+    s = 0.0;
+    q = 0.0;
+    for (int k = 0; k < CR_CHUNKS; ++k) {
+        s += ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c];
+        q += ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, int n_towers, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float momentum, int unbiased, float* moving_mean,
+                                                           float* moving_var, float* mean, float* invstd, float* scale,
+                                                           float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
     float mm = 0.f, mv = 0.f;
-    if (cok && rg == 0 && moving_mean != nullptr) {
+    if (moving_mean != nullptr) {
         mm = moving_mean[c];
         mv = moving_var[c];
     }
     for (int tw = 0; tw < n_towers; ++tw) {
-        double s = 0.0, q = 0.0;
-        if (cok) {
-            const int64_t r0 = (int64_t)tw * rows_per_tower;
-            for (int64_t r = rg; r < rows_per_tower; r += 16) {
-                s += (double)stat_sum[(r0 + r) * C + c];
-                q += (double)stat_sq[(r0 + r) * C + c];
-            }
+        double ss, qq;
+        colreduce_stage2(ws, tw, C, c, ss, qq);
+        const double m = ss / count;
+        double var = qq / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float istd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * istd;
+        mean[tw * C + c] = (float)m;
+        invstd[tw * C + c] = istd;
+        scale[tw * C + c] = sc;
+        shift[tw * C + c] = beta[c] - (float)m * sc;
+        if (moving_mean != nullptr) {
+            double vv = var;
+            if (unbiased) vv = var * (count / (count - (1.0 + (double)eps)));
+            mm = mm - (mm - (float)m) * (1.0f - momentum);
+            mv = mv - (mv - (float)vv) * (1.0f - momentum);
         }
-        red[0][rg][cl] = s;
-        red[1][rg][cl] = q;
-        __syncthreads();
-        if (rg == 0 && cok) {
-            double ss = 0.0, qq = 0.0;
-            for (int i = 0; i < 16; ++i) {
-                ss += red[0][i][cl];
-                qq += red[1][i][cl];
-            }
-            const double m = ss / count;
-            double var = qq / count - m * m;
-            if (var < 0.0) var = 0.0;
-            const float istd = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = gamma[c] * istd;
-            mean[tw * C + c] = (float)m;
-            invstd[tw * C + c] = istd;
-            scale[tw * C + c] = sc;
-            shift[tw * C + c] = beta[c] - (float)m * sc;
-            if (moving_mean != nullptr) {
-                double vv = var;
-                if (unbiased) vv = var * (count / (count - (1.0 + (double)eps)));
-                mm = mm - (mm - (float)m) * (1.0f - momentum);
-                mv = mv - (mv - (float)vv) * (1.0f - momentum);
-            }
-        }
-        __syncthreads();
     }
-    if (cok && rg == 0 && moving_mean != nullptr) {
+    if (moving_mean != nullptr) {
         moving_mean[c] = mm;
         moving_var[c] = mv;
     }
@@ -83,41 +112,50 @@ __global__ void bn_infer_affine_kernel(const float* gamma, const float* beta, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// grid = (n_windows, BN_SEG); threads: P lanes over channel vectors x RP row lanes (no integer divisions on the
+// element path); a block owns pooled rows q = seg, seg+BN_SEG, ... of one window.
 template <typename T, int POOL>
 __global__ __launch_bounds__(256) void bn_drop_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ drop,
-                                                               int64_t total, int64_t wpt, int64_t L, int C, T* __restrict__ out) {
+                                                               int64_t wpt, int64_t L, int C, int P, T* __restrict__ out) {
     constexpr int VEC = Elem<T>::kVec;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const int tid = threadIdx.x;
+    const int RP = 256 / P;
+    const int pl = tid % P, rl = tid / P;
     const int CV = C / VEC;
-    const int64_t Lq = L / POOL;
-    const int cv = (int)(idx % CV);
-    const int64_t r = idx / CV;
-    const int64_t q = r % Lq, n = r / Lq;
-    const int c0 = cv * VEC;
+    const int64_t n = blockIdx.x;
+    const int seg = blockIdx.y;
     const int64_t tw = n / wpt;
-    float sc[VEC], sh[VEC], dr[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        sc[i] = scale[tw * C + c0 + i];
-        sh[i] = shift[tw * C + c0 + i];
-        dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
-    }
-    float best[VEC];
-#pragma unroll
-    for (int j = 0; j < POOL; ++j) {
-        const Vec16<T> v = load16<T>(z + (n * L + q * POOL + j) * C + c0);
+    const int64_t Lq = L / POOL;
+    for (int cv = pl; cv < CV; cv += P) {
+        const int c0 = cv * VEC;
+        float sc[VEC], sh[VEC], dr[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float y = fmaf(v.get(i), sc[i], sh[i]) * dr[i];
-            best[i] = (j == 0 || y > best[i]) ? y : best[i];
+            sc[i] = scale[tw * C + c0 + i];
+            sh[i] = shift[tw * C + c0 + i];
+            dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
+        }
+        const T* zrow = z + n * L * C + c0;
+        T* orow = out + (n * (Lq + 2) + 1) * C + c0;
+        for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Lq; q += (int64_t)RP * BN_SEG) {
+            Vec16<T> v[POOL];
+#pragma unroll
+            for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
+            Vec16<T> o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float best = fmaf(v[0].get(i), sc[i], sh[i]) * dr[i];
+#pragma unroll
+                for (int j = 1; j < POOL; ++j) {
+                    const float y = fmaf(v[j].get(i), sc[i], sh[i]) * dr[i];
+                    best = y > best ? y : best;
+                }
+                o.set(i, best);
+            }
+            store16<T>(orow + q * C, o);
         }
     }
-    Vec16<T> o;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) o.set(i, best[i]);
-    store16<T>(out + (n * (Lq + 2) + 1 + q) * C + c0, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,60 +282,29 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part_dy, const float* __restrict__ part_dyz,
-                                                                int64_t rows_per_tower, int n_towers, int C, double count,
-                                                                float* c1, float* c2, float* grad_gamma, float* grad_beta) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const bool cok = c < C;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int n_towers, int C, double count,
+                                                               float* c1, float* c2, float* grad_gamma, float* grad_beta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
     double gg = 0.0, gb = 0.0;
     for (int tw = 0; tw < n_towers; ++tw) {
-        double s = 0.0, q = 0.0;
-        if (cok) {
-            const int64_t r0 = (int64_t)tw * rows_per_tower;
-            for (int64_t r = rg; r < rows_per_tower; r += 16) {
-                s += (double)part_dy[(r0 + r) * C + c];
-                q += (double)part_dyz[(r0 + r) * C + c];
-            }
-        }
-        red[0][rg][cl] = s;
-        red[1][rg][cl] = q;
-        __syncthreads();
-        if (rg == 0 && cok) {
-            double ss = 0.0, qq = 0.0;
-            for (int i = 0; i < 16; ++i) {
-                ss += red[0][i][cl];
-                qq += red[1][i][cl];
-            }
-            c1[tw * C + c] = (float)(ss / count);
-            c2[tw * C + c] = (float)(qq / count);
-            gb += ss;
-            gg += qq;
-        }
-        __syncthreads();
+        double ss, qq;
+        colreduce_stage2(ws, tw, C, c, ss, qq);
+        c1[tw * C + c] = (float)(ss / count);
+        c2[tw * C + c] = (float)(qq / count);
+        gb += ss;
+        gg += qq;
     }
-    if (rg == 0 && cok) {
-        grad_gamma[c] = (float)gg;
-        grad_beta[c] = (float)gb;
-    }
+    grad_gamma[c] = (float)gg;
+    grad_beta[c] = (float)gb;
 }
 
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int64_t rows, int C, float* out) {
-    __shared__ double red[16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const bool cok = c < C;
-    double s = 0.0;
-    if (cok)
-        for (int64_t r = rg; r < rows; r += 16) s += (double)part[r * C + c];
-    red[rg][cl] = s;
-    __syncthreads();
-    if (rg == 0 && cok) {
-        double ss = 0.0;
-        for (int i = 0; i < 16; ++i) ss += red[i][cl];
-        out[c] = (float)ss;
-    }
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ ws, int C, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double ss, qq;
+    colreduce_stage2(ws, 0, C, c, ss, qq);
+    out[c] = (float)ss;
 }
 
 static int lanes_for(int cv) {
@@ -310,16 +317,22 @@ static int lanes_for(int cv) {
 
 using namespace vm;
 
+extern "C" int64_t vm_colreduce_workspace_bytes(int n_segments, int C) {
+    return (int64_t)n_segments * CR_CHUNKS * 2 * C * (int64_t)sizeof(double);
+}
+
 extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                               double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                               int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                              float* scale, float* shift, void* stream) {
-    VM_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && invstd && scale && shift, "vm_bn_finalize: null pointer");
+                              float* scale, float* shift, void* ws, void* stream) {
+    VM_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && invstd && scale && shift && ws, "vm_bn_finalize: null pointer");
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
-                       rows_per_tower, n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var,
-                       moving_mean, moving_var, mean, invstd, scale, shift);
+    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
+                       stat_sum, stat_sq, rows_per_tower, C, (double*)ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                       n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
+                       mean, invstd, scale, shift);
     return check_launch("vm_bn_finalize");
 }
 
@@ -353,9 +366,9 @@ extern "C" int vm_bn_drop_pool_fwd(const void* z, const float* scale, const floa
     VM_REQUIRE(z && scale && shift && out, "vm_bn_drop_pool_fwd: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_drop_pool_fwd: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
-        const int64_t total = n_windows * (L / POOL) * (C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_drop_pool_fwd_kernel<T, POOL>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)z, scale, shift, drop, total, windows_per_tower, L, C, (T*)out);
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_drop_pool_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, (T*)out);
     }));
     return check_launch("vm_bn_drop_pool_fwd");
 }
@@ -379,13 +392,15 @@ extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float*
 
 extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
                                   int C, double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta,
-                                  void* stream) {
-    VM_REQUIRE(part_dy && part_dyz && c1 && c2 && grad_gamma && grad_beta, "vm_bn_bwd_finalize: null pointer");
+                                  void* ws, void* stream) {
+    VM_REQUIRE(part_dy && part_dyz && c1 && c2 && grad_gamma && grad_beta && ws, "vm_bn_bwd_finalize: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
                "vm_bn_bwd_finalize: n_windows must be a multiple of windows_per_tower");
     const int n_towers = (int)(n_windows / windows_per_tower);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part_dy, part_dyz,
-                       windows_per_tower * BN_SEG, n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
+    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
+                       part_dy, part_dyz, windows_per_tower * BN_SEG, C, (double*)ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                       n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
     return check_launch("vm_bn_bwd_finalize");
 }
 
@@ -404,8 +419,11 @@ extern "C" int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* 
     return check_launch("vm_bn_pool_bwd_apply");
 }
 
-extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* stream) {
-    VM_REQUIRE(part && out && rows > 0 && C > 0, "vm_colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, rows, C, out);
+extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {
+    VM_REQUIRE(part && out && ws && rows > 0 && C > 0, "vm_colsum: bad argument");
+    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, part,
+                       (const float*)nullptr, rows, C, (double*)ws);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
+                       out);
     return check_launch("vm_colsum");
 }

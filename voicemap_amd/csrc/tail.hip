@@ -86,47 +86,65 @@ __global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __
 }
 
 // ---- Dense ------------------------------------------------------------------------------------------
-__global__ void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
-                                 int64_t rows, int n_in, int n_out, float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * n_out) return;
-    const int o = (int)(idx % n_out);
-    const int64_t r = idx / n_out;
-    float acc = b ? b[o] : 0.f;
+// Tiny fp32 GEMMs (256 x 512 x 64 at cfg-A).  blockIdx.y carries the index of the broadcast operand's row, so
+// that operand is read with wave-uniform (scalar) loads and the other one coalesced across the 64 lanes.
+__global__ __launch_bounds__(64) void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int n_in, int n_out,
+                                                       float* __restrict__ out) {
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (o >= n_out) return;
     const float* ir = in + r * n_in;
-    for (int i = 0; i < n_in; ++i) acc = fmaf(ir[i], w[(int64_t)i * n_out + o], acc);
-    out[idx] = acc;
+    float a0 = b ? b[o] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= n_in; i += 4) {
+        a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
+        a1 = fmaf(ir[i + 1], w[(int64_t)(i + 1) * n_out + o], a1);
+        a2 = fmaf(ir[i + 2], w[(int64_t)(i + 2) * n_out + o], a2);
+        a3 = fmaf(ir[i + 3], w[(int64_t)(i + 3) * n_out + o], a3);
+    }
+    for (; i < n_in; ++i) a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
+    out[r * n_out + o] = (a0 + a1) + (a2 + a3);
 }
 
-__global__ void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout, int64_t rows, int n_in,
-                                   int n_out, float* __restrict__ grad_w, float* __restrict__ grad_b) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nw = (int64_t)n_in * n_out;
-    if (idx < nw) {
-        const int o = (int)(idx % n_out);
-        const int i = (int)(idx / n_out);
-        float acc = 0.f;
-        for (int64_t r = 0; r < rows; ++r) acc = fmaf(in[r * n_in + i], dout[r * n_out + o], acc);
-        grad_w[idx] = acc;
-    } else if (idx < nw + n_out) {
-        const int o = (int)(idx - nw);
-        float acc = 0.f;
-        for (int64_t r = 0; r < rows; ++r) acc += dout[r * n_out + o];
-        grad_b[o] = acc;
+// grad_w[i][o] = sum_r in[r][i]*dout[r][o]; blockIdx.y = i.  The last y-row computes grad_b.
+__global__ __launch_bounds__(64) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                         int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
+                                                         float* __restrict__ grad_b) {
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (o >= n_out) return;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n_in) {
+        int64_t r = 0;
+        for (; r + 2 <= rows; r += 2) {
+            a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
+            a1 = fmaf(in[(r + 1) * n_in + i], dout[(r + 1) * n_out + o], a1);
+        }
+        for (; r < rows; ++r) a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
+        grad_w[(int64_t)i * n_out + o] = a0 + a1;
+    } else {
+        for (int64_t r = 0; r < rows; ++r) a0 += dout[r * n_out + o];
+        grad_b[o] = a0;
     }
 }
 
-__global__ void dense_bwd_in_kernel(const float* __restrict__ w, const float* __restrict__ dout, int64_t rows, int n_in,
-                                    int n_out, float* __restrict__ din) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * n_in) return;
-    const int i = (int)(idx % n_in);
-    const int64_t r = idx / n_in;
-    float acc = 0.f;
+// din[r][i] = sum_o dout[r][o]*w[i][o]; blockIdx.y = r, lanes over i (w rows are short: L2-resident).
+__global__ __launch_bounds__(64) void dense_bwd_in_kernel(const float* __restrict__ w, const float* __restrict__ dout,
+                                                          int n_in, int n_out, float* __restrict__ din) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (i >= n_in) return;
     const float* wr = w + (int64_t)i * n_out;
     const float* dr = dout + r * n_out;
-    for (int o = 0; o < n_out; ++o) acc = fmaf(dr[o], wr[o], acc);
-    din[idx] = acc;
+    float a0 = 0.f, a1 = 0.f;
+    int o = 0;
+    for (; o + 2 <= n_out; o += 2) {
+        a0 = fmaf(dr[o], wr[o], a0);
+        a1 = fmaf(dr[o + 1], wr[o + 1], a1);
+    }
+    for (; o < n_out; ++o) a0 = fmaf(dr[o], wr[o], a0);
+    din[r * n_in + i] = a0 + a1;
 }
 
 // ---- siamese head + loss, forward and backward ----------------------------------------------------------
@@ -358,23 +376,27 @@ extern "C" int vm_global_maxpool_bwd(const float* dg, const int32_t* gidx, int64
 extern "C" int vm_dense_fwd(const float* in, const float* w, const float* b, int64_t rows, int n_in, int n_out, float* out,
                             void* stream) {
     VM_REQUIRE(in && w && out && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_fwd: bad argument");
-    const int64_t total = rows * n_out;
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, rows,
-                       n_in, n_out, out);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // grid.y is limited to 65535
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(dense_fwd_kernel, dim3((n_out + 63) / 64, (unsigned)nr), dim3(64), 0, (hipStream_t)stream,
+                           in + r0 * n_in, w, b, n_in, n_out, out + r0 * n_out);
+    }
     return check_launch("vm_dense_fwd");
 }
 
 extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t rows, int n_in, int n_out,
                             float* grad_w, float* grad_b, float* din, void* stream) {
     VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
-    const int64_t tw = (int64_t)n_in * n_out + n_out;
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((unsigned)cdiv(tw, 256)), dim3(256), 0, (hipStream_t)stream, in, dout, rows,
+    VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64), 0, (hipStream_t)stream, in, dout, rows,
                        n_in, n_out, grad_w, grad_b);
     int rc = check_launch("vm_dense_bwd(w)");
     if (rc || din == nullptr) return rc;
-    const int64_t ti = rows * n_in;
-    hipLaunchKernelGGL(dense_bwd_in_kernel, dim3((unsigned)cdiv(ti, 256)), dim3(256), 0, (hipStream_t)stream, w, dout, rows,
-                       n_in, n_out, din);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(dense_bwd_in_kernel, dim3((n_in + 63) / 64, (unsigned)nr), dim3(64), 0, (hipStream_t)stream, w,
+                           dout + r0 * n_out, n_in, n_out, din + r0 * n_in);
+    }
     return check_launch("vm_dense_bwd(in)");
 }
 

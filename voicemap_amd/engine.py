@@ -247,6 +247,8 @@ class HipEncoderEngine:
             pl["dlogits"] = torch.empty_like(pl["logits"])
             pl["cce_ws"] = torch.empty(2 * n_windows, dtype=f32, device=dev)
         pl["pre_ws"] = torch.empty(2 * n_windows, dtype=torch.float64, device=dev)
+        cmax = max(b[1] for b in self.blocks)
+        pl["cr_ws"] = torch.empty(self.lib.query("vm_colreduce_workspace_bytes", 2, cmax) // 8, dtype=torch.float64, device=dev)
         self._plans[key] = pl
         return pl
 
@@ -294,7 +296,7 @@ class HipEncoderEngine:
             if training:
                 self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
                          self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
-                         _p(b["scale"]), _p(b["shift"]), st)
+                         _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), st)
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
             dm = drop_masks[i] if (drop_masks is not None and training) else None
@@ -323,10 +325,11 @@ class HipEncoderEngine:
             common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
             self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                     _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), st)
+                     _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, pool, dt, _p(b["du"]),
                      _p(b["pdu"]), st)
-            self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), st)
+            self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]),
+                       st)
             gw = _p(self.view(f"conv{i+1}.kernel", G))
             if i == 0:
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
