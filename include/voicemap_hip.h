@@ -62,10 +62,32 @@ int64_t vm_conv1_stat_rows(int64_t L);
 int vm_conv1_fwd(const float* x, const float* w, const float* bias, int64_t n_windows, int64_t L, int F,
                  int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
 /* wgrad of block 1: dW[k][c] = sum_{n,t} x[n][t+k] * du[n][t][c] over all windows.
- * du: (n_windows, L+2, F) padded `dtype`.  ws: (n_windows, 32, F) fp32 partials; grad_w (32,1,F) is
- * overwritten with the fixed-order sum (deterministic). */
+ * du: (n_windows, L+2, F) padded `dtype`.  ws: vm_conv1_wgrad_workspace_bytes() of scratch for the per-window partials;
+ * grad_w (32,1,F) is overwritten with the fixed-order sum (deterministic). */
+int64_t vm_conv1_wgrad_workspace_bytes(int64_t n_windows, int F);
 int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L, int F, int dtype,
                    float* ws, float* grad_w, void* stream);
+
+/* Fused block 1 for bf16 storage (voicemap/models.py:13-19: Conv1D(F,32) -> BatchNormalization -> SpatialDropout1D ->
+ * MaxPool1D(pool)): the full-resolution relu(conv) tensor is never written.
+ *   training (inference = 0): out = e (n_windows, L/pool, F) bf16 = per-pool-window max (gamma >= 0) or min (gamma < 0) of
+ *     bf16(relu(conv+b)) -- BN is a monotone per-channel affine, so pooling commutes with it; the affine + dropout are then
+ *     applied to e by vm_bn_drop_pool_fwd(z = e, L = L/pool, pool = 1).  gamma_or_scale = gamma (F); shift ignored;
+ *     stat_sum / stat_sq as for vm_conv1_fwd (over all L positions).
+ *   inference (inference = 1): out = padded act (n_windows, L/pool + 2, F) bf16 = bf16(extreme * scale + shift);
+ *     gamma_or_scale = scale, shift from vm_bn_infer_affine.
+ * pool: 2 or 4. */
+int vm_conv1_fused_fwd(const float* x, const float* w, const float* bias, const float* gamma_or_scale, const float* shift,
+                       int64_t n_windows, int64_t L, int F, int pool, int inference, void* out, float* stat_sum,
+                       float* stat_sq, void* stream);
+/* Backward of the same block from dp (n_windows, L/pool, F) bf16: recomputes the conv tile on the matrix cores,
+ * evaluates the pool/dropout/BN/ReLU backward in registers (c1, c2 from vm_bn_pool_bwd_reduce(z = e, pool = 1) +
+ * vm_bn_bwd_finalize(count = wpt*L)) and accumulates grad_w (32,1,F) and grad_b (F) (overwritten; fixed order). */
+int64_t vm_conv1_fused_bwd_workspace_bytes(int64_t n_windows, int64_t L, int F);
+int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const void* dp, const float* scale,
+                       const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
+                       int64_t n_windows, int64_t windows_per_tower, int64_t L, int F, int pool, void* ws, float* grad_w,
+                       float* grad_b, void* stream);
 
 /* ---- a1 blocks 2-4: Conv1D(c_out, 3, padding='same', activation='relu')  (voicemap/models.py:22,27,32)
  * implicit GEMM on MFMA.  in: padded (n_windows, L+2, c_in) `dtype`; wf: (c_out, 3*c_in) `dtype` from

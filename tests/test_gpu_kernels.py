@@ -84,7 +84,7 @@ def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
     dx = torch.empty(n, l, cin, dtype=tdt, device="cuda")
     L().call("vm_conv_dgrad", p(dup), p(wd), n, l, cin, cout, vm, p(dx), stream())
     assert rel_err(dx.float().cpu().numpy(), gx.numpy()) < TOL[dt]
-    ws = torch.empty(L().query("vm_conv_wgrad_workspace_bytes", n, l, cin, cout) // 4, device="cuda")
+    ws = torch.empty(L().query("vm_conv_wgrad_workspace_bytes", n, l, cin, cout) // 4 + 16, device="cuda")
     gwd = torch.empty(3, cin, cout, device="cuda")
     L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gwd), stream())
     # fp32 accumulation of exact products of the (rounded) operands: tight in both modes
@@ -100,7 +100,7 @@ def test_conv1_wgrad(dt):
     du = quant(r.normal(0, 1, (n, l, f)), dt)
     xp = np.zeros((n, l + 31), np.float32)
     xp[:, 15:15 + l] = x
-    ws = torch.empty(n * 32 * f, device="cuda")
+    ws = torch.empty(L().query("vm_conv1_wgrad_workspace_bytes", n, f) // 4 + 16, device="cuda")
     gw = torch.empty(32, 1, f, device="cuda")
     L().call("vm_conv1_wgrad", p(dev(xp)), p(padded(du, tdt)), n, l, f, vm, p(ws), p(gw), stream())
     xt = torch.tensor(xp, dtype=torch.float64)
@@ -366,3 +366,84 @@ def test_nshot_distances(dist, k, n):
     ref = np.stack([O.n_shot_prediction(q[t], s[t], n, k, dist) for t in range(tasks)])
     assert rel_err(pred.cpu().numpy(), ref) < 1e-5
     assert np.array_equal(am.cpu().numpy(), ref.argmin(1).astype(np.int32))
+
+
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,wpt,l,f,pool,use_drop", [(4, 2, 700, 16, 4, True), (2, 1, 1200, 128, 4, False), (2, 2, 530, 40, 2, True),
+                                                     (2, 1, 300, 160, 4, False)])
+def test_conv1_fused_block(n, wpt, l, f, pool, use_drop):
+    """Fused bf16 block 1 (conv k=32 -> relu -> BN -> dropout -> maxpool) forward, inference forward and backward vs
+    the oracle with the same bf16 storage point (z rounded forward, du rounded backward)."""
+    r = rng(20)
+    x = r.normal(0, 0.05, (n, l)).astype(np.float32)
+    w = r.normal(0, 0.2, (32, 1, f)).astype(np.float32)
+    b = r.normal(0, 0.05, (f,)).astype(np.float32)
+    gamma = (r.normal(1.0, 0.3, f) * np.where(r.random(f) < 0.25, -1, 1)).astype(np.float32)
+    beta = r.normal(0, 0.3, f).astype(np.float32)
+    drop = ((r.random((n, f)) > 0.3) / 0.7).astype(np.float32) if use_drop else None
+    xp = np.zeros((n, l + 31), np.float32)
+    xp[:, 15:15 + l] = x
+    lq = l // pool
+    towers = n // wpt
+    f32 = dict(dtype=torch.float32, device="cuda")
+    rows = L().query("vm_conv1_stat_rows", l)
+    xd, wd_, bd, gd, btd = dev(xp), dev(w), dev(b), dev(gamma), dev(beta)
+    dropd = dev(drop) if drop is not None else None
+    e = torch.empty(n, lq, f, dtype=torch.bfloat16, device="cuda")
+    ss, sq = torch.zeros(n * rows, f, **f32), torch.zeros(n * rows, f, **f32)
+    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(gd), None, n, l, f, pool, 0, p(e), p(ss), p(sq), stream())
+
+    # ---- oracle: z with the bf16 storage point, BN per tower, dropout, pool
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    wr, br = T(w).requires_grad_(True), T(b).requires_grad_(True)
+    gr, btr = T(gamma).requires_grad_(True), T(beta).requires_grad_(True)
+    z = O._store(O.conv1d_same_relu(T(x)[:, :, None], wr, br), "bf16")
+    zz = z.detach()
+    pooled_max = O.maxpool1d(zz, pool)
+    pooled_min = -O.maxpool1d(-zz, pool)
+    e_ref = torch.where(T(gamma) >= 0, pooled_max, pooled_min)
+    assert rel_err(e.float().cpu().numpy(), e_ref.numpy()) < 2e-3
+    assert rel_err(ss.cpu().numpy().reshape(n, rows, f).sum(1), zz.sum(1).numpy()) < 2e-4
+    assert rel_err(sq.cpu().numpy().reshape(n, rows, f).sum(1), (zz * zz).sum(1).numpy()) < 2e-4
+
+    # ---- BN finalize + affine/dropout on the pooled tensor == pool(BN(z)*drop)
+    mean, invstd, scale, shift = (torch.empty(towers, f, **f32) for _ in range(4))
+    crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, f) // 8, dtype=torch.float64, device="cuda")
+    L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, f, float(wpt * l), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
+             p(mean), p(invstd), p(scale), p(shift), p(crws), stream())
+    act = torch.zeros(n, lq + 2, f, dtype=torch.bfloat16, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(dropd), n, wpt, lq, f, 1, 1, p(act), stream())
+    out_ref, _ = _bn_block_oracle(z, gr, btr, T(drop) if drop is not None else None, pool, wpt)
+    assert rel_err(act.float().cpu().numpy()[:, 1:-1], out_ref.detach().numpy()) < 8e-3
+
+    # ---- backward
+    dpq = quant(r.normal(0, 1, (n, lq, f)), "bf16")
+    gw_ref, gb_ref, gg_ref, gbt_ref = torch.autograd.grad((out_ref * dpq).sum(), [wr, br, gr, btr])
+    prow = L().query("vm_bn_part_rows")
+    pa, pb = torch.zeros(n * prow, f, **f32), torch.zeros(n * prow, f, **f32)
+    c1, c2 = torch.empty(towers, f, **f32), torch.empty(towers, f, **f32)
+    ggam, gbet = torch.empty(f, **f32), torch.empty(f, **f32)
+    dpd = dpq.to("cuda", torch.bfloat16).contiguous()
+    L().call("vm_bn_pool_bwd_reduce", p(e), p(dpd), p(scale), p(shift), p(mean), p(invstd), p(dropd), n, wpt, lq, f, 1, 1,
+             p(pa), p(pb), stream())
+    L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, f, float(wpt * l), p(c1), p(c2), p(ggam), p(gbet), p(crws), stream())
+    ws = torch.empty(L().query("vm_conv1_fused_bwd_workspace_bytes", n, l, f) // 4 + 16, **f32)
+    gw, gb = torch.empty(32, 1, f, **f32), torch.empty(f, **f32)
+    L().call("vm_conv1_fused_bwd", p(xd), p(wd_), p(bd), p(dpd), p(scale), p(mean), p(invstd), p(dropd), p(c1), p(c2), n, wpt,
+             l, f, pool, p(ws), p(gw), p(gb), stream())
+    assert rel_err(ggam.cpu().numpy(), gg_ref.numpy()) < 2e-2
+    assert rel_err(gbet.cpu().numpy(), gbt_ref.numpy()) < 2e-2
+    assert rel_err(gw.cpu().numpy(), gw_ref.numpy()) < 2e-2
+    assert rel_err(gb.cpu().numpy(), gb_ref.numpy()) < 2e-2
+
+    # ---- inference forward: moving-statistics affine applied in the epilogue, padded output
+    mm, mv = r.normal(0.1, 0.05, f).astype(np.float32), (r.random(f) * 0.01 + 1e-4).astype(np.float32)
+    sc_i, sh_i = torch.empty(f, **f32), torch.empty(f, **f32)
+    L().call("vm_bn_infer_affine", p(gd), p(btd), p(dev(mm)), p(dev(mv)), 1e-3, f, p(sc_i), p(sh_i), stream())
+    act_i = torch.zeros(n, lq + 2, f, dtype=torch.bfloat16, device="cuda")
+    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(sc_i), p(sh_i), n, l, f, pool, 1, p(act_i), None, None, stream())
+    y_i = O.batchnorm_infer(zz, T(gamma), T(beta), T(mm), T(mv), 1e-3)
+    ref_i = O.maxpool1d(y_i, pool).numpy()
+    a = act_i.float().cpu().numpy()
+    assert np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
+    assert rel_err(a[:, 1:-1], ref_i) < 8e-3

@@ -35,7 +35,11 @@ SIGNATURES = {
     "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
     "vm_conv1_stat_rows": (L, [L]),
     "vm_conv1_fwd": (I, [P, P, P, L, L, I, I, P, P, P, P]),
+    "vm_conv1_wgrad_workspace_bytes": (L, [L, I]),
     "vm_conv1_wgrad": (I, [P, P, L, L, I, I, P, P, P]),
+    "vm_conv1_fused_fwd": (I, [P, P, P, P, P, L, L, I, I, I, P, P, P, P]),
+    "vm_conv1_fused_bwd_workspace_bytes": (L, [L, L, I]),
+    "vm_conv1_fused_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P, P]),
     "vm_conv_stat_rows": (L, [L]),
     "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),

@@ -92,6 +92,12 @@ __device__ inline double wave_sum_d(double v) {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// reduce.hip: out0[i] (i < n0) / out1[i - n0] = sum over `slabs` slabs of ws[k][i], two fixed-order stages.
+// `part` needs slab_sum_part_bytes(nel) bytes of scratch.
+constexpr int SLAB_RCH = 16;
+int64_t slab_sum_part_bytes(int64_t nel);
+int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n0, float* out1, void* part, hipStream_t stream);
+
 }  // namespace vm
 
 #define VM_DISPATCH_DTYPE(dtype, ...)                               \

@@ -135,14 +135,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     }
 }
 
-__global__ void conv1_slab_reduce_kernel(const float* ws, int64_t slabs, int64_t n, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int64_t k = 0; k < slabs; ++k) s += ws[k * n + i];
-    out[i] = s;
-}
-
 }  // namespace vm
 
 using namespace vm;
@@ -165,6 +157,10 @@ extern "C" int vm_conv1_fwd(const float* x, const float* w, const float* bias, i
     return check_launch("vm_conv1_fwd");
 }
 
+extern "C" int64_t vm_conv1_wgrad_workspace_bytes(int64_t n_windows, int F) {
+    return n_windows * C1_K * (int64_t)F * (int64_t)sizeof(float) + slab_sum_part_bytes((int64_t)C1_K * F);
+}
+
 extern "C" int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L, int F, int dtype, float* ws,
                               float* grad_w, void* stream) {
     VM_REQUIRE(x && du && ws && grad_w, "vm_conv1_wgrad: null pointer");
@@ -176,7 +172,5 @@ extern "C" int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows,
     int rc = check_launch("vm_conv1_wgrad");
     if (rc) return rc;
     const int64_t n = (int64_t)C1_K * F;
-    hipLaunchKernelGGL(conv1_slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)ws, n_windows, n, grad_w);
-    return check_launch("vm_conv1_wgrad(reduce)");
+    return slab_sum((const float*)ws, n_windows, n, grad_w, n, nullptr, ws + n_windows * n, (hipStream_t)stream);
 }

@@ -348,14 +348,6 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     }
 }
 
-__global__ void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
-    out[i] = s;
-}
-
 // fp32 Keras kernel (3, c_in, c_out) -> wf[co][k*c_in + ci] = W[k][ci][co];  wd[ci][j*c_out + co] = W[2-j][ci][co]
 template <typename T>
 __global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, T* wd) {
@@ -445,7 +437,8 @@ extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int 
 }
 
 extern "C" int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out) {
-    return (int64_t)vm_conv_wgrad_splits(n_windows, L, c_in, c_out) * 3 * c_in * c_out * (int64_t)sizeof(float);
+    return (int64_t)vm_conv_wgrad_splits(n_windows, L, c_in, c_out) * 3 * c_in * c_out * (int64_t)sizeof(float) +
+           slab_sum_part_bytes(3LL * c_in * c_out);
 }
 
 extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
@@ -476,9 +469,7 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
     int rc = check_launch("vm_conv_wgrad");
     if (rc) return rc;
     const int64_t n = 3LL * c_in * c_out;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)ws, splits, n, grad_w);
-    return check_launch("vm_conv_wgrad(reduce)");
+    return slab_sum((const float*)ws, splits, n, grad_w, n, nullptr, (float*)ws + (int64_t)splits * n, (hipStream_t)stream);
 }
 
 extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream) {

@@ -1,0 +1,52 @@
+// Deterministic sum over split-K / per-window partial slabs:  out[i] = sum_k ws[k][i]  in two fixed-order stages
+// (SLAB_RCH fp64 partials per element, then their sum), so a long reduction over hundreds of slabs is spread over
+// many workgroups instead of being one serial loop per output element.
+#include "common.hpp"
+
+namespace vm {
+
+__global__ __launch_bounds__(256) void slab_stage1_kernel(const float* __restrict__ ws, int64_t slabs, int64_t nel,
+                                                          double* __restrict__ part) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nel) return;
+    const int64_t per = (slabs + SLAB_RCH - 1) / SLAB_RCH;
+    const int64_t lo = blockIdx.y * per;
+    int64_t hi = lo + per;
+    if (hi > slabs) hi = slabs;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t k = lo;
+    for (; k + 2 <= hi; k += 2) {
+        s0 += (double)ws[k * nel + i];
+        s1 += (double)ws[(k + 1) * nel + i];
+    }
+    if (k < hi) s0 += (double)ws[k * nel + i];
+    part[(int64_t)blockIdx.y * nel + i] = s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void slab_stage2_kernel(const double* __restrict__ part, int64_t nel, int64_t n0,
+                                                          float* __restrict__ out0, float* __restrict__ out1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nel) return;
+    double s = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < SLAB_RCH; ++k) s += part[(int64_t)k * nel + i];
+    if (i < n0) {
+        out0[i] = (float)s;
+    } else {
+        out1[i - n0] = (float)s;
+    }
+}
+
+int64_t slab_sum_part_bytes(int64_t nel) { return (int64_t)SLAB_RCH * nel * (int64_t)sizeof(double) + 64; }
+
+int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n0, float* out1, void* part, hipStream_t stream) {
+    uintptr_t a = reinterpret_cast<uintptr_t>(part);
+    a = (a + 63) / 64 * 64;
+    double* pp = reinterpret_cast<double*>(a);
+    hipLaunchKernelGGL(slab_stage1_kernel, dim3((unsigned)cdiv(nel, 256), SLAB_RCH), dim3(256), 0, stream, ws, slabs, nel, pp);
+    hipLaunchKernelGGL(slab_stage2_kernel, dim3((unsigned)cdiv(nel, 256)), dim3(256), 0, stream, (const double*)pp, nel, n0, out0,
+                       out1);
+    return check_launch("slab_sum");
+}
+
+}  // namespace vm

@@ -65,6 +65,9 @@ class HipEncoderEngine:
         self.bn_eps, self.bn_momentum = float(bn_eps), float(bn_momentum)
         self.unbiased = bool(unbiased_moving_variance)
         self.nb = len(self.blocks)
+        # bf16 storage: block 1 runs the fused MFMA kernels (no full-resolution z1 / du1 in HBM); fp32 storage keeps
+        # the exact fp32 vector-ALU path
+        self.fuse_block1 = self.dtype == VM_BF16 and self.blocks[0][2] in (2, 4)
 
         # ---- flat parameter store, Keras trainable_weights order -------------------------------------
         spec: List[Tuple[str, Tuple[int, ...]]] = []
@@ -212,7 +215,11 @@ class HipEncoderEngine:
         for i, (k, c, pool) in enumerate(self.blocks):
             L = ls[i]
             b = {}
-            b["z"] = torch.empty(n_windows, L, c, dtype=tdt, device=dev)
+            fused = (i == 0 and self.fuse_block1)
+            if fused:
+                b["e"] = torch.empty(n_windows, ls[1], c, dtype=tdt, device=dev)  # pooled extreme of relu(conv)
+            else:
+                b["z"] = torch.empty(n_windows, L, c, dtype=tdt, device=dev)
             b["act"] = torch.zeros(n_windows, ls[i + 1] + 2, c, dtype=tdt, device=dev)  # halo rows stay zero
             rows = self.lib.query("vm_conv1_stat_rows" if i == 0 else "vm_conv_stat_rows", L)
             b["stat_rows"] = rows
@@ -222,7 +229,8 @@ class HipEncoderEngine:
                 b["ssum"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
                 b["ssq"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
                 b["dp"] = torch.empty(n_windows, ls[i + 1], c, dtype=tdt, device=dev)
-                b["du"] = torch.zeros(n_windows, L + 2, c, dtype=tdt, device=dev)
+                if not fused:
+                    b["du"] = torch.zeros(n_windows, L + 2, c, dtype=tdt, device=dev)
                 for nm in ("pa", "pb", "pdu"):
                     b[nm] = torch.empty(n_windows * prow, c, dtype=f32, device=dev)
             pl[i] = b
@@ -237,7 +245,9 @@ class HipEncoderEngine:
             for i in range(1, self.nb):
                 ws = max(ws, self.lib.query("vm_conv_wgrad_workspace_bytes", n_windows, ls[i], self.blocks[i - 1][1],
                                             self.blocks[i][1]))
-            ws = max(ws, n_windows * 32 * self.blocks[0][1] * 4)
+            ws = max(ws, self.lib.query("vm_conv1_wgrad_workspace_bytes", n_windows, self.blocks[0][1]))
+            if self.fuse_block1:
+                ws = max(ws, self.lib.query("vm_conv1_fused_bwd_workspace_bytes", n_windows, l0, self.blocks[0][1]))
             pl["wgrad_ws"] = torch.empty(ws // 4 + 16, dtype=f32, device=dev)
         pl["pred"] = torch.empty(max(n_windows // 2, 1), dtype=f32, device=dev)
         pl["loss_acc"] = torch.zeros(2, dtype=f32, device=dev)
@@ -284,6 +294,24 @@ class HipEncoderEngine:
             ssum = _p(b["ssum"]) if training else None
             ssq = _p(b["ssq"]) if training else None
             bias = _p(self.view(f"conv{i+1}.bias"))
+            gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
+            mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
+            if i == 0 and self.fuse_block1:
+                w1 = _p(self.view("conv1.kernel"))
+                if training:
+                    self._call("vm_conv1_fused_fwd", _p(pl["x0"]), w1, bias, gam, None, n, L, c, pool, 0, _p(b["e"]), ssum, ssq,
+                               st)
+                    self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
+                               self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
+                               _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), st)
+                    dm = drop_masks[i] if drop_masks is not None else None
+                    self._call("vm_bn_drop_pool_fwd", _p(b["e"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt,
+                               pl["L"][1], c, 1, dt, _p(b["act"]), st)
+                else:
+                    self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
+                    self._call("vm_conv1_fused_fwd", _p(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), n, L, c, pool, 1,
+                               _p(b["act"]), None, None, st)
+                continue
             if i == 0:
                 self._call("vm_conv1_fwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), bias, n, L, c, dt, _p(b["z"]), ssum,
                          ssq, st)
@@ -291,8 +319,6 @@ class HipEncoderEngine:
                 cin = self.blocks[i - 1][1]
                 self._call("vm_conv_fwd", _p(pl[i - 1]["act"]), _p(self.wf[i]), bias, n, L, cin, c, dt, _p(b["z"]), ssum, ssq,
                          st)
-            gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
-            mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
             if training:
                 self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
                          self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
@@ -322,6 +348,16 @@ class HipEncoderEngine:
             k, c, pool = self.blocks[i]
             b, L = pl[i], pl["L"][i]
             dm = _p(drop[i]) if drop is not None and drop[i] is not None else None
+            if i == 0 and self.fuse_block1:
+                Lq = pl["L"][1]
+                self._call("vm_bn_pool_bwd_reduce", _p(b["e"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
+                           _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, _p(b["pa"]), _p(b["pb"]), st)
+                self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                           _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
+                self._call("vm_conv1_fused_bwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
+                           _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
+                           c, pool, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
+                continue
             common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
             self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
