@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--loss", default="contrastive")
     ap.add_argument("--dominant", default="vm_conv_wgrad", help="entry point timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
     ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
     a = ap.parse_args()
 
@@ -66,6 +67,8 @@ def main():
     F, E = 128, 64
     blocks = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
     eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
+    if a.gemm_kb:
+        eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
     parallel.attach(eng, n_gpus)
     parallel.broadcast_state(eng)
 
@@ -143,7 +146,7 @@ def main():
            "roofline": roof}
 
     if a.breakdown and rank == 0:
-        names = ["vm_decimate_whiten", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd",
+        names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
                  "vm_bn_pool_bwd_reduce", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply", "vm_colsum", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]

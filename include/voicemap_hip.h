@@ -42,6 +42,8 @@ int vm_abi_version(void);
 int vm_check_device(void);
 
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
+/* tuning hook for A/B measurements, not part of the drop-in surface: ("gemm_kb", 64 | 128) = bytes of K per GEMM slice. */
+int vm_set_tuning(const char* key, int value);
 
 /* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------
  * raw: (n_windows, raw_len) fp32 (or int16 if raw_is_i16, scaled by 1/32768).  Takes every

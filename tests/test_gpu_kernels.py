@@ -46,9 +46,17 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
+@pytest.fixture
+def gemm_kb(request):
+    L().call("vm_set_tuning", b"gemm_kb", request.param)
+    yield request.param
+    L().call("vm_set_tuning", b"gemm_kb", 128)
+
+
+@pytest.mark.parametrize("gemm_kb", [128, 64], indirect=True)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8)])
-def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
+def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kb):
     vm, tdt = DTYPES[dt]
     r = rng(2)
     x = quant(r.normal(0, 1.0, (n, l, cin)), dt)

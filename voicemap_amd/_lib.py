@@ -31,6 +31,7 @@ SIGNATURES = {
     "vm_abi_version": (I, []),
     "vm_check_device": (I, []),
     "vm_fill_zero": (I, [P, L, P]),
+    "vm_set_tuning": (I, [c_char_p, I]),
     "vm_decimate_whiten_workspace_bytes": (L, [L]),
     "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
     "vm_conv1_stat_rows": (L, [L]),

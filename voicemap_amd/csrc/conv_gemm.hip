@@ -7,22 +7,34 @@
 //   wgrad   : dW[kk][co]    =       sum_(n,t) A[(n,t)][kk] * dU[(n,t+1)][co]          TN GEMM, K = positions
 // One compute core serves all three and both storage types: v_mfma_f32_32x32x16_bf16 (8 bf16 per lane) or
 // v_mfma_f32_32x32x2_f32 (exact fp32, 1 float per lane).  Workgroup = 4 waves (2x2), 128x128 output tile,
-// 64-byte K slices staged through LDS (80-byte row pitch: conflict-free ds_read_b128 fragment reads),
-// global->register prefetch of slice k+1 overlapped with the MFMAs of slice k, two LDS buffers, one barrier
-// per slice.  Tiles never straddle windows (grid = window x t-tile x n-tile), so the halo is never crossed
-// and every row of a tile belongs to one BatchNorm tower.
+// KB-byte K slices (KB = 128: 64 bf16 / 32 fp32) staged through LDS with a (KB+16)-byte row pitch (conflict-free
+// ds_read_b128 fragment reads), global->register prefetch of slice k+1 overlapped with the MFMAs of slice k, two
+// LDS buffers, one barrier per slice.  The MFMAs are issued with the operands swapped (D = B.A^T) so that a lane's
+// four consecutive accumulator registers are four consecutive *output columns*: the epilogue moves the tile through
+// LDS with 16-byte writes and leaves the workgroup as whole 16-byte, fully coalesced row segments (and the wgrad
+// slab as 16-byte fp32 stores) instead of 2-byte column-strided stores.
+// Tiles never straddle windows (grid = window x t-tile x n-tile), so the halo is never crossed and every row of a
+// tile belongs to one BatchNorm tower.
+#include <string.h>
+
 #include "common.hpp"
 
 namespace vm {
 
 constexpr int BM = 128, BN = 128;
-constexpr int KBYTES = 64;    // bytes of K per slice and row
-constexpr int PITCH = 80;     // LDS row pitch in bytes
-constexpr int TILE_BYTES = BM * PITCH;
+
+template <int KB>
+struct Geo {
+    static constexpr int PITCH = KB + 16;          // LDS row pitch in bytes
+    static constexpr int TILE = BM * PITCH;        // one operand tile
+    static constexpr int CH = KB / 16;             // 16-byte chunks per row
+    static constexpr int NCHUNK = BM * CH / 256;   // chunks per thread per operand
+};
+constexpr int OUT_PITCH = BN * 4 + 16;  // fp32 epilogue tile row pitch (bytes)
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16> {
-    static constexpr int KSTEPS = 2;  // 2 x (32x32x16) per 32-element slice
+    static constexpr int KSTEP_BYTES = 32;  // one 32x32x16: 16 bf16 of K
     using Frag = bf16x8;
     __device__ static inline Frag load(const char* row_ptr, int s, int kh) {
         return *reinterpret_cast<const Frag*>(row_ptr + (s * 2 + kh) * 16);
@@ -32,7 +44,7 @@ template <> struct Mfma<bf16> {
     }
 };
 template <> struct Mfma<float> {
-    static constexpr int KSTEPS = 8;  // 8 x (32x32x2) per 16-element slice
+    static constexpr int KSTEP_BYTES = 8;  // one 32x32x2: 2 floats of K
     using Frag = float;
     __device__ static inline Frag load(const char* row_ptr, int s, int kh) {
         return *reinterpret_cast<const float*>(row_ptr + (s * 2 + kh) * 4);
@@ -42,31 +54,54 @@ template <> struct Mfma<float> {
     }
 };
 
-// One 64-byte K slice: every wave multiplies its 64x64 sub-tile.  lds_a / lds_b: [128][PITCH] bytes.
-template <typename T>
+// One KB-byte K slice: every wave multiplies its 64 (m) x 64 (n) sub-tile.  lds_a / lds_b: [128][PITCH] bytes.
+// acc[im][in] = B_in . A_im^T, i.e. register r of lane l holds  m = 32*im + (l&31),  n = 32*in + (r&3) + 8*(r>>2) + 4*(l>>5).
+template <typename T, int KB>
 __device__ inline void mma_slice(const char* lds_a, const char* lds_b, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+    constexpr int PITCH = Geo<KB>::PITCH;
+    constexpr int KSTEPS = KB / Mfma<T>::KSTEP_BYTES;
     const int r = lane & 31, kh = lane >> 5;
     const char* pa0 = lds_a + (wm * 64 + r) * PITCH;
     const char* pa1 = pa0 + 32 * PITCH;
     const char* pb0 = lds_b + (wn * 64 + r) * PITCH;
     const char* pb1 = pb0 + 32 * PITCH;
 #pragma unroll
-    for (int s = 0; s < Mfma<T>::KSTEPS; ++s) {
+    for (int s = 0; s < KSTEPS; ++s) {
         typename Mfma<T>::Frag a0 = Mfma<T>::load(pa0, s, kh), a1 = Mfma<T>::load(pa1, s, kh);
         typename Mfma<T>::Frag b0 = Mfma<T>::load(pb0, s, kh), b1 = Mfma<T>::load(pb1, s, kh);
-        acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
-        acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
-        acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
-        acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+        acc[0][0] = Mfma<T>::run(b0, a0, acc[0][0]);
+        acc[0][1] = Mfma<T>::run(b1, a0, acc[0][1]);
+        acc[1][0] = Mfma<T>::run(b0, a1, acc[1][0]);
+        acc[1][1] = Mfma<T>::run(b1, a1, acc[1][1]);
     }
 }
 
-// Accumulator element -> tile coordinates (MFMA 32x32 C/D layout: col = lane&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
-__device__ inline int acc_row(int wm, int im, int reg, int lane) {
-    return wm * 64 + im * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+__device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
-__device__ inline int acc_col(int wn, int in, int lane) { return wn * 64 + in * 32 + (lane & 31); }
+
+// accumulators -> fp32 tile in LDS, out_tile[m][n] with OUT_PITCH-byte rows (16-byte writes, conflict-free)
+__device__ inline void acc_to_lds(char* out_tile, int wm, int wn, int lane, const f32x16 (&acc)[2][2]) {
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        const int m = wm * 64 + im * 32 + (lane & 31);
+#pragma unroll
+        for (int in = 0; in < 2; ++in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = wn * 64 + in * 32 + 8 * g + 4 * hi;
+                f32x4 v = {acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(out_tile + m * OUT_PITCH + n * 4) = v;
+            }
+        }
+    }
+}
 
 enum { EPI_FWD = 0, EPI_DGRAD = 1 };
 
@@ -84,11 +119,17 @@ struct NtArgs {
     int tilesL, tilesN;
 };
 
-template <typename T, int EPI>
+template <int KB>
+constexpr int nt_lds_bytes() {
+    return (2 * 2 * Geo<KB>::TILE > BM * OUT_PITCH + 4096) ? 2 * 2 * Geo<KB>::TILE : BM * OUT_PITCH + 4096;
+}
+
+template <typename T, int EPI, int KB>
 __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p) {
+    using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
-    constexpr int BK = KBYTES / (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][A|B]
+    constexpr int BK = KB / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<KB>()];  // [buf][A|B] in the K loop, then the fp32 tile
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     int64_t b = blockIdx.x;
@@ -98,40 +139,33 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p) {
     const int64_t n = b / p.tilesL;
     const int t0 = tl * BM, n0 = tn * BN;
 
-    // staging assignment: 2 x 16-byte chunks of A and of B per thread
-    const T* a_ptr[2];
-    const T* b_ptr[2];
-    int lds_off[2], kch[2];
+    const T* a_base = p.a + n * p.a_win_stride;
+    int a_off[G::NCHUNK], b_off[G::NCHUNK], lds_off[G::NCHUNK], kch[G::NCHUNK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + i * 256, row = id >> 2, ch = id & 3;
+    for (int i = 0; i < G::NCHUNK; ++i) {
+        const int id = tid + i * 256, row = id / G::CH, ch = id % G::CH;
         int t = t0 + row;
         t = t < p.L ? t : p.L - 1;
         int nn = n0 + row;
         nn = nn < p.N ? nn : p.N - 1;
-        a_ptr[i] = p.a + n * p.a_win_stride + (int64_t)t * p.a_c + ch * VEC;
-        b_ptr[i] = p.bt + (int64_t)nn * p.Ktot + ch * VEC;
-        lds_off[i] = row * PITCH + ch * 16;
+        a_off[i] = t * p.a_c + ch * VEC;
+        b_off[i] = nn * p.Ktot + ch * VEC;
+        lds_off[i] = row * G::PITCH + ch * 16;
         kch[i] = ch * VEC;
     }
     const int nk = (p.Ktot + BK - 1) / BK;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc(acc);
 
-    u32x4 ra[2], rb[2];
+    u32x4 ra[G::NCHUNK], rb[G::NCHUNK];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < G::NCHUNK; ++i) {
             const int kk = kt * BK + kch[i];
             if (kk < p.Ktot) {
-                ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (int64_t)kt * BK);
-                rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (int64_t)kt * BK);
+                ra[i] = *reinterpret_cast<const u32x4*>(a_base + a_off[i] + kt * BK);
+                rb[i] = *reinterpret_cast<const u32x4*>(p.bt + b_off[i] + kt * BK);
             } else {
                 ra[i] = u32x4{0, 0, 0, 0};
                 rb[i] = u32x4{0, 0, 0, 0};
@@ -140,84 +174,95 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p) {
     };
     gload(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        char* ta = lds + ((kt & 1) * 2 + 0) * G::TILE;
+        char* tb = lds + ((kt & 1) * 2 + 1) * G::TILE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(&lds[buf][0][lds_off[i]]) = ra[i];
-            *reinterpret_cast<u32x4*>(&lds[buf][1][lds_off[i]]) = rb[i];
+        for (int i = 0; i < G::NCHUNK; ++i) {
+            *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
+            *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
         }
         __syncthreads();
         if (kt + 1 < nk) gload(kt + 1);
-        mma_slice<T>(lds[buf][0], lds[buf][1], wm, wn, lane, acc);
+        mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
     }
 
-    // ---- epilogue ----
-    if (EPI == EPI_FWD) {
-        float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    // ---- epilogue: accumulators -> fp32 LDS tile -> (bias, ReLU, convert) -> 16-byte coalesced row segments ----
+    __syncthreads();
+    acc_to_lds(lds, wm, wn, lane, acc);
+    __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;  // 8-column chunk, row group
+    const int ncol = n0 + c8 * 8;
+    const bool cok = ncol < p.N;  // N is a multiple of 8: a chunk is entirely in or out
+    float bias8[8], s8[8], q8[8];
 #pragma unroll
-        for (int in = 0; in < 2; ++in) {
-            const int col = n0 + acc_col(wn, in, lane);
-            const bool cok = col < p.N;
-            const float bias = cok ? p.bias[col] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+        bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
+        s8[i] = 0.f;
+        q8[i] = 0.f;
+    }
 #pragma unroll
-            for (int im = 0; im < 2; ++im) {
+    for (int j = 0; j < 8; ++j) {
+        const int row = rg + 16 * j;
+        const int t = t0 + row;
+        if (cok && t < p.L) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            Vec16<T> o0, o1;  // 8 outputs: one 16-byte vector for bf16, two for fp32
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = t0 + acc_row(wm, im, r, lane);
-                    if (cok && t < p.L) {
-                        float v = acc[im][in][r] + bias;
-                        v = v > 0.f ? v : 0.f;
-                        const T tv = Elem<T>::from_f(v);
-                        p.out[(n * p.L + t) * (int64_t)p.N + col] = tv;
-                        const float vr = Elem<T>::to_f(tv);
-                        csum[in] += vr;
-                        csq[in] += vr * vr;
-                    }
+            for (int i = 0; i < 8; ++i) {
+                float x = v[i] + bias8[i];
+                if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                const T tx = Elem<T>::from_f(x);
+                if (EPI == EPI_FWD) {
+                    const float xr = Elem<T>::to_f(tx);
+                    s8[i] += xr;
+                    q8[i] += xr * xr;
                 }
+                if (sizeof(T) == 2) {
+                    o0.set(i, x);
+                } else if (i < 4) {
+                    o0.set(i, x);
+                } else {
+                    o1.set(i - 4, x);
+                }
+            }
+            T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+            store16<T>(dst, o0);
+            if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+        }
+    }
+    if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+        // the 4 row groups of a wave (lanes 0-15, 16-31, 32-47, 48-63) hold the same column chunk
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s8[i] += __shfl_xor(s8[i], 16, 64);
+            s8[i] += __shfl_xor(s8[i], 32, 64);
+            q8[i] += __shfl_xor(q8[i], 16, 64);
+            q8[i] += __shfl_xor(q8[i], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);  // [4 waves][2][128]
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
+                red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
             }
         }
-        if (p.stat_sum != nullptr) {
-            __syncthreads();  // all waves done with the K-loop LDS
-            float* red = reinterpret_cast<float*>(&lds[0][0][0]);  // [2 (sum|sq)][2 (wm)][128]
-#pragma unroll
-            for (int in = 0; in < 2; ++in) {
-                float s = csum[in] + __shfl_xor(csum[in], 32, 64);
-                float q = csq[in] + __shfl_xor(csq[in], 32, 64);
-                if (lane < 32) {
-                    const int c = wn * 64 + in * 32 + lane;
-                    red[(0 * 2 + wm) * 128 + c] = s;
-                    red[(1 * 2 + wm) * 128 + c] = q;
-                }
-            }
-            __syncthreads();
-            if (tid < 128 && n0 + tid < p.N) {
-                const int64_t row = n * p.tilesL + tl;
-                p.stat_sum[row * p.N + n0 + tid] = red[0 * 128 + tid] + red[1 * 128 + tid];
-                p.stat_sq[row * p.N + n0 + tid] = red[2 * 128 + tid] + red[3 * 128 + tid];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int in = 0; in < 2; ++in) {
-            const int col = n0 + acc_col(wn, in, lane);
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int im = 0; im < 2; ++im) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = t0 + acc_row(wm, im, r, lane);
-                    if (t < p.L) p.out[(n * p.L + t) * (int64_t)p.N + col] = Elem<T>::from_f(acc[im][in][r]);
-                }
-            }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const int64_t row = n * p.tilesL + tl;
+            p.stat_sum[row * p.N + n0 + tid] = (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
+            p.stat_sq[row * p.N + n0 + tid] = (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
-// of windows [w_begin, w_end).  Each stage brings BK positions x 128 columns of both operands; a thread loads
-// 4 consecutive positions x 16 bytes and writes them position-contiguous so the fragment reads are the same
-// 16-byte K-contiguous reads as in the NT kernel.
+// of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
+// 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
+// same 16-byte K-contiguous reads as in the NT kernel.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct TnArgs {
@@ -231,8 +276,8 @@ struct TnArgs {
     int64_t n_windows, win_per_split;
 };
 
-template <typename T> struct Transpose4;
-template <> struct Transpose4<bf16> {
+template <typename T, int PITCH> struct Transpose4;
+template <int PITCH> struct Transpose4<bf16, PITCH> {
     // 4 position rows of 8 bf16 -> 8 columns of 4 bf16 (8 bytes each)
     __device__ static inline uint32_t half(const u32x4& v, int j) { return (v[j >> 1] >> ((j & 1) * 16)) & 0xffffu; }
     __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
@@ -245,7 +290,7 @@ template <> struct Transpose4<bf16> {
         }
     }
 };
-template <> struct Transpose4<float> {
+template <int PITCH> struct Transpose4<float, PITCH> {
     __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -255,12 +300,15 @@ template <> struct Transpose4<float> {
     }
 };
 
-template <typename T>
+template <typename T, int KB>
 __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
+    using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
-    constexpr int BKP = KBYTES / (int)sizeof(T);  // positions per stage
-    constexpr int PG = BKP / 4;                   // groups of 4 positions
-    __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
+    constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
+    constexpr int PG = BKP / 4;               // groups of 4 positions
+    constexpr int ITEMS = (128 / VEC) * PG;   // (column group, position group) items per operand
+    constexpr int NIT = ITEMS / 128;          // items per thread (threads 0..127 stage X, 128..255 stage dU)
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * G::TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     int64_t b = blockIdx.x;
@@ -270,30 +318,22 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     const int split = (int)(b / p.tilesI);
     const int i0 = ti * BM, j0 = tj * BN;
 
-    // staging role: threads 0..127 stage X (rows of the output tile), 128..255 stage dU (columns)
     const bool is_x = tid < 128;
-    const int item = tid & 127;
-    const int pg = item % PG, cg = item / PG;
-    const int col0 = cg * VEC;  // first of VEC tile columns handled by this thread
-    const T* base;
-    int64_t win_stride;
-    int row_c;
-    bool col_ok;
-    if (is_x) {
-        const int kk = i0 + col0;
-        col_ok = kk < p.Kk;
-        base = p.x + (col_ok ? kk : 0);
-        win_stride = p.x_win_stride;
-        row_c = p.c_in;
-    } else {
-        const int co = j0 + col0;
-        col_ok = co < p.c_out;
-        base = p.du + p.c_out + (col_ok ? co : 0);  // +1 halo row: dU row t lives at padded row t+1
-        win_stride = p.du_win_stride;
-        row_c = p.c_out;
+    const T* base0 = is_x ? p.x : p.du + p.c_out;  // +1 halo row: dU row t lives at padded row t+1
+    const int64_t win_stride = is_x ? p.x_win_stride : p.du_win_stride;
+    const int row_c = is_x ? p.c_in : p.c_out;
+    const int which = is_x ? 0 : 1;
+    int pg[NIT], col0[NIT], goff[NIT];
+    bool col_ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = (tid & 127) + it * 128;
+        pg[it] = item % PG;
+        col0[it] = (item / PG) * VEC;
+        const int gcol = (is_x ? i0 : j0) + col0[it];
+        col_ok[it] = gcol < (is_x ? p.Kk : p.c_out);
+        goff[it] = col_ok[it] ? gcol : 0;
     }
-    char* my_tile0 = &lds[0][is_x ? 0 : 1][0];
-    char* my_tile1 = &lds[1][is_x ? 0 : 1][0];
 
     const int64_t w_begin = (int64_t)split * p.win_per_split;
     int64_t w_end = w_begin + p.win_per_split;
@@ -302,47 +342,53 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     const int64_t n_stages = (w_end - w_begin) * stages_per_win;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc(acc);
 
-    u32x4 rv[4];
+    u32x4 rv[NIT][4];
     auto gload = [&](int64_t st) {
         const int64_t n = w_begin + st / stages_per_win;
-        const int t0 = (int)(st % stages_per_win) * BKP + pg * 4;
+        const int tb = (int)(st % stages_per_win) * BKP;
+        const T* wbase = base0 + n * win_stride;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = t0 + r;
-            if (col_ok && t < p.L) {
-                rv[r] = *reinterpret_cast<const u32x4*>(base + n * win_stride + (int64_t)t * row_c);
-            } else {
-                rv[r] = u32x4{0, 0, 0, 0};
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = tb + pg[it] * 4 + r;
+                if (col_ok[it] && t < p.L) {
+                    rv[it][r] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)t * row_c + goff[it]);
+                } else {
+                    rv[it][r] = u32x4{0, 0, 0, 0};
+                }
             }
         }
     };
     if (n_stages > 0) gload(0);
     for (int64_t st = 0; st < n_stages; ++st) {
-        char* tile = (st & 1) ? my_tile1 : my_tile0;
-        Transpose4<T>::store(tile, col0, pg, rv);
+        const int buf = (int)(st & 1);
+        char* mine = lds + (buf * 2 + which) * G::TILE;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) Transpose4<T, G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
         __syncthreads();
         if (st + 1 < n_stages) gload(st + 1);
-        mma_slice<T>(lds[st & 1][0], lds[st & 1][1], wm, wn, lane, acc);
+        mma_slice<T, KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
     }
 
+    // slab tile: row = kk (m side), 4 consecutive co per register group -> 16-byte fp32 stores
     float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
 #pragma unroll
-    for (int in = 0; in < 2; ++in) {
-        const int col = j0 + acc_col(wn, in, lane);
-        if (col >= p.c_out) continue;
+    for (int im = 0; im < 2; ++im) {
+        const int row = i0 + wm * 64 + im * 32 + (lane & 31);
+        if (row >= p.Kk) continue;
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int in = 0; in < 2; ++in) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + acc_row(wm, im, r, lane);
-                if (row < p.Kk) out[(int64_t)row * p.c_out + col] = acc[im][in][r];
+            for (int g = 0; g < 4; ++g) {
+                const int col = j0 + wn * 64 + in * 32 + 8 * g + 4 * hi;
+                if (col < p.c_out) {  // c_out is a multiple of 8 -> the 4 columns are all valid
+                    f32x4 v = {acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
             }
         }
     }
@@ -364,6 +410,8 @@ __global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, 
     wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
 }
 
+int g_gemm_kb = 128;  // K-slice bytes (tuning knob, vm_set_tuning("gemm_kb", 64 | 128))
+
 }  // namespace vm
 
 using namespace vm;
@@ -372,12 +420,22 @@ static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 
+template <typename T, int EPI>
+static void launch_nt(const NtArgs<T>& a, int64_t grid, hipStream_t stream) {
+    if (g_gemm_kb == 64) {
+        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 64>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 128>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    }
+}
+
 extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in,
                            int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* stream) {
     VM_REQUIRE(in && wf && bias && z, "vm_conv_fwd: null pointer");
     VM_REQUIRE(n_windows > 0 && L > 0 && c_in > 0 && c_out > 0, "vm_conv_fwd: bad sizes");
     VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_fwd: channels must be multiples of 8 (got %d, %d)", c_in, c_out);
     VM_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "vm_conv_fwd: stat_sum/stat_sq must both be set or NULL");
+    VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd: window too large");
     VM_DISPATCH_DTYPE(dtype, {
         NtArgs<T> a;
         a.a = (const T*)in;
@@ -395,7 +453,7 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.tilesN = tiles(c_out, BN);
         const int64_t grid = n_windows * a.tilesL * a.tilesN;
         VM_REQUIRE(grid < (1LL << 31), "vm_conv_fwd: grid too large");
-        hipLaunchKernelGGL((conv_nt_kernel<T, EPI_FWD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        launch_nt<T, EPI_FWD>(a, grid, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
 }
@@ -405,6 +463,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
     VM_REQUIRE(du && wd && dx, "vm_conv_dgrad: null pointer");
     VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_dgrad: bad sizes");
     VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_dgrad: channels must be multiples of 8");
+    VM_REQUIRE((L + 2) * (int64_t)c_out < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_dgrad: window too large");
     VM_DISPATCH_DTYPE(dtype, {
         NtArgs<T> a;
         a.a = (const T*)du;
@@ -422,7 +481,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.tilesN = tiles(c_in, BN);
         const int64_t grid = n_windows * a.tilesL * a.tilesN;
         VM_REQUIRE(grid < (1LL << 31), "vm_conv_dgrad: grid too large");
-        hipLaunchKernelGGL((conv_nt_kernel<T, EPI_DGRAD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        launch_nt<T, EPI_DGRAD>(a, grid, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
 }
@@ -464,7 +523,11 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
-        hipLaunchKernelGGL((conv_tn_kernel<T>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        if (g_gemm_kb == 64) {
+            hipLaunchKernelGGL((conv_tn_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        } else {
+            hipLaunchKernelGGL((conv_tn_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        }
     });
     int rc = check_launch("vm_conv_wgrad");
     if (rc) return rc;
@@ -480,4 +543,14 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
                            c_in, c_out, (T*)wf, (T*)wd);
     });
     return check_launch("vm_prep_conv_weights");
+}
+
+// Tuning hook for A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
+extern "C" int vm_set_tuning(const char* key, int value) {
+    if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
+        g_gemm_kb = value;
+        return VM_OK;
+    }
+    vm::set_error("vm_set_tuning: unknown key/value");
+    return VM_ERR_ARG;
 }
