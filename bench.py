@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--dominant", default="vm_conv_wgrad", help="entry point timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
+    ap.add_argument("--nt-blocks", type=int, default=0, help="tuning: persistent grid of the NT conv GEMMs, 0 = library default")
     ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
     a = ap.parse_args()
 
@@ -69,6 +70,8 @@ def main():
     eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
     if a.gemm_kb:
         eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
+    if a.nt_blocks:
+        eng.lib.call("vm_set_tuning", b"nt_blocks", a.nt_blocks)
     parallel.attach(eng, n_gpus)
     parallel.broadcast_state(eng)
 

@@ -125,40 +125,46 @@ constexpr int nt_lds_bytes() {
 }
 
 template <typename T, int EPI, int KB>
-__global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p) {
+__global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_groups) {
     using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BK = KB / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<KB>()];  // [buf][A|B] in the K loop, then the fp32 tile
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    int64_t b = blockIdx.x;
-    const int tn = (int)(b % p.tilesN);
-    b /= p.tilesN;
-    const int tl = (int)(b % p.tilesL);
-    const int64_t n = b / p.tilesL;
-    const int t0 = tl * BM, n0 = tn * BN;
-
-    const T* a_base = p.a + n * p.a_win_stride;
-    int a_off[G::NCHUNK], b_off[G::NCHUNK], lds_off[G::NCHUNK], kch[G::NCHUNK];
-#pragma unroll
-    for (int i = 0; i < G::NCHUNK; ++i) {
-        const int id = tid + i * 256, row = id / G::CH, ch = id % G::CH;
-        int t = t0 + row;
-        t = t < p.L ? t : p.L - 1;
-        int nn = n0 + row;
-        nn = nn < p.N ? nn : p.N - 1;
-        a_off[i] = t * p.a_c + ch * VEC;
-        b_off[i] = nn * p.Ktot + ch * VEC;
-        lds_off[i] = row * G::PITCH + ch * 16;
-        kch[i] = ch * VEC;
-    }
     const int nk = (p.Ktot + BK - 1) / BK;
 
-    f32x16 acc[2][2];
-    zero_acc(acc);
+    // staging geometry that does not depend on the tile
+    int lds_off[G::NCHUNK], kch[G::NCHUNK], srow[G::NCHUNK];
+#pragma unroll
+    for (int i = 0; i < G::NCHUNK; ++i) {
+        const int id = tid + i * 256;
+        srow[i] = id / G::CH;
+        const int ch = id % G::CH;
+        lds_off[i] = srow[i] * G::PITCH + ch * 16;
+        kch[i] = ch * VEC;
+    }
 
+    // A workgroup walks (window, t-tile) groups and, inside a group, all n-tiles: the A tile is re-read from this
+    // CU's caches.  The first K slice of the NEXT tile is requested before the epilogue of the current one, so its
+    // HBM latency hides behind the LDS round trip and the stores.
+    const T* a_base = nullptr;
+    int a_off[G::NCHUNK], b_off[G::NCHUNK];
     u32x4 ra[G::NCHUNK], rb[G::NCHUNK];
+    auto setup = [&](int64_t group, int tn) {
+        const int tl = (int)(group % p.tilesL);
+        const int64_t n = group / p.tilesL;
+        a_base = p.a + n * p.a_win_stride;
+#pragma unroll
+        for (int i = 0; i < G::NCHUNK; ++i) {
+            int t = tl * BM + srow[i];
+            t = t < p.L ? t : p.L - 1;
+            int nn = tn * BN + srow[i];
+            nn = nn < p.N ? nn : p.N - 1;
+            a_off[i] = t * p.a_c + kch[i];
+            b_off[i] = nn * p.Ktot + kch[i];
+        }
+    };
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < G::NCHUNK; ++i) {
@@ -172,89 +178,115 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p) {
             }
         }
     };
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        char* ta = lds + ((kt & 1) * 2 + 0) * G::TILE;
-        char* tb = lds + ((kt & 1) * 2 + 1) * G::TILE;
-#pragma unroll
-        for (int i = 0; i < G::NCHUNK; ++i) {
-            *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
-            *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);
-        mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
-    }
 
-    // ---- epilogue: accumulators -> fp32 LDS tile -> (bias, ReLU, convert) -> 16-byte coalesced row segments ----
-    __syncthreads();
-    acc_to_lds(lds, wm, wn, lane, acc);
-    __syncthreads();
-    const int c8 = tid & 15, rg = tid >> 4;  // 8-column chunk, row group
-    const int ncol = n0 + c8 * 8;
-    const bool cok = ncol < p.N;  // N is a multiple of 8: a chunk is entirely in or out
-    float bias8[8], s8[8], q8[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
-        s8[i] = 0.f;
-        q8[i] = 0.f;
+    int64_t group = blockIdx.x;
+    int tn = 0;
+    if (group < n_groups) {
+        setup(group, tn);
+        gload(0);
     }
+    while (group < n_groups) {
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        for (int kt = 0; kt < nk; ++kt) {
+            char* ta = lds + ((kt & 1) * 2 + 0) * G::TILE;
+            char* tb = lds + ((kt & 1) * 2 + 1) * G::TILE;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = rg + 16 * j;
-        const int t = t0 + row;
-        if (cok && t < p.L) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
-            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            Vec16<T> o0, o1;  // 8 outputs: one 16-byte vector for bf16, two for fp32
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float x = v[i] + bias8[i];
-                if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
-                const T tx = Elem<T>::from_f(x);
-                if (EPI == EPI_FWD) {
-                    const float xr = Elem<T>::to_f(tx);
-                    s8[i] += xr;
-                    q8[i] += xr * xr;
-                }
-                if (sizeof(T) == 2) {
-                    o0.set(i, x);
-                } else if (i < 4) {
-                    o0.set(i, x);
-                } else {
-                    o1.set(i - 4, x);
-                }
+            for (int i = 0; i < G::NCHUNK; ++i) {
+                *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
+                *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
             }
-            T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
-            store16<T>(dst, o0);
-            if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+            __syncthreads();
+            if (kt + 1 < nk) gload(kt + 1);
+            mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
         }
-    }
-    if (EPI == EPI_FWD && p.stat_sum != nullptr) {
-        // the 4 row groups of a wave (lanes 0-15, 16-31, 32-47, 48-63) hold the same column chunk
+        // coordinates of the finished tile
+        const int tl = (int)(group % p.tilesL);
+        const int64_t n = group / p.tilesL;
+        const int t0 = tl * BM, n0 = tn * BN;
+        // advance and prefetch
+        if (++tn == p.tilesN) {
+            tn = 0;
+            group += gridDim.x;
+        }
+        if (group < n_groups) {
+            setup(group, tn);
+            gload(0);
+        }
+
+        // ---- epilogue: accumulators -> fp32 LDS tile -> (bias, ReLU, convert) -> 16-byte coalesced row segments ----
+        __syncthreads();
+        acc_to_lds(lds, wm, wn, lane, acc);
+        __syncthreads();
+        const int c8 = tid & 15, rg = tid >> 4;  // 8-column chunk, row group
+        const int ncol = n0 + c8 * 8;
+        const bool cok = ncol < p.N;  // N is a multiple of 8: a chunk is entirely in or out
+        float bias8[8], s8[8], q8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s8[i] += __shfl_xor(s8[i], 16, 64);
-            s8[i] += __shfl_xor(s8[i], 32, 64);
-            q8[i] += __shfl_xor(q8[i], 16, 64);
-            q8[i] += __shfl_xor(q8[i], 32, 64);
+            bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
+            s8[i] = 0.f;
+            q8[i] = 0.f;
         }
-        float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);  // [4 waves][2][128]
-        if (lane < 16) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
-                red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
+        for (int j = 0; j < 8; ++j) {
+            const int row = rg + 16 * j;
+            const int t = t0 + row;
+            if (cok && t < p.L) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                Vec16<T> o0, o1;  // 8 outputs: one 16-byte vector for bf16, two for fp32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float x = v[i] + bias8[i];
+                    if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                    const T tx = Elem<T>::from_f(x);
+                    if (EPI == EPI_FWD) {
+                        const float xr = Elem<T>::to_f(tx);
+                        s8[i] += xr;
+                        q8[i] += xr * xr;
+                    }
+                    if (sizeof(T) == 2) {
+                        o0.set(i, x);
+                    } else if (i < 4) {
+                        o0.set(i, x);
+                    } else {
+                        o1.set(i - 4, x);
+                    }
+                }
+                T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+                store16<T>(dst, o0);
+                if (sizeof(T) == 4) store16<T>(dst + 4, o1);
             }
         }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
-            const int64_t row = n * p.tilesL + tl;
-            p.stat_sum[row * p.N + n0 + tid] = (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
-            p.stat_sq[row * p.N + n0 + tid] = (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
+        if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+            // the 4 row groups of a wave (lanes 0-15, 16-31, 32-47, 48-63) hold the same column chunk
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s8[i] += __shfl_xor(s8[i], 16, 64);
+                s8[i] += __shfl_xor(s8[i], 32, 64);
+                q8[i] += __shfl_xor(q8[i], 16, 64);
+                q8[i] += __shfl_xor(q8[i], 32, 64);
+            }
+            float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);  // [4 waves][2][128]
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
+                    red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
+                }
+            }
+            __syncthreads();
+            if (tid < 128 && n0 + tid < p.N) {
+                const int64_t row = n * p.tilesL + tl;
+                p.stat_sum[row * p.N + n0 + tid] =
+                    (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
+                p.stat_sq[row * p.N + n0 + tid] =
+                    (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
+            }
         }
+        __syncthreads();  // the fp32 tile is consumed before the next tile's K loop overwrites the buffers
     }
 }
 
@@ -279,13 +311,14 @@ struct TnArgs {
 template <typename T, int PITCH> struct Transpose4;
 template <int PITCH> struct Transpose4<bf16, PITCH> {
     // 4 position rows of 8 bf16 -> 8 columns of 4 bf16 (8 bytes each)
-    __device__ static inline uint32_t half(const u32x4& v, int j) { return (v[j >> 1] >> ((j & 1) * 16)) & 0xffffu; }
+    // v_perm_b32: result bytes selected from {first operand = bytes 7..4, second = bytes 3..0}
     __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;  // high / low halves of the two dwords
             u32x2 o;
-            o[0] = half(v[0], j) | (half(v[1], j) << 16);
-            o[1] = half(v[2], j) | (half(v[3], j) << 16);
+            o[0] = __builtin_amdgcn_perm(v[1][j >> 1], v[0][j >> 1], sel);
+            o[1] = __builtin_amdgcn_perm(v[3][j >> 1], v[2][j >> 1], sel);
             *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + pg * 8) = o;
         }
     }
@@ -323,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     const int64_t win_stride = is_x ? p.x_win_stride : p.du_win_stride;
     const int row_c = is_x ? p.c_in : p.c_out;
     const int which = is_x ? 0 : 1;
-    int pg[NIT], col0[NIT], goff[NIT];
+    int pg[NIT], col0[NIT], toff[NIT];
     bool col_ok[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
         col0[it] = (item / PG) * VEC;
         const int gcol = (is_x ? i0 : j0) + col0[it];
         col_ok[it] = gcol < (is_x ? p.Kk : p.c_out);
-        goff[it] = col_ok[it] ? gcol : 0;
+        toff[it] = pg[it] * 4 * row_c + (col_ok[it] ? gcol : 0);  // element offset of this item's first row in a stage
     }
 
     const int64_t w_begin = (int64_t)split * p.win_per_split;
@@ -344,32 +377,38 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     f32x16 acc[2][2];
     zero_acc(acc);
 
+    // (window, stage-in-window) cursor of the NEXT stage to load -- incremented, never divided
+    int64_t ld_n = w_begin;
+    int ld_s = 0;
     u32x4 rv[NIT][4];
-    auto gload = [&](int64_t st) {
-        const int64_t n = w_begin + st / stages_per_win;
-        const int tb = (int)(st % stages_per_win) * BKP;
-        const T* wbase = base0 + n * win_stride;
+    auto gload = [&]() {
+        const int tb = ld_s * BKP;
+        const T* wbase = base0 + ld_n * win_stride + (int64_t)tb * row_c;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = tb + pg[it] * 4 + r;
                 if (col_ok[it] && t < p.L) {
-                    rv[it][r] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)t * row_c + goff[it]);
+                    rv[it][r] = *reinterpret_cast<const u32x4*>(wbase + toff[it] + r * row_c);
                 } else {
                     rv[it][r] = u32x4{0, 0, 0, 0};
                 }
             }
         }
+        if (++ld_s == stages_per_win) {
+            ld_s = 0;
+            ++ld_n;
+        }
     };
-    if (n_stages > 0) gload(0);
+    if (n_stages > 0) gload();
     for (int64_t st = 0; st < n_stages; ++st) {
         const int buf = (int)(st & 1);
         char* mine = lds + (buf * 2 + which) * G::TILE;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) Transpose4<T, G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
         __syncthreads();
-        if (st + 1 < n_stages) gload(st + 1);
+        if (st + 1 < n_stages) gload();
         mma_slice<T, KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
     }
 
@@ -420,12 +459,15 @@ static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 
+int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
+
 template <typename T, int EPI>
-static void launch_nt(const NtArgs<T>& a, int64_t grid, hipStream_t stream) {
+static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
+    const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     if (g_gemm_kb == 64) {
-        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 64>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 64>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
     } else {
-        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 128>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 128>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
     }
 }
 
@@ -451,9 +493,7 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.Ktot = 3 * c_in;
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_out, BN);
-        const int64_t grid = n_windows * a.tilesL * a.tilesN;
-        VM_REQUIRE(grid < (1LL << 31), "vm_conv_fwd: grid too large");
-        launch_nt<T, EPI_FWD>(a, grid, (hipStream_t)stream);
+        launch_nt<T, EPI_FWD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
 }
@@ -479,9 +519,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.Ktot = 3 * c_out;
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_in, BN);
-        const int64_t grid = n_windows * a.tilesL * a.tilesN;
-        VM_REQUIRE(grid < (1LL << 31), "vm_conv_dgrad: grid too large");
-        launch_nt<T, EPI_DGRAD>(a, grid, (hipStream_t)stream);
+        launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
 }
@@ -549,6 +587,10 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_blocks") == 0 && value > 0) {
+        g_nt_blocks = value;
         return VM_OK;
     }
     vm::set_error("vm_set_tuning: unknown key/value");
