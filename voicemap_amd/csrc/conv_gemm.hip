@@ -117,6 +117,8 @@ struct NtArgs {
     int a_c;               // row stride of a (elements)
     int L, N, Ktot;
     int tilesL, tilesN;
+    int ablate;  // timing experiments only (results are wrong when != 0): 1 no epilogue stores, 2 no epilogue,
+                 // 4 no MFMA, 8 no K-loop global loads after the first slice
 };
 
 template <int KB>
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
                 *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
             }
             __syncthreads();
-            if (kt + 1 < nk) gload(kt + 1);
-            mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
+            if (kt + 1 < nk && !(p.ablate & 8)) gload(kt + 1);
+            if (!(p.ablate & 4)) mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
         }
         // coordinates of the finished tile
         const int tl = (int)(group % p.tilesL);
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
 
         // ---- epilogue: accumulators -> fp32 LDS tile -> (bias, ReLU, convert) -> 16-byte coalesced row segments ----
         __syncthreads();
+        if (p.ablate & 2) continue;
         acc_to_lds(lds, wm, wn, lane, acc);
         __syncthreads();
         const int c8 = tid & 15, rg = tid >> 4;  // 8-column chunk, row group
@@ -256,8 +259,10 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
                     }
                 }
                 T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
-                store16<T>(dst, o0);
-                if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+                if (!(p.ablate & 1)) {
+                    store16<T>(dst, o0);
+                    if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+                }
             }
         }
         if (EPI == EPI_FWD && p.stat_sum != nullptr) {
@@ -305,6 +310,7 @@ struct TnArgs {
     int c_in, c_out, L;
     int Kk;  // 3*c_in
     int tilesI, tilesJ, splits;
+    int xcd_remap;
     int64_t n_windows, win_per_split;
 };
 
@@ -344,7 +350,18 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 2 * G::TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    // All output tiles of one split stream the SAME positions of X and dU, so they should share an L2: workgroup b
+    // runs on XCD b % 8 (observed dispatch order; only speed depends on it), hence split s is given the workgroups
+    // {b : b % 8 == s % 8}.  Splits beyond the last multiple of 8 fall back to the plain order.
     int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
     const int tj = (int)(b % p.tilesJ);
     b /= p.tilesJ;
     const int ti = (int)(b % p.tilesI);
@@ -459,6 +476,8 @@ static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 
+int g_nt_ablate = 0;
+int g_tn_xcd = 1;
 int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
 
 template <typename T, int EPI>
@@ -493,6 +512,7 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.Ktot = 3 * c_in;
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_out, BN);
+        a.ablate = g_nt_ablate;
         launch_nt<T, EPI_FWD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
@@ -519,6 +539,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.Ktot = 3 * c_out;
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_in, BN);
+        a.ablate = g_nt_ablate;
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
@@ -558,6 +579,7 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.tilesI = tiles(3 * c_in, BM);
         a.tilesJ = tiles(c_out, BN);
         a.splits = splits;
+        a.xcd_remap = g_tn_xcd;
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
@@ -587,6 +609,14 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_ablate") == 0) {
+        g_nt_ablate = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "tn_xcd") == 0) {
+        g_tn_xcd = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_blocks") == 0 && value > 0) {
