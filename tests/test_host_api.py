@@ -1,0 +1,209 @@
+"""CPU tests of the host-side mirror of the reference API (voicemap_amd.{models,utils,librispeech,keras_like}): the
+reference's own dataset tests (tests/tests.py:16-68) restated on a synthetic speaker table, its whitening test
+(:71-90), and the signatures / error behaviour of the build functions.  No GPU needed."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import voicemap_oracle as O
+from voicemap_amd import keras_like as K
+from voicemap_amd import models, utils
+from voicemap_amd.librispeech import LibriSpeechDataset, SyntheticSpeechDataset
+
+
+@pytest.fixture(scope="module")
+def dataset():
+    np.random.seed(0)
+    return SyntheticSpeechDataset(num_speakers=40, files_per_speaker=6, seconds=3)  # dev-clean has 40 speakers
+
+
+# ---- tests/tests.py:16-29 -------------------------------------------------------------------------------
+def test_verification_pairs(dataset):
+    alike = dataset.get_alike_pairs(16)
+    assert len(alike) == 16
+    assert all(dataset[i][1] == dataset[j][1] for i, j in alike), "All alike pairs must come from the same speaker."
+    differing = dataset.get_differing_pairs(16)
+    assert all(dataset[i][1] != dataset[j][1] for i, j in differing), "All differing pairs must come from different speakers."
+
+
+# ---- tests/tests.py:31-68 -------------------------------------------------------------------------------
+def test_n_shot_task(dataset):
+    n, k = 1, 5
+    query_sample, support = dataset.build_n_shot_task(k, n)
+    assert query_sample[1] == support[1][0]
+    assert query_sample[1] not in support[1][1:]
+    assert len(np.unique(support[1])) == k
+    assert support[0].shape == (k * n, 48000) and query_sample[0].shape == (48000,)
+    n, k = 5, 5
+    query_sample, support = dataset.build_n_shot_task(k, n)
+    assert all(pd.Series(support[1]).value_counts() == 5)
+    for i in range(0, n * k, n):
+        assert np.all(support[1][i:i + n] == support[1][i])
+    with pytest.raises(ValueError):
+        dataset.build_n_shot_task(dataset.unique_speakers, 1)
+    with pytest.raises(ValueError):
+        dataset.build_n_shot_task(1, 1)
+
+
+def test_verification_batch_layout(dataset):
+    ([x1, x2], y) = dataset.build_verification_batch(8)
+    assert x1.shape == (8, 48000, 1) and x2.shape == (8, 48000, 1) and y.shape == (8, 1)
+    assert np.array_equal(y[:, 0], [0, 0, 0, 0, 1, 1, 1, 1])  # 0 = same speaker (librispeech.py:194)
+    gen = dataset.yield_verification_batches(4)
+    ([a, b], yy) = next(gen)
+    assert a.shape == (4, 48000, 1) and yy.shape == (4, 1)
+
+
+def test_dataset_getitem_modes():
+    d = SyntheticSpeechDataset(num_speakers=4, files_per_speaker=3, seconds=3, stochastic=False)
+    a, la = d[0]
+    b, lb = d[0]
+    assert np.array_equal(a, b) and la == lb and len(a) == 48000
+    assert len(d) == 12 and d.num_classes() == 4 and d.unique_speakers == 4
+    assert set(["speaker_id", "sex", "subset", "speaker_minutes", "name", "filepath", "length", "seconds", "id"]) <= set(d.df.columns)
+    short = SyntheticSpeechDataset(num_speakers=3, files_per_speaker=2, seconds=3, pad=True, stochastic=False,
+                                   min_file_seconds=1.0, max_file_seconds=2.0)
+    x, _ = short[0]
+    assert len(x) == 48000 and np.all(x[40000:] == 0)  # zero padded at the end when not stochastic
+    nopad = SyntheticSpeechDataset(num_speakers=3, files_per_speaker=2, seconds=3, pad=False, min_file_seconds=1.0,
+                                   max_file_seconds=2.0)
+    assert len(nopad) == 0  # files shorter than the fragment are dropped (librispeech.py:86)
+    sex = SyntheticSpeechDataset(num_speakers=4, files_per_speaker=2, seconds=3, label="sex")
+    assert sex[0][1] in (True, False)
+    with pytest.raises(AssertionError):
+        SyntheticSpeechDataset(label="age")
+
+
+def test_speakers_table_parse_rule():
+    import config
+    p = os.path.join(config.PATH, "tests", "golden", "SPEAKERS_head.TXT")
+    df = LibriSpeechDataset.read_speakers_table(p)
+    assert list(df.columns) == ["id", "sex", "subset", "minutes", "name"]
+    assert df.iloc[0]["id"] == 14 and df.iloc[0]["sex"] == "F" and df.iloc[0]["subset"] == "train-clean-360"
+    assert df.iloc[0]["name"] == "Kristin LeMoine"
+
+
+# ---- tests/tests.py:71-90 -------------------------------------------------------------------------------
+def test_whitening_no_batch(golden_dir):
+    desired_rms = 0.038021
+    c = np.load(os.path.join(golden_dir, "clips_human_eval.npz"))
+    clip = c["query"].astype(np.float64) / 32768.0
+    data = np.stack([clip] * 2)[:, :, np.newaxis]
+    w = utils.whiten(data, desired_rms)
+    assert np.isclose(w.mean().item(), 0)
+    assert np.isclose(np.sqrt(np.power(w[0, :], 2).mean()).item(), desired_rms, rtol=1e-3)
+    assert np.array_equal(w, O.whiten(data, desired_rms))
+    with pytest.raises(ValueError):
+        utils.whiten(data[:, :, 0])
+
+
+def test_preprocessors_and_lazy_batches():
+    r = np.random.default_rng(0)
+    x = r.normal(0.01, 0.05, (4, 4800, 1))
+    pre = utils.preprocess_instances(4)
+    lazy = pre(x)
+    assert lazy.shape == (4, 1200, 1) and len(lazy) == 4
+    assert np.allclose(np.asarray(lazy), O.preprocess_instances(4)(x))
+    assert np.allclose(np.asarray(utils.preprocess_instances(4, whitening=False)(x)), x[:, ::4, :])
+    bp = utils.BatchPreProcessor("siamese", pre)
+    ([a, b], lab) = bp(([x, x[::-1]], np.zeros((4, 1))))
+    assert isinstance(a, utils.LazyWindows) and np.array_equal(lab, np.zeros((4, 1)))
+    bc = utils.BatchPreProcessor("classifier", pre, lambda y: y + 1)
+    xi, yi = bc((x, np.zeros((4, 1))))
+    assert np.all(yi == 1)
+    assert bc.instance_preprocessor is pre
+    with pytest.raises(AssertionError):
+        utils.BatchPreProcessor("triplet", pre)
+
+
+def test_contrastive_loss_matches_oracle():
+    import torch
+    r = np.random.default_rng(1)
+    y = (r.random((16, 1)) > 0.5).astype(float)
+    p = r.random((16, 1))
+    assert np.isclose(utils.contrastive_loss(y, p), O.contrastive_loss(torch.tensor(y), torch.tensor(p)).item())
+
+
+# ---- voicemap/models.py signatures and error behaviour ---------------------------------------------------
+def test_build_functions_surface():
+    enc = models.get_baseline_convolutional_encoder(128, 64, dropout=0.0)
+    assert [type(l).__name__ for l in enc.layers[:4]] == ["Conv1D", "BatchNormalization", "SpatialDropout1D", "MaxPool1D"]
+    assert len(enc.layers) == 18 and enc.layers[-1].units == 64
+    net = models.build_siamese_net(enc, (12000, 1), distance_metric="uniform_euclidean")
+    assert net.layers[2] is enc and len(net.layers) == 6
+    with pytest.raises(AssertionError):
+        models.build_siamese_net(enc, (12000, 1), distance_metric="manhattan")
+    for name in ("weighted_euclidean", "uniform_l1", "dot_product", "cosine_distance"):
+        with pytest.raises(NotImplementedError):
+            models.build_siamese_net(enc, (12000, 1), distance_metric=name)
+    models.build_siamese_net(models.get_baseline_convolutional_encoder(32, 128), (12000, 1), "weighted_l1")
+    lines = []
+    e2 = models.get_baseline_convolutional_encoder(128, 64, (12000, 1), dropout=0.0)
+    e2.summary(print_fn=lines.append)
+    txt = "\n".join(lines)
+    assert "Total params: 1,026,368" in txt and "Trainable params: 1,023,808" in txt  # + 2 head params = 1 023 810
+    clf = models.get_baseline_convolutional_encoder(16, 32, (12000, 1))
+    clf.add(K.Dense(40, activation="softmax"))
+    assert clf.classifier_units == 40 and clf.layers[-1].name == "dense_2"
+    with pytest.raises(NotImplementedError):
+        clf.add(K.Dense(3, activation="softmax"))
+    clf.pop()
+    assert clf.classifier_units == 0
+
+
+def test_keras_like_callbacks(tmp_path):
+    class FakeModel:
+        def __init__(self):
+            self.lr, self.saved = 1e-3, []
+        def get_lr(self): return self.lr
+        def set_lr(self, v): self.lr = v
+        def save(self, p): self.saved.append(p)
+    m = FakeModel()
+    csvp = str(tmp_path / "logs" / "run.csv")
+    cbs = [K.CSVLogger(csvp), K.ModelCheckpoint(str(tmp_path / "m.npz"), monitor="val_1-shot_acc", mode="max", save_best_only=True),
+           K.ReduceLROnPlateau(monitor="val_1-shot_acc", mode="max", patience=2)]
+    for cb in cbs:
+        cb.set_model(m)
+        cb.on_train_begin()
+    accs = [0.3, 0.5, 0.4, 0.45, 0.2]
+    for ep, a in enumerate(accs):
+        logs = {"loss": 1.0 / (ep + 1), "acc": 0.5, "val_loss": 1.0, "val_acc": 0.5, "val_1-shot_acc": a}
+        for cb in cbs:
+            cb.on_epoch_end(ep, logs)
+    for cb in cbs:
+        cb.on_train_end()
+    assert len(m.saved) == 2            # improvements at epochs 0 and 1 only
+    assert np.isclose(m.lr, 1e-4)       # no improvement for 2 epochs after the best -> one reduction by 0.1
+    rows = open(csvp).read().strip().split("\n")
+    assert rows[0].split(",")[0] == "epoch" and "val_1-shot_acc" in rows[0] and len(rows) == 6
+    assert np.array_equal(K.to_categorical([1, 0, 2], 3), np.eye(3, dtype=np.float32)[[1, 0, 2]])
+    opt = K.Adam(clipnorm=1.)
+    assert (opt.lr, opt.beta_1, opt.beta_2, opt.epsilon, opt.clipnorm) == (1e-3, 0.9, 0.999, 1e-7, 1.0)
+
+
+def test_batch_feeder_generator_and_sequence():
+    def gen():
+        i = 0
+        while True:
+            yield i, -i
+            i += 1
+    f = K.BatchFeeder(gen(), workers=3, max_queue_size=4)
+    got = sorted(f.get()[0] for _ in range(20))
+    f.close()
+    assert len(set(got)) == 20 and max(got) < 20 + 3 + 4  # unordered across workers, nothing duplicated or lost for long
+
+    class Seq(K.Sequence):
+        def __len__(self): return 5
+        def __getitem__(self, i): return i, i
+    f0 = K.BatchFeeder(Seq(), workers=0)
+    assert [f0.get()[0] for _ in range(7)] == [0, 1, 2, 3, 4, 0, 1]
+
+
+def test_voicemap_alias_package():
+    import voicemap
+    from voicemap.models import get_baseline_convolutional_encoder, build_siamese_net  # noqa: F401
+    from voicemap.utils import whiten, NShotEvaluationCallback, BatchPreProcessor, preprocess_instances, contrastive_loss  # noqa: F401
+    from voicemap.librispeech import LibriSpeechDataset as L2
+    assert L2 is LibriSpeechDataset and voicemap.models is models

@@ -119,6 +119,7 @@ class HipEncoderEngine:
         # Adam(clipnorm=1.) defaults of the reference scripts
         self.lr, self.beta_1, self.beta_2, self.adam_eps, self.decay, self.clipnorm = 1e-3, 0.9, 0.999, 1e-7, 0.0, 1.0
         self.iterations = 0
+        self.last_infer_l0 = 0
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
@@ -486,11 +487,41 @@ class HipEncoderEngine:
         x = x.reshape(n, -1).to(self.device)
         l0 = x.shape[1] if preprocessed else (x.shape[1] + downsampling - 1) // downsampling
         pl = self.plan(n, l0, False)
+        self.last_infer_l0 = l0
         if preprocessed:
             self.load_preprocessed(pl, x)
         else:
             self.preprocess(pl, x, downsampling, whitening, windows_per_tower or n)
         return self.forward(pl, n, None)
+
+    def siamese_eval(self, x1, x2, y, loss: str = "contrastive", preprocessed: bool = True, downsampling: int = 4,
+                     whitening: bool = True):
+        """test_on_batch of the siamese model: inference-mode forward + loss / accuracy (no gradients are used; the
+        head kernel writes its backward outputs into scratch)."""
+        x1 = torch.as_tensor(x1)
+        x2 = torch.as_tensor(x2)
+        pairs = x1.shape[0]
+        x = torch.cat([x1.reshape(pairs, -1), x2.reshape(pairs, -1)], 0)
+        self.embed(x, preprocessed, downsampling, whitening, windows_per_tower=pairs)
+        pl = self.plan(2 * pairs, self.last_infer_l0, False)
+        yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
+        if "scratch" not in pl:
+            pl["scratch"] = torch.empty(2 * pairs * self.E + self.E + 8, dtype=torch.float32, device=self.device)
+        sc = pl["scratch"]
+        off = 2 * pairs * self.E
+        self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), _p(yd),
+                   pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc),
+                   sc.data_ptr() + 4 * off, sc.data_ptr() + 4 * (off + self.E), self.stream())
+        return pl
+
+    def classifier_head_eval(self, pl: dict, labels: torch.Tensor):
+        """Dense(num_classes, softmax) + categorical CE / accuracy on the embeddings of an inference plan."""
+        n = pl["n"]
+        self._call("vm_dense_fwd", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), n, self.E,
+                   self.num_classes, _p(pl["logits"]), self.stream())
+        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, _p(pl["prob"]), _p(pl["loss_acc"]),
+                   None, _p(pl["cce_ws"]), self.stream())
+        return pl["prob"]
 
     def siamese_predict(self, x1, x2, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True):
         """siamese.predict([x1, x2]) -> (pairs, 1) probabilities (inference-mode BN)."""
