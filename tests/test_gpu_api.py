@@ -1,0 +1,141 @@
+"""-m gpu tests of the drop-in Python surface (voicemap_amd.models / utils / librispeech driving the HIP engine): a
+miniature of experiments/train_siamese.py with all four callbacks, n-shot evaluation against the oracle on identical
+tasks, checkpoint round trip, the classifier script's flow, and the reference's known-answer task through the public API."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import voicemap_oracle as O
+from voicemap_amd import keras_like as K
+from voicemap_amd import models, utils
+from voicemap_amd.librispeech import SyntheticSpeechDataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_params(eng):
+    return {k: torch.tensor(v, dtype=torch.float64) for k, v in eng.get_params().items()}
+
+
+def test_fit_generator_like_train_siamese(tmp_path):
+    np.random.seed(0)
+    train = SyntheticSpeechDataset(num_speakers=30, files_per_speaker=4, seconds=0.6, pad=True)
+    valid = SyntheticSpeechDataset(num_speakers=12, files_per_speaker=4, seconds=0.6, stochastic=False, pad=True, seed=5)
+    bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
+    train_gen = (bp(b) for b in train.yield_verification_batches(8))
+    valid_gen = (bp(b) for b in valid.yield_verification_batches(8))
+    enc = models.get_baseline_convolutional_encoder(16, 32, dropout=0.05, dtype="f32")
+    net = models.build_siamese_net(enc, (2400, 1), distance_metric="uniform_euclidean")
+    net.compile(loss="binary_crossentropy", optimizer=K.Adam(clipnorm=1.), metrics=["accuracy"])
+    csvp = str(tmp_path / "logs" / "run.csv")
+    ckpt = str(tmp_path / "models" / "best.npz")
+    hist = net.fit_generator(generator=train_gen, steps_per_epoch=3, validation_data=valid_gen, validation_steps=2, epochs=2,
+                             workers=2, use_multiprocessing=True, verbose=0,
+                             callbacks=[utils.NShotEvaluationCallback(6, 1, 5, valid, preprocessor=bp),
+                                        K.CSVLogger(csvp),
+                                        K.ModelCheckpoint(ckpt, monitor="val_1-shot_acc", mode="max", save_best_only=True),
+                                        K.ReduceLROnPlateau(monitor="val_1-shot_acc", mode="max", verbose=0)])
+    assert set(hist.history) >= {"loss", "acc", "val_loss", "val_acc", "val_1-shot_acc", "lr"}
+    assert len(hist.history["loss"]) == 2 and all(np.isfinite(hist.history["loss"]))
+    assert net.engine.iterations == 6
+    header = open(csvp).readline().strip().split(",")
+    assert header == ["epoch", "acc", "loss", "lr", "val_1-shot_acc", "val_acc", "val_loss"]
+    assert os.path.exists(ckpt)
+    # checkpoint round trip: same predictions, optimizer state restored
+    ([x1, x2], _) = bp(valid.build_verification_batch(4))
+    loaded = models.load_model(ckpt)
+    assert loaded.engine.iterations in (3, 6)
+    net2 = models.load_model(ckpt)
+    assert np.array_equal(loaded.predict([x1, x2]), net2.predict([x1, x2]))
+    # encoder shares the trained weights (utils.py:141 uses model.layers[2])
+    e = net.layers[2].predict(x1)
+    assert e.shape == (4, 32) and np.isfinite(e).all()
+
+
+@pytest.mark.parametrize("n,k,dist", [(1, 5, "euclidean"), (5, 5, "euclidean"), (3, 4, "cosine"), (2, 6, "dot_product")])
+def test_n_shot_evaluation_matches_oracle(n, k, dist):
+    valid = SyntheticSpeechDataset(num_speakers=14, files_per_speaker=8, seconds=0.5, stochastic=False, seed=3)
+    enc = models.get_baseline_convolutional_encoder(16, 32, dropout=0.0, dtype="f32")
+    net = models.build_siamese_net(enc, (2000, 1))
+    net.compile(loss=utils.contrastive_loss, optimizer=K.Adam(clipnorm=1.))
+    eng = net._ensure_engine()
+    # make the moving statistics non-trivial
+    r = np.random.default_rng(0)
+    eng.set_params({f"bn{i}.moving_mean": r.normal(0.05, 0.02, c) for i, (_, c, _) in enumerate(eng.blocks, 1)})
+    eng.set_params({f"bn{i}.moving_variance": r.uniform(0.01, 0.1, c) for i, (_, c, _) in enumerate(eng.blocks, 1)})
+    bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
+    num_tasks = 12
+    np.random.seed(11)
+    got = utils.n_shot_task_evaluation(net, valid, bp, num_tasks, n, k, network_type="siamese", distance=dist)
+    # the oracle on the very same tasks (same RNG stream)
+    arch = O.EncoderArch(blocks=eng.blocks, embedding_dimension=32, dropout=0.0)
+    p = _oracle_params(eng)
+    pre = O.preprocess_instances(4)
+    np.random.seed(11)
+    want = 0
+    for _ in range(num_tasks):
+        q, s = valid.build_n_shot_task(k, n)
+        if n == 1:
+            i1 = pre(np.stack([q[0]] * k)[:, :, None])
+            i2 = pre(s[0][:, :, None])
+            pred, _, _ = O.siamese_forward(arch, p, torch.tensor(i1), torch.tensor(i2), False)
+            want += int(pred[:, 0].argmin() == 0)
+        else:
+            qe = O.encoder_forward(arch, p, torch.tensor(pre(q[0].reshape(1, -1, 1))), False).numpy()
+            se = O.encoder_forward(arch, p, torch.tensor(pre(s[0][:, :, None])), False).numpy()
+            want += int(np.argmin(O.n_shot_prediction(qe, se, n, k, dist)) == 0)
+    assert got == want
+
+
+def test_classifier_flow_like_train_classifier():
+    np.random.seed(1)
+    train = SyntheticSpeechDataset(num_speakers=10, files_per_speaker=4, seconds=0.5)
+    speakers = sorted(train.df["speaker_id"].unique())
+    mapping = {s: i for i, s in enumerate(speakers)}
+
+    def label_pre(y):
+        return K.to_categorical(np.array([mapping[i] for i in y[:, 0]])[:, None], train.num_classes())
+
+    bp = utils.BatchPreProcessor("classifier", utils.preprocess_instances(4), label_pre)
+
+    class Batched(K.Sequence):
+        def __len__(self):
+            return len(train) // 8
+
+        def __getitem__(self, item):
+            idx = range(item * 8, item * 8 + 8)
+            X = np.stack([train[i][0][:, None] for i in idx])
+            y = np.stack([train[i][1] for i in idx])[:, None]
+            return bp((X, y))
+
+    clf = models.get_baseline_convolutional_encoder(16, 32, (2000, 1), dropout=0.0, dtype="f32")
+    clf.add(K.Dense(train.num_classes(), activation="softmax"))
+    clf.compile(loss="categorical_crossentropy", optimizer=K.Adam(clipnorm=1.), metrics=["accuracy"])
+    valid = SyntheticSpeechDataset(num_speakers=10, files_per_speaker=4, seconds=0.5, stochastic=False, seed=9)
+    hist = clf.fit_generator(Batched(), steps_per_epoch=4, epochs=2, verbose=0, workers=0,
+                             callbacks=[utils.NShotEvaluationCallback(5, 1, 5, valid, preprocessor=bp, mode="classifier")])
+    assert np.isfinite(hist.history["loss"]).all() and "val_1-shot_acc" in hist.history
+    prob = clf.predict(Batched()[0][0])
+    assert prob.shape == (8, 10) and np.allclose(prob.sum(1), 1, atol=1e-5)
+    emb = utils.get_bottleneck(clf, Batched()[0][0])
+    assert emb.shape == (8, 32)
+
+
+def test_known_answer_task_through_public_api(golden_dir):
+    """notebooks/Human_Evaluation.ipynb cell 8 via load_keras_checkpoint_npz + n_shot_task_evaluation."""
+    c = np.load(os.path.join(golden_dir, "clips_human_eval.npz"))
+
+    class OneTask:
+        unique_speakers = 6
+
+        def build_n_shot_task(self, k, n=1):
+            q = c["query"].astype(np.float64) / 32768.0
+            s = c["support"].astype(np.float64) / 32768.0
+            order = [4, 0, 1, 2, 3]  # correct speaker first, as build_n_shot_task lays tasks out
+            return (q, 0), (s[order], np.arange(5))
+
+    net = models.load_keras_checkpoint_npz(os.path.join(golden_dir, "ckpt_cfgCK_weights.npz"), dtype="f32")
+    bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
+    assert utils.n_shot_task_evaluation(net, OneTask(), bp, 1, 1, 5, network_type="siamese") == 1

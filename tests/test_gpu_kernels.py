@@ -55,7 +55,8 @@ def gemm_kb(request):
 
 @pytest.mark.parametrize("gemm_kb", [128, 64], indirect=True)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8)])
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
+                                          (3, 131, 96, 32)])
 def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kb):
     vm, tdt = DTYPES[dt]
     r = rng(2)

@@ -296,6 +296,186 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT GEMM, direct-to-LDS variant.  The register-staged kernel above is bound by its LDS *writes*
+// (ds_write_b128 sustains ~79 B/clk/CU: 32 KB per 128-byte slice = ~415 clk, more than the 16 MFMAs per wave it feeds;
+// measured: removing the MFMAs saves 10 % of its time, removing nothing else saves more).  Here the K slices go from
+// global memory straight into LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  An LDS-DMA writes
+// wave-uniform base + lane*16, so the tile is stored UNPADDED ([128 rows][KB bytes]) and bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index that is applied to the per-lane
+// SOURCE address and again when reading:
+//     KB = 128: chunk' = chunk ^ ((row >> 1) & 7)      (two rows per 256-byte bank line)
+//     KB =  64: chunk' = chunk ^ ((row >> 2) & 3)      (four rows per bank line)
+// Requires K*sizeof(T) to be a multiple of KB (no zero-filled K tail); other shapes use the kernel above.
+template <int KB>
+__device__ inline int swz(int row, int chunk) {
+    return KB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+}
+
+template <typename T, int KB>
+__device__ inline void mma_slice_swz(const char* lds_a, const char* lds_b, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+    constexpr int KSTEPS = KB / Mfma<T>::KSTEP_BYTES;
+    constexpr int SUB = 16 / (Mfma<T>::KSTEP_BYTES / 2);  // fragments per 16-byte chunk: 1 (bf16), 4 (fp32)
+    const int r = lane & 31, kh = lane >> 5;
+    const int ra0 = wm * 64 + r, ra1 = ra0 + 32, rb0 = wn * 64 + r, rb1 = rb0 + 32;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const int f = s * 2 + kh;            // fragment index along K
+        const int ch = f / SUB, sub = f % SUB;
+        const int off = sub * (16 / SUB);
+        typename Mfma<T>::Frag a0 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_a + ra0 * KB + swz<KB>(ra0, ch) * 16 + off);
+        typename Mfma<T>::Frag a1 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_a + ra1 * KB + swz<KB>(ra1, ch) * 16 + off);
+        typename Mfma<T>::Frag b0 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_b + rb0 * KB + swz<KB>(rb0, ch) * 16 + off);
+        typename Mfma<T>::Frag b1 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_b + rb1 * KB + swz<KB>(rb1, ch) * 16 + off);
+        acc[0][0] = Mfma<T>::run(b0, a0, acc[0][0]);
+        acc[0][1] = Mfma<T>::run(b1, a0, acc[0][1]);
+        acc[1][0] = Mfma<T>::run(b0, a1, acc[1][0]);
+        acc[1][1] = Mfma<T>::run(b1, a1, acc[1][1]);
+    }
+}
+
+template <int KB>
+constexpr int glds_lds_bytes() {
+    return (2 * 2 * BM * KB > BM * OUT_PITCH + 4096) ? 2 * 2 * BM * KB : BM * OUT_PITCH + 4096;
+}
+
+template <typename T, int EPI, int KB>
+__global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t n_groups) {
+    constexpr int BK = KB / (int)sizeof(T);
+    constexpr int RPI = 1024 / KB;        // rows per wave-instruction (64 lanes x 16 bytes)
+    constexpr int CPR = KB / 16;          // chunks per row
+    constexpr int NI = BM / RPI / 4;      // instructions per wave per operand per slice
+    constexpr int OPB = BM * KB;          // bytes of one operand tile
+    __shared__ __attribute__((aligned(16))) char lds[glds_lds_bytes<KB>()];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int nk = p.Ktot / BK;
+
+    // lane -> (row within the instruction's rows, physical chunk); the source chunk undoes the swizzle
+    int srow[NI], src_chunk_bytes[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        srow[i] = (w + 4 * i) * RPI + lane / CPR;
+        src_chunk_bytes[i] = swz<KB>(srow[i], lane % CPR) * 16;
+    }
+
+    for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const int tl = (int)(group % p.tilesL);
+        const int64_t n = group / p.tilesL;
+        const int t0 = tl * BM;
+        const char* a_rows[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int t = t0 + srow[i];
+            t = t < p.L ? t : p.L - 1;
+            a_rows[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)t * p.a_c) + src_chunk_bytes[i];
+        }
+        for (int tn = 0; tn < p.tilesN; ++tn) {
+            const int n0 = tn * BN;
+            const char* b_rows[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int nn = n0 + srow[i];
+                nn = nn < p.N ? nn : p.N - 1;
+                b_rows[i] = reinterpret_cast<const char*>(p.bt + (int64_t)nn * p.Ktot) + src_chunk_bytes[i];
+            }
+            auto issue = [&](int kt) {
+                char* bufbase = lds + (kt & 1) * 2 * OPB;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int dst = __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
+                    __builtin_amdgcn_global_load_lds(a_rows[i] + (int64_t)kt * KB,
+                                                     (__attribute__((address_space(3))) void*)(bufbase + dst), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(b_rows[i] + (int64_t)kt * KB,
+                                                     (__attribute__((address_space(3))) void*)(bufbase + OPB + dst), 16, 0, 0);
+                }
+            };
+            f32x16 acc[2][2];
+            zero_acc(acc);
+            issue(0);
+            for (int kt = 0; kt < nk; ++kt) {
+                __syncthreads();  // slice kt has landed for every wave (the compiler drains vmcnt before the barrier)
+                if (kt + 1 < nk) issue(kt + 1);
+                const char* bufbase = lds + (kt & 1) * 2 * OPB;
+                mma_slice_swz<T, KB>(bufbase, bufbase + OPB, wm, wn, lane, acc);
+            }
+
+            // ---- epilogue (same as the register-staged kernel) ----
+            __syncthreads();
+            acc_to_lds(lds, wm, wn, lane, acc);
+            __syncthreads();
+            const int c8 = tid & 15, rg = tid >> 4;
+            const int ncol = n0 + c8 * 8;
+            const bool cok = ncol < p.N;
+            float bias8[8], s8[8], q8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
+                s8[i] = 0.f;
+                q8[i] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = rg + 16 * j;
+                const int t = t0 + row;
+                if (cok && t < p.L) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    Vec16<T> o0, o1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float x = v[i] + bias8[i];
+                        if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                        const T tx = Elem<T>::from_f(x);
+                        if (EPI == EPI_FWD) {
+                            const float xr = Elem<T>::to_f(tx);
+                            s8[i] += xr;
+                            q8[i] += xr * xr;
+                        }
+                        if (sizeof(T) == 2) {
+                            o0.set(i, x);
+                        } else if (i < 4) {
+                            o0.set(i, x);
+                        } else {
+                            o1.set(i - 4, x);
+                        }
+                    }
+                    T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+                    store16<T>(dst, o0);
+                    if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+                }
+            }
+            if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s8[i] += __shfl_xor(s8[i], 16, 64);
+                    s8[i] += __shfl_xor(s8[i], 32, 64);
+                    q8[i] += __shfl_xor(q8[i], 16, 64);
+                    q8[i] += __shfl_xor(q8[i], 32, 64);
+                }
+                float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);
+                if (lane < 16) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
+                        red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
+                    }
+                }
+                __syncthreads();
+                if (tid < 128 && n0 + tid < p.N) {
+                    const int64_t row = n * p.tilesL + tl;
+                    p.stat_sum[row * p.N + n0 + tid] =
+                        (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
+                    p.stat_sq[row * p.N + n0 + tid] =
+                        (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
+                }
+            }
+            __syncthreads();  // the fp32 tile is consumed before the next tile's DMA overwrites the buffers
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
 // of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
 // 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
@@ -480,9 +660,20 @@ int g_nt_ablate = 0;
 int g_tn_xcd = 1;
 int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
 
+int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
+
 template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
+    const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
+    if (g_nt_glds && a.ablate == 0 && kbytes % 128 == 0 && g_gemm_kb == 128) {
+        hipLaunchKernelGGL((conv_nt_glds_kernel<T, EPI, 128>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
+        return;
+    }
+    if (g_nt_glds && a.ablate == 0 && kbytes % 64 == 0) {
+        hipLaunchKernelGGL((conv_nt_glds_kernel<T, EPI, 64>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
+        return;
+    }
     if (g_gemm_kb == 64) {
         hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 64>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
     } else {
@@ -609,6 +800,10 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_glds") == 0) {
+        g_nt_glds = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_ablate") == 0) {
