@@ -306,6 +306,15 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
 //     KB = 128: chunk' = chunk ^ ((row >> 1) & 7)      (two rows per 256-byte bank line)
 //     KB =  64: chunk' = chunk ^ ((row >> 2) & 3)      (four rows per bank line)
 // Requires K*sizeof(T) to be a multiple of KB (no zero-filled K tail); other shapes use the kernel above.
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_base + lane*16.  The body only exists in
+// the device pass: the host pass of hipcc cannot type-check the LDS address-space cast and would silently drop the
+// kernel's launch stub.
+__device__ inline void glds16(const char* gsrc, char* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+#endif
+}
+
 template <int KB>
 __device__ inline int swz(int row, int chunk) {
     return KB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
@@ -383,10 +392,8 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t 
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int dst = __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
-                    __builtin_amdgcn_global_load_lds(a_rows[i] + (int64_t)kt * KB,
-                                                     (__attribute__((address_space(3))) void*)(bufbase + dst), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(b_rows[i] + (int64_t)kt * KB,
-                                                     (__attribute__((address_space(3))) void*)(bufbase + OPB + dst), 16, 0, 0);
+                    glds16(a_rows[i] + (int64_t)kt * KB, bufbase + dst);
+                    glds16(b_rows[i] + (int64_t)kt * KB, bufbase + OPB + dst);
                 }
             };
             f32x16 acc[2][2];
