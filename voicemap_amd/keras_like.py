@@ -179,7 +179,17 @@ class BatchFeeder:
         return item
 
     def close(self):
+        """Stop the producer threads and wait for them: a producer that is still sampling would otherwise keep consuming
+        the global numpy RNG after fit_generator has returned."""
         self.stop.set()
+        for t in self.threads:
+            while t.is_alive():
+                try:  # unblock a producer waiting on a full queue
+                    self.q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
+        self.threads = []
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ class _TrainableModel:
         if steps_per_epoch is None:
             steps_per_epoch = len(generator)
         history = K.History()
-        cbs = [history] + list(callbacks or [])
+        cbs = list(callbacks or []) + [history]  # Keras appends History last: it sees what the other callbacks logged
         for cb in cbs:
             cb.set_model(self)
             cb.set_params({"epochs": epochs, "steps": steps_per_epoch, "verbose": verbose})
