@@ -1,0 +1,66 @@
+"""Shared pieces of the experiment drivers (MI355X versions of the reference's experiments/*.py harness):
+argument parsing, dataset construction (LibriSpeech on disk or the synthetic stand-in) and the callback list that
+experiments/train_siamese.py:73-93 of the reference wires up, in the order it relies on."""
+import argparse
+import os
+
+import numpy as np
+
+from config import LIBRISPEECH_SAMPLING_RATE, PATH
+from voicemap_amd.keras_like import CSVLogger, ModelCheckpoint, ReduceLROnPlateau
+from voicemap_amd.librispeech import LibriSpeechDataset, SyntheticSpeechDataset
+from voicemap_amd.utils import NShotEvaluationCallback
+
+
+def base_parser(description, **defaults):
+    d = dict(n_seconds=3.0, downsampling=4, batchsize=64, filters=128, embedding_dimension=64, dropout=0.0, epochs=50,
+             steps=500, validation_steps=100, tasks=500, n_shot=1, k_way=5, pad=True)
+    d.update(defaults)
+    p = argparse.ArgumentParser(description=description)
+    p.add_argument("--n-seconds", type=float, default=d["n_seconds"])
+    p.add_argument("--downsampling", type=int, default=d["downsampling"])
+    p.add_argument("--batchsize", type=int, default=d["batchsize"])
+    p.add_argument("--filters", type=int, default=d["filters"])
+    p.add_argument("--embedding-dimension", type=int, default=d["embedding_dimension"])
+    p.add_argument("--dropout", type=float, default=d["dropout"])
+    p.add_argument("--epochs", type=int, default=d["epochs"])
+    p.add_argument("--steps-per-epoch", type=int, default=d["steps"], help="evaluate_every_n_batches of the reference")
+    p.add_argument("--validation-steps", type=int, default=d["validation_steps"])
+    p.add_argument("--num-evaluation-tasks", type=int, default=d["tasks"])
+    p.add_argument("--n-shot", type=int, default=d["n_shot"])
+    p.add_argument("--k-way", type=int, default=d["k_way"])
+    p.add_argument("--no-pad", dest="pad", action="store_false", default=d["pad"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--workers", type=int, default=min(8, os.cpu_count() or 1))
+    p.add_argument("--synthetic", action="store_true", help="generated speakers instead of LibriSpeech on disk")
+    p.add_argument("--training-set", nargs="+", default=["train-clean-100", "train-clean-360"])
+    p.add_argument("--validation-set", default="dev-clean")
+    return p
+
+
+def datasets(a, pad):
+    if a.synthetic:
+        train = SyntheticSpeechDataset(num_speakers=64, files_per_speaker=8, seconds=a.n_seconds, pad=pad, seed=0)
+        valid = SyntheticSpeechDataset(num_speakers=24, files_per_speaker=8, seconds=a.n_seconds, stochastic=False, pad=pad,
+                                       seed=1)
+    else:
+        train = LibriSpeechDataset(a.training_set, a.n_seconds, pad=pad)
+        valid = LibriSpeechDataset(a.validation_set, a.n_seconds, stochastic=False, pad=pad)
+    return train, valid
+
+
+def input_length(a):
+    return int(LIBRISPEECH_SAMPLING_RATE * a.n_seconds / a.downsampling)
+
+
+def standard_callbacks(a, valid, preprocessor, mode, param_str, plateau_patience=10):
+    """n-shot metric FIRST (it creates logs['val_{n}-shot_acc']), then the callbacks that monitor it."""
+    key = "val_{}-shot_acc".format(a.n_shot)
+    return [NShotEvaluationCallback(a.num_evaluation_tasks, a.n_shot, a.k_way, valid, preprocessor=preprocessor, mode=mode),
+            CSVLogger(PATH + "/logs/{}.csv".format(param_str)),
+            ModelCheckpoint(PATH + "/models/{}.npz".format(param_str), monitor=key, mode="max", save_best_only=True, verbose=True),
+            ReduceLROnPlateau(monitor=key, mode="max", verbose=1, patience=plateau_patience)]
+
+
+def seed_everything(seed=0):
+    np.random.seed(seed)

@@ -743,13 +743,29 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
     return check_launch("vm_conv_dgrad");
 }
 
+// Split of the position reduction over windows.  All workgroups of a launch do the same amount of work
+// (windows_per_split windows) and 512 of them are resident at a time (2 per CU), so the launch takes
+// rounds = ceil(tiles * splits / 512) rounds of windows_per_split windows each -- a 1548-workgroup launch pays a whole
+// 4th round for 12 stragglers -- plus the write + re-read of one fp32 slab per split.  Pick the split that minimises
+//     rounds * wps * t_window  +  splits * t_slab
+// with t_window = 2*128*128*L flop at ~1 TFLOP/s per resident workgroup and t_slab = 8 bytes * 3*c_in*c_out at ~3 TB/s.
 extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
     const int64_t t = (int64_t)tiles(3 * c_in, BM) * tiles(c_out, BN);
-    int64_t s = (1536 + t - 1) / t;
-    if (s > n_windows) s = n_windows;
-    if (s < 1) s = 1;
-    const int64_t wps = (n_windows + s - 1) / s;
-    return (int)((n_windows + wps - 1) / wps);
+    const int64_t slots = 512;
+    const double t_window = 2.0 * BM * BN * (double)L / 1.0e12;
+    const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
+    int64_t best_wps = 1;
+    double best_cost = -1.0;
+    for (int64_t wps = 1; wps <= n_windows; ++wps) {
+        const int64_t splits = (n_windows + wps - 1) / wps;
+        const int64_t rounds = (t * splits + slots - 1) / slots;
+        const double cost = (double)(rounds * wps) * t_window + (double)splits * t_slab;
+        if (best_cost < 0.0 || cost < best_cost) {
+            best_cost = cost;
+            best_wps = wps;
+        }
+    }
+    return (int)((n_windows + best_wps - 1) / best_wps);
 }
 
 extern "C" int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out) {
