@@ -637,6 +637,121 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad, 256 x 256 output tile.  The 128 x 128 kernel above is bound by LDS traffic, not by the matrix cores: per
+// 128-byte stage it writes 32 KB (transposed 8-byte writes, ~85 B/clk) and reads 64 KB for 16 MFMAs per wave.  With a
+// 256 x 256 tile and 64 x 128 per wave (8 waves) a stage writes 64 KB and reads 192 KB for 32 MFMAs per wave: LDS
+// cycles per MFMA cycle drop from 1.25 to 0.75.  One workgroup per CU (144 KB of LDS, 128 accumulator registers).
+template <typename T, int KB>
+__global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
+    using G = Geo<KB>;
+    constexpr int VEC = Elem<T>::kVec;
+    constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
+    constexpr int PG = BKP / 4;
+    constexpr int TM = 256, TN_ = 256;
+    constexpr int OPB = TM * G::PITCH;        // bytes of one operand tile (256 rows)
+    constexpr int KSTEPS = KB / Mfma<T>::KSTEP_BYTES;
+    static_assert((TM / VEC) * PG == 512, "one item per thread and operand");
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * OPB];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = (int)(b % p.tilesJ);
+    b /= p.tilesJ;
+    const int ti = (int)(b % p.tilesI);
+    const int split = (int)(b / p.tilesI);
+    const int i0 = ti * TM, j0 = tj * TN_;
+
+    // every thread stages one item of X and one of dU per stage
+    const int pg = tid % PG, col0 = (tid / PG) * VEC;
+    const bool x_ok = i0 + col0 < p.Kk, d_ok = j0 + col0 < p.c_out;
+    const int x_toff = pg * 4 * p.c_in + (x_ok ? i0 + col0 : 0);
+    const int d_toff = pg * 4 * p.c_out + (d_ok ? j0 + col0 : 0);
+    const T* d_base0 = p.du + p.c_out;  // dU row t lives at padded row t+1
+
+    const int64_t w_begin = (int64_t)split * p.win_per_split;
+    int64_t w_end = w_begin + p.win_per_split;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const int stages_per_win = (p.L + BKP - 1) / BKP;
+    const int64_t n_stages = (w_end - w_begin) * stages_per_win;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int64_t ld_n = w_begin;
+    int ld_s = 0;
+    u32x4 rx[4], rd[4];
+    auto gload = [&]() {
+        const int tb = ld_s * BKP;
+        const T* xb = p.x + ld_n * p.x_win_stride + (int64_t)tb * p.c_in;
+        const T* db = d_base0 + ld_n * p.du_win_stride + (int64_t)tb * p.c_out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool tok = tb + pg * 4 + r < p.L;
+            rx[r] = (x_ok && tok) ? *reinterpret_cast<const u32x4*>(xb + x_toff + r * p.c_in) : u32x4{0, 0, 0, 0};
+            rd[r] = (d_ok && tok) ? *reinterpret_cast<const u32x4*>(db + d_toff + r * p.c_out) : u32x4{0, 0, 0, 0};
+        }
+        if (++ld_s == stages_per_win) {
+            ld_s = 0;
+            ++ld_n;
+        }
+    };
+    if (n_stages > 0) gload();
+    const int r = lane & 31, kh = lane >> 5;
+    for (int64_t st = 0; st < n_stages; ++st) {
+        char* ta = lds + (int)(st & 1) * 2 * OPB;
+        char* tb_ = ta + OPB;
+        Transpose4<T, G::PITCH>::store(ta, col0, pg, rx);
+        Transpose4<T, G::PITCH>::store(tb_, col0, pg, rd);
+        __syncthreads();
+        if (st + 1 < n_stages) gload();
+        const char* pa = ta + (wm * 64 + r) * G::PITCH;
+        const char* pb = tb_ + (wn * 128 + r) * G::PITCH;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            typename Mfma<T>::Frag a0 = Mfma<T>::load(pa, s, kh), a1 = Mfma<T>::load(pa + 32 * G::PITCH, s, kh);
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                typename Mfma<T>::Frag bf = Mfma<T>::load(pb + in * 32 * G::PITCH, s, kh);
+                acc[0][in] = Mfma<T>::run(bf, a0, acc[0][in]);
+                acc[1][in] = Mfma<T>::run(bf, a1, acc[1][in]);
+            }
+        }
+    }
+
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        const int row = i0 + wm * 64 + im * 32 + (lane & 31);
+        if (row >= p.Kk) continue;
+#pragma unroll
+        for (int in = 0; in < 4; ++in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = j0 + wn * 128 + in * 32 + 8 * g + 4 * hi;
+                if (col < p.c_out) {
+                    f32x4 v = {acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
+            }
+        }
+    }
+}
+
 // fp32 Keras kernel (3, c_in, c_out) -> wf[co][k*c_in + ci] = W[k][ci][co];  wd[ci][j*c_out + co] = W[2-j][ci][co]
 template <typename T>
 __global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, T* wd) {
@@ -743,16 +858,21 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
     return check_launch("vm_conv_dgrad");
 }
 
+int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
+
+static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_in >= 192 && c_out >= 192; }
+
 // Split of the position reduction over windows.  All workgroups of a launch do the same amount of work
-// (windows_per_split windows) and 512 of them are resident at a time (2 per CU), so the launch takes
-// rounds = ceil(tiles * splits / 512) rounds of windows_per_split windows each -- a 1548-workgroup launch pays a whole
-// 4th round for 12 stragglers -- plus the write + re-read of one fp32 slab per split.  Pick the split that minimises
-//     rounds * wps * t_window  +  splits * t_slab
-// with t_window = 2*128*128*L flop at ~1 TFLOP/s per resident workgroup and t_slab = 8 bytes * 3*c_in*c_out at ~3 TB/s.
+// (windows_per_split windows) and a fixed number of them is resident at a time (2 per CU for the 128-tile kernel, 1 per
+// CU for the 256-tile kernel), so the launch takes rounds = ceil(tiles * splits / slots) rounds of windows_per_split
+// windows each -- a launch of 3 rounds + 12 workgroups pays a whole 4th round -- plus the write + re-read of one fp32
+// slab per split.  Pick the split that minimises   rounds * wps * t_window  +  splits * t_slab.
 extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
-    const int64_t t = (int64_t)tiles(3 * c_in, BM) * tiles(c_out, BN);
-    const int64_t slots = 512;
-    const double t_window = 2.0 * BM * BN * (double)L / 1.0e12;
+    const bool big = tn_use_256(c_in, c_out);
+    const int tile = big ? 256 : 128;
+    const int64_t t = (int64_t)tiles(3 * c_in, tile) * tiles(c_out, tile);
+    const int64_t slots = big ? 256 : 512;
+    const double t_window = 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
     const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
     int64_t best_wps = 1;
     double best_cost = -1.0;
@@ -790,14 +910,17 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.c_out = c_out;
         a.L = (int)L;
         a.Kk = 3 * c_in;
-        a.tilesI = tiles(3 * c_in, BM);
-        a.tilesJ = tiles(c_out, BN);
+        const bool big = tn_use_256(c_in, c_out);
+        a.tilesI = tiles(3 * c_in, big ? 256 : BM);
+        a.tilesJ = tiles(c_out, big ? 256 : BN);
         a.splits = splits;
         a.xcd_remap = g_tn_xcd;
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
-        if (g_gemm_kb == 64) {
+        if (big) {
+            hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, a);
+        } else if (g_gemm_kb == 64) {
             hipLaunchKernelGGL((conv_tn_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
         } else {
             hipLaunchKernelGGL((conv_tn_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -831,6 +954,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_ablate") == 0) {
         g_nt_ablate = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "tn_tile") == 0 && (value == 128 || value == 256)) {
+        g_tn_tile = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "tn_xcd") == 0) {
