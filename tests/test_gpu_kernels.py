@@ -46,14 +46,23 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 1, "nt_glds": 1, "tn_tile": 256}
+
+
 @pytest.fixture
 def gemm_kb(request):
-    L().call("vm_set_tuning", b"gemm_kb", request.param)
+    """Selects one of the GEMM kernel variants (all must agree with the oracle): ring-pipelined LDS-DMA (default),
+    two-buffer LDS-DMA, register-staged with 128- or 64-byte K slices, 256- or 128-wide wgrad tiles."""
+    for k, v in request.param.items():
+        L().call("vm_set_tuning", k.encode(), v)
     yield request.param
-    L().call("vm_set_tuning", b"gemm_kb", 128)
+    for k, v in GEMM_DEFAULTS.items():
+        L().call("vm_set_tuning", k.encode(), v)
 
 
-@pytest.mark.parametrize("gemm_kb", [128, 64], indirect=True)
+@pytest.mark.parametrize("gemm_kb", [{}, {"nt_ring": 0}, {"nt_ring": 0, "nt_glds": 0, "tn_tile": 128},
+                                     {"nt_ring": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
+                         ids=["ring", "glds2", "reg128", "reg64"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
                                           (3, 131, 96, 32)])

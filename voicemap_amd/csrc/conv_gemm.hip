@@ -347,6 +347,83 @@ constexpr int glds_lds_bytes() {
     return (2 * 2 * BM * KB > BM * OUT_PITCH + 4096) ? 2 * 2 * BM * KB : BM * OUT_PITCH + 4096;
 }
 
+// Shared epilogue of the NT kernels: accumulators -> fp32 LDS tile -> (bias, ReLU, convert, BN partial statistics) ->
+// 16-byte coalesced row segments.  `lds` must hold BM*OUT_PITCH + 4096 bytes; callers barrier before and after.
+template <typename T, int EPI>
+__device__ inline void nt_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[2][2], int64_t n, int tl, int t0, int n0,
+                                   int tid, int lane, int w, int wm, int wn) {
+    __syncthreads();
+    acc_to_lds(lds, wm, wn, lane, acc);
+    __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;
+    const int ncol = n0 + c8 * 8;
+    const bool cok = ncol < p.N;
+    float bias8[8], s8[8], q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
+        s8[i] = 0.f;
+        q8[i] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = rg + 16 * j;
+        const int t = t0 + row;
+        if (cok && t < p.L) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            Vec16<T> o0, o1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float x = v[i] + bias8[i];
+                if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                const T tx = Elem<T>::from_f(x);
+                if (EPI == EPI_FWD) {
+                    const float xr = Elem<T>::to_f(tx);
+                    s8[i] += xr;
+                    q8[i] += xr * xr;
+                }
+                if (sizeof(T) == 2) {
+                    o0.set(i, x);
+                } else if (i < 4) {
+                    o0.set(i, x);
+                } else {
+                    o1.set(i - 4, x);
+                }
+            }
+            T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+            store16<T>(dst, o0);
+            if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+        }
+    }
+    if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s8[i] += __shfl_xor(s8[i], 16, 64);
+            s8[i] += __shfl_xor(s8[i], 32, 64);
+            q8[i] += __shfl_xor(q8[i], 16, 64);
+            q8[i] += __shfl_xor(q8[i], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
+                red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const int64_t row = n * p.tilesL + tl;
+            p.stat_sum[row * p.N + n0 + tid] =
+                (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
+            p.stat_sq[row * p.N + n0 + tid] =
+                (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
+        }
+    }
+}
+
 template <typename T, int EPI, int KB>
 __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t n_groups) {
     constexpr int BK = KB / (int)sizeof(T);
@@ -406,77 +483,97 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t 
                 mma_slice_swz<T, KB>(bufbase, bufbase + OPB, wm, wn, lane, acc);
             }
 
-            // ---- epilogue (same as the register-staged kernel) ----
-            __syncthreads();
-            acc_to_lds(lds, wm, wn, lane, acc);
-            __syncthreads();
-            const int c8 = tid & 15, rg = tid >> 4;
-            const int ncol = n0 + c8 * 8;
-            const bool cok = ncol < p.N;
-            float bias8[8], s8[8], q8[8];
+            // ---- epilogue ----
+            nt_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, tid, lane, w, wm, wn);
+            __syncthreads();  // the fp32 tile is consumed before the next tile's DMA overwrites the buffers
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT GEMM, ring-pipelined direct-to-LDS variant.  With two buffers the DMA of slice k+1 only has the MFMAs of slice k to
+// land, and measurements say the K loop is bound by that latency (HBM-class ~2 us under load), not by MFMA or LDS
+// throughput.  Here a ring of RING = 4 buffers of 64-byte slices keeps RING-1 = 3 slices in flight: the wait before the
+// barrier is a *counted* s_waitcnt vmcnt(N) (N = DMAs of the slices that may still be flying) and the barrier is the raw
+// s_barrier -- __syncthreads() would make hipcc drain vmcnt to 0 and collapse the pipeline to depth 1.
+// Ordering argument: the DMA of slice kt+3 overwrites the buffer read in iteration kt-1; every wave has finished those
+// reads (their MFMAs consumed them) before it arrives at barrier kt, and the DMA is issued after that barrier.
+template <int N>
+__device__ inline void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void conv_nt_ring_kernel(NtArgs<T> p, int64_t n_groups) {
+    constexpr int KB = 64, RING = 4;
+    constexpr int BK = KB / (int)sizeof(T);
+    constexpr int RPI = 1024 / KB;        // 16 rows per wave-instruction
+    constexpr int CPR = KB / 16;          // 4 chunks per row
+    constexpr int NI = BM / RPI / 4;      // 2 instructions per wave per operand per slice
+    constexpr int G = 2 * NI;             // DMAs per wave per slice
+    constexpr int OPB = BM * KB;          // 8 KB per operand tile
+    constexpr int LDS_BYTES = (RING * 2 * OPB > BM * OUT_PITCH + 4096) ? RING * 2 * OPB : BM * OUT_PITCH + 4096;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int nk = p.Ktot / BK;
+
+    int srow[NI], src_chunk_bytes[NI];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bias8[i] = (EPI == EPI_FWD && cok) ? p.bias[ncol + i] : 0.f;
-                s8[i] = 0.f;
-                q8[i] = 0.f;
+    for (int i = 0; i < NI; ++i) {
+        srow[i] = (w + 4 * i) * RPI + lane / CPR;
+        src_chunk_bytes[i] = swz<KB>(srow[i], lane % CPR) * 16;
+    }
+
+    for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const int tl = (int)(group % p.tilesL);
+        const int64_t n = group / p.tilesL;
+        const int t0 = tl * BM;
+        const char* a_rows[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int t = t0 + srow[i];
+            t = t < p.L ? t : p.L - 1;
+            a_rows[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)t * p.a_c) + src_chunk_bytes[i];
+        }
+        for (int tn = 0; tn < p.tilesN; ++tn) {
+            const int n0 = tn * BN;
+            const char* b_rows[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int nn = n0 + srow[i];
+                nn = nn < p.N ? nn : p.N - 1;
+                b_rows[i] = reinterpret_cast<const char*>(p.bt + (int64_t)nn * p.Ktot) + src_chunk_bytes[i];
             }
+            auto issue = [&](int kt) {
+                char* bufbase = lds + (kt % RING) * 2 * OPB;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = rg + 16 * j;
-                const int t = t0 + row;
-                if (cok && t < p.L) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
-                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    Vec16<T> o0, o1;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float x = v[i] + bias8[i];
-                        if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
-                        const T tx = Elem<T>::from_f(x);
-                        if (EPI == EPI_FWD) {
-                            const float xr = Elem<T>::to_f(tx);
-                            s8[i] += xr;
-                            q8[i] += xr * xr;
-                        }
-                        if (sizeof(T) == 2) {
-                            o0.set(i, x);
-                        } else if (i < 4) {
-                            o0.set(i, x);
-                        } else {
-                            o1.set(i - 4, x);
-                        }
-                    }
-                    T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
-                    store16<T>(dst, o0);
-                    if (sizeof(T) == 4) store16<T>(dst + 4, o1);
+                for (int i = 0; i < NI; ++i) {
+                    const int dst = __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
+                    glds16(a_rows[i] + (int64_t)kt * KB, bufbase + dst);
+                    glds16(b_rows[i] + (int64_t)kt * KB, bufbase + OPB + dst);
                 }
+            };
+            f32x16 acc[2][2];
+            zero_acc(acc);
+#pragma unroll
+            for (int k0 = 0; k0 < RING - 1; ++k0)
+                if (k0 < nk) issue(k0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int ahead = nk - 1 - kt;  // slices after kt that have been issued and may still be in flight
+                if (ahead >= RING - 2) {
+                    wait_vmcnt<(RING - 2) * G>();
+                } else if (ahead == 1) {
+                    wait_vmcnt<G>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                if (kt + RING - 1 < nk) issue(kt + RING - 1);
+                const char* bufbase = lds + (kt % RING) * 2 * OPB;
+                mma_slice_swz<T, KB>(bufbase, bufbase + OPB, wm, wn, lane, acc);
             }
-            if (EPI == EPI_FWD && p.stat_sum != nullptr) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s8[i] += __shfl_xor(s8[i], 16, 64);
-                    s8[i] += __shfl_xor(s8[i], 32, 64);
-                    q8[i] += __shfl_xor(q8[i], 16, 64);
-                    q8[i] += __shfl_xor(q8[i], 32, 64);
-                }
-                float* red = reinterpret_cast<float*>(lds + BM * OUT_PITCH);
-                if (lane < 16) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
-                        red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
-                    }
-                }
-                __syncthreads();
-                if (tid < 128 && n0 + tid < p.N) {
-                    const int64_t row = n * p.tilesL + tl;
-                    p.stat_sum[row * p.N + n0 + tid] =
-                        (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
-                    p.stat_sq[row * p.N + n0 + tid] =
-                        (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
-                }
-            }
+            nt_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, tid, lane, w, wm, wn);
             __syncthreads();  // the fp32 tile is consumed before the next tile's DMA overwrites the buffers
         }
     }
@@ -782,12 +879,17 @@ int g_nt_ablate = 0;
 int g_tn_xcd = 1;
 int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
 
+int g_nt_ring = 1;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
 int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
 
 template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
+    if (g_nt_ring && a.ablate == 0 && kbytes % 64 == 0) {
+        hipLaunchKernelGGL((conv_nt_ring_kernel<T, EPI>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
+        return;
+    }
     if (g_nt_glds && a.ablate == 0 && kbytes % 128 == 0 && g_gemm_kb == 128) {
         hipLaunchKernelGGL((conv_nt_glds_kernel<T, EPI, 128>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
         return;
@@ -946,6 +1048,10 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_ring") == 0) {
+        g_nt_ring = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_glds") == 0) {
