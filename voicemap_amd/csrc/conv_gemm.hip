@@ -117,6 +117,7 @@ struct NtArgs {
     int a_c;               // row stride of a (elements)
     int L, N, Ktot;
     int tilesL, tilesN;
+    int order;   // tile order of the LDS-DMA kernels: 0 sequential n-tiles per workgroup, 1 concurrent n-tiles per XCD
     int ablate;  // timing experiments only (results are wrong when != 0): 1 no epilogue stores, 2 no epilogue,
                  // 4 no MFMA, 8 no K-loop global loads after the first slice
 };
@@ -444,7 +445,26 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t 
         src_chunk_bytes[i] = swz<KB>(srow[i], lane % CPR) * 16;
     }
 
-    for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    // Tile order.  order 1 (default when the group count is a multiple of 8): the n-tiles of one (window, t-tile) group --
+    // which all stream the SAME A rows -- are given to workgroups that run at the same time on the same XCD
+    // (workgroup b is dispatched to XCD b % 8), so the A tile is fetched into that L2 once instead of once per n-tile
+    // (PMC: FETCH_SIZE of the forward launches was 4.5x the algorithmic bytes with the sequential order 0).
+    const int64_t total_tiles = n_groups * p.tilesN;
+    const bool xcd_order = p.order == 1 && (n_groups & 7) == 0;
+    for (int64_t it = 0;; ++it) {
+        int64_t group;
+        int tn;
+        if (xcd_order) {
+            const int64_t v = blockIdx.x + it * gridDim.x;
+            if (v >= total_tiles) break;
+            const int64_t j = v >> 3;
+            tn = (int)(j % p.tilesN);
+            group = (j / p.tilesN) * 8 + (v & 7);
+        } else {
+            group = blockIdx.x + (it / p.tilesN) * gridDim.x;
+            tn = (int)(it % p.tilesN);
+            if (group >= n_groups) break;
+        }
         const int tl = (int)(group % p.tilesL);
         const int64_t n = group / p.tilesL;
         const int t0 = tl * BM;
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t 
             t = t < p.L ? t : p.L - 1;
             a_rows[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)t * p.a_c) + src_chunk_bytes[i];
         }
-        for (int tn = 0; tn < p.tilesN; ++tn) {
+        {
             const int n0 = tn * BN;
             const char* b_rows[NI];
 #pragma unroll
@@ -525,7 +545,26 @@ __global__ __launch_bounds__(256) void conv_nt_ring_kernel(NtArgs<T> p, int64_t 
         src_chunk_bytes[i] = swz<KB>(srow[i], lane % CPR) * 16;
     }
 
-    for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    // Tile order.  order 1 (default when the group count is a multiple of 8): the n-tiles of one (window, t-tile) group --
+    // which all stream the SAME A rows -- are given to workgroups that run at the same time on the same XCD
+    // (workgroup b is dispatched to XCD b % 8), so the A tile is fetched into that L2 once instead of once per n-tile
+    // (PMC: FETCH_SIZE of the forward launches was 4.5x the algorithmic bytes with the sequential order 0).
+    const int64_t total_tiles = n_groups * p.tilesN;
+    const bool xcd_order = p.order == 1 && (n_groups & 7) == 0;
+    for (int64_t it = 0;; ++it) {
+        int64_t group;
+        int tn;
+        if (xcd_order) {
+            const int64_t v = blockIdx.x + it * gridDim.x;
+            if (v >= total_tiles) break;
+            const int64_t j = v >> 3;
+            tn = (int)(j % p.tilesN);
+            group = (j / p.tilesN) * 8 + (v & 7);
+        } else {
+            group = blockIdx.x + (it / p.tilesN) * gridDim.x;
+            tn = (int)(it % p.tilesN);
+            if (group >= n_groups) break;
+        }
         const int tl = (int)(group % p.tilesL);
         const int64_t n = group / p.tilesL;
         const int t0 = tl * BM;
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_nt_ring_kernel(NtArgs<T> p, int64_t 
             t = t < p.L ? t : p.L - 1;
             a_rows[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)t * p.a_c) + src_chunk_bytes[i];
         }
-        for (int tn = 0; tn < p.tilesN; ++tn) {
+        {
             const int n0 = tn * BN;
             const char* b_rows[NI];
 #pragma unroll
@@ -879,7 +918,8 @@ int g_nt_ablate = 0;
 int g_tn_xcd = 1;
 int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
 
-int g_nt_ring = 1;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
+int g_nt_order = 1;
+int g_nt_ring = 0;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
 int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
 
 template <typename T, int EPI>
@@ -928,6 +968,7 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_out, BN);
         a.ablate = g_nt_ablate;
+        a.order = g_nt_order;
         launch_nt<T, EPI_FWD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
@@ -955,6 +996,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.tilesL = tiles(L, BM);
         a.tilesN = tiles(c_in, BN);
         a.ablate = g_nt_ablate;
+        a.order = g_nt_order;
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
@@ -1048,6 +1090,10 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_order") == 0) {
+        g_nt_order = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_ring") == 0) {
