@@ -73,7 +73,10 @@ def main():
         eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
-        eng.lib.call("vm_set_tuning", k.encode(), int(v))
+        if k == "overlap_wgrad":
+            eng.overlap_wgrad = bool(int(v))
+        else:
+            eng.lib.call("vm_set_tuning", k.encode(), int(v))
     if a.nt_blocks:
         eng.lib.call("vm_set_tuning", b"nt_blocks", a.nt_blocks)
     parallel.attach(eng, n_gpus)

@@ -185,19 +185,35 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
         const int cv = cvb + pl;
         const bool cok = cv < CV;
         const int c0 = cv * VEC;
-        float sc[VEC], sh[VEC], dr[VEC], mu[VEC], is[VEC], k1[VEC], k2[VEC], accA[VEC], accB[VEC];
+        // Per-channel constants folded on entry (fewer live registers -> more waves in flight on these HBM-bound passes):
+        //   arg-max of y = (z*scale+shift)*drop over a pool window == arg-max of z if scale*drop >= 0, else arg-min
+        //   reduce: dy = drop*dp,  dy*zhat = dp * (ka*z + kb),            ka = drop*invstd, kb = -drop*invstd*mean
+        //   apply : du = [z>0] * (kc*z + kb + [arg] ka*dp),                ka = scale*drop, kb = scale*(invstd*c2*mean - c1),
+        //                                                                  kc = -scale*invstd*c2
+        float ka[VEC], kb[VEC], kc[VEC], accA[VEC], accB[VEC];
+        bool use_min[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             accA[i] = 0.f;
             accB[i] = 0.f;
+            ka[i] = kb[i] = kc[i] = 0.f;
+            use_min[i] = false;
             if (cok) {
-                sc[i] = scale[tw * C + c0 + i];
-                sh[i] = shift[tw * C + c0 + i];
-                mu[i] = mean[tw * C + c0 + i];
-                is[i] = invstd[tw * C + c0 + i];
-                dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
-                k1[i] = APPLY ? c1[tw * C + c0 + i] : 0.f;
-                k2[i] = APPLY ? c2[tw * C + c0 + i] : 0.f;
+                const float sc = scale[tw * C + c0 + i];
+                const float mu = mean[tw * C + c0 + i];
+                const float is = invstd[tw * C + c0 + i];
+                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
+                use_min[i] = sc * dr < 0.f;
+                if (APPLY) {
+                    const float k1 = c1[tw * C + c0 + i], k2 = c2[tw * C + c0 + i];
+                    ka[i] = sc * dr;
+                    kb[i] = sc * (is * k2 * mu - k1);
+                    kc[i] = -sc * is * k2;
+                } else {
+                    ka[i] = dr * is;
+                    kb[i] = -dr * is * mu;
+                    kc[i] = dr;
+                }
             }
         }
         if (cok) {
@@ -211,50 +227,41 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                 const bool has_dp = q < Lq;
                 Vec16<T> dv;
                 if (has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
-                int arg[VEC];
+                Vec16<T> ov[POOL];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    float best = 0.f;
-                    arg[i] = 0;
+                    float zj[POOL];
 #pragma unroll
-                    for (int j = 0; j < POOL; ++j) {
-                        if (j < nrows) {
-                            const float y = fmaf(zv[j].get(i), sc[i], sh[i]) * dr[i];
-                            if (j == 0 || y > best) {
-                                best = y;
-                                arg[i] = j;
-                            }
+                    for (int j = 0; j < POOL; ++j) zj[j] = j < nrows ? zv[j].get(i) : 0.f;
+                    float ext = zj[0];
+                    int arg = 0;
+#pragma unroll
+                    for (int j = 1; j < POOL; ++j) {
+                        const bool better = use_min[i] ? (zj[j] < ext) : (zj[j] > ext);  // strict: first extreme wins
+                        if (j < nrows && better) {
+                            ext = zj[j];
+                            arg = j;
+                        }
+                    }
+                    const float dpv = has_dp ? dv.get(i) : 0.f;
+                    if (!APPLY) {
+                        accA[i] += kc[i] * dpv;
+                        accB[i] += dpv * fmaf(ka[i], ext, kb[i]);
+                    } else {
+                        const float ady = ka[i] * dpv;
+#pragma unroll
+                        for (int j = 0; j < POOL; ++j) {
+                            float g = fmaf(kc[i], zj[j], kb[i]) + (j == arg ? ady : 0.f);
+                            g = zj[j] > 0.f ? g : 0.f;
+                            ov[j].set(i, g);
+                            if (j < nrows) accA[i] += ov[j].get(i);
                         }
                     }
                 }
-                if (!APPLY) {
+                if (APPLY) {
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        float zsel = zv[0].get(i);
-#pragma unroll
-                        for (int j = 1; j < POOL; ++j) zsel = (arg[i] == j) ? zv[j].get(i) : zsel;
-                        const float dy = dr[i] * dv.get(i);
-                        accA[i] += dy;
-                        accB[i] += dy * ((zsel - mu[i]) * is[i]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < POOL; ++j) {
-                        if (j < nrows) {
-                            Vec16<T> o;
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                const float zz = zv[j].get(i);
-                                const float dy = (has_dp && arg[i] == j) ? dr[i] * dv.get(i) : 0.f;
-                                const float zh = (zz - mu[i]) * is[i];
-                                float g = sc[i] * (dy - k1[i] - zh * k2[i]);
-                                g = zz > 0.f ? g : 0.f;
-                                o.set(i, g);
-                                accA[i] += o.get(i);
-                            }
-                            store16<T>(du + (n * (L + 2) + 1 + q * POOL + j) * C + c0, o);
-                        }
-                    }
+                    for (int j = 0; j < POOL; ++j)
+                        if (j < nrows) store16<T>(du + (n * (L + 2) + 1 + q * POOL + j) * C + c0, ov[j]);
                 }
             }
         }

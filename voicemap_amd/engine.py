@@ -120,6 +120,10 @@ class HipEncoderEngine:
         self.lr, self.beta_1, self.beta_2, self.adam_eps, self.decay, self.clipnorm = 1e-3, 0.9, 0.999, 1e-7, 0.0, 1.0
         self.iterations = 0
         self.last_infer_l0 = 0
+        # weight-gradient GEMMs only feed the optimizer: they run on a side stream, concurrently with the dgrad ->
+        # BN-backward chain of the earlier blocks (which is the critical path of backward)
+        self.overlap_wgrad = True
+        self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
@@ -244,8 +248,9 @@ class HipEncoderEngine:
             pl["dgmax"] = torch.empty(n_windows, cl, dtype=f32, device=dev)
             ws = 0
             for i in range(1, self.nb):
-                ws = max(ws, self.lib.query("vm_conv_wgrad_workspace_bytes", n_windows, ls[i], self.blocks[i - 1][1],
-                                            self.blocks[i][1]))
+                wsi = self.lib.query("vm_conv_wgrad_workspace_bytes", n_windows, ls[i], self.blocks[i - 1][1], self.blocks[i][1])
+                pl[i]["wgrad_ws"] = torch.empty(wsi // 4 + 16, dtype=f32, device=dev)  # one per block: wgrads may overlap
+                pl[i]["ev"] = torch.cuda.Event()
             ws = max(ws, self.lib.query("vm_conv1_wgrad_workspace_bytes", n_windows, self.blocks[0][1]))
             if self.fuse_block1:
                 ws = max(ws, self.lib.query("vm_conv1_fused_bwd_workspace_bytes", n_windows, l0, self.blocks[0][1]))
@@ -372,8 +377,17 @@ class HipEncoderEngine:
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
             else:
                 cin = self.blocks[i - 1][1]
-                self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(pl["wgrad_ws"]), gw, st)
+                if self.overlap_wgrad:
+                    b["ev"].record()
+                    with torch.cuda.stream(self.side_stream):
+                        self.side_stream.wait_event(b["ev"])
+                        self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw,
+                                   self.stream())
+                else:
+                    self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, st)
                 self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(pl[i - 1]["dp"]), st)
+        if self.overlap_wgrad:
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
 
     # ------------------------------------------------------------------------------------------------
     def siamese_head(self, pl: dict, y: Optional[torch.Tensor], loss: str = "contrastive"):
