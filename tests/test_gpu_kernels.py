@@ -46,7 +46,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1}
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1}
 
 
 @pytest.fixture
@@ -60,9 +60,10 @@ def gemm_kb(request):
         L().call("vm_set_tuning", k.encode(), v)
 
 
-@pytest.mark.parametrize("gemm_kb", [{}, {"nt_ring": 1}, {"nt_order": 0}, {"nt_glds": 0, "tn_tile": 128},
-                                     {"nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
-                         ids=["glds2", "ring", "seq-order", "reg128", "reg64"])
+@pytest.mark.parametrize("gemm_kb", [{}, {"nt_tepi": 0}, {"nt_tepi": 0, "nt_ring": 1}, {"nt_order": 0},
+                                     {"nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
+                                     {"nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
+                         ids=["tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
                                           (3, 131, 96, 32), (8, 140, 64, 384)])

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 --pmc counter_collection.csv files: mean counter value per launch, per (kernel, grid size)."""
+import collections
+import csv
+import glob
+import sys
+
+
+def short(name):
+    name = name.split("(")[0]
+    for key in ("conv_nt_glds", "conv_nt_ring", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_fwd",
+                "conv1_fused_bwd", "conv1_fused_fwd", "global_maxpool", "slab_stage", "colreduce", "whiten", "dense", "adam", "siamese"):
+        if key in name:
+            extra = ""
+            if "conv_nt" in name:
+                extra = "<fwd>" if ("Li0E" in name or ", 0," in name or "E, 128>" in name and "int, E" in name) else "<dgrad?>"
+            if "bn_pool_bwd" in name:
+                extra = "<apply>" if ("Lb1E" in name or "bool, E>" in name) else "<reduce>"
+            return key + extra
+    return name[-40:]
+
+
+def main(paths):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for pth in paths:
+        for f in glob.glob(pth + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                key = (short(r["Kernel_Name"]), r["Grid_Size"])
+                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for v in agg.values() for c in v})
+    print(",".join(["kernel", "grid"] + counters))
+    rows = []
+    for (k, g), cs in agg.items():
+        rows.append([k, g] + ["%.4g" % (sum(cs[c]) / len(cs[c])) if c in cs else "" for c in counters])
+    rows.sort(key=lambda r: -float(r[2 + counters.index("SQ_WAVE_CYCLES")] or 0) if "SQ_WAVE_CYCLES" in counters else 0)
+    for r in rows[:30]:
+        print(",".join(r))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -425,14 +425,128 @@ __device__ inline void nt_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
     }
 }
 
-template <typename T, int EPI, int KB>
-__global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t n_groups) {
+// Epilogue variant that stages the tile in the STORAGE type: bias + ReLU + convert happen in registers (the swapped MFMA
+// layout gives every lane 4 consecutive output columns, so the bias is one float4 per register group), the LDS tile is
+// [128][128*sizeof(T) + 16] (35 KB for bf16 instead of 68 KB of fp32) and the read-back is a pure 16-byte copy plus the
+// BatchNorm partial sums.  With 64-byte K slices this brings the workgroup's LDS to 39 KB: three workgroups per CU.
+template <typename T>
+constexpr int tile_pitch_t() { return BN * (int)sizeof(T) + 16; }
+
+template <typename T, int EPI>
+__device__ inline void nt_epilogue_t(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[2][2], int64_t n, int tl, int t0, int n0,
+                                     int tid, int lane, int w, int wm, int wn) {
+    constexpr int TP = tile_pitch_t<T>();
+    __syncthreads();
+    {
+        const int hi = lane >> 5;
+#pragma unroll
+        for (int in = 0; in < 2; ++in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + in * 32 + 8 * g + 4 * hi;
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_FWD && n0 + nl < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+                    const int m = wm * 64 + im * 32 + (lane & 31);
+                    T o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[im][in][4 * g + j] + b4[j];
+                        if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                        o[j] = Elem<T>::from_f(x);
+                    }
+                    char* dst = lds + m * TP + nl * (int)sizeof(T);
+                    if (sizeof(T) == 2) {
+                        *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<const u32x2*>(o);
+                    } else {
+                        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(o);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;
+    const int ncol = n0 + c8 * 8;
+    const bool cok = ncol < p.N;
+    float s8[8], q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s8[i] = 0.f;
+        q8[i] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = rg + 16 * j;
+        const int t = t0 + row;
+        if (cok && t < p.L) {
+            T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+            const char* src = lds + row * TP + c8 * 8 * (int)sizeof(T);
+            const Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(src);
+            store16<T>(dst, v0);
+            if (sizeof(T) == 4) {
+                const Vec16<T> v1 = *reinterpret_cast<const Vec16<T>*>(src + 16);
+                store16<T>(dst + 4, v1);
+                if (EPI == EPI_FWD) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s8[i] += v0.get(i);
+                        q8[i] += v0.get(i) * v0.get(i);
+                        s8[4 + i] += v1.get(i);
+                        q8[4 + i] += v1.get(i) * v1.get(i);
+                    }
+                }
+            } else if (EPI == EPI_FWD) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xr = v0.get(i);
+                    s8[i] += xr;
+                    q8[i] += xr * xr;
+                }
+            }
+        }
+    }
+    if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s8[i] += __shfl_xor(s8[i], 16, 64);
+            s8[i] += __shfl_xor(s8[i], 32, 64);
+            q8[i] += __shfl_xor(q8[i], 16, 64);
+            q8[i] += __shfl_xor(q8[i], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(lds + BM * TP);
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[(w * 2 + 0) * 128 + c8 * 8 + i] = s8[i];
+                red[(w * 2 + 1) * 128 + c8 * 8 + i] = q8[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const int64_t row = n * p.tilesL + tl;
+            p.stat_sum[row * p.N + n0 + tid] =
+                (red[0 * 128 + tid] + red[2 * 128 + tid]) + (red[4 * 128 + tid] + red[6 * 128 + tid]);
+            p.stat_sq[row * p.N + n0 + tid] =
+                (red[1 * 128 + tid] + red[3 * 128 + tid]) + (red[5 * 128 + tid] + red[7 * 128 + tid]);
+        }
+    }
+}
+
+template <typename T, int KB>
+constexpr int glds_t_lds_bytes() {
+    return (2 * 2 * BM * KB > BM * tile_pitch_t<T>() + 4096) ? 2 * 2 * BM * KB : BM * tile_pitch_t<T>() + 4096;
+}
+
+template <typename T, int EPI, int KB, bool TEPI = false>
+__global__ __launch_bounds__(256, (TEPI && sizeof(T) == 2) ? 3 : 2) void conv_nt_glds_kernel(NtArgs<T> p, int64_t n_groups) {
     constexpr int BK = KB / (int)sizeof(T);
     constexpr int RPI = 1024 / KB;        // rows per wave-instruction (64 lanes x 16 bytes)
     constexpr int CPR = KB / 16;          // chunks per row
     constexpr int NI = BM / RPI / 4;      // instructions per wave per operand per slice
     constexpr int OPB = BM * KB;          // bytes of one operand tile
-    __shared__ __attribute__((aligned(16))) char lds[glds_lds_bytes<KB>()];
+    __shared__ __attribute__((aligned(16))) char lds[TEPI ? glds_t_lds_bytes<T, KB>() : glds_lds_bytes<KB>()];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int nk = p.Ktot / BK;
@@ -504,7 +618,11 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(NtArgs<T> p, int64_t 
             }
 
             // ---- epilogue ----
-            nt_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, tid, lane, w, wm, wn);
+            if (TEPI) {
+                nt_epilogue_t<T, EPI>(p, lds, acc, n, tl, t0, n0, tid, lane, w, wm, wn);
+            } else {
+                nt_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, tid, lane, w, wm, wn);
+            }
             __syncthreads();  // the fp32 tile is consumed before the next tile's DMA overwrites the buffers
         }
     }
@@ -918,6 +1036,8 @@ int g_nt_ablate = 0;
 int g_tn_xcd = 1;
 int g_nt_blocks = 512;  // persistent NT grid (2 workgroups per CU on 256 CUs); vm_set_tuning("nt_blocks", n)
 
+int g_nt_tepi = 1;      // bf16: 64-byte slices + storage-typed epilogue tile (39 KB LDS, 3 workgroups per CU)
+int g_nt_blocks3 = 768;  // persistent grid of that variant
 int g_nt_order = 1;
 int g_nt_ring = 0;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
 int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
@@ -926,6 +1046,11 @@ template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
+    if (g_nt_tepi && a.ablate == 0 && kbytes % 64 == 0 && sizeof(T) == 2) {
+        const int64_t g3 = n_groups * a.tilesN < g_nt_blocks3 ? n_groups * a.tilesN : g_nt_blocks3;
+        hipLaunchKernelGGL((conv_nt_glds_kernel<T, EPI, 64, true>), dim3((unsigned)g3), dim3(256), 0, stream, a, n_groups);
+        return;
+    }
     if (g_nt_ring && a.ablate == 0 && kbytes % 64 == 0) {
         hipLaunchKernelGGL((conv_nt_ring_kernel<T, EPI>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
         return;
@@ -1090,6 +1215,14 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {
         g_gemm_kb = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_tepi") == 0) {
+        g_nt_tepi = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_blocks3") == 0 && value > 0) {
+        g_nt_blocks3 = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_order") == 0) {
