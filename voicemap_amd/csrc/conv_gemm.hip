@@ -1046,7 +1046,9 @@ template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
-    if (g_nt_tepi && a.ablate == 0 && kbytes % 64 == 0 && sizeof(T) == 2) {
+    // measured at cfg-A: the 3-workgroup variant wins for the forward (epilogue-heavy, K = 384..1152: 0.94 -> 0.87 ms) and
+    // loses for dgrad (K = 768..1536, light epilogue: 0.73 -> 0.81 ms), which keeps the 128-byte-slice kernel
+    if (g_nt_tepi && EPI == EPI_FWD && a.ablate == 0 && kbytes % 64 == 0 && sizeof(T) == 2) {
         const int64_t g3 = n_groups * a.tilesN < g_nt_blocks3 ? n_groups * a.tilesN : g_nt_blocks3;
         hipLaunchKernelGGL((conv_nt_glds_kernel<T, EPI, 64, true>), dim3((unsigned)g3), dim3(256), 0, stream, a, n_groups);
         return;
