@@ -945,10 +945,12 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Two register sets: the loads of stage st+2 are issued while stage st is multiplied, so a load has two full stages
+    // (~2 us of MFMA at one workgroup per CU) to come back -- with one set the K loop was bound by that latency.
     int64_t ld_n = w_begin;
     int ld_s = 0;
-    u32x4 rx[4], rd[4];
-    auto gload = [&]() {
+    u32x4 rx0[4], rd0[4], rx1[4], rd1[4];
+    auto gload = [&](u32x4 (&rx)[4], u32x4 (&rd)[4]) {
         const int tb = ld_s * BKP;
         const T* xb = p.x + ld_n * p.x_win_stride + (int64_t)tb * p.c_in;
         const T* db = d_base0 + ld_n * p.du_win_stride + (int64_t)tb * p.c_out;
@@ -963,15 +965,14 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
             ++ld_n;
         }
     };
-    if (n_stages > 0) gload();
     const int r = lane & 31, kh = lane >> 5;
-    for (int64_t st = 0; st < n_stages; ++st) {
+    auto step = [&](int64_t st, u32x4 (&rx)[4], u32x4 (&rd)[4]) {
         char* ta = lds + (int)(st & 1) * 2 * OPB;
         char* tb_ = ta + OPB;
         Transpose4<T, G::PITCH>::store(ta, col0, pg, rx);
         Transpose4<T, G::PITCH>::store(tb_, col0, pg, rd);
         __syncthreads();
-        if (st + 1 < n_stages) gload();
+        if (st + 2 < n_stages) gload(rx, rd);
         const char* pa = ta + (wm * 64 + r) * G::PITCH;
         const char* pb = tb_ + (wn * 128 + r) * G::PITCH;
 #pragma unroll
@@ -984,6 +985,12 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
                 acc[1][in] = Mfma<T>::run(bf, a1, acc[1][in]);
             }
         }
+    };
+    if (n_stages > 0) gload(rx0, rd0);
+    if (n_stages > 1) gload(rx1, rd1);
+    for (int64_t st = 0; st < n_stages; st += 2) {
+        step(st, rx0, rd0);
+        if (st + 1 < n_stages) step(st + 1, rx1, rd1);
     }
 
     float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
