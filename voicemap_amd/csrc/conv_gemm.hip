@@ -325,21 +325,33 @@ template <typename T, int KB>
 __device__ inline void mma_slice_swz(const char* lds_a, const char* lds_b, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
     constexpr int KSTEPS = KB / Mfma<T>::KSTEP_BYTES;
     constexpr int SUB = 16 / (Mfma<T>::KSTEP_BYTES / 2);  // fragments per 16-byte chunk: 1 (bf16), 4 (fp32)
+    using Frag = typename Mfma<T>::Frag;
     const int r = lane & 31, kh = lane >> 5;
     const int ra0 = wm * 64 + r, ra1 = ra0 + 32, rb0 = wn * 64 + r, rb1 = rb0 + 32;
+    auto frag = [&](const char* base, int row, int s) -> Frag {
+        const int f = s * 2 + kh;  // fragment index along K
+        return *reinterpret_cast<const Frag*>(base + row * KB + swz<KB>(row, f / SUB) * 16 + (f % SUB) * (16 / SUB));
+    };
+    // software-pipelined by one k-step: the fragments of step s+1 are requested before the MFMAs of step s are issued,
+    // so an LDS read has a whole k-step (4 MFMAs = 128 cycles) plus the other wave's time to return
+    Frag a0 = frag(lds_a, ra0, 0), a1 = frag(lds_a, ra1, 0), b0 = frag(lds_b, rb0, 0), b1 = frag(lds_b, rb1, 0);
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-        const int f = s * 2 + kh;            // fragment index along K
-        const int ch = f / SUB, sub = f % SUB;
-        const int off = sub * (16 / SUB);
-        typename Mfma<T>::Frag a0 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_a + ra0 * KB + swz<KB>(ra0, ch) * 16 + off);
-        typename Mfma<T>::Frag a1 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_a + ra1 * KB + swz<KB>(ra1, ch) * 16 + off);
-        typename Mfma<T>::Frag b0 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_b + rb0 * KB + swz<KB>(rb0, ch) * 16 + off);
-        typename Mfma<T>::Frag b1 = *reinterpret_cast<const typename Mfma<T>::Frag*>(lds_b + rb1 * KB + swz<KB>(rb1, ch) * 16 + off);
+        Frag na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (s + 1 < KSTEPS) {
+            na0 = frag(lds_a, ra0, s + 1);
+            na1 = frag(lds_a, ra1, s + 1);
+            nb0 = frag(lds_b, rb0, s + 1);
+            nb1 = frag(lds_b, rb1, s + 1);
+        }
         acc[0][0] = Mfma<T>::run(b0, a0, acc[0][0]);
         acc[0][1] = Mfma<T>::run(b1, a0, acc[0][1]);
         acc[1][0] = Mfma<T>::run(b0, a1, acc[1][0]);
         acc[1][1] = Mfma<T>::run(b1, a1, acc[1][1]);
+        a0 = na0;
+        a1 = na1;
+        b0 = nb0;
+        b1 = nb1;
     }
 }
 
