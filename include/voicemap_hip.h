@@ -151,6 +151,17 @@ int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, cons
                          const float* invstd, const float* drop, const float* c1, const float* c2,
                          int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
                          void* du, float* part_du, void* stream);
+/* The same two passes for the LAST block, with dp given in the sparse form GlobalMaxPool1D's backward produces:
+ * dp[n][q][c] = dg[n][c] if q == gidx[n][c] else 0 (dg, gidx as in vm_global_maxpool_fwd/bwd).  Avoids writing and
+ * re-reading the dense (n_windows, L/pool, C) tensor (voicemap/models.py:35-37). */
+int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                               int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_dy,
+                               float* part_dyz, void* stream);
+int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
+                              int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, void* du,
+                              float* part_du, void* stream);
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
 

@@ -466,3 +466,43 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop):
     a = act_i.float().cpu().numpy()
     assert np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
     assert rel_err(a[:, 1:-1], ref_i) < 8e-3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_bn_pool_bwd_sparse_gmax_form_equals_dense(dt):
+    """The last block's BN-backward passes fed with (dg, gidx) must equal the passes fed with the dense tensor that
+    vm_global_maxpool_bwd would have written -- bit for bit."""
+    vm, tdt = DTYPES[dt]
+    r = rng(30)
+    n, wpt, l, c, pool = 4, 2, 46, 24, 2
+    lq = l // pool
+    z = quant(np.maximum(r.normal(0.2, 1.0, (n, l, c)), 0.0), dt).to("cuda", tdt).contiguous()
+    f32 = dict(dtype=torch.float32, device="cuda")
+    scale = dev(r.normal(1.0, 0.3, (2, c)) * np.where(r.random((2, c)) < 0.3, -1, 1))
+    shift, mean = dev(r.normal(0, 0.3, (2, c))), dev(r.normal(0.3, 0.1, (2, c)))
+    invstd = dev(r.uniform(0.5, 2.0, (2, c)))
+    c1, c2 = dev(r.normal(0, 0.01, (2, c))), dev(r.normal(0, 0.01, (2, c)))
+    dg = dev(r.normal(0, 1, (n, c)))
+    gidx = dev(r.integers(0, lq, (n, c)), torch.int32)
+    dense = torch.empty(n, lq, c, dtype=tdt, device="cuda")
+    L().call("vm_global_maxpool_bwd", p(dg), p(gidx), n, lq, c, vm, p(dense), stream())
+    rows = L().query("vm_bn_part_rows")
+    outs = []
+    for sparse in (False, True):
+        pa, pb, pdu = (torch.zeros(n * rows, c, **f32) for _ in range(3))
+        du = torch.zeros(n, l + 2, c, dtype=tdt, device="cuda")
+        if sparse:
+            head = (p(z), p(dg), p(gidx))
+            L().call("vm_bn_pool_bwd_reduce_gmax", *head, p(scale), p(shift), p(mean), p(invstd), None, n, wpt, l, c, pool, vm,
+                     p(pa), p(pb), stream())
+            L().call("vm_bn_pool_bwd_apply_gmax", *head, p(scale), p(shift), p(mean), p(invstd), None, p(c1), p(c2), n, wpt, l, c,
+                     pool, vm, p(du), p(pdu), stream())
+        else:
+            head = (p(z), p(dense))
+            L().call("vm_bn_pool_bwd_reduce", *head, p(scale), p(shift), p(mean), p(invstd), None, n, wpt, l, c, pool, vm, p(pa),
+                     p(pb), stream())
+            L().call("vm_bn_pool_bwd_apply", *head, p(scale), p(shift), p(mean), p(invstd), None, p(c1), p(c2), n, wpt, l, c, pool,
+                     vm, p(du), p(pdu), stream())
+        outs.append((pa.clone(), pb.clone(), pdu.clone(), du.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ drop, const float* __restrict__ c1,
                                                           const float* __restrict__ c2, int64_t wpt, int64_t L, int C, int P,
                                                           T* __restrict__ du, float* __restrict__ part_a,
-                                                          float* __restrict__ part_b) {
+                                                          float* __restrict__ part_b, const float* __restrict__ sp_dg,
+                                                          const int32_t* __restrict__ sp_idx) {
+    // sp_dg / sp_idx (optional): dp is given in its sparse GlobalMaxPool1D-backward form -- dp[n][q][c] = sp_dg[n][c] if
+    // q == sp_idx[n][c] else 0 -- instead of as a dense tensor (saves writing and re-reading it for the last block)
     constexpr int VEC = Elem<T>::kVec;
     __shared__ float red[2][256][VEC];
     const int tid = threadIdx.x;
@@ -216,6 +219,17 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                 }
             }
         }
+        float spv[VEC];
+        int spi[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            spv[i] = 0.f;
+            spi[i] = -1;
+            if (cok && sp_idx != nullptr) {
+                spi[i] = sp_idx[n * C + c0 + i];
+                spv[i] = Elem<T>::to_f(Elem<T>::from_f(sp_dg[n * C + c0 + i]));  // same rounding as the dense dp tensor
+            }
+        }
         if (cok) {
             for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Q; q += (int64_t)RP * BN_SEG) {
                 Vec16<T> zv[POOL];
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                     if (j < nrows) zv[j] = load16<T>(z + (n * L + q * POOL + j) * C + c0);
                 const bool has_dp = q < Lq;
                 Vec16<T> dv;
-                if (has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
+                if (has_dp && sp_idx == nullptr) dv = load16<T>(dp + (n * Lq + q) * C + c0);
                 Vec16<T> ov[POOL];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -243,7 +257,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                             arg = j;
                         }
                     }
-                    const float dpv = has_dp ? dv.get(i) : 0.f;
+                    float dpv = 0.f;
+                    if (has_dp) dpv = sp_idx != nullptr ? (spi[i] == (int)q ? spv[i] : 0.f) : dv.get(i);
                     if (!APPLY) {
                         accA[i] += kc[i] * dpv;
                         accB[i] += dpv * fmaf(ka[i], ext, kb[i]);
@@ -382,19 +397,38 @@ extern "C" int vm_bn_drop_pool_fwd(const void* z, const float* scale, const floa
 
 extern "C" int vm_bn_part_rows(void) { return BN_SEG; }
 
-extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
-                                     const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
-                                     int64_t L, int C, int pool, int dtype, float* part_dy, float* part_dyz, void* stream) {
-    VM_REQUIRE(z && dp && scale && shift && mean && invstd && part_dy && part_dyz, "vm_bn_pool_bwd_reduce: null pointer");
+static int bn_pool_bwd_reduce_impl(const void* z, const void* dp, const float* sp_dg, const int32_t* sp_idx, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd, const float* drop,
+                                   int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                                   float* part_dy, float* part_dyz, void* stream) {
+    VM_REQUIRE(z && (dp || (sp_dg && sp_idx)) && scale && shift && mean && invstd && part_dy && part_dyz,
+               "vm_bn_pool_bwd_reduce: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_pool_bwd_kernel<T, POOL, false>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop,
                            (const float*)nullptr, (const float*)nullptr, windows_per_tower, L, C, P, (T*)nullptr, part_dy,
-                           part_dyz);
+                           part_dyz, sp_dg, sp_idx);
     }));
     return check_launch("vm_bn_pool_bwd_reduce");
+}
+
+extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
+                                     int64_t L, int C, int pool, int dtype, float* part_dy, float* part_dyz, void* stream) {
+    VM_REQUIRE(dp, "vm_bn_pool_bwd_reduce: null pointer");
+    return bn_pool_bwd_reduce_impl(z, dp, nullptr, nullptr, scale, shift, mean, invstd, drop, n_windows, windows_per_tower, L, C,
+                                   pool, dtype, part_dy, part_dyz, stream);
+}
+
+extern "C" int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale,
+                                          const float* shift, const float* mean, const float* invstd, const float* drop,
+                                          int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                                          float* part_dy, float* part_dyz, void* stream) {
+    VM_REQUIRE(dg && gidx, "vm_bn_pool_bwd_reduce_gmax: null pointer");
+    return bn_pool_bwd_reduce_impl(z, nullptr, dg, gidx, scale, shift, mean, invstd, drop, n_windows, windows_per_tower, L, C, pool,
+                                   dtype, part_dy, part_dyz, stream);
 }
 
 extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
@@ -411,19 +445,38 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
     return check_launch("vm_bn_bwd_finalize");
 }
 
-extern "C" int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
-                                    const float* invstd, const float* drop, const float* c1, const float* c2, int64_t n_windows,
-                                    int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, void* du, float* part_du,
-                                    void* stream) {
-    VM_REQUIRE(z && dp && scale && shift && mean && invstd && c1 && c2 && du && part_du, "vm_bn_pool_bwd_apply: null pointer");
+static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp_dg, const int32_t* sp_idx, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, const float* drop, const float* c1,
+                                  const float* c2, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool,
+                                  int dtype, void* du, float* part_du, void* stream) {
+    VM_REQUIRE(z && (dp || (sp_dg && sp_idx)) && scale && shift && mean && invstd && c1 && c2 && du && part_du,
+               "vm_bn_pool_bwd_apply: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_apply: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_pool_bwd_kernel<T, POOL, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop, c1, c2,
-                           windows_per_tower, L, C, P, (T*)du, part_du, (float*)nullptr);
+                           windows_per_tower, L, C, P, (T*)du, part_du, (float*)nullptr, sp_dg, sp_idx);
     }));
     return check_launch("vm_bn_pool_bwd_apply");
+}
+
+extern "C" int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, const float* drop, const float* c1, const float* c2, int64_t n_windows,
+                                    int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, void* du, float* part_du,
+                                    void* stream) {
+    VM_REQUIRE(dp, "vm_bn_pool_bwd_apply: null pointer");
+    return bn_pool_bwd_apply_impl(z, dp, nullptr, nullptr, scale, shift, mean, invstd, drop, c1, c2, n_windows, windows_per_tower,
+                                  L, C, pool, dtype, du, part_du, stream);
+}
+
+extern "C" int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, const float* drop,
+                                         const float* c1, const float* c2, int64_t n_windows, int64_t windows_per_tower, int64_t L,
+                                         int C, int pool, int dtype, void* du, float* part_du, void* stream) {
+    VM_REQUIRE(dg && gidx, "vm_bn_pool_bwd_apply_gmax: null pointer");
+    return bn_pool_bwd_apply_impl(z, nullptr, dg, gidx, scale, shift, mean, invstd, drop, c1, c2, n_windows, windows_per_tower, L,
+                                  C, pool, dtype, du, part_du, stream);
 }
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {

@@ -349,7 +349,8 @@ class HipEncoderEngine:
         G = self.G
         self._call("vm_dense_bwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E,
                  _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), _p(pl["dgmax"]), st)
-        self._call("vm_global_maxpool_bwd", _p(pl["dgmax"]), _p(pl["gidx"]), n, Ll, cl, dt, _p(pl[self.nb - 1]["dp"]), st)
+        # GlobalMaxPool1D backward stays sparse (dgmax, gidx): the last block's BN-backward passes consume that form
+        last = self.nb - 1
         for i in range(self.nb - 1, -1, -1):
             k, c, pool = self.blocks[i]
             b, L = pl[i], pl["L"][i]
@@ -364,12 +365,18 @@ class HipEncoderEngine:
                            _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
                            c, pool, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
                 continue
-            common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
-            self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
+            sparse = (i == last and last > 0)
+            if sparse:
+                common = (_p(b["z"]), _p(pl["dgmax"]), _p(pl["gidx"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
+                          _p(b["invstd"]), dm)
+            else:
+                common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
+            self._call("vm_bn_pool_bwd_reduce_gmax" if sparse else "vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt,
+                       _p(b["pa"]), _p(b["pb"]), st)
             self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
                      _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
-            self._call("vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, pool, dt, _p(b["du"]),
-                     _p(b["pdu"]), st)
+            self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
+                       wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
             self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]),
                        st)
             gw = _p(self.view(f"conv{i+1}.kernel", G))
