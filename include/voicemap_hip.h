@@ -187,10 +187,10 @@ int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t row
  * y: (pairs) fp32 labels, 0 = same speaker (voicemap/librispeech.py:194).  y may be NULL for predict-only
  * (then loss/backward outputs are not touched).
  * pred (pairs); loss_acc[0] = loss, [1] = binary accuracy; demb (2*pairs, E); grad_hw (1 or E); grad_hb (1).
- * loss_scale multiplies the backward seed (1/world_size for data-parallel averaging is applied later, keep 1). */
+ * ws: 4*pairs floats of scratch (per-pair terms, summed in fixed order by a second small launch); unused when y is NULL. */
 int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
                          int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
-                         float* grad_hw, float* grad_hb, void* stream);
+                         float* grad_hw, float* grad_hb, float* ws, void* stream);
 
 /* ---- a9: classifier head Dense(num_classes, softmax) + categorical CE  (experiments/train_classifier.py:112,115)
  * logits (rows, n_classes) fp32 -> prob; labels int32 (rows); loss_acc[0] = mean CE (Keras clip 1e-7), [1] = accuracy;

@@ -277,7 +277,7 @@ def test_siamese_head_loss(head, loss, pairs, e):
     demb = torch.empty(2 * pairs, e, device="cuda")
     ghw, ghb = torch.empty(hw.size, device="cuda"), torch.empty(1, device="cuda")
     L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), p(dev(y)), pairs, e, HEADS[head], LOSSES[loss],
-             p(pred), p(la), p(demb), p(ghw), p(ghb), stream())
+             p(pred), p(la), p(demb), p(ghw), p(ghb), p(torch.empty(4 * pairs, device="cuda")), stream())
     et = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
     prm = {"head.kernel": torch.tensor(hw, dtype=torch.float64, requires_grad=True),
            "head.bias": torch.tensor(hb, dtype=torch.float64, requires_grad=True)}
@@ -294,7 +294,7 @@ def test_siamese_head_loss(head, loss, pairs, e):
     # predict-only launch leaves the training outputs alone and gives the same pred
     pred2 = torch.empty(pairs, device="cuda")
     L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), None, pairs, e, HEADS[head], LOSSES[loss],
-             p(pred2), None, None, None, None, stream())
+             p(pred2), None, None, None, None, None, stream())
     assert torch.equal(pred, pred2)
 
 
@@ -302,7 +302,7 @@ def test_siamese_head_rejects_unimplemented_metric():
     from voicemap_amd._lib import VoicemapHipError
     d = torch.zeros(8, device="cuda")
     with pytest.raises(VoicemapHipError):
-        L().call("vm_siamese_head_loss", p(d), p(d), p(d), None, 2, 2, 5, 0, p(d), None, None, None, None, stream())
+        L().call("vm_siamese_head_loss", p(d), p(d), p(d), None, 2, 2, 5, 0, p(d), None, None, None, None, None, stream())
 
 
 @pytest.mark.parametrize("rows,nc", [(5, 40), (3, 1172)])

@@ -88,44 +88,58 @@ __global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __
 // ---- Dense ------------------------------------------------------------------------------------------
 // Tiny fp32 GEMMs (256 x 512 x 64 at cfg-A).  blockIdx.y carries the index of the broadcast operand's row, so
 // that operand is read with wave-uniform (scalar) loads and the other one coalesced across the 64 lanes.
-__global__ __launch_bounds__(64) void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                       const float* __restrict__ b, int n_in, int n_out,
-                                                       float* __restrict__ out) {
-    const int o = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int n_in, int n_out,
+                                                        float* __restrict__ out) {
+    // 64 outputs x 4 slices of the reduction per workgroup: the dependent-load chain is 4x shorter than one thread per output
+    __shared__ float red[4][64];
+    const int ol = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;
     const int64_t r = blockIdx.y;
-    if (o >= n_out) return;
+    const int per = (n_in + 3) / 4;
+    const int i0 = kq * per, i1 = min(n_in, i0 + per);
     const float* ir = in + r * n_in;
-    float a0 = b ? b[o] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= n_in; i += 4) {
-        a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
-        a1 = fmaf(ir[i + 1], w[(int64_t)(i + 1) * n_out + o], a1);
-        a2 = fmaf(ir[i + 2], w[(int64_t)(i + 2) * n_out + o], a2);
-        a3 = fmaf(ir[i + 3], w[(int64_t)(i + 3) * n_out + o], a3);
+    float a0 = 0.f, a1 = 0.f;
+    if (o < n_out) {
+        int i = i0;
+        for (; i + 2 <= i1; i += 2) {
+            a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
+            a1 = fmaf(ir[i + 1], w[(int64_t)(i + 1) * n_out + o], a1);
+        }
+        if (i < i1) a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
     }
-    for (; i < n_in; ++i) a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
-    out[r * n_out + o] = (a0 + a1) + (a2 + a3);
+    red[kq][ol] = a0 + a1;
+    __syncthreads();
+    if (kq == 0 && o < n_out) out[r * n_out + o] = (b ? b[o] : 0.f) + ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]));
 }
 
 // grad_w[i][o] = sum_r in[r][i]*dout[r][o]; blockIdx.y = i.  The last y-row computes grad_b.
-__global__ __launch_bounds__(64) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                                         int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
-                                                         float* __restrict__ grad_b) {
-    const int o = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                          int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
+                                                          float* __restrict__ grad_b) {
+    __shared__ float red[4][64];
+    const int ol = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;
     const int i = blockIdx.y;
-    if (o >= n_out) return;
-    float a0 = 0.f, a1 = 0.f;
-    if (i < n_in) {
-        int64_t r = 0;
-        for (; r + 2 <= rows; r += 2) {
-            a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
-            a1 = fmaf(in[(r + 1) * n_in + i], dout[(r + 1) * n_out + o], a1);
+    const int64_t per = (rows + 3) / 4;
+    const int64_t r0 = rq * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float a0 = 0.f;
+    if (o < n_out) {
+        if (i < n_in) {
+            for (int64_t r = r0; r < r1; ++r) a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
+        } else {
+            for (int64_t r = r0; r < r1; ++r) a0 += dout[r * n_out + o];
         }
-        for (; r < rows; ++r) a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
-        grad_w[(int64_t)i * n_out + o] = a0 + a1;
-    } else {
-        for (int64_t r = 0; r < rows; ++r) a0 += dout[r * n_out + o];
-        grad_b[o] = a0;
+    }
+    red[rq][ol] = a0;
+    __syncthreads();
+    if (rq == 0 && o < n_out) {
+        const float t = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+        if (i < n_in) {
+            grad_w[(int64_t)i * n_out + o] = t;
+        } else {
+            grad_b[o] = t;
+        }
     }
 }
 
@@ -178,78 +192,84 @@ __device__ inline float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void siamese_head_loss_kernel(const float* __restrict__ emb, const float* __restrict__ hw,
+// pass 1: one wave per pair (lanes over the embedding dimension): distance, sigmoid, per-pair loss terms, d loss / d emb.
+// pair_ws[b] = {loss term, accuracy hit, dL/da, dL/da * distance}.
+__global__ __launch_bounds__(256) void siamese_head_pair_kernel(const float* __restrict__ emb, const float* __restrict__ hw,
                                                                 const float* __restrict__ hb, const float* __restrict__ y,
                                                                 int64_t pairs, int E, int head_kind, int loss_kind,
-                                                                float* __restrict__ pred, float* __restrict__ loss_acc,
-                                                                float* __restrict__ demb, float* __restrict__ grad_hw,
-                                                                float* __restrict__ grad_hb) {
+                                                                float* __restrict__ pred, float* __restrict__ demb,
+                                                                float* __restrict__ pair_ws) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= pairs) return;
+    const float* e1 = emb + b * E;
+    const float* e2 = emb + (pairs + b) * E;
+    float acc = 0.f;
+    for (int j = lane; j < E; j += 64) {
+        const float df = e1[j] - e2[j];
+        acc += head_kind == VM_HEAD_UNIFORM_EUCLIDEAN ? df * df : hw[j] * fabsf(df);
+    }
+    acc = wave_sum(acc);
+    float d = 0.f, a;
+    if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+        d = sqrtf(acc);
+        a = fmaf(hw[0], d, hb[0]);
+    } else {
+        a = acc + hb[0];
+    }
+    const float p = 1.0f / (1.0f + expf(-a));
+    if (lane == 0) pred[b] = p;
+    if (y == nullptr) return;
+    const float yy = y[b];
+    const float dlda = dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs;
+    if (lane == 0) {
+        pair_ws[b * 4 + 0] = loss_value(p, yy, loss_kind);
+        pair_ws[b * 4 + 1] = (rintf(p) == yy) ? 1.f : 0.f;
+        pair_ws[b * 4 + 2] = dlda;
+        pair_ws[b * 4 + 3] = dlda * d;
+    }
+    const float k = head_kind == VM_HEAD_UNIFORM_EUCLIDEAN ? dlda * hw[0] / d : 0.f;  // d == 0 -> inf/NaN like sqrt'(0) in the reference
+    for (int j = lane; j < E; j += 64) {
+        const float df = e1[j] - e2[j];
+        float g;
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+            g = k * df;
+        } else {
+            g = dlda * hw[j] * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        }
+        demb[b * E + j] = g;
+        demb[(pairs + b) * E + j] = -g;
+    }
+}
+
+// pass 2: fixed-order sums over the pairs: loss, accuracy, head gradients.
+__global__ __launch_bounds__(256) void siamese_head_reduce_kernel(const float* __restrict__ emb, const float* __restrict__ pair_ws,
+                                                                  int64_t pairs, int E, int head_kind,
+                                                                  float* __restrict__ loss_acc, float* __restrict__ grad_hw,
+                                                                  float* __restrict__ grad_hb) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
-    const float bias = hb[0];
-    float lsum = 0.f, asum = 0.f, gb = 0.f, gw0 = 0.f;
+    float l = 0.f, h = 0.f, gb = 0.f, gw = 0.f;
     for (int64_t b = tid; b < pairs; b += 256) {
-        const float* e1 = emb + b * E;
-        const float* e2 = emb + (pairs + b) * E;
-        float a = bias, d = 0.f;
-        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
-            float s = 0.f;
-            for (int j = 0; j < E; ++j) {
-                const float df = e1[j] - e2[j];
-                s = fmaf(df, df, s);
-            }
-            d = sqrtf(s);
-            a = fmaf(hw[0], d, a);
-        } else {
-            for (int j = 0; j < E; ++j) a = fmaf(hw[j], fabsf(e1[j] - e2[j]), a);
-        }
-        const float p = 1.0f / (1.0f + expf(-a));
-        pred[b] = p;
-        if (y == nullptr) continue;
-        const float yy = y[b];
-        lsum += loss_value(p, yy, loss_kind);
-        asum += (rintf(p) == yy) ? 1.f : 0.f;
-        const float dlda = dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs;
-        gb += dlda;
-        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
-            gw0 += dlda * d;
-            const float k = dlda * hw[0] / d;  // d == 0 -> inf/NaN, exactly like sqrt'(0) in the reference graph
-            for (int j = 0; j < E; ++j) {
-                const float g = k * (e1[j] - e2[j]);
-                demb[b * E + j] = g;
-                demb[(pairs + b) * E + j] = -g;
-            }
-        } else {
-            for (int j = 0; j < E; ++j) {
-                const float df = e1[j] - e2[j];
-                const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                const float g = dlda * hw[j] * sg;
-                demb[b * E + j] = g;
-                demb[(pairs + b) * E + j] = -g;
-            }
-        }
+        l += pair_ws[b * 4 + 0];
+        h += pair_ws[b * 4 + 1];
+        gb += pair_ws[b * 4 + 2];
+        gw += pair_ws[b * 4 + 3];
     }
-    if (y == nullptr) return;
-    const float ls = block_sum_256(lsum, red);
-    const float as = block_sum_256(asum, red);
+    const float ls = block_sum_256(l, red);
+    const float hs = block_sum_256(h, red);
     const float gbs = block_sum_256(gb, red);
-    const float gws = block_sum_256(gw0, red);
+    const float gws = block_sum_256(gw, red);
     if (tid == 0) {
         loss_acc[0] = ls / (float)pairs;
-        loss_acc[1] = as / (float)pairs;
+        loss_acc[1] = hs / (float)pairs;
         grad_hb[0] = gbs;
         if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) grad_hw[0] = gws;
     }
     if (head_kind == VM_HEAD_WEIGHTED_L1) {
-        // grad_hw[j] = sum_b dlda_b * |e1-e2|_j  (pred was written by this block; make it visible first)
-        __syncthreads();
         for (int j = tid; j < E; j += 256) {
             float acc = 0.f;
-            for (int64_t b = 0; b < pairs; ++b) {
-                const float p = pred[b];
-                const float dlda = dloss_dpred(p, y[b], loss_kind) * p * (1.0f - p) / (float)pairs;
-                acc = fmaf(dlda, fabsf(emb[b * E + j] - emb[(pairs + b) * E + j]), acc);
-            }
+            for (int64_t b = 0; b < pairs; ++b) acc = fmaf(pair_ws[b * 4 + 2], fabsf(emb[b * E + j] - emb[(pairs + b) * E + j]), acc);
             grad_hw[j] = acc;
         }
     }
@@ -378,7 +398,7 @@ extern "C" int vm_dense_fwd(const float* in, const float* w, const float* b, int
     VM_REQUIRE(in && w && out && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_fwd: bad argument");
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // grid.y is limited to 65535
         const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        hipLaunchKernelGGL(dense_fwd_kernel, dim3((n_out + 63) / 64, (unsigned)nr), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(dense_fwd_kernel, dim3((n_out + 63) / 64, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
                            in + r0 * n_in, w, b, n_in, n_out, out + r0 * n_out);
     }
     return check_launch("vm_dense_fwd");
@@ -388,7 +408,7 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
                             float* grad_w, float* grad_b, float* din, void* stream) {
     VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
     VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64), 0, (hipStream_t)stream, in, dout, rows,
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(256), 0, (hipStream_t)stream, in, dout, rows,
                        n_in, n_out, grad_w, grad_b);
     int rc = check_launch("vm_dense_bwd(w)");
     if (rc || din == nullptr) return rc;
@@ -402,16 +422,20 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
 
 extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
                                     int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
-                                    float* grad_hw, float* grad_hb, void* stream) {
+                                    float* grad_hw, float* grad_hb, float* ws, void* stream) {
     VM_REQUIRE(emb && head_w && head_b && pred, "vm_siamese_head_loss: null pointer");
     VM_REQUIRE(pairs > 0 && E > 0, "vm_siamese_head_loss: bad sizes");
     VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1,
                "vm_siamese_head_loss: head_kind %d not implemented (the reference raises NotImplementedError too)", head_kind);
     VM_REQUIRE(loss_kind == VM_LOSS_CONTRASTIVE || loss_kind == VM_LOSS_BCE, "vm_siamese_head_loss: unknown loss %d", loss_kind);
-    VM_REQUIRE(y == nullptr || (loss_acc && demb && grad_hw && grad_hb), "vm_siamese_head_loss: training outputs missing");
-    hipLaunchKernelGGL(siamese_head_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, head_w, head_b, y, pairs, E,
-                       head_kind, loss_kind, pred, loss_acc, demb, grad_hw, grad_hb);
-    return check_launch("vm_siamese_head_loss");
+    VM_REQUIRE(y == nullptr || (loss_acc && demb && grad_hw && grad_hb && ws), "vm_siamese_head_loss: training outputs missing");
+    hipLaunchKernelGGL(siamese_head_pair_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, head_w,
+                       head_b, y, pairs, E, head_kind, loss_kind, pred, demb, ws);
+    int rc = check_launch("vm_siamese_head_loss");
+    if (rc || y == nullptr) return rc;
+    hipLaunchKernelGGL(siamese_head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, (const float*)ws, pairs, E,
+                       head_kind, loss_acc, grad_hw, grad_hb);
+    return check_launch("vm_siamese_head_loss(reduce)");
 }
 
 extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float* prob,

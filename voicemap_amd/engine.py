@@ -257,6 +257,7 @@ class HipEncoderEngine:
             pl["wgrad_ws"] = torch.empty(ws // 4 + 16, dtype=f32, device=dev)
         pl["pred"] = torch.empty(max(n_windows // 2, 1), dtype=f32, device=dev)
         pl["loss_acc"] = torch.zeros(2, dtype=f32, device=dev)
+        pl["head_ws"] = torch.empty(4 * max(n_windows // 2, 1), dtype=f32, device=dev)
         if self.head == "classifier":
             pl["logits"] = torch.empty(n_windows, self.num_classes, dtype=f32, device=dev)
             pl["prob"] = torch.empty_like(pl["logits"])
@@ -407,7 +408,7 @@ class HipEncoderEngine:
                       _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]),
                       _p(pl["loss_acc"]) if train else None, _p(pl["demb"]) if train else None,
                       _p(self.view("head.kernel", G)) if train else None, _p(self.view("head.bias", G)) if train else None,
-                      self.stream())
+                      _p(pl["head_ws"]), self.stream())
         return pl["pred"][:pairs]
 
     def classifier_head(self, pl: dict, labels: Optional[torch.Tensor]):
@@ -532,7 +533,7 @@ class HipEncoderEngine:
         off = 2 * pairs * self.E
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), _p(yd),
                    pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc),
-                   sc.data_ptr() + 4 * off, sc.data_ptr() + 4 * (off + self.E), self.stream())
+                   sc.data_ptr() + 4 * off, sc.data_ptr() + 4 * (off + self.E), _p(pl["head_ws"]), self.stream())
         return pl
 
     def classifier_head_eval(self, pl: dict, labels: torch.Tensor):
