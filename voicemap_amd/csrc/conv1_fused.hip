@@ -360,12 +360,19 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     }
 }
 
+int g_f1_blocks = 768;  // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
+
 static int f1_splits(int64_t n_windows, int chunks) {
-    int s = (int)((768 + n_windows - 1) / n_windows);  // aim for >= ~768 workgroups
+    int s = (int)((g_f1_blocks + n_windows - 1) / n_windows);  // aim for >= g_f1_blocks workgroups
     if (s < 1) s = 1;
     if (s > chunks) s = chunks;
     const int cps = (chunks + s - 1) / s;
     return (chunks + cps - 1) / cps;
+}
+
+int f1_set_blocks(int v) {
+    g_f1_blocks = v;
+    return 0;
 }
 
 }  // namespace vm
