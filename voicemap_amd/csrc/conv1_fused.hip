@@ -246,6 +246,8 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const float k1 = cok ? c1[tw * F + c] : 0.f;
     const float k2 = cok ? c2[tw * F + c] : 0.f;
     const bool use_min = sc < 0.f;
+    // du = [z>0] * (gc*z + gb0 + [arg] ga*dp)   (same folding as bn_pool_bwd_kernel)
+    const float ga = sc * dr, gb0 = sc * (is * k2 * mu - k1), gc = -sc * is * k2;
 
     f32x16 accw;
 #pragma unroll
@@ -289,12 +291,12 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                         }
                     }
                     const int64_t q = tg / POOL + pw;
-                    float dy = 0.f;
-                    if (cok && q < Lq) dy = dr * (float)dp[(n * Lq + q) * F + c];
+                    float ady = 0.f;
+                    if (cok && q < Lq) ady = ga * (float)dp[(n * Lq + q) * F + c];
 #pragma unroll
                     for (int j = 0; j < POOL; ++j) {
                         const float zz = zb[pw * POOL + j];
-                        float gz = sc * ((j == arg ? dy : 0.f) - k1 - (zz - mu) * is * k2);
+                        float gz = fmaf(gc, zz, gb0) + (j == arg ? ady : 0.f);
                         gz = (zz > 0.f && tg + pw * POOL + j < L) ? gz : 0.f;
                         const bf16 gb = (bf16)gz;
                         dub[4 * g + pw * POOL + j] = gb;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     }
 }
 
-int g_f1_blocks = 768;  // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
+int g_f1_blocks = 2048;  // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
 
 static int f1_splits(int64_t n_windows, int chunks) {
     int s = (int)((g_f1_blocks + n_windows - 1) / n_windows);  // aim for >= g_f1_blocks workgroups
