@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--loss", default="contrastive")
     ap.add_argument("--dominant", default="vm_conv_wgrad", help="entry point timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="run the weight-gradient GEMMs on a side stream")
     ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
     ap.add_argument("--tune", default="", help="extra tuning knobs key=value,key=value (vm_set_tuning)")
     ap.add_argument("--nt-blocks", type=int, default=0, help="tuning: persistent grid of the NT conv GEMMs, 0 = library default")
@@ -69,6 +70,7 @@ def main():
     F, E = 128, 64
     blocks = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
     eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
+    eng.overlap_wgrad = bool(a.overlap_wgrad)
     if a.gemm_kb:
         eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
     for kv in [t for t in a.tune.split(",") if t]:

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoicemap_hip.so")
+LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "libvoicemap_hip.so")  # env: A/B experiments
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16 = 0, 1

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoicemap_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"] + os.environ.get("VM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

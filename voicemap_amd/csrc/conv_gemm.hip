@@ -19,6 +19,10 @@
 
 #include "common.hpp"
 
+#ifndef VM_MFMA_SETPRIO
+#define VM_MFMA_SETPRIO 0  // experiment: raise wave priority around MFMA clusters (build with -DVM_MFMA_SETPRIO=1)
+#endif
+
 namespace vm {
 
 constexpr int BM = 128, BN = 128;
@@ -344,10 +348,16 @@ __device__ inline void mma_slice_swz(const char* lds_a, const char* lds_b, int w
             nb0 = frag(lds_b, rb0, s + 1);
             nb1 = frag(lds_b, rb1, s + 1);
         }
+#if VM_MFMA_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         acc[0][0] = Mfma<T>::run(b0, a0, acc[0][0]);
         acc[0][1] = Mfma<T>::run(b1, a0, acc[0][1]);
         acc[1][0] = Mfma<T>::run(b0, a1, acc[1][0]);
         acc[1][1] = Mfma<T>::run(b1, a1, acc[1][1]);
+#if VM_MFMA_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         a0 = na0;
         a1 = na1;
         b0 = nb0;
