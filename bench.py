@@ -142,7 +142,14 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": nflops / t_avg / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["algorithmic_bytes"] = nbytes
     roof["traffic"] = None
+    try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), if this shape was profiled
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            key = "%s|%d|%d|%d|%d" % (a.dominant, shape["n_windows"], shape["L"], shape["c_in"], shape["c_out"])
+            roof["traffic"] = json.load(f)["kernels"][key]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     roof["kernel"] = a.dominant
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape

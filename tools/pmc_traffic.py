@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Build profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
+MI355X_MICROARCH.md prescribes):   python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+
+HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024  (gfx950 rocprofv3 reports exactly half of a wide coalesced streaming
+read) + WRITE_SIZE[KB] * 1024, averaged over the launches of one (kernel, grid) family.  The wgrad launches of the
+three conv blocks have distinct grids, which is how a family is mapped back to its conv shape; bench.py looks the dominant
+kernel's shape up in this file to fill roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def per_family(d, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main(fetch_dir, write_dir, out):
+    from voicemap_amd import _lib
+    lib = _lib.lib()
+    fetch, write = per_family(fetch_dir, "FETCH_SIZE"), per_family(write_dir, "WRITE_SIZE")
+    res = {"note": "hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes); gfx950 FETCH_SIZE counts half of a wide streaming read",
+           "kernels": {}}
+    n = 256
+    for (L, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
+        splits = lib.query("vm_conv_wgrad_splits", n, L, cin, cout)
+        big = 3 * cin >= 192 and cout >= 192
+        tile = 256 if big else 128
+        blocks = splits * (-(-3 * cin // tile)) * (-(-cout // tile))
+        grid = blocks * (512 if big else 256)
+        for (name, g), fv in fetch.items():
+            if "conv_tn" in name and g == grid:
+                wv = write.get((name, g), 0.0)
+                res["kernels"]["vm_conv_wgrad|%d|%d|%d|%d" % (n, L, cin, cout)] = {
+                    "fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024, "grid": g}
+    # everything else: per (kernel, grid) family, for the record
+    fam = {}
+    for (name, g), fv in fetch.items():
+        if "vm" in name:
+            wv = write.get((name, g), 0.0)
+            fam["%s|grid%d" % (name[-70:], g)] = {"fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024}
+    res["families"] = fam
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out, "with", len(res["kernels"]), "wgrad shapes")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
