@@ -46,7 +46,8 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1}
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 0, "nt_p8_phases": 2,
+                 "nt_p8_blocks": 256}
 
 
 @pytest.fixture
@@ -60,13 +61,15 @@ def gemm_kb(request):
         L().call("vm_set_tuning", k.encode(), v)
 
 
-@pytest.mark.parametrize("gemm_kb", [{}, {"nt_tepi": 0}, {"nt_tepi": 0, "nt_ring": 1}, {"nt_order": 0},
-                                     {"nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
-                                     {"nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
-                         ids=["tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
+@pytest.mark.parametrize("gemm_kb", [{}, {"nt_p8_blocks": 3}, {"nt_p8_blocks": 8, "nt_order": 0}, {"nt_p8": 0},
+                                     {"nt_p8": 0, "nt_tepi": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_ring": 1},
+                                     {"nt_p8": 0, "nt_order": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
+                                     {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
+                         ids=["p8", "p8-3wg", "p8-8wg-seq", "tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
-                                          (3, 131, 96, 32), (8, 140, 64, 384)])
+                                          (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),
+                                          (16, 1030, 256, 256)])
 def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kb):
     vm, tdt = DTYPES[dt]
     r = rng(2)

@@ -17,6 +17,8 @@
 // tile belongs to one BatchNorm tower.
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 #ifndef VM_MFMA_SETPRIO
@@ -759,6 +761,387 @@ __global__ __launch_bounds__(256) void conv_nt_ring_kernel(NtArgs<T> p, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT GEMM, 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each), phase-interleaved LDS-DMA pipeline (bf16 only).
+//
+// The 128^2 kernels above are bound by their issue structure (one DMA wait + barrier per K slice; every technique that
+// keeps that structure measured within noise).  This kernel changes the structure:
+//  * A K tile of 64 elements is staged as four 16 KB half tiles (A_lo / A_hi: rows 0-63 / 64-127 of every wave's
+//    128 rows; B_c0 / B_c1: columns 0-31 / 32-63 of every wave's 64 columns: a half tile is what ONE phase reads);
+//    two K tiles are resident (128 KB).  A K tile is computed in four phases (one 64 x 32 quadrant of every wave's
+//    128 x 64 sub-tile each); every phase is a READ slot (fragment ds_reads + the DMA of one half tile of a K tile up to
+//    two ahead) and an MFMA slot (8 x v_mfma_f32_32x32x16_bf16), each closed by a raw s_barrier.
+//  * The waves of rows 128-255 (waves 4-7: they share SIMDs pairwise with waves 0-3) run ONE SLOT BEHIND the others (one
+//    extra barrier up front, one less at the end): while one wave of a SIMD feeds the matrix pipe the other one does its
+//    LDS reads and address arithmetic, and s_setprio keeps the MFMA wave ahead.
+//  * The only DMA wait is a counted s_waitcnt vmcnt(6) once per K tile, so three half tiles stay in flight across
+//    barriers; the stream of K tiles runs across output tiles, so the first K tiles of the next output tile are landing
+//    while a wave runs its (wave-private, barrier-free) epilogue.
+// Stream position g (K tile g of this workgroup's stream) lives in buffer g & 1.  Phases of K tile g:
+//   phase 0: read A_lo, B_c0 | DMA B0(g+1) | MFMA A_lo x B_c0
+//   phase 1: read B_c1       | DMA A0(g+2) | MFMA A_lo x B_c1
+//   phase 2: read A_hi       | DMA B1(g+2) | MFMA A_hi x B_c1
+//   phase 3: read B_c0       | DMA A1(g+2) | vmcnt(6): all of K tile g+1 has landed | MFMA A_hi x B_c0
+// (A_lo / A_hi: the wave's rows 0-63 / 64-127; B_c0 / B_c1: its columns 0-31 / 32-63.)
+// Slots: group y (0: waves 0-3, 1: waves 4-7) runs READ(p) in slot 2p+y and MFMA(p) in slot 2p+y+1.
+// WAR: every READ slot ends with lgkmcnt(0) before its barrier, so the fragment reads of phase p are complete at the end
+//   of slot 2p (group 0) / 2p+1 (group 1); a half tile last read in phase p is re-staged in READ(p+1): slots 2p+2 / 2p+3.
+//   A0(g) is last read in phase 0 -> re-staged in phase 1; B1(g): 1 -> 2; A1(g): 2 -> 3; B0(g): 3 -> phase 0 of g+1.
+// RAW: group y waits (counted) for its own DMAs of K tile g+1 at the end of READ(g,3) = slot 8g+6+y; the first reads of
+//   K tile g+1 are in slot 8g+8, after the barriers closing both of those slots.
+// ------------------------------------------------------------------------------------------------
+namespace p8 {
+constexpr int HALF = 128 * 128;        // 16 KB: 128 rows x 128 bytes (64 bf16 of K)
+constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
+constexpr int SCR = 4096;              // per-wave epilogue scratch: 32 rows x 32 fp32
+constexpr int LDS_BYTES = 2 * BUF + 8 * SCR;  // 160 KB: one workgroup per CU
+enum { H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3 };
+typedef bf16x8 FragA[2][4];
+typedef bf16x8 FragB[4];
+}  // namespace p8
+
+template <int EPI, int PH>
+__global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_groups) {
+    using namespace p8;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int nk = p.Ktot / 64;
+
+    // ---- this workgroup's tiles (same XCD-concurrent order as the kernels above; here tilesL counts 256-row tiles) ----
+    const int total_tiles = n_groups * p.tilesN;
+    if ((int)blockIdx.x >= total_tiles) return;
+    const int my_tiles = (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int G = my_tiles * nk;  // K tiles in the stream
+    const bool xcd_order = p.order == 1 && (n_groups & 7) == 0;
+    auto decode = [&](int it, int& n, int& tl, int& tn) {
+        const unsigned v = blockIdx.x + (unsigned)it * gridDim.x;
+        unsigned group;
+        if (xcd_order) {
+            const unsigned j = v >> 3;
+            tn = (int)(j % (unsigned)p.tilesN);
+            group = (j / (unsigned)p.tilesN) * 8 + (v & 7);
+        } else {
+            tn = (int)(v % (unsigned)p.tilesN);
+            group = v / (unsigned)p.tilesN;
+        }
+        // wave-uniform by construction; say so, so that tile coordinates live in SGPRs and the DMA addresses use the
+        // scalar-base form (the divisions above are done on the vector ALU)
+        tn = __builtin_amdgcn_readfirstlane(tn);
+        tl = __builtin_amdgcn_readfirstlane((int)(group % (unsigned)p.tilesL));
+        n = __builtin_amdgcn_readfirstlane((int)(group / (unsigned)p.tilesL));
+    };
+
+    // ---- DMA geometry: a half tile is 2 rounds of 64 rows; wave w fills rows 8w..8w+7 of a round (lane-linear) ----
+    const int rr = w * 8 + (lane >> 3);
+    const int schunk = ((lane & 7) ^ (((w & 1) << 2) | (lane >> 4))) * 16;  // source chunk that undoes swz<128>
+    const char* const a_base = reinterpret_cast<const char*>(p.a);
+    const char* const b_base = reinterpret_cast<const char*>(p.bt);
+    const int a_pitch = p.a_c * 2, b_pitch = p.Ktot * 2;
+    const int64_t a_win = p.a_win_stride * 2;
+    // A half h holds, for both row groups, the rows read in the same phase: LDS row q <-> tile row (q>>6)*128 + h*64 + (q&63);
+    // B half h likewise: LDS row q <-> tile column (q>>5)*64 + h*32 + (q&31).  (The WAR schedule above is per half tile.)
+    const int b_col = (rr >> 5) * 64 + (rr & 31);
+    auto stage = [&](int h, int buf, int n, int t0, int n0, int kt) {
+        char* dst = lds + buf * BUF + h * HALF + w * 1024;
+        if (h < 2) {
+            const char* src = a_base + n * a_win + kt * 128;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int t = t0 + j * 128 + h * 64 + rr;
+                t = t < p.L ? t : p.L - 1;
+                glds16(src + ((unsigned)t * (unsigned)a_pitch + (unsigned)schunk), dst + j * 8192);
+            }
+        } else {
+            const char* src = b_base + (int64_t)(n0 + (h - 2) * 32) * b_pitch + kt * 128;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                glds16(src + ((unsigned)(b_col + j * 128) * (unsigned)b_pitch + (unsigned)schunk), dst + j * 8192);
+        }
+    };
+
+    // ---- fragment geometry ----
+    const int r = lane & 31, kh = lane >> 5;
+    int off[4];  // byte offset of k-step s of row r inside a 32-row block (swizzled chunk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) off[s] = r * 128 + (((s * 2 + kh) ^ ((r >> 1) & 7)) * 16);
+    const int a_rows = wm * 64 * 128;  // this wave's 64 rows inside an A half tile
+    const int b_rows = wn * 32 * 128;  // its 32 columns inside a B half tile
+    auto read_a = [&](FragA& fa, int buf, int ih) {
+        if (p.ablate & 16) return;
+        const char* base = lds + buf * BUF + ih * HALF + a_rows;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fa[i][s] = *reinterpret_cast<const bf16x8*>(base + i * 32 * 128 + off[s]);
+    };
+    auto read_b = [&](FragB& fb, int buf, int jn) {
+        if (p.ablate & 16) return;
+        const char* base = lds + buf * BUF + (2 + jn) * HALF + b_rows;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(base + off[s]);
+    };
+    auto mma = [&](const FragA& fa, const FragB& fb, f32x16& c0, f32x16& c1) {
+        if (p.ablate & 4) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], fa[0][s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], fa[1][s], c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    // ---- tile state ----
+    int n_c, n_n = 0, tl_c, tn_c, tl_n = 0, tn_n = 0;
+    decode(0, n_c, tl_c, tn_c);
+    if (my_tiles > 1) decode(1, n_n, tl_n, tn_n);
+    int it = 0, kt = 0;
+    // DMA of half h of stream position g + d (d = 1, 2): current tile or the next one
+    const int abl = p.ablate;  // timing experiments only: 2 no epilogue, 4 no MFMA, 8 no in-loop DMA, 16 no fragment reads
+    auto stage_ahead = [&](int h, int g, int d) {
+        if (g + d >= G || (abl & 8)) return;
+        if ((abl & 64) && h >= 2) return;  // 64: no B DMA
+        const int k2 = kt + d;
+        if (abl & 32) {  // 32: A rows always from window 0, tile 0 (cache-hot source)
+            stage(h, (g + d) & 1, 0, 0, tn_c * 256, k2 < nk ? k2 : k2 - nk);
+        } else if (k2 < nk) {
+            stage(h, (g + d) & 1, n_c, tl_c * 256, tn_c * 256, k2);
+        } else {
+            stage(h, (g + d) & 1, n_n, tl_n * 256, tn_n * 256, k2 - nk);
+        }
+    };
+
+    // ---- bias of this wave's columns in read-back layout (lane -> 4 consecutive columns of a 32-column block) ----
+    f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int bias_tn = -1;
+    auto load_bias = [&](int tn) {
+        if (EPI != EPI_FWD || tn == bias_tn) return;
+        bias_tn = tn;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+            bias4[jn] = *reinterpret_cast<const f32x4*>(p.bias + (tn * 256 + wn * 64 + jn * 32) + (unsigned)((lane & 7) * 4));
+        // make the loads complete HERE: the compiler's own wait for them must not land inside the pipelined loop
+        asm volatile("" : "+v"(bias4[0]), "+v"(bias4[1]));
+    };
+
+    f32x16 acc[4][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+
+    // ---- epilogue of the current tile: wave-private, through 4 KB of fp32 scratch per (row block, column block) ----
+    auto epilogue = [&]() {
+        char* scr = lds + 2 * BUF + w * SCR;
+        // The epilogue sits inside the K-tile loop: without this the compiler hoists every lane-dependent offset below out
+        // of the loop and keeps ~40 of them live across the MFMA pipeline (spills).  Recompute them per tile instead.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int hi = ln >> 5, m = ln & 31;
+        const int rb = ln >> 3, c = ln & 7;  // read-back: row within a group of 8, 16-byte chunk
+        const int t_base = tl_c * 256 + wm * 128;
+        const int col_base = tn_c * 256 + wn * 64;
+        // wave-uniform base + 32-bit lane offset: the stores use the scalar-base form (no 64-bit address VGPRs)
+        bf16* const out_u = p.out + ((int64_t)n_c * p.L + t_base) * p.N + col_base;
+        float s4[2][4], q4[2][4];
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[jn][e] = q4[jn][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+                    *reinterpret_cast<f32x4*>(scr + m * 128 + (((2 * g4 + hi) ^ (m & 7)) * 16)) = v;
+                }
+                f32x4 vv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    vv[k] = *reinterpret_cast<const f32x4*>(scr + (k * 8 + rb) * 128 + ((c ^ rb) * 16));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = k * 8 + rb;
+                    const f32x4 v = vv[k];
+                    const bool ok = t_base + i * 32 + row < p.L;
+                    bf16 o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        if (EPI == EPI_FWD) {
+                            x += bias4[jn][e];
+                            x = x > 0.f ? x : 0.f;
+                        }
+                        o[e] = (bf16)x;
+                        if (EPI == EPI_FWD) {
+                            const float xr = ok ? (float)o[e] : 0.f;
+                            s4[jn][e] += xr;
+                            q4[jn][e] += xr * xr;
+                        }
+                    }
+                    if (ok) *reinterpret_cast<u32x2*>(out_u + (unsigned)((i * 32 + row) * p.N + jn * 32 + c * 4)) = *reinterpret_cast<const u32x2*>(o);
+                }
+            }
+        }
+        if (EPI == EPI_FWD && p.stat_sum != nullptr) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        s4[jn][e] += __shfl_xor(s4[jn][e], o, 64);
+                        q4[jn][e] += __shfl_xor(q4[jn][e], o, 64);
+                    }
+                }
+            const int tiles128 = (p.L + 127) / 128;  // rows of the statistics buffers per window (vm_conv_stat_rows)
+            const int srow = tl_c * 2 + wm;
+            if (ln < 8 && srow < tiles128) {
+                const int64_t row = (int64_t)n_c * tiles128 + srow;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const f32x4 sv = {s4[jn][0], s4[jn][1], s4[jn][2], s4[jn][3]};
+                    const f32x4 qv = {q4[jn][0], q4[jn][1], q4[jn][2], q4[jn][3]};
+                    *reinterpret_cast<f32x4*>(p.stat_sum + (row * p.N + col_base + jn * 32) + (unsigned)(c * 4)) = sv;
+                    *reinterpret_cast<f32x4*>(p.stat_sq + (row * p.N + col_base + jn * 32) + (unsigned)(c * 4)) = qv;
+                }
+            }
+        }
+    };
+
+    // ---- prologue: K tile 0 and what the last phases of stream position -1 would have issued (nk >= 3) ----
+    load_bias(tn_c);
+    stage(H_A0, 0, n_c, tl_c * 256, tn_c * 256, 0);
+    stage(H_B1, 0, n_c, tl_c * 256, tn_c * 256, 0);
+    stage(H_A1, 0, n_c, tl_c * 256, tn_c * 256, 0);
+    stage(H_B0, 0, n_c, tl_c * 256, tn_c * 256, 0);
+    if (PH == 4) {
+        stage(H_A0, 1, n_c, tl_c * 256, tn_c * 256, 1);
+        stage(H_B1, 1, n_c, tl_c * 256, tn_c * 256, 1);
+        stage(H_A1, 1, n_c, tl_c * 256, tn_c * 256, 1);
+        wait_vmcnt<6>();
+    } else {
+        stage(H_A0, 1, n_c, tl_c * 256, tn_c * 256, 1);
+        stage(H_B0, 1, n_c, tl_c * 256, tn_c * 256, 1);
+        wait_vmcnt<4>();
+    }
+    slot_end();
+    zero();
+    if (wm == 1) slot_end();  // rows 128-255 run one slot behind
+
+    // ---- the stream ----
+    FragA fa;
+    FragB fb, fb1;
+    if (abl & 16) {  // defined (garbage-free) operands for the no-read timing experiment
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fa[0][s] = fa[1][s] = fb[s] = fb1[s] = bf16x8{};
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        const int buf = g & 1;
+        if (PH == 4) {
+            // phase 0
+            read_a(fa, buf, 0);
+            read_b(fb, buf, 0);
+            stage_ahead(H_B0, g, 1);
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[0][0], acc[1][0]);
+            slot_end();
+            // phase 1
+            read_b(fb, buf, 1);
+            stage_ahead(H_A0, g, 2);
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[0][1], acc[1][1]);
+            slot_end();
+            // phase 2
+            read_a(fa, buf, 1);
+            stage_ahead(H_B1, g, 2);
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[2][1], acc[3][1]);
+            slot_end();
+            // phase 3
+            read_b(fb, buf, 0);
+            stage_ahead(H_A1, g, 2);
+            if (g + 1 < G) {
+                if (abl & 64) {
+                    wait_vmcnt<4>();
+                } else if (g + 2 < G) {
+                    wait_vmcnt<6>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[2][0], acc[3][0]);
+            slot_end();
+        } else {
+            // Two phases of 16 MFMAs (half the barriers, no second read of B_c0):
+            //   phase 0: read A_lo, B_c0, B_c1 | DMA B1(g+1), A1(g+1) | MFMA A_lo x (B_c0, B_c1)
+            //   phase 1: read A_hi             | DMA A0(g+2), B0(g+2) | vmcnt(4): K tile g+1 has landed | MFMA A_hi x (B_c0, B_c1)
+            // WAR: A0, B0, B1 are last read in phase 0 (re-staged from phase 1 on), A1 in phase 1 (re-staged in phase 0 of
+            // g+1).  RAW: group y waits at the end of READ(g,1) = slot 4g+2+y, the first reads of g+1 are in slot 4g+4.
+            read_a(fa, buf, 0);
+            read_b(fb, buf, 0);
+            read_b(fb1, buf, 1);
+            stage_ahead(H_B1, g, 1);
+            stage_ahead(H_A1, g, 1);
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[0][0], acc[1][0]);
+            mma(fa, fb1, acc[0][1], acc[1][1]);
+            slot_end();
+            read_a(fa, buf, 1);
+            stage_ahead(H_A0, g, 2);
+            stage_ahead(H_B0, g, 2);
+            if (g + 1 < G) {
+                if (g + 2 < G && !(abl & 8)) {
+                    wait_vmcnt<4>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[2][0], acc[3][0]);
+            mma(fa, fb1, acc[2][1], acc[3][1]);
+            slot_end();
+        }
+        if (++kt == nk) {
+            if (!(abl & 2)) epilogue();
+            zero();
+            kt = 0;
+            ++it;
+            n_c = n_n;
+            tl_c = tl_n;
+            tn_c = tn_n;
+            if (it < my_tiles) load_bias(tn_c);
+            if (it + 1 < my_tiles) decode(it + 1, n_n, tl_n, tn_n);
+        }
+    }
+    if (wm == 0) slot_end();  // balance the barrier count of the two groups
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
 // of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
 // 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
@@ -1070,11 +1453,45 @@ int g_nt_blocks3 = 768;  // persistent grid of that variant
 int g_nt_order = 1;
 int g_nt_ring = 0;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
 int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
+// 256 x 256 phase-interleaved kernel for bf16 shapes with N % 256 == 0; vm_set_tuning("nt_p8", 0 | 1).  Off by default:
+// at cfg-A its launches are 5-10 % faster than the 128^2 kernels (230 vs 260 us for the block-3 dgrad) but the step is not
+// (4.97 vs 4.92 ms, interleaved A/B): with one lock-step workgroup per CU every CU writes its output tile at the same
+// time (a 33 MB burst per tile round that runs at HBM speed with the matrix pipes idle), and the kernels around it slow
+// down by as much as it gains.  Ablations (block-3 dgrad, us): full 249, no epilogue 186, no DMA 147, neither 116 (= 78 %
+// of the MFMA peak), barrier skeleton alone 47.
+int g_nt_p8 = 0;
+int g_nt_p8_blocks = 256;
+int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
+
+template <typename T, int EPI>
+static bool launch_nt8(const NtArgs<T>&, int64_t, hipStream_t) { return false; }
+template <int EPI>
+static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
+    if (!g_nt_p8 || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
+        n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
+    NtArgs<bf16> b = a;
+    b.tilesL = (a.L + 255) / 256;
+    b.tilesN = a.N / 256;
+    const int64_t n_groups = n_windows * b.tilesL;
+    const int64_t total = n_groups * b.tilesN;
+    const int64_t grid = total < g_nt_p8_blocks ? total : g_nt_p8_blocks;
+    if (g_nt_p8_phases == 4) {
+        hipLaunchKernelGGL((conv_nt8_kernel<EPI, 4>), dim3((unsigned)grid), dim3(512), 0, stream, b, (int)n_groups);
+    } else {
+        hipLaunchKernelGGL((conv_nt8_kernel<EPI, 2>), dim3((unsigned)grid), dim3(512), 0, stream, b, (int)n_groups);
+    }
+    return true;
+}
+template <>
+bool launch_nt8<bf16, EPI_FWD>(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t s) { return launch_nt8_bf16<EPI_FWD>(a, n_windows, s); }
+template <>
+bool launch_nt8<bf16, EPI_DGRAD>(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t s) { return launch_nt8_bf16<EPI_DGRAD>(a, n_windows, s); }
 
 template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
+    if (launch_nt8<T, EPI>(a, n_groups / a.tilesL, stream)) return;
     // measured at cfg-A: the 3-workgroup variant wins for the forward (epilogue-heavy, K = 384..1152: 0.94 -> 0.87 ms) and
     // loses for dgrad (K = 768..1536, light epilogue: 0.73 -> 0.81 ms), which keeps the 128-byte-slice kernel
     if (g_nt_tepi && EPI == EPI_FWD && a.ablate == 0 && kbytes % 64 == 0 && sizeof(T) == 2) {
@@ -1269,6 +1686,19 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_glds") == 0) {
         g_nt_glds = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_p8") == 0) {
+        g_nt_p8 = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_p8_phases") == 0 && (value == 2 || value == 4)) {
+        g_nt_p8_phases = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_p8_blocks") == 0) {
+        VM_REQUIRE(value >= 1 && value <= 4096, "vm_set_tuning: nt_p8_blocks out of range");
+        g_nt_p8_blocks = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_ablate") == 0) {
