@@ -159,21 +159,23 @@ __global__ __launch_bounds__(256) void bn_drop_pool_fwd_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shared body of the two backward passes.  grid = (n_windows, BN_SEG); a block owns pool groups
+// Apply pass of the BatchNorm / ReLU / max-pool backward.  grid = (n_windows, BN_SEG); a block owns pool groups
 // q = seg, seg+BN_SEG, ... of one window.  threads: P lanes over channel vectors x RP row lanes.
-template <typename T, int POOL, bool APPLY>
-__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dp,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ drop, const float* __restrict__ c1,
-                                                          const float* __restrict__ c2, int64_t wpt, int64_t L, int C, int P,
-                                                          T* __restrict__ du, float* __restrict__ part_a,
-                                                          float* __restrict__ part_b, const float* __restrict__ sp_dg,
-                                                          const int32_t* __restrict__ sp_idx) {
-    // sp_dg / sp_idx (optional): dp is given in its sparse GlobalMaxPool1D-backward form -- dp[n][q][c] = sp_dg[n][c] if
-    // q == sp_idx[n][c] else 0 -- instead of as a dense tensor (saves writing and re-reading it for the last block)
+//   du = [z>0] * (kc*z + kb + [arg] ka*dp),   ka = scale*drop, kb = scale*(invstd*c2*mean - c1), kc = -scale*invstd*c2
+// (arg-max of y = (z*scale+shift)*drop over a pool window == arg-max of z if scale*drop >= 0, else arg-min; the first
+// extreme wins).  Also emits the per-segment column sums of du (bias gradient of the convolution below).
+// SP: dp is given in its sparse GlobalMaxPool1D-backward form -- dp[n][q][c] = sp_dg[n][c] if q == sp_idx[n][c] else 0 --
+// instead of as a dense tensor (saves writing and re-reading it for the last block).
+template <typename T, int POOL, bool SP>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ dp,
+                                                                const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ drop,
+                                                                const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                int64_t wpt, int64_t L, int C, int P, T* __restrict__ du,
+                                                                float* __restrict__ part_a, const float* __restrict__ sp_dg,
+                                                                const int32_t* __restrict__ sp_idx) {
     constexpr int VEC = Elem<T>::kVec;
-    __shared__ float red[2][256][VEC];
+    __shared__ float red[256][VEC];
     const int tid = threadIdx.x;
     const int RP = 256 / P;
     const int pl = tid % P, rl = tid / P;
@@ -182,52 +184,41 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
     const int seg = blockIdx.y;
     const int64_t tw = n / wpt;
     const int64_t Lq = L / POOL;
-    const int64_t Q = APPLY ? (L + POOL - 1) / POOL : Lq;  // apply also covers the remainder rows of a floor pool
+    const int64_t Q = (L + POOL - 1) / POOL;  // also covers the remainder rows of a floor pool
 
     for (int cvb = 0; cvb < CV; cvb += P) {
         const int cv = cvb + pl;
         const bool cok = cv < CV;
         const int c0 = cv * VEC;
-        // Per-channel constants folded on entry (fewer live registers -> more waves in flight on these HBM-bound passes):
-        //   arg-max of y = (z*scale+shift)*drop over a pool window == arg-max of z if scale*drop >= 0, else arg-min
-        //   reduce: dy = drop*dp,  dy*zhat = dp * (ka*z + kb),            ka = drop*invstd, kb = -drop*invstd*mean
-        //   apply : du = [z>0] * (kc*z + kb + [arg] ka*dp),                ka = scale*drop, kb = scale*(invstd*c2*mean - c1),
-        //                                                                  kc = -scale*invstd*c2
-        float ka[VEC], kb[VEC], kc[VEC], accA[VEC], accB[VEC];
-        bool use_min[VEC];
+        float ka[VEC], kb[VEC], kc[VEC], acc[VEC], sgn[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            accA[i] = 0.f;
-            accB[i] = 0.f;
+            acc[i] = 0.f;
             ka[i] = kb[i] = kc[i] = 0.f;
-            use_min[i] = false;
+            sgn[i] = 1.f;
             if (cok) {
                 const float sc = scale[tw * C + c0 + i];
                 const float mu = mean[tw * C + c0 + i];
                 const float is = invstd[tw * C + c0 + i];
                 const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
-                use_min[i] = sc * dr < 0.f;
-                if (APPLY) {
-                    const float k1 = c1[tw * C + c0 + i], k2 = c2[tw * C + c0 + i];
-                    ka[i] = sc * dr;
-                    kb[i] = sc * (is * k2 * mu - k1);
-                    kc[i] = -sc * is * k2;
-                } else {
-                    ka[i] = dr * is;
-                    kb[i] = -dr * is * mu;
-                    kc[i] = dr;
-                }
+                const float k1 = c1[tw * C + c0 + i], k2 = c2[tw * C + c0 + i];
+                sgn[i] = sc * dr < 0.f ? -1.f : 1.f;
+                ka[i] = sc * dr;
+                kb[i] = sc * (is * k2 * mu - k1);
+                kc[i] = -sc * is * k2;
             }
         }
-        float spv[VEC];
-        int spi[VEC];
+        float spv[SP ? VEC : 1];
+        int spi[SP ? VEC : 1];
+        if (SP) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            spv[i] = 0.f;
-            spi[i] = -1;
-            if (cok && sp_idx != nullptr) {
-                spi[i] = sp_idx[n * C + c0 + i];
-                spv[i] = Elem<T>::to_f(Elem<T>::from_f(sp_dg[n * C + c0 + i]));  // same rounding as the dense dp tensor
+            for (int i = 0; i < VEC; ++i) {
+                spv[i] = 0.f;
+                spi[i] = -1;
+                if (cok) {
+                    spi[i] = sp_idx[n * C + c0 + i];
+                    spv[i] = Elem<T>::to_f(Elem<T>::from_f(sp_dg[n * C + c0 + i]));  // same rounding as the dense dp tensor
+                }
             }
         }
         if (cok) {
@@ -240,51 +231,136 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                     if (j < nrows) zv[j] = load16<T>(z + (n * L + q * POOL + j) * C + c0);
                 const bool has_dp = q < Lq;
                 Vec16<T> dv;
-                if (has_dp && sp_idx == nullptr) dv = load16<T>(dp + (n * Lq + q) * C + c0);
+                if (!SP && has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
                 Vec16<T> ov[POOL];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float zj[POOL];
 #pragma unroll
                     for (int j = 0; j < POOL; ++j) zj[j] = j < nrows ? zv[j].get(i) : 0.f;
-                    float ext = zj[0];
+                    float ext = sgn[i] * zj[0];
                     int arg = 0;
 #pragma unroll
                     for (int j = 1; j < POOL; ++j) {
-                        const bool better = use_min[i] ? (zj[j] < ext) : (zj[j] > ext);  // strict: first extreme wins
-                        if (j < nrows && better) {
-                            ext = zj[j];
+                        const float y = sgn[i] * zj[j];
+                        if (j < nrows && y > ext) {  // strict: the first extreme wins
+                            ext = y;
                             arg = j;
                         }
                     }
                     float dpv = 0.f;
-                    if (has_dp) dpv = sp_idx != nullptr ? (spi[i] == (int)q ? spv[i] : 0.f) : dv.get(i);
-                    if (!APPLY) {
-                        accA[i] += kc[i] * dpv;
-                        accB[i] += dpv * fmaf(ka[i], ext, kb[i]);
-                    } else {
-                        const float ady = ka[i] * dpv;
+                    if (has_dp) dpv = SP ? (spi[i] == (int)q ? spv[i] : 0.f) : dv.get(i);
+                    const float ady = ka[i] * dpv;
 #pragma unroll
-                        for (int j = 0; j < POOL; ++j) {
-                            float g = fmaf(kc[i], zj[j], kb[i]) + (j == arg ? ady : 0.f);
-                            g = zj[j] > 0.f ? g : 0.f;
-                            ov[j].set(i, g);
-                            if (j < nrows) accA[i] += ov[j].get(i);
-                        }
+                    for (int j = 0; j < POOL; ++j) {
+                        float g = fmaf(kc[i], zj[j], kb[i]) + (j == arg ? ady : 0.f);
+                        g = zj[j] > 0.f ? g : 0.f;
+                        ov[j].set(i, g);
+                        if (j < nrows) acc[i] += ov[j].get(i);
                     }
                 }
-                if (APPLY) {
 #pragma unroll
-                    for (int j = 0; j < POOL; ++j)
-                        if (j < nrows) store16<T>(du + (n * (L + 2) + 1 + q * POOL + j) * C + c0, ov[j]);
-                }
+                for (int j = 0; j < POOL; ++j)
+                    if (j < nrows) store16<T>(du + (n * (L + 2) + 1 + q * POOL + j) * C + c0, ov[j]);
             }
         }
         // reduce over the RP row lanes
 #pragma unroll
+        for (int i = 0; i < VEC; ++i) red[tid][i] = acc[i];
+        __syncthreads();
+        if (rl == 0 && cok) {
+            const int64_t row = n * BN_SEG + seg;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float a = 0.f;
+                for (int r = 0; r < RP; ++r) a += red[r * P + pl][i];
+                part_a[row * C + c0 + i] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduce pass, dense dp.  Same grid/thread mapping as above.  The per-channel constants are factored OUT of the loop:
+//   sum dy      = drop * S0,                       S0 = sum dp
+//   sum dy*zhat = drop*invstd * (S1 - mean*S0),    S1 = sum dp * ext(z)     (ext = max or min over the pool window, by the
+//                                                                            sign of scale*drop, as in the forward pass)
+// so the loop carries 2 accumulators + a sign per channel (the general kernel above carries 5 + the sparse operands and
+// runs at 4 waves per SIMD); two pool groups are loaded before either is consumed.  Read-only stream: z + dp.
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __restrict__ z, const T* __restrict__ dp,
+                                                                 const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ drop,
+                                                                 int64_t wpt, int64_t L, int C, int P,
+                                                                 float* __restrict__ part_a, float* __restrict__ part_b) {
+    constexpr int VEC = Elem<T>::kVec;
+    __shared__ float red[2][256][VEC];
+    const int tid = threadIdx.x;
+    const int RP = 256 / P;
+    const int pl = tid % P, rl = tid / P;
+    const int CV = C / VEC;
+    const int64_t n = blockIdx.x;
+    const int seg = blockIdx.y;
+    const int64_t tw = n / wpt;
+    const int64_t Lq = L / POOL;
+    const int64_t stride = (int64_t)RP * BN_SEG;
+    for (int cvb = 0; cvb < CV; cvb += P) {
+        const int cv = cvb + pl;
+        const bool cok = cv < CV;
+        const int c0 = cv * VEC;
+        float sgn[VEC], s0[VEC], s1[VEC];
+#pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            red[0][tid][i] = accA[i];
-            red[1][tid][i] = accB[i];
+            s0[i] = 0.f;
+            s1[i] = 0.f;
+            sgn[i] = 1.f;
+            if (cok) {
+                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
+                sgn[i] = scale[tw * C + c0 + i] * dr < 0.f ? -1.f : 1.f;
+            }
+        }
+        if (cok) {
+            const T* zb = z + n * L * C + c0;
+            const T* db = dp + n * Lq * C + c0;
+            auto consume = [&](const Vec16<T> (&zv)[POOL], const Vec16<T>& dv) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float m = sgn[i] * zv[0].get(i);
+#pragma unroll
+                    for (int j = 1; j < POOL; ++j) {
+                        const float y = sgn[i] * zv[j].get(i);
+                        m = y > m ? y : m;
+                    }
+                    const float d = dv.get(i);
+                    s0[i] += d;
+                    s1[i] = fmaf(d, sgn[i] * m, s1[i]);
+                }
+            };
+            int64_t q = seg + (int64_t)rl * BN_SEG;
+            for (; q + stride < Lq; q += 2 * stride) {
+                Vec16<T> za[POOL], zc[POOL];
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) za[j] = load16<T>(zb + (q * POOL + j) * C);
+                const Vec16<T> da = load16<T>(db + q * C);
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) zc[j] = load16<T>(zb + ((q + stride) * POOL + j) * C);
+                const Vec16<T> dc = load16<T>(db + (q + stride) * C);
+                consume(za, da);
+                consume(zc, dc);
+            }
+            if (q < Lq) {
+                Vec16<T> za[POOL];
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) za[j] = load16<T>(zb + (q * POOL + j) * C);
+                const Vec16<T> da = load16<T>(db + q * C);
+                consume(za, da);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[0][tid][i] = s0[i];
+            red[1][tid][i] = s1[i];
         }
         __syncthreads();
         if (rl == 0 && cok) {
@@ -296,11 +372,53 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
                     a += red[0][r * P + pl][i];
                     b += red[1][r * P + pl][i];
                 }
-                part_a[row * C + c0 + i] = a;
-                if (!APPLY) part_b[row * C + c0 + i] = b;
+                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
+                const float mu = mean[tw * C + c0 + i], is = invstd[tw * C + c0 + i];
+                part_a[row * C + c0 + i] = dr * a;
+                part_b[row * C + c0 + i] = dr * is * (b - mu * a);
             }
         }
         __syncthreads();
+    }
+}
+
+// Reduce pass when dp is the sparse GlobalMaxPool1D-backward form: dy is non-zero at ONE pool group per (window, channel),
+// so the two sums need z at that group only -- a gather of n*C*POOL elements instead of a pass over z.
+// Writes all BN_SEG partial rows of a window (row 0 = the value, the others 0).
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_gmax_kernel(const T* __restrict__ z, const float* __restrict__ dg,
+                                                                      const int32_t* __restrict__ gidx,
+                                                                      const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd, const float* __restrict__ drop,
+                                                                      int64_t n_windows, int64_t wpt, int64_t L, int C,
+                                                                      float* __restrict__ part_a, float* __restrict__ part_b) {
+    const int64_t e = blockIdx.x * 256LL + threadIdx.x;
+    if (e >= n_windows * C) return;
+    const int64_t n = e / C;
+    const int c = (int)(e - n * C);
+    const int64_t tw = n / wpt;
+    const int64_t Lq = L / POOL;
+    const int q = gidx[e];
+    float a = 0.f, b = 0.f;
+    if (q >= 0 && q < Lq) {
+        const float dr = drop ? drop[e] : 1.0f;
+        const float sc = scale[tw * C + c], mu = mean[tw * C + c], is = invstd[tw * C + c];
+        const bool use_min = sc * dr < 0.f;
+        const T* zp = z + (n * L + (int64_t)q * POOL) * C + c;
+        float ext = Elem<T>::to_f(zp[0]);
+#pragma unroll
+        for (int j = 1; j < POOL; ++j) {
+            const float zj = Elem<T>::to_f(zp[(int64_t)j * C]);
+            if (use_min ? (zj < ext) : (zj > ext)) ext = zj;
+        }
+        const float d = Elem<T>::to_f(Elem<T>::from_f(dg[e]));  // same rounding as the dense dp tensor
+        a = dr * d;
+        b = dr * is * d * (ext - mu);
+    }
+#pragma unroll
+    for (int s = 0; s < BN_SEG; ++s) {
+        part_a[(n * BN_SEG + s) * C + c] = s == 0 ? a : 0.f;
+        part_b[(n * BN_SEG + s) * C + c] = s == 0 ? b : 0.f;
     }
 }
 
@@ -397,38 +515,34 @@ extern "C" int vm_bn_drop_pool_fwd(const void* z, const float* scale, const floa
 
 extern "C" int vm_bn_part_rows(void) { return BN_SEG; }
 
-static int bn_pool_bwd_reduce_impl(const void* z, const void* dp, const float* sp_dg, const int32_t* sp_idx, const float* scale,
-                                   const float* shift, const float* mean, const float* invstd, const float* drop,
-                                   int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
-                                   float* part_dy, float* part_dyz, void* stream) {
-    VM_REQUIRE(z && (dp || (sp_dg && sp_idx)) && scale && shift && mean && invstd && part_dy && part_dyz,
-               "vm_bn_pool_bwd_reduce: null pointer");
-    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce: bad sizes");
-    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
-        const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_kernel<T, POOL, false>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop,
-                           (const float*)nullptr, (const float*)nullptr, windows_per_tower, L, C, P, (T*)nullptr, part_dy,
-                           part_dyz, sp_dg, sp_idx);
-    }));
-    return check_launch("vm_bn_pool_bwd_reduce");
-}
-
 extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
                                      int64_t L, int C, int pool, int dtype, float* part_dy, float* part_dyz, void* stream) {
-    VM_REQUIRE(dp, "vm_bn_pool_bwd_reduce: null pointer");
-    return bn_pool_bwd_reduce_impl(z, dp, nullptr, nullptr, scale, shift, mean, invstd, drop, n_windows, windows_per_tower, L, C,
-                                   pool, dtype, part_dy, part_dyz, stream);
+    VM_REQUIRE(z && dp && scale && shift && mean && invstd && part_dy && part_dyz, "vm_bn_pool_bwd_reduce: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, windows_per_tower, L, C, P,
+                           part_dy, part_dyz);
+    }));
+    return check_launch("vm_bn_pool_bwd_reduce");
 }
 
 extern "C" int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale,
                                           const float* shift, const float* mean, const float* invstd, const float* drop,
                                           int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
                                           float* part_dy, float* part_dyz, void* stream) {
-    VM_REQUIRE(dg && gidx, "vm_bn_pool_bwd_reduce_gmax: null pointer");
-    return bn_pool_bwd_reduce_impl(z, nullptr, dg, gidx, scale, shift, mean, invstd, drop, n_windows, windows_per_tower, L, C, pool,
-                                   dtype, part_dy, part_dyz, stream);
+    VM_REQUIRE(z && dg && gidx && scale && shift && mean && invstd && part_dy && part_dyz,
+               "vm_bn_pool_bwd_reduce_gmax: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce_gmax: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        const int64_t blocks = (n_windows * C + 255) / 256;
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_gmax_kernel<T, POOL>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)z, dg, gidx, scale, mean, invstd, drop, n_windows, windows_per_tower, L, C, part_dy,
+                           part_dyz);
+    }));
+    return check_launch("vm_bn_pool_bwd_reduce_gmax");
 }
 
 extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
@@ -454,9 +568,15 @@ static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_apply: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_kernel<T, POOL, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop, c1, c2,
-                           windows_per_tower, L, C, P, (T*)du, part_du, (float*)nullptr, sp_dg, sp_idx);
+        if (sp_idx != nullptr) {
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                               L, C, P, (T*)du, part_du, sp_dg, sp_idx);
+        } else {
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                               L, C, P, (T*)du, part_du, sp_dg, sp_idx);
+        }
     }));
     return check_launch("vm_bn_pool_bwd_apply");
 }
