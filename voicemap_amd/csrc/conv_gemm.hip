@@ -1418,6 +1418,237 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad, 256 x 256 output tile, LDS-DMA staging + hardware-transposing fragment reads (bf16 only).
+//
+// Both operands of the TN GEMM are position-major in memory (X[pos][ci], dU[pos][co]) while an MFMA lane wants 8
+// consecutive POSITIONS of one channel.  The kernels above transpose in registers (4 x 16-byte loads, v_perm_b32,
+// 8-byte ds_writes).  gfx950 can transpose on the LDS read instead: ds_read_b64_tr_b16 gives lane i of a 16-lane group
+// element (i & 3) of the 8-byte words read by lanes 4j + (i >> 2), j = 0..3 (tools/probe/tr_read_probe.hip) -- i.e. column
+// i of a [4 positions][16 channels] block.  So the tiles are staged UNtransposed by global_load_lds (no VALU, no ds_write)
+// as blocks of [64 positions][32 channels] (64-byte rows: the 32 lanes served per LDS cycle read 4 rows x 64 bytes = 256
+// contiguous bytes, conflict-free), and a fragment is two transposing reads.
+//
+// The pipeline is the one of conv_nt8_kernel (2-phase form): 8 waves as 2 (kk) x 4 (co), 128 x 64 per wave, a stage of 64
+// positions staged as four 16 KB half tiles (A_lo / A_hi: kk rows 0-63 / 64-127 of every wave's 128; B_c0 / B_c1: co
+// columns 0-31 / 32-63 of every wave's 64), two stages resident, waves 4-7 one slot behind waves 0-3, counted vmcnt.
+// No epilogue inside the stream: the 256 x 256 fp32 tile is written once, to the split's slab.
+//   phase 0: read A_lo, B_c0, B_c1 | DMA B1(g+1), A1(g+1) | MFMA A_lo x (B_c0, B_c1)
+//   phase 1: read A_hi             | DMA A0(g+2), B0(g+2) | vmcnt(4): stage g+1 has landed | MFMA A_hi x (B_c0, B_c1)
+// Positions past the end of a window are neutralised on the dU side: their source row is the (zero) halo row L+1 of the
+// padded dU tensor, so whatever X row is fetched for them contributes nothing.
+// ------------------------------------------------------------------------------------------------
+namespace t8 {
+constexpr int BLK = 64 * 64;           // one block: 64 positions x 32 channels (64-byte rows)
+constexpr int HALF = 4 * BLK;          // 16 KB
+constexpr int BUF = 4 * HALF;          // A_lo A_hi B_c0 B_c1
+constexpr int LDS_BYTES = 2 * BUF;     // 128 KB
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+}  // namespace t8
+
+__global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
+    using namespace t8;
+    using p8::FragA;
+    using p8::FragB;
+    using p8::H_A0;
+    using p8::H_A1;
+    using p8::H_B0;
+    using p8::H_B1;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = __builtin_amdgcn_readfirstlane((int)(b % p.tilesJ));
+    b /= p.tilesJ;
+    const int ti = __builtin_amdgcn_readfirstlane((int)(b % p.tilesI));
+    const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
+    const int i0 = ti * 256, j0 = tj * 256;
+
+    const int w_begin = (int)((int64_t)split * p.win_per_split);
+    int w_end = w_begin + (int)p.win_per_split;
+    if (w_end > (int)p.n_windows) w_end = (int)p.n_windows;
+    const int spw = (p.L + 63) / 64;  // stages per window
+    const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (G > 0) {
+        // ---- DMA geometry: a half tile is 16 wave-instructions of 1 KB (16 positions x 64 bytes of one block) ----
+        // instruction q = 8 j + w (j = 0, 1): block q >> 2, position quarter q & 3; lane -> position lane >> 2, chunk lane & 3
+        const int dpos = (w & 3) * 16 + (lane >> 2);
+        const int dchunk = (lane & 3) * 8;  // elements
+        const char* const x_base = reinterpret_cast<const char*>(p.x);
+        const char* const d_base = reinterpret_cast<const char*>(p.du);
+        auto stage = [&](int h, int buf, int n, int st) {
+            char* dst = lds + buf * BUF + h * HALF + w * 1024;
+            int t = st * 64 + dpos;
+            if (h < 2) {
+                t = t < p.L ? t : p.L - 1;
+                const char* src = x_base + n * p.x_win_stride * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int bq = j * 2 + (w >> 2);  // block: row group bq >> 1, 32-row block bq & 1
+                    int kk0 = i0 + (bq >> 1) * 128 + h * 64 + (bq & 1) * 32;
+                    kk0 = kk0 < p.Kk ? kk0 : 0;
+                    glds16(src + (unsigned)(t * p.c_in + kk0 + dchunk) * 2u, dst + j * 8192);
+                }
+            } else {
+                t = (t < p.L ? t : p.L) + 1;  // row L+1 of the padded tensor is the zero halo
+                const char* src = d_base + n * p.du_win_stride * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int bq = j * 2 + (w >> 2);  // block = column group (wave column) bq
+                    int co0 = j0 + bq * 64 + (h - 2) * 32;
+                    co0 = co0 < p.c_out ? co0 : 0;
+                    glds16(src + (unsigned)(t * p.c_out + co0 + dchunk) * 2u, dst + j * 8192);
+                }
+            }
+        };
+
+        // ---- fragment geometry: two transposing 8-byte reads per fragment ----
+        const int li = lane & 15, lg = (lane >> 4) & 1, kh = lane >> 5;
+        const int lane_off = (kh * 8 + (li >> 2)) * 64 + lg * 32 + (li & 3) * 8;
+        // Inline asm on purpose: for the ds_read_tr builtin hipcc inserts s_waitcnt vmcnt(0) before every read that follows
+        // a global_load_lds (it cannot tell which LDS bytes the DMA writes), which would drain the DMA pipeline twice per
+        // stage.  The asm form is invisible to that pass -- and to its lgkmcnt bookkeeping: read_done() below is the wait.
+        auto tr8 = [&](const char* ptr) -> bf16x8 {
+            const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ptr;
+            u32x2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi) : "v"(a));
+            const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        auto read_a = [&](FragA& fa, int buf, int ih) {
+            const char* base = lds + buf * BUF + ih * HALF + wm * 2 * BLK + lane_off;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[i][s] = tr8(base + i * BLK + s * 1024);
+        };
+        auto read_b = [&](FragB& fb, int buf, int jn) {
+            const char* base = lds + buf * BUF + (2 + jn) * HALF + wn * BLK + lane_off;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fb[s] = tr8(base + s * 1024);
+        };
+        auto mma = [&](const FragA& fa, const FragB& fb, f32x16& c0, f32x16& c1) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], fa[0][s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], fa[1][s], c1, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto slot_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+        // stream cursors: (n1, s1) = position g+1, (n2, s2) = position g+2
+        int n1 = w_begin, s1 = 0, n2, s2;
+        auto advance = [&](int& n, int& s) {
+            if (++s == spw) {
+                s = 0;
+                ++n;
+            }
+        };
+        // ---- prologue: stage 0 whole, A0/B0 of stage 1 ----
+        stage(H_A0, 0, n1, s1);
+        stage(H_B1, 0, n1, s1);
+        stage(H_A1, 0, n1, s1);
+        stage(H_B0, 0, n1, s1);
+        advance(n1, s1);  // -> position 1
+        n2 = n1;
+        s2 = s1;
+        if (G > 1) {
+            stage(H_A0, 1, n1, s1);
+            stage(H_B0, 1, n1, s1);
+            wait_vmcnt<4>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        advance(n2, s2);  // -> position 2
+        slot_end();
+        if (wm == 1) slot_end();  // kk rows 128-255 run one slot behind
+
+        FragA fa;
+        FragB fb, fb1;
+        for (int g = 0; g < G; ++g) {
+            const int buf = g & 1;
+            read_a(fa, buf, 0);
+            read_b(fb, buf, 0);
+            read_b(fb1, buf, 1);
+            if (g + 1 < G) {
+                stage(H_B1, buf ^ 1, n1, s1);
+                stage(H_A1, buf ^ 1, n1, s1);
+            }
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[0][0], acc[1][0]);
+            mma(fa, fb1, acc[0][1], acc[1][1]);
+            slot_end();
+            read_a(fa, buf, 1);
+            if (g + 2 < G) {
+                stage(H_A0, buf, n2, s2);
+                stage(H_B0, buf, n2, s2);
+                wait_vmcnt<4>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            read_done();
+            slot_end();
+            mma(fa, fb, acc[2][0], acc[3][0]);
+            mma(fa, fb1, acc[2][1], acc[3][1]);
+            slot_end();
+            n1 = n2;
+            s1 = s2;
+            advance(n2, s2);
+        }
+        if (wm == 0) slot_end();  // balance the barrier count of the two groups
+    }
+
+    // ---- the split's slab tile ----
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i0 + wm * 128 + i * 32 + (lane & 31);
+        if (row >= p.Kk) continue;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = j0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+                if (col < p.c_out) {
+                    const f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
+            }
+        }
+    }
+}
+
 // fp32 Keras kernel (3, c_in, c_out) -> wf[co][k*c_in + ci] = W[k][ci][co];  wd[ci][j*c_out + co] = W[2-j][ci][co]
 template <typename T>
 __global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, T* wd) {
@@ -1577,6 +1808,16 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
 
 int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 
+int g_tn_p8 = 1;  // LDS-DMA + transposing-read wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_p8", 0 | 1)
+template <typename T>
+static bool launch_tn8(const TnArgs<T>&, int64_t, hipStream_t) { return false; }
+template <>
+bool launch_tn8<bf16>(const TnArgs<bf16>& a, int64_t grid, hipStream_t stream) {
+    if (!g_tn_p8 || a.c_in % 32 != 0 || a.c_out % 32 != 0 || a.n_windows >= (1LL << 30)) return false;
+    hipLaunchKernelGGL(conv_tn8_kernel, dim3((unsigned)grid), dim3(512), 0, stream, a);
+    return true;
+}
+
 static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_in >= 192 && c_out >= 192; }
 
 // Split of the position reduction over windows.  All workgroups of a launch do the same amount of work
@@ -1635,7 +1876,8 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
-        if (big) {
+        if (big && launch_tn8<T>(a, grid, (hipStream_t)stream)) {
+        } else if (big) {
             hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, a);
         } else if (g_gemm_kb == 64) {
             hipLaunchKernelGGL((conv_tn_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1686,6 +1928,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_glds") == 0) {
         g_nt_glds = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "tn_p8") == 0) {
+        g_tn_p8 = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_p8") == 0) {
