@@ -165,6 +165,14 @@ int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gid
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
 
+/* LAST block only: vm_bn_drop_pool_fwd fused with GlobalMaxPool1D (voicemap/models.py:31-37).  The pooled tensor of the
+ * last block is never materialised: gmax / gidx are exactly what vm_global_maxpool_fwd would return for it (values rounded
+ * to `dtype`, gidx = first maximum).  ws: vm_bn_drop_pool_gmax_workspace_bytes(n_windows, C) bytes. */
+int64_t vm_bn_drop_pool_gmax_workspace_bytes(int64_t n_windows, int C);
+int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_windows,
+                             int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* gmax, int32_t* gidx,
+                             void* ws, void* stream);
+
 /* ---- a1 tail: GlobalMaxPool1D + Dense(E)  (voicemap/models.py:37-39) ------------------------------------
  * act: padded (n_windows, L+2, C) `dtype`; gmax (n_windows, C) fp32; gidx (n_windows, C) int32 = first argmax. */
 int vm_global_maxpool_fwd(const void* act, int64_t n_windows, int64_t L, int C, int dtype, float* gmax,

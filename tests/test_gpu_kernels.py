@@ -252,6 +252,31 @@ def test_global_maxpool(dt, n, l, c):
     assert np.array_equal(dp.float().cpu().numpy().astype(np.float64), ref)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 750, 64, 2, True), (2, 1, 37, 136, 4, False), (3, 3, 9, 8, 2, True),
+                                                     (2, 2, 64, 512, 1, False)])
+def test_bn_drop_pool_gmax_fused_equals_two_pass(dt, n, wpt, l, c, pool, use_drop):
+    """Last block: the fused BN-apply + dropout + max-pool + global max must return exactly what vm_bn_drop_pool_fwd followed
+    by vm_global_maxpool_fwd returns (values AND first-argmax indices; coarse value grid -> many ties)."""
+    vm, tdt = DTYPES[dt]
+    r = rng(31)
+    towers = n // wpt
+    z = quant(np.maximum(np.round(r.normal(0.2, 1.0, (n, l, c)) * 2) / 2, 0.0), dt).to("cuda", tdt).contiguous()
+    scale = dev(np.round(r.normal(1.0, 0.3, (towers, c)) * 4) / 4 * np.where(r.random((towers, c)) < 0.3, -1, 1))
+    shift = dev(np.round(r.normal(0, 0.3, (towers, c)) * 4) / 4)
+    drop = dev((r.random((n, c)) > 0.2) / 0.8) if use_drop else None
+    lq = l // pool
+    act = torch.zeros(n, lq + 2, c, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), p(drop), n, wpt, l, c, pool, vm, p(act), stream())
+    g0, i0 = torch.empty(n, c, device="cuda"), torch.empty(n, c, dtype=torch.int32, device="cuda")
+    L().call("vm_global_maxpool_fwd", p(act), n, lq, c, vm, p(g0), p(i0), stream())
+    g1, i1 = torch.empty_like(g0), torch.empty_like(i0)
+    ws = torch.empty(L().query("vm_bn_drop_pool_gmax_workspace_bytes", n, c) // 4, device="cuda")
+    L().call("vm_bn_drop_pool_gmax_fwd", p(z), p(scale), p(shift), p(drop), n, wpt, l, c, pool, vm, p(g1), p(i1), p(ws), stream())
+    assert torch.equal(g0, g1)
+    assert torch.equal(i0, i1)
+
+
 def test_dense_fwd_bwd():
     r = rng(7)
     rows, ni, no = 10, 72, 33

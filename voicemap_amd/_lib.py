@@ -59,6 +59,8 @@ SIGNATURES = {
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),
+    "vm_bn_drop_pool_gmax_workspace_bytes": (L, [L, I]),
+    "vm_bn_drop_pool_gmax_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P, P, P]),
     "vm_global_maxpool_fwd": (I, [P, L, L, I, I, P, P, P]),
     "vm_global_maxpool_bwd": (I, [P, P, L, L, I, I, P, P]),
     "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),

@@ -159,6 +159,118 @@ __global__ __launch_bounds__(256) void bn_drop_pool_fwd_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// Last block: BatchNorm apply + dropout + max-pool + GlobalMaxPool1D in one pass over z (voicemap/models.py:31-37).  The
+// pooled tensor of the last block has no other consumer (its BN backward works from z and the sparse (dg, gidx) form), so
+// it is never written: every block keeps the running maximum of the storage-rounded pooled values of its pool groups
+// (first maximum wins, as in vm_global_maxpool_fwd) and a second kernel reduces the BN_SEG segment partials.
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    const float* __restrict__ drop, int64_t wpt, int64_t L,
+                                                                    int C, int P, float* __restrict__ part_v,
+                                                                    int32_t* __restrict__ part_i) {
+    constexpr int VEC = Elem<T>::kVec;
+    __shared__ float rv[256][VEC];
+    __shared__ int ri[256][VEC];
+    const int tid = threadIdx.x;
+    const int RP = 256 / P;
+    const int pl = tid % P, rl = tid / P;
+    const int CV = C / VEC;
+    const int64_t n = blockIdx.x;
+    const int seg = blockIdx.y;
+    const int64_t tw = n / wpt;
+    const int64_t Lq = L / POOL;
+    for (int cvb = 0; cvb < CV; cvb += P) {
+        const int cv = cvb + pl;
+        const bool cok = cv < CV;
+        const int c0 = cv * VEC;
+        float best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            best[i] = -INFINITY;
+            bi[i] = 0x7fffffff;
+        }
+        if (cok) {
+            float sc[VEC], sh[VEC], dr[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sc[i] = scale[tw * C + c0 + i];
+                sh[i] = shift[tw * C + c0 + i];
+                dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
+            }
+            const T* zrow = z + n * L * C + c0;
+            for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Lq; q += (int64_t)RP * BN_SEG) {
+                Vec16<T> v[POOL];
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float y = fmaf(v[0].get(i), sc[i], sh[i]) * dr[i];
+#pragma unroll
+                    for (int j = 1; j < POOL; ++j) {
+                        const float yj = fmaf(v[j].get(i), sc[i], sh[i]) * dr[i];
+                        y = yj > y ? yj : y;
+                    }
+                    y = Elem<T>::to_f(Elem<T>::from_f(y));  // the value the pooled tensor would have held
+                    if (y > best[i] || bi[i] == 0x7fffffff) {
+                        best[i] = y;
+                        bi[i] = (int)q;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            rv[tid][i] = best[i];
+            ri[tid][i] = bi[i];
+        }
+        __syncthreads();
+        if (rl == 0 && cok) {
+            const int64_t row = n * BN_SEG + seg;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float b = rv[pl][i];
+                int k = ri[pl][i];
+                for (int r = 1; r < RP; ++r) {
+                    const float y = rv[r * P + pl][i];
+                    const int kk = ri[r * P + pl][i];
+                    if (kk != 0x7fffffff && (k == 0x7fffffff || y > b || (y == b && kk < k))) {
+                        b = y;
+                        k = kk;
+                    }
+                }
+                part_v[row * C + c0 + i] = b;
+                part_i[row * C + c0 + i] = k;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gmax_segments_kernel(const float* __restrict__ part_v, const int32_t* __restrict__ part_i,
+                                                            int64_t n_windows, int C, float* __restrict__ gmax,
+                                                            int32_t* __restrict__ gidx) {
+    const int64_t e = blockIdx.x * 256LL + threadIdx.x;
+    if (e >= n_windows * C) return;
+    const int64_t n = e / C;
+    const int c = (int)(e - n * C);
+    float b = -INFINITY;
+    int k = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < BN_SEG; ++s) {
+        const float y = part_v[(n * BN_SEG + s) * C + c];
+        const int kk = part_i[(n * BN_SEG + s) * C + c];
+        if (kk != 0x7fffffff && (k == 0x7fffffff || y > b || (y == b && kk < k))) {
+            b = y;
+            k = kk;
+        }
+    }
+    gmax[e] = b;
+    gidx[e] = k;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Apply pass of the BatchNorm / ReLU / max-pool backward.  grid = (n_windows, BN_SEG); a block owns pool groups
 // q = seg, seg+BN_SEG, ... of one window.  threads: P lanes over channel vectors x RP row lanes.
 //   du = [z>0] * (kc*z + kb + [arg] ka*dp),   ka = scale*drop, kb = scale*(invstd*c2*mean - c1), kc = -scale*invstd*c2
@@ -511,6 +623,27 @@ extern "C" int vm_bn_drop_pool_fwd(const void* z, const float* scale, const floa
                            (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, (T*)out);
     }));
     return check_launch("vm_bn_drop_pool_fwd");
+}
+
+extern "C" int64_t vm_bn_drop_pool_gmax_workspace_bytes(int64_t n_windows, int C) {
+    return n_windows * BN_SEG * (int64_t)C * 8;
+}
+
+extern "C" int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const float* shift, const float* drop,
+                                        int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                                        float* gmax, int32_t* gidx, void* ws, void* stream) {
+    VM_REQUIRE(z && scale && shift && gmax && gidx && ws, "vm_bn_drop_pool_gmax_fwd: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_drop_pool_gmax_fwd: bad sizes");
+    float* part_v = (float*)ws;
+    int32_t* part_i = (int32_t*)(part_v + n_windows * BN_SEG * (int64_t)C);
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i);
+    }));
+    hipLaunchKernelGGL(gmax_segments_kernel, dim3((unsigned)((n_windows * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       part_v, part_i, n_windows, C, gmax, gidx);
+    return check_launch("vm_bn_drop_pool_gmax_fwd");
 }
 
 extern "C" int vm_bn_part_rows(void) { return BN_SEG; }

@@ -241,6 +241,8 @@ class HipEncoderEngine:
                     b[nm] = torch.empty(n_windows * prow, c, dtype=f32, device=dev)
             pl[i] = b
         cl = self.blocks[-1][1]
+        pl["gmax_ws"] = torch.empty(self.lib.query("vm_bn_drop_pool_gmax_workspace_bytes", n_windows, cl) // 4, dtype=f32,
+                                    device=dev)
         pl["gmax"] = torch.empty(n_windows, cl, dtype=f32, device=dev)
         pl["gidx"] = torch.empty(n_windows, cl, dtype=torch.int32, device=dev)
         pl["emb"] = torch.empty(n_windows, self.E, dtype=f32, device=dev)
@@ -297,6 +299,7 @@ class HipEncoderEngine:
         assert n_towers <= 2 or not training, "at most two towers per call"
         wpt = windows_per_tower if training else n
         pl["wpt"], pl["drop"] = wpt, drop_masks
+        fused_tail = False
         for i, (k, c, pool) in enumerate(self.blocks):
             b, L = pl[i], pl["L"][i]
             ssum = _p(b["ssum"]) if training else None
@@ -334,10 +337,18 @@ class HipEncoderEngine:
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
             dm = drop_masks[i] if (drop_masks is not None and training) else None
+            if i == self.nb - 1:
+                # last block: BN apply + dropout + max-pool + GlobalMaxPool1D in one pass; its pooled tensor has no other
+                # consumer and is never written
+                self._call("vm_bn_drop_pool_gmax_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt, L, c, pool,
+                           dt, _p(pl["gmax"]), _p(pl["gidx"]), _p(pl["gmax_ws"]), st)
+                fused_tail = True
+                continue
             self._call("vm_bn_drop_pool_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt, L, c, pool, dt,
                      _p(b["act"]), st)
         cl, Ll = self.blocks[-1][1], pl["L"][-1]
-        self._call("vm_global_maxpool_fwd", _p(pl[self.nb - 1]["act"]), n, Ll, cl, dt, _p(pl["gmax"]), _p(pl["gidx"]), st)
+        if not fused_tail:
+            self._call("vm_global_maxpool_fwd", _p(pl[self.nb - 1]["act"]), n, Ll, cl, dt, _p(pl["gmax"]), _p(pl["gidx"]), st)
         self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
                  _p(pl["emb"]), st)
         return pl["emb"]
