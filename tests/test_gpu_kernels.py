@@ -388,7 +388,7 @@ def test_decimate_whiten(i16):
         rd = dev(raw)
     l0 = (raw_len + ds - 1) // ds
     out = torch.zeros(n, l0 + 31, device="cuda")
-    ws = torch.empty(2 * n, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L().query("vm_decimate_whiten_workspace_bytes", n) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_decimate_whiten", p(rd), int(i16), n, raw_len, ds, 1, 0.038021, wpt, p(out), p(ws), stream())
     pre = O.preprocess_instances(ds)
     ref = np.concatenate([pre(raw.astype(np.float64)[t:t + wpt, :, None]) for t in range(0, n, wpt)])[:, :, 0]

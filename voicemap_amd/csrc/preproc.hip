@@ -13,15 +13,20 @@ template <typename R> __device__ inline float raw_to_f(R v);
 template <> __device__ inline float raw_to_f<float>(float v) { return v; }
 template <> __device__ inline float raw_to_f<int16_t>(int16_t v) { return (float)v * (1.0f / 32768.0f); }
 
-// pass 1: per-window sum and sum of squares of the decimated samples.  grid = n_windows.
+constexpr int WS_SEG = 8;  // partial-sum segments per window
+
+// pass 1: partial sum and sum of squares of the decimated samples.  grid = (n_windows, WS_SEG).
 template <typename R>
 __global__ __launch_bounds__(256) void whiten_stats_kernel(const R* __restrict__ raw, int64_t raw_len, int ds, int64_t L0,
-                                                           double* __restrict__ wsum, double* __restrict__ wsq) {
+                                                           double* __restrict__ psum, double* __restrict__ psq) {
     __shared__ double red[2][4];
     const int64_t n = blockIdx.x;
+    const int seg = blockIdx.y;
     const R* r = raw + n * raw_len;
+    const int64_t per = (L0 + WS_SEG - 1) / WS_SEG;
+    const int64_t i1 = (seg + 1) * per < L0 ? (seg + 1) * per : L0;
     double s = 0.0, q = 0.0;
-    for (int64_t i = threadIdx.x; i < L0; i += 256) {
+    for (int64_t i = seg * per + threadIdx.x; i < i1; i += 256) {
         const double v = (double)raw_to_f<R>(r[i * ds]);
         s += v;
         q += v * v;
@@ -34,36 +39,46 @@ __global__ __launch_bounds__(256) void whiten_stats_kernel(const R* __restrict__
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        wsum[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        wsq[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        psum[n * WS_SEG + seg] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        psq[n * WS_SEG + seg] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// pass 1b: per-window mean and ONE scale per tower (utils.py:94-98).  grid = n_towers; fixed summation order.
+__global__ __launch_bounds__(256) void whiten_finalize_kernel(const double* __restrict__ psum, const double* __restrict__ psq,
+                                                              int64_t wpt, int64_t L0, float rms, double* __restrict__ mean,
+                                                              double* __restrict__ scale) {
+    __shared__ double red[4];
+    const int64_t tw = blockIdx.x;
+    double q = 0.0;
+    for (int64_t j = threadIdx.x; j < wpt * WS_SEG; j += 256) q += psq[tw * wpt * WS_SEG + j];
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        scale[tw] = (double)rms / sqrt(tot / ((double)wpt * (double)L0));
+    }
+    for (int64_t j = threadIdx.x; j < wpt; j += 256) {
+        double s = 0.0;
+        for (int k = 0; k < WS_SEG; ++k) s += psum[(tw * wpt + j) * WS_SEG + k];
+        mean[tw * wpt + j] = s / (double)L0;
     }
 }
 
 // pass 2: write (x - mean_n) * scale_tower with the halo.  grid = (ceil((L0+31)/256), n_windows).
 template <typename R>
 __global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__ raw, int64_t raw_len, int ds, int64_t L0,
-                                                           int whitening, float rms, int64_t wpt, const double* __restrict__ wsum,
-                                                           const double* __restrict__ wsq, float* __restrict__ out) {
-    __shared__ double s_mean, s_scale;
+                                                           int whitening, int64_t wpt, const double* __restrict__ mean,
+                                                           const double* __restrict__ scale, float* __restrict__ out) {
     const int64_t n = blockIdx.y;
-    if (threadIdx.x == 0) {
-        if (whitening) {
-            const int64_t tw = n / wpt;
-            double q = 0.0;
-            for (int64_t j = 0; j < wpt; ++j) q += wsq[tw * wpt + j];
-            s_mean = wsum[n] / (double)L0;
-            s_scale = (double)rms / sqrt(q / ((double)wpt * (double)L0));
-        } else {
-            s_mean = 0.0;
-            s_scale = 1.0;
-        }
-    }
-    __syncthreads();
+    const double m = whitening ? mean[n] : 0.0;
+    const double sc = whitening ? scale[n / wpt] : 1.0;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L0 + HALO) return;
     const int64_t t = i - HALO_L;
     float v = 0.f;
-    if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(raw[n * raw_len + t * ds]) - s_mean) * s_scale);
+    if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(raw[n * raw_len + t * ds]) - m) * sc);
     out[n * (L0 + HALO) + i] = v;
 }
 
@@ -71,7 +86,9 @@ __global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__
 
 using namespace vm;
 
-extern "C" int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows) { return 2 * n_windows * (int64_t)sizeof(double); }
+extern "C" int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows) {
+    return (2 * WS_SEG + 2) * n_windows * (int64_t)sizeof(double);  // partials, per-window means, per-tower scales
+}
 
 extern "C" int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_windows, int64_t raw_len, int downsampling,
                                   int whitening, float rms, int64_t windows_per_tower, float* out, void* ws, void* stream) {
@@ -79,21 +96,32 @@ extern "C" int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_win
     VM_REQUIRE(n_windows > 0 && raw_len > 0 && downsampling > 0 && windows_per_tower > 0, "vm_decimate_whiten: bad sizes");
     VM_REQUIRE(n_windows % windows_per_tower == 0, "vm_decimate_whiten: n_windows must be a multiple of windows_per_tower");
     const int64_t L0 = (raw_len + downsampling - 1) / downsampling;  // len(x[::d])
-    double* wsum = (double*)ws;
-    double* wsq = wsum + n_windows;
+    double* psum = (double*)ws;
+    double* psq = psum + n_windows * WS_SEG;
+    double* mean = psq + n_windows * WS_SEG;
+    double* scale = mean + n_windows;
+    const dim3 g1((unsigned)n_windows, WS_SEG);
     const dim3 g2((unsigned)cdiv(L0 + HALO, 256), (unsigned)n_windows);
+    const unsigned towers = (unsigned)(n_windows / windows_per_tower);
+    hipStream_t st = (hipStream_t)stream;
     if (raw_is_i16) {
-        if (whitening)
-            hipLaunchKernelGGL((whiten_stats_kernel<int16_t>), dim3((unsigned)n_windows), dim3(256), 0, (hipStream_t)stream,
-                               (const int16_t*)raw, raw_len, downsampling, L0, wsum, wsq);
-        hipLaunchKernelGGL((whiten_apply_kernel<int16_t>), g2, dim3(256), 0, (hipStream_t)stream, (const int16_t*)raw, raw_len,
-                           downsampling, L0, whitening, rms, windows_per_tower, wsum, wsq, out);
+        if (whitening) {
+            hipLaunchKernelGGL((whiten_stats_kernel<int16_t>), g1, dim3(256), 0, st, (const int16_t*)raw, raw_len, downsampling, L0,
+                               psum, psq);
+            hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
+                               scale);
+        }
+        hipLaunchKernelGGL((whiten_apply_kernel<int16_t>), g2, dim3(256), 0, st, (const int16_t*)raw, raw_len, downsampling, L0,
+                           whitening, windows_per_tower, mean, scale, out);
     } else {
-        if (whitening)
-            hipLaunchKernelGGL((whiten_stats_kernel<float>), dim3((unsigned)n_windows), dim3(256), 0, (hipStream_t)stream,
-                               (const float*)raw, raw_len, downsampling, L0, wsum, wsq);
-        hipLaunchKernelGGL((whiten_apply_kernel<float>), g2, dim3(256), 0, (hipStream_t)stream, (const float*)raw, raw_len,
-                           downsampling, L0, whitening, rms, windows_per_tower, wsum, wsq, out);
+        if (whitening) {
+            hipLaunchKernelGGL((whiten_stats_kernel<float>), g1, dim3(256), 0, st, (const float*)raw, raw_len, downsampling, L0,
+                               psum, psq);
+            hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
+                               scale);
+        }
+        hipLaunchKernelGGL((whiten_apply_kernel<float>), g2, dim3(256), 0, st, (const float*)raw, raw_len, downsampling, L0,
+                           whitening, windows_per_tower, mean, scale, out);
     }
     return check_launch("vm_decimate_whiten");
 }

@@ -266,7 +266,8 @@ class HipEncoderEngine:
             pl["prob"] = torch.empty_like(pl["logits"])
             pl["dlogits"] = torch.empty_like(pl["logits"])
             pl["cce_ws"] = torch.empty(2 * n_windows, dtype=f32, device=dev)
-        pl["pre_ws"] = torch.empty(2 * n_windows, dtype=torch.float64, device=dev)
+        pl["pre_ws"] = torch.empty(self.lib.query("vm_decimate_whiten_workspace_bytes", n_windows) // 8, dtype=torch.float64,
+                                   device=dev)
         cmax = max(b[1] for b in self.blocks)
         pl["cr_ws"] = torch.empty(self.lib.query("vm_colreduce_workspace_bytes", 2, cmax) // 8, dtype=torch.float64, device=dev)
         self._plans[key] = pl
