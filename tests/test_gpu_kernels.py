@@ -46,7 +46,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 0, "nt_p8_phases": 2, "tn_p8": 1,
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 0, "nt_p8_phases": 2, "tn_p8": 1, "tn_x": 1,
                  "nt_p8_blocks": 256}
 
 
@@ -62,7 +62,7 @@ def gemm_kb(request):
 
 
 @pytest.mark.parametrize("gemm_kb", [{}, {"nt_p8_blocks": 3}, {"nt_p8_blocks": 8, "nt_order": 0}, {"nt_p8": 0},
-                                     {"nt_p8": 0, "nt_tepi": 0, "tn_p8": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_ring": 1},
+                                     {"nt_p8": 0, "nt_tepi": 0, "tn_p8": 0, "tn_x": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_ring": 1, "tn_x": 0},
                                      {"nt_p8": 0, "nt_order": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
                                      {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
                          ids=["p8", "p8-3wg", "p8-8wg-seq", "tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])

@@ -124,6 +124,7 @@ struct NtArgs {
     int L, N, Ktot;
     int tilesL, tilesN;
     int order;   // tile order of the LDS-DMA kernels: 0 sequential n-tiles per workgroup, 1 concurrent n-tiles per XCD
+    int skew;    // conv_nt8_kernel: start delay (units of 127*64 clocks) per workgroup phase (blockIdx >> 3) & 3
     int ablate;  // timing experiments only (results are wrong when != 0): 1 no epilogue stores, 2 no epilogue,
                  // 4 no MFMA, 8 no K-loop global loads after the first slice
 };
@@ -1024,6 +1025,13 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
         }
     };
 
+    // Optional start skew: with one lock-step workgroup per CU every CU reaches its epilogue at the same time and the chip
+    // writes a 33 MB burst per tile round; delaying the workgroups of an XCD by 0..3 units spreads the bursts.
+    if (p.skew > 0) {
+        const int reps = (((int)blockIdx.x >> 3) & 3) * p.skew;
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
     // ---- prologue: K tile 0 and what the last phases of stream position -1 would have issued (nk >= 3) ----
     load_bias(tn_c);
     stage(H_A0, 0, n_c, tl_c * 256, tn_c * 256, 0);
@@ -1157,6 +1165,8 @@ struct TnArgs {
     int Kk;  // 3*c_in
     int tilesI, tilesJ, splits;
     int xcd_remap;
+    int ablate;  // conv_tn8_kernel timing experiments (wrong results): 4 no MFMA, 8 no in-loop DMA, 16 no fragment reads,
+                 // 32 no A DMA, 64 no B DMA
     int64_t n_windows, win_per_split;
 };
 
@@ -1495,7 +1505,10 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
         const int dchunk = (lane & 3) * 8;  // elements
         const char* const x_base = reinterpret_cast<const char*>(p.x);
         const char* const d_base = reinterpret_cast<const char*>(p.du);
+        const int abl = p.ablate;
         auto stage = [&](int h, int buf, int n, int st) {
+            if ((abl & 32) && h < 2) return;
+            if ((abl & 64) && h >= 2) return;
             char* dst = lds + buf * BUF + h * HALF + w * 1024;
             int t = st * 64 + dpos;
             if (h < 2) {
@@ -1536,6 +1549,7 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
             return __builtin_bit_cast(bf16x8, v);
         };
         auto read_a = [&](FragA& fa, int buf, int ih) {
+            if (abl & 16) return;
             const char* base = lds + buf * BUF + ih * HALF + wm * 2 * BLK + lane_off;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1543,11 +1557,13 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
                 for (int s = 0; s < 4; ++s) fa[i][s] = tr8(base + i * BLK + s * 1024);
         };
         auto read_b = [&](FragB& fb, int buf, int jn) {
+            if (abl & 16) return;
             const char* base = lds + buf * BUF + (2 + jn) * HALF + wn * BLK + lane_off;
 #pragma unroll
             for (int s = 0; s < 4; ++s) fb[s] = tr8(base + s * 1024);
         };
         auto mma = [&](const FragA& fa, const FragB& fb, f32x16& c0, f32x16& c1) {
+            if (abl & 4) return;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -1594,12 +1610,16 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
 
         FragA fa;
         FragB fb, fb1;
+        if (abl & 16) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fa[0][s] = fa[1][s] = fb[s] = fb1[s] = bf16x8{};
+        }
         for (int g = 0; g < G; ++g) {
             const int buf = g & 1;
             read_a(fa, buf, 0);
             read_b(fb, buf, 0);
             read_b(fb1, buf, 1);
-            if (g + 1 < G) {
+            if (g + 1 < G && !(abl & 8)) {
                 stage(H_B1, buf ^ 1, n1, s1);
                 stage(H_A1, buf ^ 1, n1, s1);
             }
@@ -1609,10 +1629,14 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
             mma(fa, fb1, acc[0][1], acc[1][1]);
             slot_end();
             read_a(fa, buf, 1);
-            if (g + 2 < G) {
+            if (g + 2 < G && !(abl & 8)) {
                 stage(H_A0, buf, n2, s2);
                 stage(H_B0, buf, n2, s2);
-                wait_vmcnt<4>();
+                if (abl & 96) {
+                    wait_vmcnt<2>();
+                } else {
+                    wait_vmcnt<4>();
+                }
             } else {
                 wait_vmcnt<0>();
             }
@@ -1643,6 +1667,249 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
                 if (col < p.c_out) {
                     const f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
                     *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, input-resident form: output tile = (3 taps x 128 input channels) x 128 output channels.
+//
+// Ablating conv_tn8_kernel shows that it is bound by its LDS-DMA traffic, not by the matrix cores (block 3, us: full 316,
+// no MFMA 300, no DMA 202): with kk = tap * C_in + ci tiled 256-wide, a tile's A operand is re-fetched for every tap and
+// every output-channel tile, and 256-wide tiles waste 10-25 % on C_out = 384 / Kk = 384.  Here a workgroup owns 128 input
+// channels for ALL THREE taps: the A operand of tap t at position p is X[p + t], so one staged block of X rows serves the
+// three taps (the fragment reads just start 0, 1 or 2 rows later) and the DMA bytes per MFMA drop by ~45 %; the tiles
+// (384 x 128) divide every layer of the model exactly.
+//   * A lives in a ring of 256 position rows per 32-channel block (4 blocks, 64 KB): stage g occupies rows (g & 3) * 64..+63,
+//     tap reads run up to 2 rows into the next stage's rows (ring indices wrap with an AND).  B (dU) has 4 stage buffers of
+//     4 blocks [64 positions][32 channels] (64 KB).  A stage is 64 positions; a window takes ceil((L + 2) / 64) stages so that
+//     its last stage holds the zero halo row L + 1; positions >= L are neutralised on the dU side (source row L + 1 = zero
+//     halo), so what the A rows of such positions hold does not matter as long as it is finite (the ring is zeroed once).
+//   * 8 waves = 4 (input-channel blocks of 32) x 2 (64 output channels): a wave owns 3 taps x 32 ci x 64 co = 6 accumulator
+//     tiles; 24 MFMAs per stage in two clusters of 12; waves 4-7 (channel blocks 2, 3) run one slot behind waves 0-3.
+//   * DMA runs three stages ahead: stage g + 3 is issued in the second READ slot of stage g (into the ring slot of stage
+//     g - 1, whose last reads completed a phase earlier) and the counted vmcnt(4) there retires stage g + 2 -- stage g + 1
+//     needs it for its tap overflow rows.
+//   phase 0: read A(t0), A(t1), B_c0, B_c1 | MFMA t0 x c0, t0 x c1, t1 x c0
+//   phase 1: read A(t2) | DMA stage g+3 | vmcnt(4) | MFMA t1 x c1, t2 x c0, t2 x c1
+// ------------------------------------------------------------------------------------------------
+namespace t8x {
+constexpr int ROWS = 256;                  // ring rows per A block
+constexpr int ABLK = ROWS * 64;            // 16 KB
+constexpr int A_BYTES = 4 * ABLK;          // 64 KB
+constexpr int BBLK = 64 * 64;              // 4 KB
+constexpr int BSTAGE = 4 * BBLK;           // 16 KB
+constexpr int LDS_BYTES = A_BYTES + 4 * BSTAGE;  // 128 KB
+struct Frag4 {  // 4 k-steps; the two 8-byte halves are only joined at the MFMA, i.e. after the lgkmcnt wait
+    u32x2 lo[4], hi[4];
+};
+}  // namespace t8x
+
+__global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
+    using namespace t8x;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;  // channel block (0..3), output-column half (0..1); waves 4-7 = blocks 2, 3
+
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = __builtin_amdgcn_readfirstlane((int)(b % p.tilesJ));
+    b /= p.tilesJ;
+    const int ti = __builtin_amdgcn_readfirstlane((int)(b % p.tilesI));
+    const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
+    const int ci0 = ti * 128, j0 = tj * 128;
+
+    const int w_begin = (int)((int64_t)split * p.win_per_split);
+    int w_end = w_begin + (int)p.win_per_split;
+    if (w_end > (int)p.n_windows) w_end = (int)p.n_windows;
+    const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
+    const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
+
+    if (G > 0) {
+        // zero the A ring once: tap-overflow reads of never-staged rows must be finite
+        for (int i = tid * 16; i < A_BYTES; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+
+        // ---- DMA geometry: per stage 16 wave-instructions for A and 16 for B (16 positions x 64 bytes of one block each) ----
+        const int dpos = (w & 3) * 16 + (lane >> 2);
+        const int dchunk = (lane & 3) * 8;  // elements
+        const char* const x_base = reinterpret_cast<const char*>(p.x);
+        const char* const d_base = reinterpret_cast<const char*>(p.du);
+        const int abl = p.ablate;
+        auto stage = [&](int slot, int n, int st) {
+            const int t = st * 64 + dpos;
+            if (!(abl & 32)) {
+                int r = t < p.L + 1 ? t : p.L + 1;  // padded row of tap 0 at position t; rows past the halo are never used
+                const char* src = x_base + n * p.x_win_stride * 2;
+                char* dst = lds + slot * 4096 + (w & 3) * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int blk = j * 2 + (w >> 2);
+                    int c0 = ci0 + blk * 32;
+                    c0 = c0 < p.c_in ? c0 : 0;
+                    glds16(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + blk * ABLK);
+                }
+            }
+            if (!(abl & 64)) {
+                const int r = (t < p.L ? t : p.L) + 1;  // row L + 1 of the padded dU tensor is the zero halo
+                const char* src = d_base + n * p.du_win_stride * 2;
+                char* dst = lds + A_BYTES + slot * BSTAGE + (w & 3) * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int blk = j * 2 + (w >> 2);
+                    int co0 = j0 + blk * 32;
+                    co0 = co0 < p.c_out ? co0 : 0;
+                    glds16(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + blk * BBLK);
+                }
+            }
+        };
+
+        // ---- fragment reads (transposing, see conv_tn8_kernel) ----
+        const int li = lane & 15, lg = (lane >> 4) & 1, kh = lane >> 5;
+        const int lane_off = (kh * 8 + (li >> 2)) * 64 + lg * 32 + (li & 3) * 8;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+        auto tr_pair = [&](u32x2& lo, u32x2& hi, uint32_t a_lo, uint32_t a_hi) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
+        };
+        auto read_a = [&](Frag4& fa, int slot, int tap) {
+            if (abl & 16) return;
+            const uint32_t blk = lds0 + wm * ABLK;
+            const uint32_t u = slot * 4096 + tap * 64 + lane_off;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                tr_pair(fa.lo[s], fa.hi[s], blk + ((u + s * 1024) & (ABLK - 1)), blk + ((u + s * 1024 + 256) & (ABLK - 1)));
+        };
+        auto read_b = [&](Frag4& fb, int slot, int jn) {
+            if (abl & 16) return;
+            const uint32_t a = lds0 + A_BYTES + slot * BSTAGE + (wn * 2 + jn) * BBLK + lane_off;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 1024, a + s * 1024 + 256);
+        };
+        auto mma = [&](const Frag4& fa, const Frag4& fb, f32x16& c) {
+            if (abl & 4) return;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const u32x4 av = {fa.lo[s][0], fa.lo[s][1], fa.hi[s][0], fa.hi[s][1]};
+                const u32x4 bv = {fb.lo[s][0], fb.lo[s][1], fb.hi[s][0], fb.hi[s][1]};
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), c, 0, 0, 0);
+            }
+        };
+        auto slot_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+        // stream cursor of the stage to be staged next
+        int nn = w_begin, ss = 0, staged = 0;
+        auto stage_next = [&]() {
+            stage(staged & 3, nn, ss);
+            ++staged;
+            if (++ss == spw) {
+                ss = 0;
+                ++nn;
+            }
+        };
+        // ---- prologue: stages 0, 1, 2 ----
+        stage_next();
+        if (G > 1) stage_next();
+        if (G > 2) {
+            stage_next();
+            if (abl & 96) {
+                wait_vmcnt<2>();
+            } else {
+                wait_vmcnt<4>();
+            }
+        } else {
+            wait_vmcnt<0>();
+        }
+        slot_end();
+        if (w >= 4) slot_end();  // channel blocks 2, 3 run one slot behind
+
+        Frag4 fa0, fa1, fb0, fb1;
+        if (abl & 16) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fa0.lo[s] = fa0.hi[s] = fa1.lo[s] = fa1.hi[s] = u32x2{0, 0};
+                fb0.lo[s] = fb0.hi[s] = fb1.lo[s] = fb1.hi[s] = u32x2{0, 0};
+            }
+        }
+        for (int g = 0; g < G; ++g) {
+            const int slot = g & 3;
+            read_a(fa0, slot, 0);
+            read_a(fa1, slot, 1);
+            read_b(fb0, slot, 0);
+            read_b(fb1, slot, 1);
+            read_done();
+            slot_end();
+            __builtin_amdgcn_s_setprio(1);
+            mma(fa0, fb0, acc[0][0]);
+            mma(fa0, fb1, acc[0][1]);
+            mma(fa1, fb0, acc[1][0]);
+            __builtin_amdgcn_s_setprio(0);
+            slot_end();
+            read_a(fa0, slot, 2);
+            if (staged < G && !(abl & 8)) {
+                stage_next();
+                if (abl & 96) {
+                    wait_vmcnt<2>();
+                } else {
+                    wait_vmcnt<4>();
+                }
+            } else {
+                wait_vmcnt<0>();
+            }
+            read_done();
+            slot_end();
+            __builtin_amdgcn_s_setprio(1);
+            mma(fa1, fb1, acc[1][1]);
+            mma(fa0, fb0, acc[2][0]);
+            mma(fa0, fb1, acc[2][1]);
+            __builtin_amdgcn_s_setprio(0);
+            slot_end();
+        }
+        if (w < 4) slot_end();  // balance the barrier count of the two groups
+    }
+
+    // ---- the split's slab tile: rows kk = tap * C_in + ci ----
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+    const int ci = ci0 + wm * 32 + (lane & 31);
+    if (ci0 + wm * 32 < p.c_in) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t row = (int64_t)t * p.c_in + ci;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = j0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+                    if (col < p.c_out) {
+                        const f32x4 v = {acc[t][jn][4 * g4], acc[t][jn][4 * g4 + 1], acc[t][jn][4 * g4 + 2], acc[t][jn][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(out + row * p.c_out + col) = v;
+                    }
                 }
             }
         }
@@ -1692,6 +1959,7 @@ int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_
 // of the MFMA peak), barrier skeleton alone 47.
 int g_nt_p8 = 0;
 int g_nt_p8_blocks = 256;
+int g_nt_p8_skew = 0;
 int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
 
 template <typename T, int EPI>
@@ -1701,6 +1969,7 @@ static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_
     if (!g_nt_p8 || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
         n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
     NtArgs<bf16> b = a;
+    b.skew = g_nt_p8_skew;
     b.tilesL = (a.L + 255) / 256;
     b.tilesN = a.N / 256;
     const int64_t n_groups = n_windows * b.tilesL;
@@ -1808,7 +2077,15 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
 
 int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 
+int g_tn_x = 1;   // input-resident (3 taps x 128 ci) x 128 co wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_x", 0 | 1)
+static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 32 == 0 && c_out % 32 == 0 && c_in >= 64 && c_out >= 64; }
 int g_tn_p8 = 1;  // LDS-DMA + transposing-read wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_p8", 0 | 1)
+template <typename T>
+static void launch_tn8x(const TnArgs<T>&, int64_t, hipStream_t) {}
+template <>
+void launch_tn8x<bf16>(const TnArgs<bf16>& a, int64_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(conv_tn8x_kernel, dim3((unsigned)grid), dim3(512), 0, stream, a);
+}
 template <typename T>
 static bool launch_tn8(const TnArgs<T>&, int64_t, hipStream_t) { return false; }
 template <>
@@ -1827,10 +2104,11 @@ static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_i
 // slab per split.  Pick the split that minimises   rounds * wps * t_window  +  splits * t_slab.
 extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
     const bool big = tn_use_256(c_in, c_out);
+    const bool xres = tn_x_shape(c_in, c_out);  // (the fp32 kernels then run with a split count tuned for the bf16 tiling)
     const int tile = big ? 256 : 128;
-    const int64_t t = (int64_t)tiles(3 * c_in, tile) * tiles(c_out, tile);
-    const int64_t slots = big ? 256 : 512;
-    const double t_window = 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
+    const int64_t t = xres ? (int64_t)tiles(c_in, 128) * tiles(c_out, 128) : (int64_t)tiles(3 * c_in, tile) * tiles(c_out, tile);
+    const int64_t slots = (big || xres) ? 256 : 512;
+    const double t_window = xres ? 2.0 * 384 * 128 * (double)L / 5.0e12 : 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
     const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
     int64_t best_wps = 1;
     double best_cost = -1.0;
@@ -1869,14 +2147,18 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.L = (int)L;
         a.Kk = 3 * c_in;
         const bool big = tn_use_256(c_in, c_out);
-        a.tilesI = tiles(3 * c_in, big ? 256 : BM);
-        a.tilesJ = tiles(c_out, big ? 256 : BN);
+        const bool xres = sizeof(T) == 2 && tn_x_shape(c_in, c_out) && n_windows < (1LL << 30);
+        a.tilesI = xres ? tiles(c_in, 128) : tiles(3 * c_in, big ? 256 : BM);
+        a.tilesJ = xres ? tiles(c_out, 128) : tiles(c_out, big ? 256 : BN);
         a.splits = splits;
         a.xcd_remap = g_tn_xcd;
+        a.ablate = g_nt_ablate;
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
-        if (big && launch_tn8<T>(a, grid, (hipStream_t)stream)) {
+        if (xres) {
+            launch_tn8x<T>(a, grid, (hipStream_t)stream);
+        } else if (big && launch_tn8<T>(a, grid, (hipStream_t)stream)) {
         } else if (big) {
             hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, a);
         } else if (g_gemm_kb == 64) {
@@ -1930,6 +2212,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
         g_nt_glds = value;
         return VM_OK;
     }
+    if (key != nullptr && strcmp(key, "tn_x") == 0) {
+        g_tn_x = value;
+        return VM_OK;
+    }
     if (key != nullptr && strcmp(key, "tn_p8") == 0) {
         g_tn_p8 = value;
         return VM_OK;
@@ -1940,6 +2226,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_phases") == 0 && (value == 2 || value == 4)) {
         g_nt_p8_phases = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_p8_skew") == 0 && value >= 0 && value <= 64) {
+        g_nt_p8_skew = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_p8_blocks") == 0) {

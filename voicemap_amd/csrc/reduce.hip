@@ -9,7 +9,7 @@ __global__ __launch_bounds__(256) void slab_stage1_kernel(const float* __restric
                                                           double* __restrict__ part) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nel) return;
-    const int64_t per = (slabs + SLAB_RCH - 1) / SLAB_RCH;
+    const int64_t per = (slabs + gridDim.y - 1) / gridDim.y;
     const int64_t lo = blockIdx.y * per;
     int64_t hi = lo + per;
     if (hi > slabs) hi = slabs;
@@ -23,13 +23,34 @@ __global__ __launch_bounds__(256) void slab_stage1_kernel(const float* __restric
     part[(int64_t)blockIdx.y * nel + i] = s0 + s1;
 }
 
-__global__ __launch_bounds__(256) void slab_stage2_kernel(const double* __restrict__ part, int64_t nel, int64_t n0,
+// one stage: few slabs and enough elements to fill the chip on their own
+__global__ __launch_bounds__(256) void slab_single_kernel(const float* __restrict__ ws, int64_t slabs, int64_t nel, int64_t n0,
+                                                          float* __restrict__ out0, float* __restrict__ out1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nel) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t k = 0;
+    for (; k + 4 <= slabs; k += 4) {
+        s0 += (double)ws[k * nel + i];
+        s1 += (double)ws[(k + 1) * nel + i];
+        s2 += (double)ws[(k + 2) * nel + i];
+        s3 += (double)ws[(k + 3) * nel + i];
+    }
+    for (; k < slabs; ++k) s0 += (double)ws[k * nel + i];
+    const double s = (s0 + s1) + (s2 + s3);
+    if (i < n0) {
+        out0[i] = (float)s;
+    } else {
+        out1[i - n0] = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_stage2_kernel(const double* __restrict__ part, int rch, int64_t nel, int64_t n0,
                                                           float* __restrict__ out0, float* __restrict__ out1) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nel) return;
     double s = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < SLAB_RCH; ++k) s += part[(int64_t)k * nel + i];
+    for (int k = 0; k < rch; ++k) s += part[(int64_t)k * nel + i];
     if (i < n0) {
         out0[i] = (float)s;
     } else {
@@ -43,9 +64,18 @@ int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n
     uintptr_t a = reinterpret_cast<uintptr_t>(part);
     a = (a + 63) / 64 * 64;
     double* pp = reinterpret_cast<double*>(a);
-    hipLaunchKernelGGL(slab_stage1_kernel, dim3((unsigned)cdiv(nel, 256), SLAB_RCH), dim3(256), 0, stream, ws, slabs, nel, pp);
-    hipLaunchKernelGGL(slab_stage2_kernel, dim3((unsigned)cdiv(nel, 256)), dim3(256), 0, stream, (const double*)pp, nel, n0, out0,
-                       out1);
+    // partial rows: enough workgroups to fill the chip (~2048), at least 4 slabs per partial, at most SLAB_RCH
+    const int64_t blocks = cdiv(nel, 256);
+    int64_t rch = cdiv(2048, blocks);
+    if (rch > slabs / 4) rch = slabs / 4;
+    if (rch > SLAB_RCH) rch = SLAB_RCH;
+    if (rch <= 1) {
+        hipLaunchKernelGGL(slab_single_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, slabs, nel, n0, out0, out1);
+        return check_launch("slab_sum");
+    }
+    hipLaunchKernelGGL(slab_stage1_kernel, dim3((unsigned)blocks, (unsigned)rch), dim3(256), 0, stream, ws, slabs, nel, pp);
+    hipLaunchKernelGGL(slab_stage2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)pp, (int)rch, nel, n0,
+                       out0, out1);
     return check_launch("slab_sum");
 }
 
