@@ -1707,6 +1707,7 @@ struct Frag4 {  // 4 k-steps; the two 8-byte halves are only joined at the MFMA,
 };
 }  // namespace t8x
 
+template <bool FREE>
 __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
     using namespace t8x;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -1804,14 +1805,22 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 1024, a + s * 1024 + 256);
         };
-        auto mma = [&](const Frag4& fa, const Frag4& fb, f32x16& c) {
+        // three accumulator tiles per cluster, k-steps interleaved: consecutive MFMAs never depend on each other
+        auto mma3 = [&](const Frag4& a0, const Frag4& b0, f32x16& c0, const Frag4& a1, const Frag4& b1, f32x16& c1, const Frag4& a2,
+                        const Frag4& b2, f32x16& c2) {
             if (abl & 4) return;
+            auto op = [](const Frag4& f, int s) {
+                const u32x4 v = {f.lo[s][0], f.lo[s][1], f.hi[s][0], f.hi[s][1]};
+                return __builtin_bit_cast(bf16x8, v);
+            };
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const u32x4 av = {fa.lo[s][0], fa.lo[s][1], fa.hi[s][0], fa.hi[s][1]};
-                const u32x4 bv = {fb.lo[s][0], fb.lo[s][1], fb.hi[s][0], fb.hi[s][1]};
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), c, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b0, s), op(a0, s), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b1, s), op(a1, s), c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b2, s), op(a2, s), c2, 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         };
         auto slot_end = [&]() {
             __builtin_amdgcn_sched_barrier(0);
@@ -1835,18 +1844,7 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
         // ---- prologue: stages 0, 1, 2 ----
         stage_next();
         if (G > 1) stage_next();
-        if (G > 2) {
-            stage_next();
-            if (abl & 96) {
-                wait_vmcnt<2>();
-            } else {
-                wait_vmcnt<4>();
-            }
-        } else {
-            wait_vmcnt<0>();
-        }
-        slot_end();
-        if (w >= 4) slot_end();  // channel blocks 2, 3 run one slot behind
+        if (G > 2) stage_next();
 
         Frag4 fa0, fa1, fb0, fb1;
         if (abl & 16) {
@@ -1856,23 +1854,60 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
                 fb0.lo[s] = fb0.hi[s] = fb1.lo[s] = fb1.hi[s] = u32x2{0, 0};
             }
         }
-        for (int g = 0; g < G; ++g) {
-            const int slot = g & 3;
-            read_a(fa0, slot, 0);
-            read_a(fa1, slot, 1);
-            read_b(fb0, slot, 0);
-            read_b(fb1, slot, 1);
-            read_done();
-            slot_end();
-            __builtin_amdgcn_s_setprio(1);
-            mma(fa0, fb0, acc[0][0]);
-            mma(fa0, fb1, acc[0][1]);
-            mma(fa1, fb0, acc[1][0]);
-            __builtin_amdgcn_s_setprio(0);
-            slot_end();
-            read_a(fa0, slot, 2);
-            if (staged < G && !(abl & 8)) {
-                stage_next();
+        if (FREE) {
+            // Free-running form: ONE barrier per stage (after the counted DMA wait); inside a stage every wave pipelines its
+            // own fragment reads against its MFMAs with counted lgkmcnt waits (LDS returns in order; the asm reads are
+            // invisible to the compiler, hence the explicit waits and scheduling fences), and the two waves of a SIMD
+            // interleave freely.
+            auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+            auto mma2 = [&](const Frag4& a, const Frag4& b0, f32x16& c0, const Frag4& b1, f32x16& c1, int s0, int s1) {
+                if (abl & 4) return;
+                auto op = [](const Frag4& f, int s) {
+                    const u32x4 v = {f.lo[s][0], f.lo[s][1], f.hi[s][0], f.hi[s][1]};
+                    return __builtin_bit_cast(bf16x8, v);
+                };
+#pragma unroll
+                for (int s = s0; s < s1; ++s) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b0, s), op(a, s), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b1, s), op(a, s), c1, 0, 0, 0);
+                }
+            };
+            for (int g = 0; g < G; ++g) {
+                const int slot = g & 3;
+                // stages g and g+1 landed (stage g+2 may still be in flight)
+                if (g + 2 < G && !(abl & 8)) {
+                    if (abl & 96) {
+                        wait_vmcnt<2>();
+                    } else {
+                        wait_vmcnt<4>();
+                    }
+                } else {
+                    wait_vmcnt<0>();
+                }
+                slot_end();
+                if (staged < G && !(abl & 8)) stage_next();  // stage g+3 -> ring slot of stage g-1 (every wave is past it)
+                read_a(fa0, slot, 0);
+                read_b(fb0, slot, 0);
+                read_b(fb1, slot, 1);
+                read_a(fa1, slot, 1);
+                fence();
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // A(t0), B_c0, B_c1 (A(t1) may be in flight)
+                fence();
+                mma2(fa0, fb0, acc[0][0], fb1, acc[0][1], 0, 4);
+                fence();
+                read_done();  // A(t1)
+                fence();
+                read_a(fa0, slot, 2);
+                fence();
+                mma2(fa1, fb0, acc[1][0], fb1, acc[1][1], 0, 4);
+                fence();
+                read_done();  // A(t2)
+                fence();
+                mma2(fa0, fb0, acc[2][0], fb1, acc[2][1], 0, 4);
+                fence();
+            }
+        } else {
+            if (G > 2) {
                 if (abl & 96) {
                     wait_vmcnt<2>();
                 } else {
@@ -1881,16 +1916,36 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
             } else {
                 wait_vmcnt<0>();
             }
-            read_done();
             slot_end();
-            __builtin_amdgcn_s_setprio(1);
-            mma(fa1, fb1, acc[1][1]);
-            mma(fa0, fb0, acc[2][0]);
-            mma(fa0, fb1, acc[2][1]);
-            __builtin_amdgcn_s_setprio(0);
-            slot_end();
+            if (w >= 4) slot_end();  // channel blocks 2, 3 run one slot behind
+            for (int g = 0; g < G; ++g) {
+                const int slot = g & 3;
+                read_a(fa0, slot, 0);
+                read_a(fa1, slot, 1);
+                read_b(fb0, slot, 0);
+                read_b(fb1, slot, 1);
+                read_done();
+                slot_end();
+                mma3(fa0, fb0, acc[0][0], fa0, fb1, acc[0][1], fa1, fb0, acc[1][0]);
+                slot_end();
+                read_a(fa0, slot, 2);
+                if (staged < G && !(abl & 8)) {
+                    stage_next();
+                    if (abl & 96) {
+                        wait_vmcnt<2>();
+                    } else {
+                        wait_vmcnt<4>();
+                    }
+                } else {
+                    wait_vmcnt<0>();
+                }
+                read_done();
+                slot_end();
+                mma3(fa1, fb1, acc[1][1], fa0, fb0, acc[2][0], fa0, fb1, acc[2][1]);
+                slot_end();
+            }
+            if (w < 4) slot_end();  // balance the barrier count of the two groups
         }
-        if (w < 4) slot_end();  // balance the barrier count of the two groups
     }
 
     // ---- the split's slab tile: rows kk = tap * C_in + ci ----
@@ -2077,14 +2132,19 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
 
 int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 
-int g_tn_x = 1;   // input-resident (3 taps x 128 ci) x 128 co wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_x", 0 | 1)
+extern int g_tn_x;
+int g_tn_x = 1;   // (2: free-running form) input-resident (3 taps x 128 ci) x 128 co wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_x", 0 | 1)
 static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 32 == 0 && c_out % 32 == 0 && c_in >= 64 && c_out >= 64; }
 int g_tn_p8 = 1;  // LDS-DMA + transposing-read wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_p8", 0 | 1)
 template <typename T>
 static void launch_tn8x(const TnArgs<T>&, int64_t, hipStream_t) {}
 template <>
 void launch_tn8x<bf16>(const TnArgs<bf16>& a, int64_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(conv_tn8x_kernel, dim3((unsigned)grid), dim3(512), 0, stream, a);
+    if (g_tn_x == 2) {
+        hipLaunchKernelGGL(conv_tn8x_kernel<true>, dim3((unsigned)grid), dim3(512), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(conv_tn8x_kernel<false>, dim3((unsigned)grid), dim3(512), 0, stream, a);
+    }
 }
 template <typename T>
 static bool launch_tn8(const TnArgs<T>&, int64_t, hipStream_t) { return false; }
