@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (cfg: 128)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--loss", default="contrastive")
-    ap.add_argument("--dominant", default="vm_conv_wgrad", help="entry point timed with HIP events for the roofline object")
+    ap.add_argument("--dominant", default="auto", help="entry point whose launches the roofline object describes: auto = the "
+                    "GEMM family (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) with the largest share of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-wgrad", action="store_true", help="run the weight-gradient GEMMs on a side stream")
     ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
@@ -108,7 +109,8 @@ def main():
         step()
     torch.cuda.synchronize()
     parallel.barrier()
-    eng.timed = {a.dominant: []}
+    families = ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"] if a.dominant == "auto" else [a.dominant]
+    eng.timed = {nm: [] for nm in families}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -117,6 +119,8 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
+    totals = {nm: sum(e0.elapsed_time(e1) for e0, e1, _ in eng.timed[nm]) for nm in families}
+    a.dominant = max(totals, key=totals.get)
     recs = eng.timed[a.dominant]
     eng.timed = {}
     loss = float(pl["loss_acc"][0].item())
@@ -151,6 +155,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     roof["kernel"] = a.dominant
+    roof["family_ms_per_step"] = {nm: totals[nm] / a.steps for nm in families}
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
     roof["step_hbm_frac"] = TRAIN_BYTES_PER_WINDOW * (2 * pairs * a.steps / dt) / (HBM_PEAK_GBS * 1e9)

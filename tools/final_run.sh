@@ -12,10 +12,10 @@ timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --overlap-wg
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $O/pmc_$C
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_$C.log 2>&1; echo "pmc $C rc=$?"
+  rm -rf $O/pmc_${C}
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${C}_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_${C}_$TAG.log 2>&1; echo "pmc $C rc=$?"
 done
 cd $R
 DB=$(find $O/prof_$TAG -name "*_results.db" | head -1); python tools/rocpd_summary.py $DB $O/kernel_stats_$TAG.csv
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic_$TAG.json
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc_traffic_$TAG.json
 tail -3 $O/pytest_$TAG.log; tail -1 $O/bench_$TAG.log; tail -1 $O/bench_${TAG}_overlap.log

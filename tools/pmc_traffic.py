@@ -16,6 +16,20 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def per_order(d, counter, name_has, period):
+    """Mean counter value of the i-th (mod period) dispatch of the kernels whose name contains all of name_has."""
+    rows = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and any(all(h in r["Kernel_Name"] for h in alt) for alt in name_has):
+                rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    rows.sort()
+    out = [[] for _ in range(period)]
+    for i, (_, v) in enumerate(rows):
+        out[i % period].append(v)
+    return [sum(v) / len(v) if v else None for v in out]
+
+
 def per_family(d, counter):
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -34,15 +48,22 @@ def main(fetch_dir, write_dir, out):
     n = 256
     for (L, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
         splits = lib.query("vm_conv_wgrad_splits", n, L, cin, cout)
-        big = 3 * cin >= 192 and cout >= 192
-        tile = 256 if big else 128
-        blocks = splits * (-(-3 * cin // tile)) * (-(-cout // tile))
-        grid = blocks * (512 if big else 256)
+        grid = splits * (-(-cin // 128)) * (-(-cout // 128)) * 512  # conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
         for (name, g), fv in fetch.items():
-            if "conv_tn" in name and g == grid:
+            if "conv_tn8x" in name and g == grid:
                 wv = write.get((name, g), 0.0)
                 res["kernels"]["vm_conv_wgrad|%d|%d|%d|%d" % (n, L, cin, cout)] = {
                     "fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024, "grid": g}
+    # forward / dgrad launches share one grid size: told apart by dispatch order (forward: blocks 2,3,4; dgrad: 4,3,2)
+    shapes = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
+    # (rocprofv3 prints some instantiations demangled, with the epilogue enum elided: "<bool _Accum, int, E, 128, false>")
+    for entry, has, order in (("vm_conv_fwd", [("conv_nt", "Li0E")], shapes),
+                              ("vm_conv_dgrad", [("conv_nt", "Li1E"), ("conv_nt_glds_kernel<", "128, false>")], shapes[::-1])):
+        fv, wv = per_order(fetch_dir, "FETCH_SIZE", has, 3), per_order(write_dir, "WRITE_SIZE", has, 3)
+        for (L, cin, cout), f_, w_ in zip(order, fv, wv):
+            if f_ is not None and w_ is not None:
+                res["kernels"]["%s|%d|%d|%d|%d" % (entry, n, L, cin, cout)] = {
+                    "fetch_kb": f_, "write_kb": w_, "hbm_bytes": 2 * f_ * 1024 + w_ * 1024}
     # everything else: per (kernel, grid) family, for the record
     fam = {}
     for (name, g), fv in fetch.items():
