@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--dominant", default="auto", help="entry point whose launches the roofline object describes: auto = the "
                     "GEMM family (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) with the largest share of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-wgrad", action="store_true", help="run the weight-gradient GEMMs on a side stream")
+    ap.add_argument("--no-overlap-wgrad", action="store_true",
+                    help="keep the weight-gradient GEMMs on the main stream (default: side stream, concurrent with dgrad)")
     ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
     ap.add_argument("--tune", default="", help="extra tuning knobs key=value,key=value (vm_set_tuning)")
     ap.add_argument("--nt-blocks", type=int, default=0, help="tuning: persistent grid of the NT conv GEMMs, 0 = library default")
@@ -71,7 +72,7 @@ def main():
     F, E = 128, 64
     blocks = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
     eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
-    eng.overlap_wgrad = bool(a.overlap_wgrad)
+    eng.overlap_wgrad = not a.no_overlap_wgrad
     if a.gemm_kb:
         eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
     for kv in [t for t in a.tune.split(",") if t]:
@@ -109,7 +110,12 @@ def main():
         step()
     torch.cuda.synchronize()
     parallel.barrier()
-    families = ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"] if a.dominant == "auto" else [a.dominant]
+    # With the side-stream wgrad the backward kernels run concurrently and their durations are not attributable; the forward
+    # GEMMs never overlap anything and are the largest family of the serial breakdown as well (profiles/*breakdown*).
+    if a.dominant == "auto":
+        families = ["vm_conv_fwd"] if eng.overlap_wgrad else ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
+    else:
+        families = [a.dominant]
     eng.timed = {nm: [] for nm in families}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -176,6 +182,7 @@ def main():
                  "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]
         eng.timed = {nm: [] for nm in names}
+        was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False  # serial, so that every entry point is attributable
         reps = 3
         for _ in range(reps):
             step()
@@ -186,11 +193,13 @@ def main():
             tot = sum(e0.elapsed_time(e1) for e0, e1, _ in r_) / reps
             rows.append((nm, len(r_) // reps, tot))
         eng.timed = {}
+        eng.overlap_wgrad = was_overlap
         with open(a.breakdown, "w") as f:
             f.write("entry_point,launches_per_step,ms_per_step\n")
             for nm, cnt, tot in sorted(rows, key=lambda r: -r[2]):
                 f.write("%s,%d,%.4f\n" % (nm, cnt, tot))
             f.write("TOTAL_EVENT_MS,,%.4f\nWALL_MS_PER_STEP,,%.4f\n" % (sum(r[2] for r in rows), ms))
+            f.write("# breakdown steps run with the wgrad side stream off; WALL is the timed region (overlap %s)\n" % ("on" if was_overlap else "off"))
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         from oracle import voicemap_oracle as O

@@ -222,6 +222,13 @@ def test_full_size_properties_cfgA_bf16():
                                     apply_update=False)
         assert torch.equal(g1, eng.G), "gradients must be run-to-run bit-identical"
         assert torch.equal(loss1, pl["loss_acc"])
+        # the weight-gradient GEMMs on the side stream (default) or on the main stream: same bits
+        eng.overlap_wgrad = not eng.overlap_wgrad
+        eng.init_params(1234)
+        pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,
+                                    apply_update=False)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, eng.G), "side-stream wgrad must not change the gradients"
         assert torch.isfinite(eng.G).all() and torch.isfinite(loss1).all()
         res[dtype] = (emb.cpu().numpy(), loss1.cpu().numpy(), g1.cpu().numpy())
         del eng, pl

@@ -8,7 +8,7 @@ cd $R
 timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_$TAG.log 2>&1; echo "pytest rc=$?"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"
 timeout 300 python bench.py --steps 20 --warmup 5 --breakdown $O/breakdown_$TAG.csv > $O/bench_$TAG.log 2>&1; echo "bench rc=$?"
-timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --overlap-wgrad > $O/bench_${TAG}_overlap.log 2>&1
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-wgrad > $O/bench_${TAG}_serial.log 2>&1
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -18,4 +18,4 @@ done
 cd $R
 DB=$(find $O/prof_$TAG -name "*_results.db" | head -1); python tools/rocpd_summary.py $DB $O/kernel_stats_$TAG.csv
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc_traffic_$TAG.json
-tail -3 $O/pytest_$TAG.log; tail -1 $O/bench_$TAG.log; tail -1 $O/bench_${TAG}_overlap.log
+tail -3 $O/pytest_$TAG.log; tail -1 $O/bench_$TAG.log; tail -1 $O/bench_${TAG}_serial.log
