@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--dominant", default="auto", help="entry point whose launches the roofline object describes: auto = the "
                     "GEMM family (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) with the largest share of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side figures (other loss, embed-only pass)")
     ap.add_argument("--no-overlap-wgrad", action="store_true",
                     help="keep the weight-gradient GEMMs on the main stream (default: side stream, concurrent with dgrad)")
     ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
@@ -200,6 +201,39 @@ def main():
                 f.write("%s,%d,%.4f\n" % (nm, cnt, tot))
             f.write("TOTAL_EVENT_MS,,%.4f\nWALL_MS_PER_STEP,,%.4f\n" % (sum(r[2] for r in rows), ms))
             f.write("# breakdown steps run with the wgrad side stream off; WALL is the timed region (overlap %s)\n" % ("on" if was_overlap else "off"))
+
+    if rank == 0 and n_gpus == 1 and not a.no_extras:
+        # Side figures of SURVEY 8(d), measured after (and outside) the timed region: the same step with the other loss of
+        # the two training scripts, and the embed-only (inference) pass of the same 256 windows.
+        def timed(fn, reps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps
+        other = "bce" if a.loss == "contrastive" else "contrastive"
+        snap = (eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.iterations)
+
+        def step_other():
+            eng.preprocess(pl, xcat, 4, True, pairs)
+            eng.forward(pl, pairs, None)
+            eng.siamese_head(pl, y, other)
+            eng.backward(pl)
+            eng.optimizer_step()
+        t_other = timed(step_other)
+        pli = eng.plan(2 * pairs, l0, False)
+
+        def embed_only():
+            eng.preprocess(pli, xcat, 4, True, 2 * pairs)
+            eng.forward(pli, 2 * pairs, None)
+        t_embed = timed(embed_only)
+        eng.P.copy_(snap[0]); eng.M.copy_(snap[1]); eng.V.copy_(snap[2]); eng.iterations = snap[3]
+        eng.refresh_weights()
+        out["extras"] = {"%s_loss_ms_per_step" % other: t_other * 1e3,
+                         "embed_only_audio_s_per_s": 2 * pairs * 3.0 / t_embed, "embed_only_ms_per_256_windows": t_embed * 1e3}
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         from oracle import voicemap_oracle as O

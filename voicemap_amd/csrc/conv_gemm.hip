@@ -1688,7 +1688,7 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
 //     its last stage holds the zero halo row L + 1; positions >= L are neutralised on the dU side (source row L + 1 = zero
 //     halo), so what the A rows of such positions hold does not matter as long as it is finite (the ring is zeroed once).
 //   * 8 waves = 4 (input-channel blocks of 32) x 2 (64 output channels): a wave owns 3 taps x 32 ci x 64 co = 6 accumulator
-//     tiles; 24 MFMAs per stage in two clusters of 12; waves 4-7 (channel blocks 2, 3) run one slot behind waves 0-3.
+//     tiles; 24 MFMAs per stage in clusters of 8 and 16; waves 4-7 (channel blocks 2, 3) run one slot behind waves 0-3.
 //   * DMA runs three stages ahead: stage g + 3 is issued in the second READ slot of stage g (into the ring slot of stage
 //     g - 1, whose last reads completed a phase earlier) and the counted vmcnt(4) there retires stage g + 2 -- stage g + 1
 //     needs it for its tap overflow rows.
@@ -1697,10 +1697,10 @@ __global__ __launch_bounds__(512) void conv_tn8_kernel(TnArgs<bf16> p) {
 // ------------------------------------------------------------------------------------------------
 namespace t8x {
 constexpr int ROWS = 256;                  // ring rows per A block
-constexpr int ABLK = ROWS * 64;            // 16 KB
-constexpr int A_BYTES = 4 * ABLK;          // 64 KB
-constexpr int BBLK = 64 * 64;              // 4 KB
-constexpr int BSTAGE = 4 * BBLK;           // 16 KB
+constexpr int ABLK = ROWS * 128;           // 32 KB: one block = 64 channels, 128-byte rows (whole cache lines per DMA row)
+constexpr int A_BYTES = 2 * ABLK;          // 64 KB
+constexpr int BBLK = 64 * 128;             // 8 KB
+constexpr int BSTAGE = 2 * BBLK;           // 16 KB
 constexpr int LDS_BYTES = A_BYTES + 4 * BSTAGE;  // 128 KB
 struct Frag4 {  // 4 k-steps; the two 8-byte halves are only joined at the MFMA, i.e. after the lgkmcnt wait
     u32x2 lo[4], hi[4];
@@ -1749,43 +1749,52 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
         for (int i = tid * 16; i < A_BYTES; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
         __syncthreads();
 
-        // ---- DMA geometry: per stage 16 wave-instructions for A and 16 for B (16 positions x 64 bytes of one block each) ----
-        const int dpos = (w & 3) * 16 + (lane >> 2);
-        const int dchunk = (lane & 3) * 8;  // elements
+        // ---- DMA geometry: per stage 16 wave-instructions for A and 16 for B; one instruction = 8 position rows x 128 bytes
+        // (64 channels: whole 128-byte lines -- with 64-byte rows two instructions fetched the halves of every line and the
+        // vector L1 spent half its time on hits-on-miss).  Inside a row the two 64-byte halves (32 channels each) are swapped
+        // when bit 1 of the row index is set, so that the 4 rows x 64 bytes a transposing read touches fall in 4 different
+        // 64-byte bank segments; the swap is applied to the per-lane SOURCE chunk here and again in the read addresses.
+        const int drow = w * 8 + (lane >> 3);
+        const int dchunk = ((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8;  // elements; (row >> 1) & 1 == (lane >> 4) & 1
         const char* const x_base = reinterpret_cast<const char*>(p.x);
         const char* const d_base = reinterpret_cast<const char*>(p.du);
         const int abl = p.ablate;
         auto stage = [&](int slot, int n, int st) {
-            const int t = st * 64 + dpos;
+            const int t = st * 64 + drow;
             if (!(abl & 32)) {
                 int r = t < p.L + 1 ? t : p.L + 1;  // padded row of tap 0 at position t; rows past the halo are never used
                 const char* src = x_base + n * p.x_win_stride * 2;
-                char* dst = lds + slot * 4096 + (w & 3) * 1024;
+                char* dst = lds + slot * 8192 + w * 1024;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int blk = j * 2 + (w >> 2);
-                    int c0 = ci0 + blk * 32;
+                    int c0 = ci0 + j * 64;
                     c0 = c0 < p.c_in ? c0 : 0;
-                    glds16(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + blk * ABLK);
+                    glds16(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + j * ABLK);
                 }
             }
             if (!(abl & 64)) {
                 const int r = (t < p.L ? t : p.L) + 1;  // row L + 1 of the padded dU tensor is the zero halo
                 const char* src = d_base + n * p.du_win_stride * 2;
-                char* dst = lds + A_BYTES + slot * BSTAGE + (w & 3) * 1024;
+                char* dst = lds + A_BYTES + slot * BSTAGE + w * 1024;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int blk = j * 2 + (w >> 2);
-                    int co0 = j0 + blk * 32;
+                    int co0 = j0 + j * 64;
                     co0 = co0 < p.c_out ? co0 : 0;
-                    glds16(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + blk * BBLK);
+                    glds16(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + j * BBLK);
                 }
             }
         };
 
         // ---- fragment reads (transposing, see conv_tn8_kernel) ----
+        // lane -> row (kh * 8 + (li >> 2)) of the 16 rows of a k-step, channel lg * 16 + li of the wave's 32-channel half
         const int li = lane & 15, lg = (lane >> 4) & 1, kh = lane >> 5;
-        const int lane_off = (kh * 8 + (li >> 2)) * 64 + lg * 32 + (li & 3) * 8;
+        const int rowl = kh * 8 + (li >> 2);
+        const int sub = lg * 32 + (li & 3) * 8;
+        // A: half (wm & 1) of 64-channel block (wm >> 1); the swap bit of ring row U + rowl + tap (U % 4 == 0) depends on tap
+        int a_off[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a_off[t] = (rowl + t) * 128 + (((wm & 1) ^ (((rowl + t) >> 1) & 1)) * 64) + sub;
+        const int b_off = rowl * 128 + ((((rowl >> 1) & 1)) * 64) + sub;  // xor with the column half jn below
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
         auto tr_pair = [&](u32x2& lo, u32x2& hi, uint32_t a_lo, uint32_t a_hi) {
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
@@ -1793,19 +1802,18 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
         };
         auto read_a = [&](Frag4& fa, int slot, int tap) {
             if (abl & 16) return;
-            const uint32_t blk = lds0 + wm * ABLK;
-            const uint32_t u = slot * 4096 + tap * 64 + lane_off;
+            const uint32_t blk = lds0 + (wm >> 1) * ABLK;
+            const uint32_t u = slot * 8192 + a_off[tap];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                tr_pair(fa.lo[s], fa.hi[s], blk + ((u + s * 1024) & (ABLK - 1)), blk + ((u + s * 1024 + 256) & (ABLK - 1)));
+                tr_pair(fa.lo[s], fa.hi[s], blk + ((u + s * 2048) & (ABLK - 1)), blk + ((u + s * 2048 + 512) & (ABLK - 1)));
         };
         auto read_b = [&](Frag4& fb, int slot, int jn) {
             if (abl & 16) return;
-            const uint32_t a = lds0 + A_BYTES + slot * BSTAGE + (wn * 2 + jn) * BBLK + lane_off;
+            const uint32_t a = lds0 + A_BYTES + slot * BSTAGE + wn * BBLK + (b_off ^ (jn * 64));
 #pragma unroll
-            for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 1024, a + s * 1024 + 256);
+            for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 2048, a + s * 2048 + 512);
         };
-        // three accumulator tiles per cluster, k-steps interleaved: consecutive MFMAs never depend on each other
         auto mma3 = [&](const Frag4& a0, const Frag4& b0, f32x16& c0, const Frag4& a1, const Frag4& b1, f32x16& c1, const Frag4& a2,
                         const Frag4& b2, f32x16& c2) {
             if (abl & 4) return;
@@ -1819,6 +1827,34 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b0, s), op(a0, s), c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b1, s), op(a1, s), c1, 0, 0, 0);
                 c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b2, s), op(a2, s), c2, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // clusters of 8 (one tap) and 16 (two taps) MFMAs, k-steps interleaved over the accumulator tiles
+        auto opf = [](const Frag4& f, int s) {
+            const u32x4 v = {f.lo[s][0], f.lo[s][1], f.hi[s][0], f.hi[s][1]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        auto mma_a = [&](const Frag4& a0, const Frag4& b0, const Frag4& b1, f32x16& c0, f32x16& c1) {
+            if (abl & 4) return;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b0, s), opf(a0, s), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b1, s), opf(a0, s), c1, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto mma_b = [&](const Frag4& a0, const Frag4& a1, const Frag4& b0, const Frag4& b1, f32x16& c00, f32x16& c01, f32x16& c10,
+                         f32x16& c11) {
+            if (abl & 4) return;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b0, s), opf(a0, s), c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b1, s), opf(a0, s), c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b0, s), opf(a1, s), c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opf(b1, s), opf(a1, s), c11, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -1918,16 +1954,19 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
             }
             slot_end();
             if (w >= 4) slot_end();  // channel blocks 2, 3 run one slot behind
+            // A wave keeps at most 15 LDS reads in flight (lgkmcnt is 4 bits), so a READ slot costs about one LDS round trip
+            // per 15 reads: the slots are paired big-with-big -- READ0 (24 reads) runs beside the other group's MFMA1 (16
+            // MFMAs), READ1 (16 reads + the DMA) beside its MFMA0 (8).
             for (int g = 0; g < G; ++g) {
                 const int slot = g & 3;
                 read_a(fa0, slot, 0);
-                read_a(fa1, slot, 1);
                 read_b(fb0, slot, 0);
                 read_b(fb1, slot, 1);
                 read_done();
                 slot_end();
-                mma3(fa0, fb0, acc[0][0], fa0, fb1, acc[0][1], fa1, fb0, acc[1][0]);
+                mma_a(fa0, fb0, fb1, acc[0][0], acc[0][1]);
                 slot_end();
+                read_a(fa1, slot, 1);
                 read_a(fa0, slot, 2);
                 if (staged < G && !(abl & 8)) {
                     stage_next();
@@ -1941,7 +1980,7 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
                 }
                 read_done();
                 slot_end();
-                mma3(fa1, fb1, acc[1][1], fa0, fb0, acc[2][0], fa0, fb1, acc[2][1]);
+                mma_b(fa1, fa0, fb0, fb1, acc[1][0], acc[1][1], acc[2][0], acc[2][1]);
                 slot_end();
             }
             if (w < 4) slot_end();  // balance the barrier count of the two groups
@@ -2134,7 +2173,7 @@ int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) 
 
 extern int g_tn_x;
 int g_tn_x = 1;   // (2: free-running form) input-resident (3 taps x 128 ci) x 128 co wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_x", 0 | 1)
-static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 32 == 0 && c_out % 32 == 0 && c_in >= 64 && c_out >= 64; }
+static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 64 == 0 && c_out % 64 == 0; }
 int g_tn_p8 = 1;  // LDS-DMA + transposing-read wgrad kernel (bf16, channels % 32 == 0); vm_set_tuning("tn_p8", 0 | 1)
 template <typename T>
 static void launch_tn8x(const TnArgs<T>&, int64_t, hipStream_t) {}
