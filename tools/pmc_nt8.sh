@@ -8,7 +8,7 @@ P4="TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TA_BUSY T
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  timeout 200 rocprofv3 --pmc $P --output-format csv -d /tmp/pmc_$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $@ > /tmp/pmc_$i.log 2>&1 || tail -3 /tmp/pmc_$i.log
+  timeout 200 rocprofv3 --pmc $P --output-format csv -d /tmp/pmc_$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $@ > /tmp/pmc_$i.log 2>&1 || tail -3 /tmp/pmc_$i.log
 done
 python $R/tools/pmc_summary.py /tmp/pmc_1 /tmp/pmc_2 /tmp/pmc_3 /tmp/pmc_4 > $R/gpurun_out/pmc_nt8.csv
 grep -E "^kernel|nt8|conv_nt" $R/gpurun_out/pmc_nt8.csv
