@@ -15,6 +15,40 @@ namespace vm {
 
 constexpr int BN_SEG = 8;  // partial-sum segments per window in the backward kernels
 
+// VEC consecutive per-channel values (VEC = 4 or 8, 16-byte aligned) as 16-byte accesses: the kernels below run only a
+// dozen loop iterations per thread on the last block, so 5 x 8 scalar parameter loads per thread were a visible cost.
+template <int VEC>
+__device__ inline void loadv(const float* p, float (&v)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * k + e] = t[e];
+    }
+}
+template <int VEC>
+__device__ inline void loadvi(const int32_t* p, int (&v)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * k + e] = (int)t[e];
+    }
+}
+template <int VEC>
+__device__ inline void storev(float* p, const float (&v)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+        const f32x4 t = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        *reinterpret_cast<f32x4*>(p + 4 * k) = t;
+    }
+}
+template <int VEC>
+__device__ inline void ones(float (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = 1.0f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Column sums of (rows, C) fp32 partial matrices, two deterministic stages so that the long reduction over
 // rows is spread over many workgroups instead of C/64 of them:
@@ -130,11 +164,12 @@ __global__ __launch_bounds__(256) void bn_drop_pool_fwd_kernel(const T* __restri
     for (int cv = pl; cv < CV; cv += P) {
         const int c0 = cv * VEC;
         float sc[VEC], sh[VEC], dr[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            sc[i] = scale[tw * C + c0 + i];
-            sh[i] = shift[tw * C + c0 + i];
-            dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
+        loadv<VEC>(scale + tw * C + c0, sc);
+        loadv<VEC>(shift + tw * C + c0, sh);
+        if (drop) {
+            loadv<VEC>(drop + n * C + c0, dr);
+        } else {
+            ones<VEC>(dr);
         }
         const T* zrow = z + n * L * C + c0;
         T* orow = out + (n * (Lq + 2) + 1) * C + c0;
@@ -170,8 +205,8 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                                                                     int C, int P, float* __restrict__ part_v,
                                                                     int32_t* __restrict__ part_i) {
     constexpr int VEC = Elem<T>::kVec;
-    __shared__ float rv[256][VEC];
-    __shared__ int ri[256][VEC];
+    __shared__ __attribute__((aligned(16))) float rv[256][VEC];
+    __shared__ __attribute__((aligned(16))) int ri[256][VEC];
     const int tid = threadIdx.x;
     const int RP = 256 / P;
     const int pl = tid % P, rl = tid / P;
@@ -193,11 +228,12 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
         }
         if (cok) {
             float sc[VEC], sh[VEC], dr[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sc[i] = scale[tw * C + c0 + i];
-                sh[i] = shift[tw * C + c0 + i];
-                dr[i] = drop ? drop[n * C + c0 + i] : 1.0f;
+            loadv<VEC>(scale + tw * C + c0, sc);
+            loadv<VEC>(shift + tw * C + c0, sh);
+            if (drop) {
+                loadv<VEC>(drop + n * C + c0, dr);
+            } else {
+                ones<VEC>(dr);
             }
             const T* zrow = z + n * L * C + c0;
             for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Lq; q += (int64_t)RP * BN_SEG) {
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                                                                 float* __restrict__ part_a, const float* __restrict__ sp_dg,
                                                                 const int32_t* __restrict__ sp_idx) {
     constexpr int VEC = Elem<T>::kVec;
-    __shared__ float red[256][VEC];
+    __shared__ __attribute__((aligned(16))) float red[256][VEC];
     const int tid = threadIdx.x;
     const int RP = 256 / P;
     const int pl = tid % P, rl = tid / P;
@@ -308,29 +344,40 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
             acc[i] = 0.f;
             ka[i] = kb[i] = kc[i] = 0.f;
             sgn[i] = 1.f;
-            if (cok) {
-                const float sc = scale[tw * C + c0 + i];
-                const float mu = mean[tw * C + c0 + i];
-                const float is = invstd[tw * C + c0 + i];
-                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
-                const float k1 = c1[tw * C + c0 + i], k2 = c2[tw * C + c0 + i];
-                sgn[i] = sc * dr < 0.f ? -1.f : 1.f;
-                ka[i] = sc * dr;
-                kb[i] = sc * (is * k2 * mu - k1);
-                kc[i] = -sc * is * k2;
+        }
+        if (cok) {
+            float sc[VEC], mu[VEC], is[VEC], dr[VEC], k1[VEC], k2[VEC];
+            loadv<VEC>(scale + tw * C + c0, sc);
+            loadv<VEC>(mean + tw * C + c0, mu);
+            loadv<VEC>(invstd + tw * C + c0, is);
+            loadv<VEC>(c1 + tw * C + c0, k1);
+            loadv<VEC>(c2 + tw * C + c0, k2);
+            if (drop) {
+                loadv<VEC>(drop + n * C + c0, dr);
+            } else {
+                ones<VEC>(dr);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sgn[i] = sc[i] * dr[i] < 0.f ? -1.f : 1.f;
+                ka[i] = sc[i] * dr[i];
+                kb[i] = sc[i] * (is[i] * k2[i] * mu[i] - k1[i]);
+                kc[i] = -sc[i] * is[i] * k2[i];
             }
         }
-        float spv[SP ? VEC : 1];
-        int spi[SP ? VEC : 1];
-        if (SP) {
+        float spv[VEC];
+        int spi[VEC];
+        if constexpr (SP) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 spv[i] = 0.f;
                 spi[i] = -1;
-                if (cok) {
-                    spi[i] = sp_idx[n * C + c0 + i];
-                    spv[i] = Elem<T>::to_f(Elem<T>::from_f(sp_dg[n * C + c0 + i]));  // same rounding as the dense dp tensor
-                }
+            }
+            if (cok) {
+                loadvi<VEC>(sp_idx + n * C + c0, spi);
+                loadv<VEC>(sp_dg + n * C + c0, spv);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) spv[i] = Elem<T>::to_f(Elem<T>::from_f(spv[i]));  // same rounding as the dense dp tensor
             }
         }
         if (cok) {
@@ -382,12 +429,16 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
         __syncthreads();
         if (rl == 0 && cok) {
             const int64_t row = n * BN_SEG + seg;
+            float a[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                float a = 0.f;
-                for (int r = 0; r < RP; ++r) a += red[r * P + pl][i];
-                part_a[row * C + c0 + i] = a;
+            for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+            for (int r = 0; r < RP; ++r) {
+                float t[VEC];
+                loadv<VEC>(&red[r * P + pl][0], t);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) a[i] += t[i];
             }
+            storev<VEC>(part_a + row * C + c0, a);
         }
         __syncthreads();
     }
@@ -407,7 +458,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
                                                                  int64_t wpt, int64_t L, int C, int P,
                                                                  float* __restrict__ part_a, float* __restrict__ part_b) {
     constexpr int VEC = Elem<T>::kVec;
-    __shared__ float red[2][256][VEC];
+    __shared__ __attribute__((aligned(16))) float red[2][256][VEC];
     const int tid = threadIdx.x;
     const int RP = 256 / P;
     const int pl = tid % P, rl = tid / P;
@@ -427,10 +478,17 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
             s0[i] = 0.f;
             s1[i] = 0.f;
             sgn[i] = 1.f;
-            if (cok) {
-                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
-                sgn[i] = scale[tw * C + c0 + i] * dr < 0.f ? -1.f : 1.f;
+        }
+        if (cok) {
+            float sc[VEC], dr[VEC];
+            loadv<VEC>(scale + tw * C + c0, sc);
+            if (drop) {
+                loadv<VEC>(drop + n * C + c0, dr);
+            } else {
+                ones<VEC>(dr);
             }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) sgn[i] = sc[i] * dr[i] < 0.f ? -1.f : 1.f;
         }
         if (cok) {
             const T* zb = z + n * L * C + c0;
@@ -477,18 +535,33 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
         __syncthreads();
         if (rl == 0 && cok) {
             const int64_t row = n * BN_SEG + seg;
+            float a[VEC], b[VEC], dr[VEC], mu[VEC], is[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) a[i] = b[i] = 0.f;
+            for (int r = 0; r < RP; ++r) {
+                float ta[VEC], tb[VEC];
+                loadv<VEC>(&red[0][r * P + pl][0], ta);
+                loadv<VEC>(&red[1][r * P + pl][0], tb);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    a[i] += ta[i];
+                    b[i] += tb[i];
+                }
+            }
+            loadv<VEC>(mean + tw * C + c0, mu);
+            loadv<VEC>(invstd + tw * C + c0, is);
+            if (drop) {
+                loadv<VEC>(drop + n * C + c0, dr);
+            } else {
+                ones<VEC>(dr);
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                float a = 0.f, b = 0.f;
-                for (int r = 0; r < RP; ++r) {
-                    a += red[0][r * P + pl][i];
-                    b += red[1][r * P + pl][i];
-                }
-                const float dr = drop ? drop[n * C + c0 + i] : 1.0f;
-                const float mu = mean[tw * C + c0 + i], is = invstd[tw * C + c0 + i];
-                part_a[row * C + c0 + i] = dr * a;
-                part_b[row * C + c0 + i] = dr * is * (b - mu * a);
+                b[i] = dr[i] * is[i] * (b[i] - mu[i] * a[i]);
+                a[i] = dr[i] * a[i];
             }
+            storev<VEC>(part_a + row * C + c0, a);
+            storev<VEC>(part_b + row * C + c0, b);
         }
         __syncthreads();
     }
