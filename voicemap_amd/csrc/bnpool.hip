@@ -54,7 +54,7 @@ __device__ inline void ones(float (&v)[VEC]) {
 // rows is spread over many workgroups instead of C/64 of them:
 //   stage 1: grid (C/64, segments*CR_CHUNKS); a workgroup (64 channels x 16 row lanes) sums one row chunk of
 //            one segment (tower) in fp64 -> ws[(seg*CR_CHUNKS + chunk)][which][C]
-//   stage 2: the consumer kernel adds the CR_CHUNKS doubles per (segment, channel) in a fixed order.
+//   stage 2: the consumer kernel adds the CR_CHUNKS doubles per (segment, channel) in a fixed (butterfly) order.
 constexpr int CR_CHUNKS = 32;
 
 __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -90,12 +90,16 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     }
 }
 
-__device__ inline void colreduce_stage2(const double* __restrict__ ws, int seg, int C, int c, double& s, double& q) {
-    s = 0.0;
-    q = 0.0;
-    for (int k = 0; k < CR_CHUNKS; ++k) {
-        s += ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c];
-        q += ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c];
+// Stage 2 spread over 32 lanes (one partial each) + a fixed-order butterfly: the finalize kernels are latency-bound chains
+// of dependent loads otherwise (8 us for 512 channels).  Thread layout of the callers: 8 channels x 32 lanes per workgroup.
+__device__ inline void colreduce_stage2_par(const double* __restrict__ ws, int seg, int C, int c, int k, double& s, double& q) {
+    static_assert(CR_CHUNKS == 32, "one lane per partial");
+    s = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c];
+    q = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
     }
 }
 
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            float eps, float momentum, int unbiased, float* moving_mean,
                                                            float* moving_var, float* mean, float* invstd, float* scale,
                                                            float* shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= C) return;
     float mm = 0.f, mv = 0.f;
     if (moving_mean != nullptr) {
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
     for (int tw = 0; tw < n_towers; ++tw) {
         double ss, qq;
-        colreduce_stage2(ws, tw, C, c, ss, qq);
+        colreduce_stage2_par(ws, tw, C, c, k, ss, qq);
+        if (k != 0) continue;
         const double m = ss / count;
         double var = qq / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             mv = mv - (mv - (float)vv) * (1.0f - momentum);
         }
     }
-    if (moving_mean != nullptr) {
+    if (moving_mean != nullptr && k == 0) {
         moving_mean[c] = mm;
         moving_var[c] = mv;
     }
@@ -609,27 +614,31 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_gmax_kernel(const T* _
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int n_towers, int C, double count,
                                                                float* c1, float* c2, float* grad_gamma, float* grad_beta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= C) return;
     double gg = 0.0, gb = 0.0;
     for (int tw = 0; tw < n_towers; ++tw) {
         double ss, qq;
-        colreduce_stage2(ws, tw, C, c, ss, qq);
-        c1[tw * C + c] = (float)(ss / count);
-        c2[tw * C + c] = (float)(qq / count);
+        colreduce_stage2_par(ws, tw, C, c, k, ss, qq);
+        if (k == 0) {
+            c1[tw * C + c] = (float)(ss / count);
+            c2[tw * C + c] = (float)(qq / count);
+        }
         gb += ss;
         gg += qq;
     }
-    grad_gamma[c] = (float)gg;
-    grad_beta[c] = (float)gb;
+    if (k == 0) {
+        grad_gamma[c] = (float)gg;
+        grad_beta[c] = (float)gb;
+    }
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ ws, int C, float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= C) return;
     double ss, qq;
-    colreduce_stage2(ws, 0, C, c, ss, qq);
-    out[c] = (float)ss;
+    colreduce_stage2_par(ws, 0, C, c, k, ss, qq);
+    if (k == 0) out[c] = (float)ss;
 }
 
 static int lanes_for(int cv) {
@@ -655,7 +664,7 @@ extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
     hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
                        stat_sum, stat_sq, rows_per_tower, C, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
                        mean, invstd, scale, shift);
     return check_launch("vm_bn_finalize");
@@ -760,7 +769,7 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
     const int n_towers = (int)(n_windows / windows_per_tower);
     hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
                        part_dy, part_dyz, windows_per_tower * BN_SEG, C, (double*)ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
     return check_launch("vm_bn_bwd_finalize");
 }
@@ -809,7 +818,7 @@ extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, voi
     VM_REQUIRE(part && out && ws && rows > 0 && C > 0, "vm_colsum: bad argument");
     hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, part,
                        (const float*)nullptr, rows, C, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
                        out);
     return check_launch("vm_colsum");
 }
