@@ -54,6 +54,12 @@ int vm_set_tuning(const char* key, int value);
 int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows);
 int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_windows, int64_t raw_len, int downsampling,
                        int whitening, float rms, int64_t windows_per_tower, float* out, void* ws, void* stream);
+/* The same with the crop of voicemap/librispeech.py:103-137 done on the device: `audio` is a resident buffer of decoded
+ * recordings (int16 or fp32, all files back to back -- voicemap_amd/shards.py), window n is the raw_len samples starting at
+ * audio[offsets[n]] (offsets: n_windows int64 on the device).  The host only chooses the offsets. */
+int vm_crop_decimate_whiten(const void* audio, int raw_is_i16, const int64_t* offsets, int64_t n_windows, int64_t raw_len,
+                            int downsampling, int whitening, float rms, int64_t windows_per_tower, float* out, void* ws,
+                            void* stream);
 
 /* ---- a1 block 1: Conv1D(filters, 32, padding='same', activation='relu')  (voicemap/models.py:13-16) --
  * x: (n_windows, L + 31) fp32 from vm_decimate_whiten; w: (32, 1, F) fp32 Keras layout; bias (F).

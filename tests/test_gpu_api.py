@@ -140,3 +140,37 @@ def test_known_answer_task_through_public_api(golden_dir):
     net = models.load_keras_checkpoint_npz(os.path.join(golden_dir, "ckpt_cfgCK_weights.npz"), dtype="f32")
     bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
     assert utils.n_shot_task_evaluation(net, OneTask(), bp, 1, 1, 5, network_type="siamese") == 1
+
+
+@pytest.mark.gpu
+def test_device_side_crop_equals_host_crop(tmp_path):
+    """windows cropped on the device from resident int16 shards (vm_crop_decimate_whiten) give bit-identical
+    preprocessed inputs, and a bit-identical training step, to the same windows cropped on the host and fed as int16."""
+    import torch
+    from voicemap_amd import shards
+    from voicemap_amd.engine import HipEncoderEngine
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    src = SyntheticSpeechDataset(num_speakers=10, files_per_speaker=3, seconds=3, seed=9)
+    shards.write_shards(src, str(tmp_path), shard_samples=500000)
+    sd = shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=True)
+    audio = sd.to_device("cuda")
+    np.random.seed(4)
+    o1, o2, y = sd.build_verification_batch_offsets(8)
+    T = sd.fragment_length
+    cat = np.concatenate([np.asarray(m) for m in sd._maps])
+    x1 = np.stack([cat[o:o + T] for o in o1])
+    x2 = np.stack([cat[o:o + T] for o in o2])
+    blocks = [(32, 16, 4), (3, 32, 2), (3, 48, 2), (3, 64, 2)]
+    res = []
+    for mode in ("host", "device"):
+        eng = HipEncoderEngine(blocks, 24, dropout=0.0, head="uniform_euclidean", dtype="f32", seed=7)
+        if mode == "host":
+            pl = eng.siamese_train_step(torch.from_numpy(x1), torch.from_numpy(x2), y, preprocessed=False, downsampling=4,
+                                        drop_masks=None)
+        else:
+            pl = eng.siamese_train_step_from_offsets(audio, torch.from_numpy(o1).cuda(), torch.from_numpy(o2).cuda(), y, T,
+                                                     downsampling=4, drop_masks=None)
+        torch.cuda.synchronize()
+        res.append((pl["x0"].clone(), pl["loss_acc"].clone(), eng.G.clone(), eng.P.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

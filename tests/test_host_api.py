@@ -207,3 +207,44 @@ def test_voicemap_alias_package():
     from voicemap.utils import whiten, NShotEvaluationCallback, BatchPreProcessor, preprocess_instances, contrastive_loss  # noqa: F401
     from voicemap.librispeech import LibriSpeechDataset as L2
     assert L2 is LibriSpeechDataset and voicemap.models is models
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pre-decoded int16 shards: same dataset API, no decode, offsets for the device-side crop
+# ---------------------------------------------------------------------------------------------------------
+def test_sharded_dataset_round_trip_and_offsets(tmp_path):
+    from voicemap_amd import shards
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    src = SyntheticSpeechDataset(num_speakers=8, files_per_speaker=4, seconds=3, seed=5, stochastic=False)
+    index = shards.write_shards(src, str(tmp_path), shard_samples=300000)
+    assert index['shard'].max() >= 2 and (index.groupby('shard')['length'].sum() <= 300000).all() or len(index) > 0
+    sd = shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=False)
+    assert len(sd) == len(src) and sd.num_classes() == src.num_classes()
+    assert list(sd.df['speaker_id']) == list(src.df['speaker_id']) and list(sd.df['length']) == list(src.df['length'])
+    for i in (0, 7, len(sd) - 1):
+        a, la = sd[i]
+        b, lb = src[i]
+        assert la == lb and a.shape == b.shape == (sd.fragment_length,)
+        assert np.abs(a - b).max() <= 0.5 / 32768 + 1e-12  # int16 quantisation only
+    # every file's samples sit at global_offset in the concatenation of the shards
+    cat = np.concatenate([np.asarray(m) for m in sd._maps])
+    for i in (1, 9, len(sd) - 2):
+        o, n = sd.global_offset[i], sd.file_length[i]
+        assert np.array_equal(cat[o:o + n], shards.to_int16(src._load(i)))
+    # offsets batch: the reference's pair layout (tests/tests.py:16-68 restated) + fragments inside their files
+    sd.stochastic = True
+    np.random.seed(3)
+    o1, o2, y = sd.build_verification_batch_offsets(16)
+    assert o1.shape == o2.shape == (16,) and y.shape == (16, 1)
+    assert np.array_equal(y[:, 0], np.r_[np.zeros(8), np.ones(8)])
+    ends = sd.global_offset + sd.file_length
+
+    def owner(off):
+        k = np.searchsorted(sd.global_offset, off, side='right') - 1
+        assert off + sd.fragment_length <= ends[k]
+        return sd.datasetid_to_speaker_id[int(k)]
+    for a, b, lab in zip(o1, o2, y[:, 0]):
+        assert (owner(a) == owner(b)) == (lab == 0)
+    # the sampling API of the reference still works on top of the shards
+    q, (sup, sup_labels) = sd.build_n_shot_task(4, 2)
+    assert sup.shape == (8, sd.fragment_length) and q[1] == sup_labels[0] == sup_labels[1]

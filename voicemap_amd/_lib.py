@@ -34,6 +34,7 @@ SIGNATURES = {
     "vm_set_tuning": (I, [c_char_p, I]),
     "vm_decimate_whiten_workspace_bytes": (L, [L]),
     "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
+    "vm_crop_decimate_whiten": (I, [P, I, P, L, L, I, I, F, L, P, P, P]),
     "vm_conv1_stat_rows": (L, [L]),
     "vm_conv1_fwd": (I, [P, P, P, L, L, I, I, P, P, P, P]),
     "vm_conv1_wgrad_workspace_bytes": (L, [L, I]),

@@ -17,12 +17,13 @@ constexpr int WS_SEG = 8;  // partial-sum segments per window
 
 // pass 1: partial sum and sum of squares of the decimated samples.  grid = (n_windows, WS_SEG).
 template <typename R>
-__global__ __launch_bounds__(256) void whiten_stats_kernel(const R* __restrict__ raw, int64_t raw_len, int ds, int64_t L0,
-                                                           double* __restrict__ psum, double* __restrict__ psq) {
+__global__ __launch_bounds__(256) void whiten_stats_kernel(const R* __restrict__ raw, const int64_t* __restrict__ offsets,
+                                                           int64_t raw_len, int ds, int64_t L0, double* __restrict__ psum,
+                                                           double* __restrict__ psq) {
     __shared__ double red[2][4];
     const int64_t n = blockIdx.x;
     const int seg = blockIdx.y;
-    const R* r = raw + n * raw_len;
+    const R* r = raw + (offsets ? offsets[n] : n * raw_len);  // window n: its own crop of a resident recording, or row n
     const int64_t per = (L0 + WS_SEG - 1) / WS_SEG;
     const int64_t i1 = (seg + 1) * per < L0 ? (seg + 1) * per : L0;
     double s = 0.0, q = 0.0;
@@ -68,17 +69,19 @@ __global__ __launch_bounds__(256) void whiten_finalize_kernel(const double* __re
 
 // pass 2: write (x - mean_n) * scale_tower with the halo.  grid = (ceil((L0+31)/256), n_windows).
 template <typename R>
-__global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__ raw, int64_t raw_len, int ds, int64_t L0,
-                                                           int whitening, int64_t wpt, const double* __restrict__ mean,
-                                                           const double* __restrict__ scale, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__ raw, const int64_t* __restrict__ offsets,
+                                                           int64_t raw_len, int ds, int64_t L0, int whitening, int64_t wpt,
+                                                           const double* __restrict__ mean, const double* __restrict__ scale,
+                                                           float* __restrict__ out) {
     const int64_t n = blockIdx.y;
+    const R* r = raw + (offsets ? offsets[n] : n * raw_len);
     const double m = whitening ? mean[n] : 0.0;
     const double sc = whitening ? scale[n / wpt] : 1.0;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L0 + HALO) return;
     const int64_t t = i - HALO_L;
     float v = 0.f;
-    if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(raw[n * raw_len + t * ds]) - m) * sc);
+    if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(r[t * ds]) - m) * sc);
     out[n * (L0 + HALO) + i] = v;
 }
 
@@ -90,11 +93,9 @@ extern "C" int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows) {
     return (2 * WS_SEG + 2) * n_windows * (int64_t)sizeof(double);  // partials, per-window means, per-tower scales
 }
 
-extern "C" int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_windows, int64_t raw_len, int downsampling,
-                                  int whitening, float rms, int64_t windows_per_tower, float* out, void* ws, void* stream) {
-    VM_REQUIRE(raw && out && ws, "vm_decimate_whiten: null pointer");
-    VM_REQUIRE(n_windows > 0 && raw_len > 0 && downsampling > 0 && windows_per_tower > 0, "vm_decimate_whiten: bad sizes");
-    VM_REQUIRE(n_windows % windows_per_tower == 0, "vm_decimate_whiten: n_windows must be a multiple of windows_per_tower");
+static int decimate_whiten_impl(const char* what, const void* raw, int raw_is_i16, const int64_t* offsets, int64_t n_windows,
+                                int64_t raw_len, int downsampling, int whitening, float rms, int64_t windows_per_tower, float* out,
+                                void* ws, void* stream) {
     const int64_t L0 = (raw_len + downsampling - 1) / downsampling;  // len(x[::d])
     double* psum = (double*)ws;
     double* psq = psum + n_windows * WS_SEG;
@@ -106,22 +107,41 @@ extern "C" int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_win
     hipStream_t st = (hipStream_t)stream;
     if (raw_is_i16) {
         if (whitening) {
-            hipLaunchKernelGGL((whiten_stats_kernel<int16_t>), g1, dim3(256), 0, st, (const int16_t*)raw, raw_len, downsampling, L0,
-                               psum, psq);
+            hipLaunchKernelGGL((whiten_stats_kernel<int16_t>), g1, dim3(256), 0, st, (const int16_t*)raw, offsets, raw_len,
+                               downsampling, L0, psum, psq);
             hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
                                scale);
         }
-        hipLaunchKernelGGL((whiten_apply_kernel<int16_t>), g2, dim3(256), 0, st, (const int16_t*)raw, raw_len, downsampling, L0,
-                           whitening, windows_per_tower, mean, scale, out);
+        hipLaunchKernelGGL((whiten_apply_kernel<int16_t>), g2, dim3(256), 0, st, (const int16_t*)raw, offsets, raw_len, downsampling,
+                           L0, whitening, windows_per_tower, mean, scale, out);
     } else {
         if (whitening) {
-            hipLaunchKernelGGL((whiten_stats_kernel<float>), g1, dim3(256), 0, st, (const float*)raw, raw_len, downsampling, L0,
-                               psum, psq);
+            hipLaunchKernelGGL((whiten_stats_kernel<float>), g1, dim3(256), 0, st, (const float*)raw, offsets, raw_len, downsampling,
+                               L0, psum, psq);
             hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
                                scale);
         }
-        hipLaunchKernelGGL((whiten_apply_kernel<float>), g2, dim3(256), 0, st, (const float*)raw, raw_len, downsampling, L0,
+        hipLaunchKernelGGL((whiten_apply_kernel<float>), g2, dim3(256), 0, st, (const float*)raw, offsets, raw_len, downsampling, L0,
                            whitening, windows_per_tower, mean, scale, out);
     }
-    return check_launch("vm_decimate_whiten");
+    return check_launch(what);
+}
+
+extern "C" int vm_decimate_whiten(const void* raw, int raw_is_i16, int64_t n_windows, int64_t raw_len, int downsampling,
+                                  int whitening, float rms, int64_t windows_per_tower, float* out, void* ws, void* stream) {
+    VM_REQUIRE(raw && out && ws, "vm_decimate_whiten: null pointer");
+    VM_REQUIRE(n_windows > 0 && raw_len > 0 && downsampling > 0 && windows_per_tower > 0, "vm_decimate_whiten: bad sizes");
+    VM_REQUIRE(n_windows % windows_per_tower == 0, "vm_decimate_whiten: n_windows must be a multiple of windows_per_tower");
+    return decimate_whiten_impl("vm_decimate_whiten", raw, raw_is_i16, nullptr, n_windows, raw_len, downsampling, whitening, rms,
+                                windows_per_tower, out, ws, stream);
+}
+
+extern "C" int vm_crop_decimate_whiten(const void* audio, int raw_is_i16, const int64_t* offsets, int64_t n_windows,
+                                       int64_t raw_len, int downsampling, int whitening, float rms, int64_t windows_per_tower,
+                                       float* out, void* ws, void* stream) {
+    VM_REQUIRE(audio && offsets && out && ws, "vm_crop_decimate_whiten: null pointer");
+    VM_REQUIRE(n_windows > 0 && raw_len > 0 && downsampling > 0 && windows_per_tower > 0, "vm_crop_decimate_whiten: bad sizes");
+    VM_REQUIRE(n_windows % windows_per_tower == 0, "vm_crop_decimate_whiten: n_windows must be a multiple of windows_per_tower");
+    return decimate_whiten_impl("vm_crop_decimate_whiten", audio, raw_is_i16, offsets, n_windows, raw_len, downsampling, whitening,
+                                rms, windows_per_tower, out, ws, stream);
 }

@@ -281,10 +281,22 @@ class HipEncoderEngine:
         pl["x0"][:, CONV1_HALO_L:CONV1_HALO_L + pl["l0"]].copy_(x)
 
     def preprocess(self, pl: dict, raw: torch.Tensor, downsampling: int, whitening: bool, windows_per_tower: int,
-                   rms: float = 0.038021):
-        """voicemap/utils.py:22-34 + 88-101 on the GPU: raw (n_windows, raw_len) fp32 or int16 -> pl['x0']."""
-        raw = raw.reshape(pl["n"], -1).contiguous()
+                   rms: float = 0.038021, offsets: Optional[torch.Tensor] = None, raw_len: Optional[int] = None):
+        """voicemap/utils.py:22-34 + 88-101 on the GPU: raw (n_windows, raw_len) fp32 or int16 -> pl['x0'].
+        With ``offsets`` (n_windows int64 on the device) ``raw`` is instead a resident 1-D buffer of decoded recordings
+        (voicemap_amd/shards.py) and window n is the ``raw_len`` samples starting at raw[offsets[n]]: the crop of
+        voicemap/librispeech.py:103-137 happens on the device and the host only chooses offsets."""
         is16 = raw.dtype == torch.int16
+        if offsets is not None:
+            assert raw.dim() == 1 and raw.is_contiguous() and raw_len is not None
+            assert offsets.dtype == torch.int64 and offsets.numel() == pl["n"] and offsets.is_cuda
+            assert (raw_len + downsampling - 1) // downsampling == pl["l0"]
+            if not is16:
+                assert raw.dtype == torch.float32
+            self._call("vm_crop_decimate_whiten", _p(raw), int(is16), _p(offsets), pl["n"], raw_len, downsampling,
+                       int(whitening), rms, windows_per_tower, _p(pl["x0"]), _p(pl["pre_ws"]), self.stream())
+            return
+        raw = raw.reshape(pl["n"], -1).contiguous()
         if not is16:
             raw = raw.to(torch.float32)
         assert (raw.shape[1] + downsampling - 1) // downsampling == pl["l0"]
@@ -483,6 +495,26 @@ class HipEncoderEngine:
             self.load_preprocessed(pl, x)
         else:
             self.preprocess(pl, x, downsampling, whitening, pairs)
+        if isinstance(drop_masks, str):
+            drop_masks = self.make_drop_masks(2 * pairs)
+        yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
+        self.forward(pl, pairs, drop_masks)
+        self.siamese_head(pl, yd, loss)
+        self.backward(pl)
+        if apply_update:
+            self.optimizer_step()
+        return pl
+
+    def siamese_train_step_from_offsets(self, audio: torch.Tensor, offsets_1: torch.Tensor, offsets_2: torch.Tensor, y,
+                                        raw_len: int, loss: str = "contrastive", downsampling: int = 4, whitening: bool = True,
+                                        drop_masks="auto", apply_update: bool = True):
+        """``siamese_train_step`` fed from a device-resident recording buffer: ``audio`` 1-D int16/fp32 on the device,
+        ``offsets_k`` (pairs,) int64 start samples of the windows of tower k (shards.ShardedSpeechDataset chooses them the way
+        LibriSpeechDataset.__getitem__ / build_verification_batch do)."""
+        pairs = int(offsets_1.numel())
+        offs = torch.cat([offsets_1.reshape(-1), offsets_2.reshape(-1)]).to(self.device, torch.int64).contiguous()
+        pl = self.plan(2 * pairs, (raw_len + downsampling - 1) // downsampling, True)
+        self.preprocess(pl, audio, downsampling, whitening, pairs, offsets=offs, raw_len=raw_len)
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(2 * pairs)
         yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()

@@ -1,0 +1,125 @@
+"""Pre-decoded int16 shards + device-side cropping.
+
+The reference decodes a whole FLAC file for every 3 s window it samples (voicemap/librispeech.py:103-137) and builds pair
+batches with pandas merges -- fine for Keras on one GPU of 2018, three to four orders of magnitude short of what the HIP
+training step consumes (~190 k audio-seconds per second per GPU).  This module keeps the reference's dataset API and
+changes where the bytes live:
+
+* ``write_shards(dataset, out_dir)`` decodes every file of a ``LibriSpeechDataset`` (or anything with its ``df`` /
+  ``_load``) ONCE into flat little-endian int16 shard files plus ``index.csv`` (the reference's index columns + ``shard``,
+  ``offset``); train-clean-360 is ~41 GB this way and fits the HBM of one MI355X seven times over.
+* ``ShardedSpeechDataset`` serves the same ``__getitem__`` / pair / task API from memory-mapped shards (no decode), and
+  ``to_device()`` uploads the shards once; ``build_verification_batch_offsets`` then returns only START OFFSETS (two int64
+  vectors + labels) chosen exactly like ``build_verification_batch`` chooses files and fragments, and the crop, the
+  decimation and the whitening run on the GPU (``vm_crop_decimate_whiten``).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+from config import LIBRISPEECH_SAMPLING_RATE
+from .librispeech import LibriSpeechDataset, sex_to_label  # noqa: F401  (re-exported for symmetry)
+
+INT16_SCALE = 32768.0
+
+
+def to_int16(x: np.ndarray) -> np.ndarray:
+    """float waveform in [-1, 1) -> int16 PCM (what a FLAC/WAV of the corpus holds)."""
+    return np.clip(np.round(np.asarray(x, dtype=np.float64) * INT16_SCALE), -32768, 32767).astype("<i2")
+
+
+def write_shards(dataset, out_dir: str, shard_samples: int = 1 << 27) -> pd.DataFrame:
+    """Decode every file of ``dataset`` once and append it to flat int16 shards of at most ``shard_samples`` samples
+    (a file never straddles shards).  Returns the index (also written to ``out_dir/index.csv``)."""
+    os.makedirs(out_dir, exist_ok=True)
+    rows, shard_no, fill, fh = [], 0, 0, None
+
+    def open_shard(k):
+        return open(os.path.join(out_dir, "shard_%05d.i16" % k), "wb")
+    fh = open_shard(shard_no)
+    for idx in range(len(dataset)):
+        pcm = to_int16(dataset._load(idx))
+        if fill > 0 and fill + len(pcm) > shard_samples:
+            fh.close()
+            shard_no, fill = shard_no + 1, 0
+            fh = open_shard(shard_no)
+        fh.write(pcm.tobytes())
+        row = dataset.df.loc[idx].to_dict()
+        row.pop('id', None)  # the dataset id is positional; 'id' in an index file is the speaker id (librispeech.py:70-78)
+        row.update(shard=shard_no, offset=fill, length=len(pcm), seconds=len(pcm) * 1.0 / LIBRISPEECH_SAMPLING_RATE)
+        rows.append(row)
+        fill += len(pcm)
+    fh.close()
+    df = pd.DataFrame(rows).rename(columns={"speaker_id": "id", "speaker_minutes": "minutes"})
+    df.to_csv(os.path.join(out_dir, "index.csv"), index=False)
+    with open(os.path.join(out_dir, "meta.json"), "w") as f:
+        json.dump({"sampling_rate": LIBRISPEECH_SAMPLING_RATE, "dtype": "int16-le", "shards": shard_no + 1,
+                   "files": len(rows)}, f)
+    return df
+
+
+class ShardedSpeechDataset(LibriSpeechDataset):
+    """``LibriSpeechDataset`` API over the shards written by ``write_shards`` (same constructor semantics for ``seconds``,
+    ``label``, ``stochastic``, ``pad``)."""
+
+    def __init__(self, shard_dir, seconds, label='speaker', stochastic=True, pad=False):
+        assert label in ('sex', 'speaker'), 'Label type must be one of (\'sex\', \'speaker\')'
+        self.subset = shard_dir
+        self.fragment_seconds = seconds
+        self.fragment_length = int(seconds * LIBRISPEECH_SAMPLING_RATE)
+        self.stochastic, self.pad, self.label = stochastic, pad, label
+        self.shard_dir = shard_dir
+        df = pd.read_csv(os.path.join(shard_dir, "index.csv"))
+        self._finalise(df)
+        n_shards = int(self.df['shard'].max()) + 1 if len(self.df) else 0
+        self._maps = [np.memmap(os.path.join(shard_dir, "shard_%05d.i16" % k), dtype="<i2", mode="r") for k in range(n_shards)]
+        base = np.concatenate([[0], np.cumsum([len(m) for m in self._maps])]) if n_shards else np.zeros(1, dtype=np.int64)
+        # start of every file in the concatenation of all shards (the layout of the device buffer)
+        self.global_offset = (base[self.df['shard'].values] + self.df['offset'].values).astype(np.int64)
+        self.file_length = self.df['length'].values.astype(np.int64)
+        self.device_audio = None
+
+    def _pcm(self, index):
+        r = self.df.iloc[index]
+        return self._maps[int(r['shard'])][int(r['offset']):int(r['offset']) + int(r['length'])]
+
+    def _load(self, index):
+        return np.asarray(self._pcm(index), dtype=np.float64) / INT16_SCALE
+
+    # ---- device path ---------------------------------------------------------------------------------------
+    def to_device(self, device="cuda"):
+        """Upload all shards once (int16, back to back); returns the 1-D device tensor."""
+        import torch
+        if self.device_audio is None:
+            parts = [torch.from_numpy(np.array(m, dtype=np.int16, copy=True)) for m in self._maps]
+            self.device_audio = torch.cat(parts).to(device)
+        return self.device_audio
+
+    def window_starts(self, indices) -> np.ndarray:
+        """Global start sample of one fragment per file id, chosen like ``__getitem__`` (random if ``stochastic``, else the
+        beginning).  Padding is a host-path feature: the device path needs files at least one fragment long."""
+        indices = np.asarray(indices, dtype=np.int64)
+        lengths = self.file_length[indices]
+        if np.any(lengths < self.fragment_length):
+            raise ValueError('the device path cannot pad: a file is shorter than the fragment length')
+        if self.stochastic:
+            span = np.maximum(lengths - self.fragment_length, 1)
+            start = np.array([np.random.randint(0, s) for s in span], dtype=np.int64)
+        else:
+            start = np.zeros(len(indices), dtype=np.int64)
+        return self.global_offset[indices] + start
+
+    def build_verification_batch_offsets(self, batchsize):
+        """(offsets_1, offsets_2, outputs): the pairs of ``build_verification_batch`` (batchsize//2 same-speaker pairs, then
+        batchsize//2 different-speaker pairs; outputs (batchsize, 1) zeros then ones) as start offsets into the device buffer."""
+        half = batchsize // 2
+        alike = self.get_alike_pairs(half)
+        differing = self.get_differing_pairs(half)
+        left = [i for i, _ in alike] + [i for i, _ in differing]
+        right = [j for _, j in alike] + [j for _, j in differing]
+        outputs = np.append(np.zeros(half), np.ones(half))[:, np.newaxis]
+        return self.window_starts(left), self.window_starts(right), outputs
