@@ -33,6 +33,9 @@ def base_parser(description, **defaults):
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--workers", type=int, default=min(8, os.cpu_count() or 1))
     p.add_argument("--synthetic", action="store_true", help="generated speakers instead of LibriSpeech on disk")
+    p.add_argument("--device-data", metavar="DIR", default="",
+                   help="decode the TRAINING set once into int16 shards under DIR (reused if present), keep them resident in HBM and "
+                        "crop/decimate/whiten on the GPU; the host only draws pair offsets (voicemap_amd/shards.py)")
     p.add_argument("--training-set", nargs="+", default=["train-clean-100", "train-clean-360"])
     p.add_argument("--validation-set", default="dev-clean")
     return p
@@ -47,6 +50,16 @@ def datasets(a, pad):
         train = LibriSpeechDataset(a.training_set, a.n_seconds, pad=pad)
         valid = LibriSpeechDataset(a.validation_set, a.n_seconds, stochastic=False, pad=pad)
     return train, valid
+
+
+def device_resident(a, train):
+    """--device-data: the training set as a ShardedSpeechDataset whose audio lives on the GPU (no padding on this path)."""
+    from voicemap_amd import shards
+    if not os.path.exists(os.path.join(a.device_data, "index.csv")):
+        shards.write_shards(train, a.device_data)
+    ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False)
+    ds.to_device("cuda")
+    return ds
 
 
 def input_length(a):

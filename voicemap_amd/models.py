@@ -414,13 +414,25 @@ class SiameseNet(_TrainableModel):
             x2 = np.asarray(x2)
         if _is_lazy(x1):
             assert (x1.downsampling, x1.whitening) == (x2.downsampling, x2.whitening)
-            return fn(x1.raw, x2.raw, preprocessed=False, downsampling=x1.downsampling, whitening=x1.whitening, **kw)
+            r1, r2 = x1.raw, x2.raw
+            if type(r1).__name__ == "DeviceWindows":  # windows that only exist as offsets into a device buffer (shards.py)
+                r1, r2 = r1.gather(), r2.gather()
+            return fn(r1, r2, preprocessed=False, downsampling=x1.downsampling, whitening=x1.whitening, **kw)
         return fn(np.asarray(x1, dtype=np.float32), np.asarray(x2, dtype=np.float32), **kw)
 
     def train_on_batch(self, x, y):
         eng = self._ensure_engine()
         x1, x2 = self._pair(x)
         loss = self._loss_name()
+        if _is_lazy(x1) and _is_lazy(x2) and type(x1.raw).__name__ == type(x2.raw).__name__ == "DeviceWindows" \
+                and x1.raw.audio is x2.raw.audio:
+            # device data path: the crop happens inside the preprocessing kernel (vm_crop_decimate_whiten)
+            assert (x1.downsampling, x1.whitening) == (x2.downsampling, x2.whitening)
+            pl = eng.siamese_train_step_from_offsets(x1.raw.audio, x1.raw.offsets, x2.raw.offsets,
+                                                     np.asarray(y, dtype=np.float32), x1.raw.length, loss=loss,
+                                                     downsampling=x1.downsampling, whitening=x1.whitening)
+            la = pl["loss_acc"].cpu().numpy()
+            return float(la[0]), float(la[1])
         pl = self._run(lambda a, b, **kw: eng.siamese_train_step(a, b, np.asarray(y, dtype=np.float32), loss=loss, **kw), x1, x2)
         la = pl["loss_acc"].cpu().numpy()
         return float(la[0]), float(la[1])

@@ -62,6 +62,40 @@ def write_shards(dataset, out_dir: str, shard_samples: int = 1 << 27) -> pd.Data
     return df
 
 
+class DeviceWindows:
+    """A batch of windows that exists only as start offsets into a device-resident recording buffer; quacks like the
+    (n, T, 1) array the reference's generators yield (``shape``, ``ndim``, ``len``, ``np.asarray``) so that it flows through
+    ``BatchPreProcessor`` / ``preprocess_instances`` / ``fit_generator`` unchanged.  The models crop + decimate + whiten it on
+    the GPU (``vm_crop_decimate_whiten``); ``np.asarray`` materialises the float windows on the host (tests, oracle)."""
+
+    def __init__(self, audio, offsets, length: int):
+        import torch
+        self.audio = audio
+        self.offsets = torch.as_tensor(np.asarray(offsets, dtype=np.int64)).to(audio.device)
+        self.length = int(length)
+
+    ndim = 3
+
+    @property
+    def shape(self):
+        return (int(self.offsets.numel()), self.length, 1)
+
+    def __len__(self):
+        return int(self.offsets.numel())
+
+    def gather(self):
+        """(n, T) windows on the device, in the buffer's dtype."""
+        import torch
+        idx = self.offsets[:, None] + torch.arange(self.length, device=self.audio.device)[None, :]
+        return self.audio[idx]
+
+    def __array__(self, dtype=None, copy=None):
+        import torch
+        w = self.gather()
+        x = (w.to(torch.float64) / INT16_SCALE if w.dtype == torch.int16 else w.to(torch.float64)).cpu().numpy()[:, :, None]
+        return x.astype(dtype) if dtype is not None else x
+
+
 class ShardedSpeechDataset(LibriSpeechDataset):
     """``LibriSpeechDataset`` API over the shards written by ``write_shards`` (same constructor semantics for ``seconds``,
     ``label``, ``stochastic``, ``pad``)."""
@@ -123,3 +157,14 @@ class ShardedSpeechDataset(LibriSpeechDataset):
         right = [j for _, j in alike] + [j for _, j in differing]
         outputs = np.append(np.zeros(half), np.ones(half))[:, np.newaxis]
         return self.window_starts(left), self.window_starts(right), outputs
+
+    def build_verification_batch_device(self, batchsize):
+        """``build_verification_batch`` with the two inputs as ``DeviceWindows`` (needs ``to_device()`` first)."""
+        assert self.device_audio is not None, 'call to_device() first'
+        o1, o2, outputs = self.build_verification_batch_offsets(batchsize)
+        T = self.fragment_length
+        return [DeviceWindows(self.device_audio, o1, T), DeviceWindows(self.device_audio, o2, T)], outputs
+
+    def yield_verification_batches_device(self, batchsize):
+        while True:
+            yield self.build_verification_batch_device(batchsize)

@@ -26,7 +26,8 @@ class LazyWindows:
     ``np.asarray(lazy)`` gives exactly what the reference's preprocessor returns (float64, decimated, whitened)."""
 
     def __init__(self, raw, downsampling: int, whitening: bool):
-        raw = np.asarray(raw)
+        if type(raw).__name__ != "DeviceWindows":  # shards.DeviceWindows: offsets into a device-resident buffer, kept as is
+            raw = np.asarray(raw)
         if raw.ndim != 3:
             raise ValueError("Input must be a 3D array of shape (n_segments, n_timesteps, 1).")
         self.raw, self.downsampling, self.whitening = raw, int(downsampling), bool(whitening)
@@ -40,7 +41,7 @@ class LazyWindows:
         return self.raw.shape[0]
 
     def __array__(self, dtype=None, copy=None):
-        x = self.raw[:, ::self.downsampling, :]
+        x = np.asarray(self.raw)[:, ::self.downsampling, :]
         if self.whitening:
             x = whiten(x)
         return np.asarray(x, dtype=dtype) if dtype is not None else np.asarray(x)
