@@ -150,6 +150,37 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
         for (int rt = role.rs; rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
+                // Fast path (every tile at cfg-A): all 32 positions are pooled and in range -- no per-element predicates, no
+                // 64-bit index arithmetic, one base pointer per tile.  The kernel is VALU-bound, so instructions are time.
+                bf16* ob = INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F + c : out + (n * Lq + (t0 + 32 * rt) / POOL) * F + c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[4 * g + j] + bv;
+                        v = v > 0.f ? v : 0.f;
+                        zb[j] = bf16_round(v);
+                        if (!INFER) {
+                            csum += zb[j];
+                            csq = fmaf(zb[j], zb[j], csq);
+                        }
+                    }
+#pragma unroll
+                    for (int pw = 0; pw < 4 / POOL; ++pw) {
+                        float ext = zb[pw * POOL];
+#pragma unroll
+                        for (int j = 1; j < POOL; ++j) {
+                            const float v = zb[pw * POOL + j];
+                            ext = use_min ? fminf(ext, v) : fmaxf(ext, v);
+                        }
+                        const int qo = ((8 * g) / POOL + pw) * F + (4 / POOL) * hi * F;  // pooled row offset inside the tile
+                        ob[qo] = INFER ? (bf16)fmaf(ext, sg, sh) : (bf16)ext;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t tg = t0 + 32 * rt + 8 * g + 4 * hi;  // first of 4 consecutive positions
