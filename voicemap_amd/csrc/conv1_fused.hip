@@ -298,6 +298,45 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
             bf16 dub[16];
+            if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
+                // fast path (every tile at cfg-A): no per-element range predicates, one dp base pointer per tile
+                const bf16* dpb = dp + (n * Lq + (t0 + 32 * rt) / POOL) * F + c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[4 * g + j] + bv;
+                        v = v > 0.f ? v : 0.f;
+                        zb[j] = bf16_round(v);
+                    }
+#pragma unroll
+                    for (int pw = 0; pw < 4 / POOL; ++pw) {
+                        float ext = zb[pw * POOL];
+                        int arg = 0;
+#pragma unroll
+                        for (int j = 1; j < POOL; ++j) {
+                            const float v = zb[pw * POOL + j];
+                            const bool better = use_min ? (v < ext) : (v > ext);
+                            if (better) {
+                                ext = v;
+                                arg = j;
+                            }
+                        }
+                        const int qo = ((8 * g) / POOL + pw) * F + (4 / POOL) * hi * F;
+                        const float ady = ga * (float)dpb[qo];
+#pragma unroll
+                        for (int j = 0; j < POOL; ++j) {
+                            const float zz = zb[pw * POOL + j];
+                            float gz = fmaf(gc, zz, gb0) + (j == arg ? ady : 0.f);
+                            gz = zz > 0.f ? gz : 0.f;
+                            const bf16 gb = (bf16)gz;
+                            dub[4 * g + pw * POOL + j] = gb;
+                            bsum += (float)gb;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t tg = t0 + 32 * rt + 8 * g + 4 * hi;
@@ -334,6 +373,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                         bsum += (float)gb;
                     }
                 }
+            }
             }
             // weight gradient: dW[tap i][c] += sum_rows x_loc[32*rt + row + i] * du[row][c].  K-slot e of half kh in
             // MFMA m <-> accumulator register 8m+e of this lane <-> row 16m + 8(e>>2) + 4kh + (e&3).
