@@ -9,6 +9,8 @@
 //   du          = dz * [z > 0]                                           (ReLU fused into the conv)
 //   dgamma      = sum(dy*zhat), dbeta = sum(dy)   (both towers added)
 // pass 1 (reduce) builds the two sums, pass 2 (apply) writes du into a halo-padded tensor for dgrad/wgrad.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace vm {
@@ -386,14 +388,17 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
             }
         }
         if (cok) {
-            for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Q; q += (int64_t)RP * BN_SEG) {
+            // FULL: a whole pool group with its dp row (every group when L % POOL == 0) -- no row-count predicates
+            auto body = [&](int64_t q, auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
                 Vec16<T> zv[POOL];
                 int nrows = POOL;
-                if (q * POOL + POOL > L) nrows = (int)(L - q * POOL);
+                if (!FULL && q * POOL + POOL > L) nrows = (int)(L - q * POOL);
+                const T* zp = z + (n * L + q * POOL) * C + c0;
 #pragma unroll
                 for (int j = 0; j < POOL; ++j)
-                    if (j < nrows) zv[j] = load16<T>(z + (n * L + q * POOL + j) * C + c0);
-                const bool has_dp = q < Lq;
+                    if (FULL || j < nrows) zv[j] = load16<T>(zp + j * C);
+                const bool has_dp = FULL || q < Lq;
                 Vec16<T> dv;
                 if (!SP && has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
                 Vec16<T> ov[POOL];
@@ -401,13 +406,13 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 for (int i = 0; i < VEC; ++i) {
                     float zj[POOL];
 #pragma unroll
-                    for (int j = 0; j < POOL; ++j) zj[j] = j < nrows ? zv[j].get(i) : 0.f;
+                    for (int j = 0; j < POOL; ++j) zj[j] = (FULL || j < nrows) ? zv[j].get(i) : 0.f;
                     float ext = sgn[i] * zj[0];
                     int arg = 0;
 #pragma unroll
                     for (int j = 1; j < POOL; ++j) {
                         const float y = sgn[i] * zj[j];
-                        if (j < nrows && y > ext) {  // strict: the first extreme wins
+                        if ((FULL || j < nrows) && y > ext) {  // strict: the first extreme wins
                             ext = y;
                             arg = j;
                         }
@@ -420,13 +425,17 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                         float g = fmaf(kc[i], zj[j], kb[i]) + (j == arg ? ady : 0.f);
                         g = zj[j] > 0.f ? g : 0.f;
                         ov[j].set(i, g);
-                        if (j < nrows) acc[i] += ov[j].get(i);
+                        if (FULL || j < nrows) acc[i] += ov[j].get(i);
                     }
                 }
+                T* op = du + (n * (L + 2) + 1 + q * POOL) * C + c0;
 #pragma unroll
                 for (int j = 0; j < POOL; ++j)
-                    if (j < nrows) store16<T>(du + (n * (L + 2) + 1 + q * POOL + j) * C + c0, ov[j]);
-            }
+                    if (FULL || j < nrows) store16<T>(op + j * C, ov[j]);
+            };
+            int64_t q = seg + (int64_t)rl * BN_SEG;
+            for (; q < Lq; q += (int64_t)RP * BN_SEG) body(q, std::true_type{});
+            if (q < Q) body(q, std::false_type{});  // the remainder rows of a floor pool (q == Lq)
         }
         // reduce over the RP row lanes
 #pragma unroll
