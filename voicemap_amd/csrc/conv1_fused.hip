@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
     const bool cok = role.active && c < F;
     const int hi = lane >> 5;
     float csum = 0.f, csq = 0.f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 csum2 = {0.f, 0.f}, csq2 = {0.f, 0.f};
     if (role.active) {
         F1Weights w;
         f1_load_weights(w, wk, F, c, cok, hi);
@@ -154,17 +156,22 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 // Fast path (every tile at cfg-A): all 32 positions are pooled and in range -- no per-element predicates, no
                 // 64-bit index arithmetic, one base pointer per tile.  The kernel is VALU-bound, so instructions are time.
                 bf16* ob = INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F + c : out + (n * Lq + (t0 + 32 * rt) / POOL) * F + c;
+                const f32x2 bv2 = {bv, bv};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float zb[4];
+                    // two-wide fp32 arithmetic (v_pk_add_f32 / v_pk_fma_f32): half the VALU issue slots for bias and statistics
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[4 * g + j] + bv;
-                        v = v > 0.f ? v : 0.f;
-                        zb[j] = bf16_round(v);
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        f32x2 v = f32x2{acc[4 * g + 2 * j2], acc[4 * g + 2 * j2 + 1]} + bv2;
+                        v[0] = v[0] > 0.f ? v[0] : 0.f;
+                        v[1] = v[1] > 0.f ? v[1] : 0.f;
+                        const f32x2 zr = {bf16_round(v[0]), bf16_round(v[1])};
+                        zb[2 * j2] = zr[0];
+                        zb[2 * j2 + 1] = zr[1];
                         if (!INFER) {
-                            csum += zb[j];
-                            csq = fmaf(zb[j], zb[j], csq);
+                            csum2 += zr;
+                            csq2 = __builtin_elementwise_fma(zr, zr, csq2);
                         }
                     }
 #pragma unroll
@@ -216,6 +223,8 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
         }
     }
     if (!INFER) {
+        csum += csum2[0] + csum2[1];
+        csq += csq2[0] + csq2[1];
         csum += __shfl_xor(csum, 32, 64);
         csq += __shfl_xor(csq, 32, 64);
         if (lane < 32) {
