@@ -2045,13 +2045,14 @@ int g_nt_blocks3 = 768;  // persistent grid of that variant
 int g_nt_order = 1;
 int g_nt_ring = 0;  // ring-pipelined LDS-DMA NT kernel (4 x 64-byte slices in flight); vm_set_tuning("nt_ring", 0 | 1)
 int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_tuning("nt_glds", 0 | 1)
-// 256 x 256 phase-interleaved kernel for bf16 shapes with N % 256 == 0; vm_set_tuning("nt_p8", 0 | 1).  Off by default:
-// at cfg-A its launches are 5-10 % faster than the 128^2 kernels (230 vs 260 us for the block-3 dgrad) but the step is not
-// (4.97 vs 4.92 ms, interleaved A/B): with one lock-step workgroup per CU every CU writes its output tile at the same
-// time (a 33 MB burst per tile round that runs at HBM speed with the matrix pipes idle), and the kernels around it slow
-// down by as much as it gains.  Ablations (block-3 dgrad, us): full 249, no epilogue 186, no DMA 147, neither 116 (= 78 %
-// of the MFMA peak), barrier skeleton alone 47.
-int g_nt_p8 = 0;
+// 256 x 256 phase-interleaved kernel for bf16 shapes with N % 256 == 0; vm_set_tuning("nt_p8", 0 | 1 | 2): 0 off, 1 every
+// eligible shape, 2 (default) only K >= 1152 -- at cfg-A the block-4 forward (312 -> 275 us) and the block-3 dgrad (275 ->
+// 245 us), where it clearly beats the 128^2 kernels; on the K = 384 forward of block 2 it only ties.  Step: 3.758 -> 3.708 ms
+// (interleaved A/B, three repetitions each).  An earlier A/B, before the BN / block-1 / wgrad work, showed no step gain at
+// all: the chip runs this workload against its power limit and a faster GEMM then slowed its neighbours down by as much.
+// Ablations (block-3 dgrad, us): full 249, no epilogue 186, no DMA 147, neither 116 (= 78 % of the MFMA peak), barrier
+// skeleton alone 47.
+int g_nt_p8 = 2;
 int g_nt_p8_blocks = 256;
 int g_nt_p8_skew = 0;
 int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
@@ -2060,7 +2061,7 @@ template <typename T, int EPI>
 static bool launch_nt8(const NtArgs<T>&, int64_t, hipStream_t) { return false; }
 template <int EPI>
 static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
-    if (!g_nt_p8 || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
+    if (!g_nt_p8 || (g_nt_p8 == 2 && a.Ktot < 1152) || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
         n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
     NtArgs<bf16> b = a;
     b.skew = g_nt_p8_skew;
