@@ -42,7 +42,13 @@ int vm_abi_version(void);
 int vm_check_device(void);
 
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
-/* tuning hook for A/B measurements, not part of the drop-in surface: ("gemm_kb", 64 | 128) = bytes of K per GEMM slice. */
+/* Tuning hook for A/B measurements (process-global, benchmarking only; not part of the drop-in surface).  Kernel selection:
+ *   "nt_p8" 0|1|2   forward/dgrad: 256x256 phase-interleaved kernel off / every eligible shape / K >= 1152 only (default 2)
+ *   "tn_x"  0|1|2   wgrad: input-resident (3 taps x 128 ci) x 128 co kernel off / phase form (default) / free-running form
+ *   "tn_p8" 0|1     wgrad: LDS-DMA + transposing-read 256x256 kernel when tn_x does not apply (default 1)
+ *   "tn_tile" 128|256, "gemm_kb" 64|128, "nt_glds", "nt_tepi", "nt_ring", "nt_order", "tn_xcd": the older variants
+ *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "f1_blocks": launch geometry
+ *   "nt_ablate": timing experiments that produce WRONG results (see conv_gemm.hip). */
 int vm_set_tuning(const char* key, int value);
 
 /* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------
