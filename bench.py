@@ -80,6 +80,8 @@ def main():
         k, v = kv.split("=")
         if k == "overlap_wgrad":
             eng.overlap_wgrad = bool(int(v))
+        elif k == "pooled_reduce":
+            eng.pooled_reduce = bool(int(v))
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
     if a.nt_blocks:
@@ -179,7 +181,7 @@ def main():
     if a.breakdown and rank == 0:
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
-                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
+                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
                  "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]
         eng.timed = {nm: [] for nm in names}

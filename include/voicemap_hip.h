@@ -157,6 +157,14 @@ int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, con
 int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
                        int C, double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta,
                        void* ws, void* stream);
+/* vm_bn_pool_bwd_reduce with the pool-window extreme of z recovered from the POOLED forward output `act` (padded
+ * (n_windows, L/pool + 2, C), as written by vm_bn_drop_pool_fwd with the same scale / shift / drop) instead of re-derived from
+ * z: ext = act / (scale*drop) - shift/scale.  Reads two pooled-size tensors instead of z + dp; differs from the z form by the
+ * storage rounding of act (bit-identical sums are NOT guaranteed; channels with scale == 0 use z).  Throughput-mode option. */
+int vm_bn_pool_bwd_reduce_pooled(const void* z, const void* act, const void* dp, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                                 int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_dy,
+                                 float* part_dyz, void* stream);
 /* backward, pass 2: du[n][1+t][c] = [z>0] * scale * (dy - c1 - zhat*c2)  (padded (n_windows, L+2, C) out), plus
  * partial column sums of du -> part_du (n_windows * vm_bn_part_rows(), C) for the conv bias gradient. */
 int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,

@@ -277,6 +277,42 @@ def test_bn_drop_pool_gmax_fused_equals_two_pass(dt, n, wpt, l, c, pool, use_dro
     assert torch.equal(i0, i1)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 300, 64, 2, True), (2, 1, 64, 136, 4, False), (3, 3, 19, 8, 2, True)])
+def test_bn_pool_bwd_reduce_pooled_form(dt, n, wpt, l, c, pool, use_drop):
+    """vm_bn_pool_bwd_reduce_pooled (extreme of z recovered from the pooled forward output) against the z form: equal up to the
+    storage rounding of the pooled tensor; channels with scale == 0 (fallback to z) and dropped channels included."""
+    vm, tdt = DTYPES[dt]
+    r = rng(41)
+    towers = n // wpt
+    z = quant(np.maximum(r.normal(0.3, 1.0, (n, l, c)), 0.0), dt).to("cuda", tdt).contiguous()
+    sc = r.normal(1.0, 0.3, (towers, c)) * np.where(r.random((towers, c)) < 0.3, -1, 1)
+    sc[:, 3] = 0.0  # not invertible: this 8-channel vector must come from z
+    scale, shift = dev(sc), dev(r.normal(0, 0.3, (towers, c)))
+    mean, invstd = dev(r.normal(0.4, 0.1, (towers, c))), dev(r.uniform(0.5, 2.0, (towers, c)))
+    drop = dev((r.random((n, c)) > 0.25) / 0.75) if use_drop else None
+    lq = l // pool
+    act = torch.zeros(n, lq + 2, c, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), p(drop), n, wpt, l, c, pool, vm, p(act), stream())
+    dp = quant(r.normal(0, 1.0, (n, lq, c)), dt).to("cuda", tdt).contiguous()
+    rows = L().query("vm_bn_part_rows")
+    out = []
+    for pooled in (False, True):
+        pa, pb = (torch.zeros(n * rows, c, device="cuda") for _ in range(2))
+        if pooled:
+            L().call("vm_bn_pool_bwd_reduce_pooled", p(z), p(act), p(dp), p(scale), p(shift), p(mean), p(invstd), p(drop), n, wpt, l,
+                     c, pool, vm, p(pa), p(pb), stream())
+        else:
+            L().call("vm_bn_pool_bwd_reduce", p(z), p(dp), p(scale), p(shift), p(mean), p(invstd), p(drop), n, wpt, l, c, pool, vm,
+                     p(pa), p(pb), stream())
+        out.append((pa.view(n, rows, c).sum(1).cpu().numpy().astype(np.float64), pb.view(n, rows, c).sum(1).cpu().numpy().astype(np.float64)))
+    (a0, b0), (a1, b1) = out
+    assert np.array_equal(a0, a1)  # sum of dy does not involve z at all
+    tol = 2e-5 if dt == "f32" else 1.5e-2
+    assert rel_err(b1, b0) < tol
+    assert np.array_equal(b0[:, 3], b1[:, 3])  # the scale == 0 channel took the z path: bit-identical
+
+
 def test_dense_fwd_bwd():
     r = rng(7)
     rows, ni, no = 10, 72, 33

@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
                                                                  const float* __restrict__ scale, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ drop,
                                                                  int64_t wpt, int64_t L, int C, int P,
-                                                                 float* __restrict__ part_a, float* __restrict__ part_b) {
+                                                                 float* __restrict__ part_a, float* __restrict__ part_b,
+                                                                 const T* __restrict__ act, const float* __restrict__ shift) {
+    // act != nullptr (vm_bn_pool_bwd_reduce_pooled): the pool-window extreme of z is recovered from the POOLED forward output
+    // instead of being re-derived from z:  act = round(drop * (scale * ext + shift))  =>  ext = act / (scale*drop) - shift/scale.
+    // The pass then reads two pooled-size tensors (act, dp) instead of z + dp.  Channels with scale == 0 (the map is not
+    // invertible) fall back to z for their whole 8-channel vector.
     constexpr int VEC = Elem<T>::kVec;
     __shared__ __attribute__((aligned(16))) float red[2][256][VEC];
     const int tid = threadIdx.x;
@@ -493,6 +498,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
             s1[i] = 0.f;
             sgn[i] = 1.f;
         }
+        bool pooled = false;
+        float ra[VEC], rb[VEC];
         if (cok) {
             float sc[VEC], dr[VEC];
             loadv<VEC>(scale + tw * C + c0, sc);
@@ -503,8 +510,42 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) sgn[i] = sc[i] * dr[i] < 0.f ? -1.f : 1.f;
+            if (act != nullptr) {
+                float sh[VEC];
+                loadv<VEC>(shift + tw * C + c0, sh);
+                pooled = true;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    if (sc[i] == 0.f && dr[i] != 0.f) pooled = false;
+                    const bool live = sc[i] != 0.f && dr[i] != 0.f;  // drop == 0: dy == 0, the channel contributes nothing
+                    ra[i] = live ? 1.0f / (sc[i] * dr[i]) : 0.f;
+                    rb[i] = live ? -sh[i] / sc[i] : 0.f;
+                }
+            }
         }
-        if (cok) {
+        if (cok && pooled) {
+            const T* ab = act + (n * (Lq + 2) + 1) * C + c0;
+            const T* db = dp + n * Lq * C + c0;
+            auto consume_p = [&](const Vec16<T>& pv, const Vec16<T>& dv) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float d = dv.get(i);
+                    s0[i] += d;
+                    s1[i] = fmaf(d, fmaf(pv.get(i), ra[i], rb[i]), s1[i]);
+                }
+            };
+            int64_t q = seg + (int64_t)rl * BN_SEG;
+            for (; q + stride < Lq; q += 2 * stride) {
+                const Vec16<T> pa = load16<T>(ab + q * C), da = load16<T>(db + q * C);
+                const Vec16<T> pc = load16<T>(ab + (q + stride) * C), dc = load16<T>(db + (q + stride) * C);
+                consume_p(pa, da);
+                consume_p(pc, dc);
+            }
+            if (q < Lq) {
+                const Vec16<T> pa = load16<T>(ab + q * C), da = load16<T>(db + q * C);
+                consume_p(pa, da);
+            }
+        } else if (cok) {
             const T* zb = z + n * L * C + c0;
             const T* db = dp + n * Lq * C + c0;
             auto consume = [&](const Vec16<T> (&zv)[POOL], const Vec16<T>& dv) {
@@ -748,9 +789,25 @@ extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float*
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, windows_per_tower, L, C, P,
-                           part_dy, part_dyz);
+                           part_dy, part_dyz, (const T*)nullptr, (const float*)nullptr);
     }));
     return check_launch("vm_bn_pool_bwd_reduce");
+}
+
+extern "C" int vm_bn_pool_bwd_reduce_pooled(const void* z, const void* act, const void* dp, const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                                            int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_dy,
+                                            float* part_dyz, void* stream) {
+    VM_REQUIRE(z && act && dp && scale && shift && mean && invstd && part_dy && part_dyz,
+               "vm_bn_pool_bwd_reduce_pooled: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce_pooled: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, windows_per_tower, L, C, P,
+                           part_dy, part_dyz, (const T*)act, shift);
+    }));
+    return check_launch("vm_bn_pool_bwd_reduce_pooled");
 }
 
 extern "C" int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale,

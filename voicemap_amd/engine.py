@@ -125,6 +125,10 @@ class HipEncoderEngine:
         # ms); the results are bit-identical either way (tests/test_gpu_e2e.py).  Per-kernel timings of the backward pass are
         # only attributable with it off (bench.py --breakdown / --no-overlap-wgrad).
         self.overlap_wgrad = True
+        # BN-backward reduce of blocks 2..n-1 from the pooled forward output instead of z (vm_bn_pool_bwd_reduce_pooled): -0.34 GB
+        # of reads per step at cfg-A.  Changes the two sums by the storage rounding of the pooled tensor (1e-3 relative in
+        # bf16), so it is on for bf16 storage (the throughput mode) and off for fp32 (the exact-parity mode).
+        self.pooled_reduce = (self.dtype == _lib.VM_BF16)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
@@ -398,8 +402,15 @@ class HipEncoderEngine:
                           _p(b["invstd"]), dm)
             else:
                 common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
-            self._call("vm_bn_pool_bwd_reduce_gmax" if sparse else "vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt,
-                       _p(b["pa"]), _p(b["pb"]), st)
+            if sparse:
+                self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
+            elif self.pooled_reduce and L % pool == 0:
+                # throughput mode: the pool-window extreme comes from this block's pooled output (= the next block's input),
+                # so the pass reads two pooled-size tensors instead of z + dp
+                self._call("vm_bn_pool_bwd_reduce_pooled", _p(b["z"]), _p(b["act"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]),
+                           _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
+            else:
+                self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
                      _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
