@@ -289,10 +289,13 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     // du = [z>0] * (gc*z + gb0 + [arg] ga*dp)   (same folding as bn_pool_bwd_kernel)
     const float ga = sc * dr, gb0 = sc * (is * k2 * mu - k1), gc = -sc * is * k2;
 
-    f32x16 accw;
+    f32x16 accw, accb;  // accb: the bias gradient sum_rows du[row][c], as one more MFMA with an all-ones A operand -- the
+                        // kernel is VALU-bound and the matrix pipe is 86 % idle, so the 32 converts + adds per tile move there
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
-    float bsum = 0.f;
+    for (int r = 0; r < 16; ++r) accw[r] = accb[r] = 0.f;
+    bf16x8 ones8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones8[e] = (bf16)1.0f;
 
     const int ch_lo = split * cps;
     int ch_hi = ch_lo + cps;
@@ -341,7 +344,6 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                             gz = zz > 0.f ? gz : 0.f;
                             const bf16 gb = (bf16)gz;
                             dub[4 * g + pw * POOL + j] = gb;
-                            bsum += (float)gb;
                         }
                     }
                 }
@@ -379,7 +381,6 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                         gz = (zz > 0.f && tg + pw * POOL + j < L) ? gz : 0.f;
                         const bf16 gb = (bf16)gz;
                         dub[4 * g + pw * POOL + j] = gb;
-                        bsum += (float)gb;
                     }
                 }
             }
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                 }
                 accw = mfma_bf16(ah, bfrag, accw);
                 accw = mfma_bf16(al, bfrag, accw);
+                accb = mfma_bf16(ones8, bfrag, accb);
             }
         }
     }
@@ -416,7 +418,8 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     __shared__ float wred[4][17][64];
 #pragma unroll
     for (int r = 0; r < 16; ++r) wred[wave][r][lane] = role.active ? accw[r] : 0.f;
-    wred[wave][16][lane] = role.active ? bsum : 0.f;
+    // every accumulator row of accb holds the column sum over ALL K slots (both lane halves): count it once
+    wred[wave][16][lane] = (role.active && hi == 0) ? accb[0] : 0.f;
     __syncthreads();
     if (role.active && role.rs == 0) {
         float* slab = ws + (int64_t)blockIdx.x * 33 * F;
