@@ -44,7 +44,7 @@ def base_parser(description, **defaults):
 def datasets(a, pad):
     if a.synthetic:
         train = SyntheticSpeechDataset(num_speakers=64, files_per_speaker=8, seconds=a.n_seconds, pad=pad, seed=0)
-        valid = SyntheticSpeechDataset(num_speakers=24, files_per_speaker=8, seconds=a.n_seconds, stochastic=False, pad=pad,
+        valid = SyntheticSpeechDataset(num_speakers=72, files_per_speaker=6, seconds=a.n_seconds, stochastic=False, pad=pad,
                                        seed=1)
     else:
         train = LibriSpeechDataset(a.training_set, a.n_seconds, pad=pad)
