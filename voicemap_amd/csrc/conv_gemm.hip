@@ -957,6 +957,33 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
         const int col_base = tn_c * 256 + wn * 64;
         // wave-uniform base + 32-bit lane offset: the stores use the scalar-base form (no 64-bit address VGPRs)
         bf16* const out_u = p.out + ((int64_t)n_c * p.L + t_base) * p.N + col_base;
+        if (EPI == EPI_DGRAD) {
+            // no bias / ReLU / statistics: convert in the accumulator layout, stage 32 rows x 64 columns in the STORAGE type
+            // (8-byte writes, 16-byte read-back) and leave as whole 128-byte row segments -- half the LDS traffic and half the
+            // store instructions of the fp32 form below
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16 o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][jn][4 * g4 + e];
+                        *reinterpret_cast<u32x2*>(scr + m * 128 + (((jn * 4 + g4) ^ (m & 7)) * 16) + hi * 8) = *reinterpret_cast<const u32x2*>(o);
+                    }
+                }
+                u32x4 vv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vv[k] = *reinterpret_cast<const u32x4*>(scr + (k * 8 + rb) * 128 + ((c ^ rb) * 16));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = k * 8 + rb;
+                    if (t_base + i * 32 + row < p.L) *reinterpret_cast<u32x4*>(out_u + (unsigned)((i * 32 + row) * p.N + c * 8)) = vv[k];
+                }
+            }
+            return;
+        }
         float s4[2][4], q4[2][4];
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
