@@ -46,7 +46,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "tn_p8": 1, "tn_x": 1,
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "tn_p8": 1, "tn_x": 1,
                  "nt_p8_blocks": 256}
 
 

@@ -124,6 +124,8 @@ struct NtArgs {
     int L, N, Ktot;
     int tilesL, tilesN;
     int order;   // tile order of the LDS-DMA kernels: 0 sequential n-tiles per workgroup, 1 concurrent n-tiles per XCD
+    int korder;  // conv_nt8_kernel: 1 = walk K as (channel chunk, tap) instead of (tap, channel chunk): consecutive K tiles then
+                 // re-read the same input cache lines one row later (needs a_c % 64 == 0)
     int skew;    // conv_nt8_kernel: start delay (units of 127*64 clocks) per workgroup phase (blockIdx >> 3) & 3
     int ablate;  // timing experiments only (results are wrong when != 0): 1 no epilogue stores, 2 no epilogue,
                  // 4 no MFMA, 8 no K-loop global loads after the first slice
@@ -843,10 +845,14 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
     // A half h holds, for both row groups, the rows read in the same phase: LDS row q <-> tile row (q>>6)*128 + h*64 + (q&63);
     // B half h likewise: LDS row q <-> tile column (q>>5)*64 + h*32 + (q&31).  (The WAR schedule above is per half tile.)
     const int b_col = (rr >> 5) * 64 + (rr & 31);
+    // byte offset of K tile kt inside an (im2col / weight) row
+    const int chunks = p.a_c / 64;
+    auto koff = [&](int kt) { return p.korder ? ((kt % 3) * p.a_c + (kt / 3) * 64) * 2 : kt * 128; };
+    (void)chunks;
     auto stage = [&](int h, int buf, int n, int t0, int n0, int kt) {
         char* dst = lds + buf * BUF + h * HALF + w * 1024;
         if (h < 2) {
-            const char* src = a_base + n * a_win + kt * 128;  // wave-uniform
+            const char* src = a_base + n * a_win + koff(kt);  // wave-uniform
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 int t = t0 + j * 128 + h * 64 + rr;
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
                 glds16(src + ((unsigned)t * (unsigned)a_pitch + (unsigned)schunk), dst + j * 8192);
             }
         } else {
-            const char* src = b_base + (int64_t)(n0 + (h - 2) * 32) * b_pitch + kt * 128;  // wave-uniform
+            const char* src = b_base + (int64_t)(n0 + (h - 2) * 32) * b_pitch + koff(kt);  // wave-uniform
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 glds16(src + ((unsigned)(b_col + j * 128) * (unsigned)b_pitch + (unsigned)schunk), dst + j * 8192);
@@ -2082,6 +2088,7 @@ int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_
 int g_nt_p8 = 2;
 int g_nt_p8_blocks = 256;
 int g_nt_p8_skew = 0;
+int g_nt_p8_korder = 1;  // -0.5 % step (interleaved A/B): the same cache lines are re-read one K tile later instead of six
 int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
 
 template <typename T, int EPI>
@@ -2092,6 +2099,7 @@ static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_
         n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
     NtArgs<bf16> b = a;
     b.skew = g_nt_p8_skew;
+    b.korder = (g_nt_p8_korder && a.a_c % 64 == 0 && a.Ktot == 3 * a.a_c) ? 1 : 0;
     b.tilesL = (a.L + 255) / 256;
     b.tilesN = a.N / 256;
     const int64_t n_groups = n_windows * b.tilesL;
@@ -2353,6 +2361,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_phases") == 0 && (value == 2 || value == 4)) {
         g_nt_p8_phases = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_p8_korder") == 0) {
+        g_nt_p8_korder = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_p8_skew") == 0 && value >= 0 && value <= 64) {
