@@ -46,7 +46,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "tn_p8": 1, "tn_x": 1,
+GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "nt_korder": 0, "tn_p8": 1, "tn_x": 1,
                  "nt_p8_blocks": 256}
 
 
@@ -61,11 +61,12 @@ def gemm_kb(request):
         L().call("vm_set_tuning", k.encode(), v)
 
 
-@pytest.mark.parametrize("gemm_kb", [{}, {"nt_p8_blocks": 3}, {"nt_p8_blocks": 8, "nt_order": 0}, {"nt_p8": 0},
+@pytest.mark.parametrize("gemm_kb", [{"nt_p8": 1, "tn_x": 2}, {"nt_p8": 1, "nt_p8_blocks": 3}, {"nt_p8": 1, "nt_p8_blocks": 8, "nt_order": 0},
+                                     {"nt_p8": 1, "nt_p8_phases": 4, "nt_p8_blocks": 8, "nt_p8_korder": 0}, {"nt_p8": 0, "nt_korder": 1},
                                      {"nt_p8": 0, "nt_tepi": 0, "tn_p8": 0, "tn_x": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_ring": 1, "tn_x": 0},
                                      {"nt_p8": 0, "nt_order": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
                                      {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
-                         ids=["p8", "p8-3wg", "p8-8wg-seq", "tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
+                         ids=["p8", "p8-3wg", "p8-8wg-seq", "p8-4ph", "tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
                                           (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),

@@ -625,15 +625,20 @@ __global__ __launch_bounds__(256, (TEPI && sizeof(T) == 2) ? 3 : 2) void conv_nt
                 nn = nn < p.N ? nn : p.N - 1;
                 b_rows[i] = reinterpret_cast<const char*>(p.bt + (int64_t)nn * p.Ktot) + src_chunk_bytes[i];
             }
+            // K slice kt -> byte offset in an (im2col / weight) row; korder: (channel chunk, tap) instead of (tap, channel chunk),
+            // so that consecutive slices re-read the same input cache lines one row later
+            const int row_bytes = p.a_c * (int)sizeof(T), cpr = row_bytes / KB;
             auto issue = [&](int kt) {
                 char* bufbase = lds + (kt & 1) * 2 * OPB;
+                const int64_t ko = p.korder ? (int64_t)(kt % 3) * row_bytes + (int64_t)(kt / 3) * KB : (int64_t)kt * KB;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int dst = __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
-                    glds16(a_rows[i] + (int64_t)kt * KB, bufbase + dst);
-                    glds16(b_rows[i] + (int64_t)kt * KB, bufbase + OPB + dst);
+                    glds16(a_rows[i] + ko, bufbase + dst);
+                    glds16(b_rows[i] + ko, bufbase + OPB + dst);
                 }
             };
+            (void)cpr;
             f32x16 acc[2][2];
             zero_acc(acc);
             issue(0);
@@ -2088,6 +2093,7 @@ int g_nt_glds = 1;  // direct-to-LDS NT kernel when the shape allows it; vm_set_
 int g_nt_p8 = 2;
 int g_nt_p8_blocks = 256;
 int g_nt_p8_skew = 0;
+int g_nt_korder = 0;  // K walk of the 128^2 LDS-DMA kernels: 0 (tap, chunk), 1 (chunk, tap)
 int g_nt_p8_korder = 1;  // -0.5 % step (interleaved A/B): the same cache lines are re-read one K tile later instead of six
 int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
 
@@ -2172,6 +2178,8 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.tilesN = tiles(c_out, BN);
         a.ablate = g_nt_ablate;
         a.order = g_nt_order;
+        a.skew = 0;
+        a.korder = g_nt_korder && (c_in * (int)sizeof(T)) % 128 == 0;
         launch_nt<T, EPI_FWD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
@@ -2200,6 +2208,8 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.tilesN = tiles(c_in, BN);
         a.ablate = g_nt_ablate;
         a.order = g_nt_order;
+        a.skew = 0;
+        a.korder = g_nt_korder && (c_out * (int)sizeof(T)) % 128 == 0;
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
@@ -2361,6 +2371,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_phases") == 0 && (value == 2 || value == 4)) {
         g_nt_p8_phases = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_korder") == 0) {
+        g_nt_korder = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_p8_korder") == 0) {
