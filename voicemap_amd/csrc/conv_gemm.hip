@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, (TEPI && sizeof(T) == 2) ? 3 : 2) void conv_nt
             }
             // K slice kt -> byte offset in an (im2col / weight) row; korder: (channel chunk, tap) instead of (tap, channel chunk),
             // so that consecutive slices re-read the same input cache lines one row later
-            const int row_bytes = p.a_c * (int)sizeof(T), cpr = row_bytes / KB;
+            const int row_bytes = p.a_c * (int)sizeof(T);
             auto issue = [&](int kt) {
                 char* bufbase = lds + (kt & 1) * 2 * OPB;
                 const int64_t ko = p.korder ? (int64_t)(kt % 3) * row_bytes + (int64_t)(kt / 3) * KB : (int64_t)kt * KB;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, (TEPI && sizeof(T) == 2) ? 3 : 2) void conv_nt
                     glds16(b_rows[i] + ko, bufbase + OPB + dst);
                 }
             };
-            (void)cpr;
+
             f32x16 acc[2][2];
             zero_acc(acc);
             issue(0);
@@ -851,9 +851,7 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
     // B half h likewise: LDS row q <-> tile column (q>>5)*64 + h*32 + (q&31).  (The WAR schedule above is per half tile.)
     const int b_col = (rr >> 5) * 64 + (rr & 31);
     // byte offset of K tile kt inside an (im2col / weight) row
-    const int chunks = p.a_c / 64;
     auto koff = [&](int kt) { return p.korder ? ((kt % 3) * p.a_c + (kt / 3) * 64) * 2 : kt * 128; };
-    (void)chunks;
     auto stage = [&](int h, int buf, int n, int t0, int n0, int kt) {
         char* dst = lds + buf * BUF + h * HALF + w * 1024;
         if (h < 2) {
@@ -1851,22 +1849,6 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
             const uint32_t a = lds0 + A_BYTES + slot * BSTAGE + wn * BBLK + (b_off ^ (jn * 64));
 #pragma unroll
             for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 2048, a + s * 2048 + 512);
-        };
-        auto mma3 = [&](const Frag4& a0, const Frag4& b0, f32x16& c0, const Frag4& a1, const Frag4& b1, f32x16& c1, const Frag4& a2,
-                        const Frag4& b2, f32x16& c2) {
-            if (abl & 4) return;
-            auto op = [](const Frag4& f, int s) {
-                const u32x4 v = {f.lo[s][0], f.lo[s][1], f.hi[s][0], f.hi[s][1]};
-                return __builtin_bit_cast(bf16x8, v);
-            };
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b0, s), op(a0, s), c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b1, s), op(a1, s), c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(b2, s), op(a2, s), c2, 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
         };
         // clusters of 8 (one tap) and 16 (two taps) MFMAs, k-steps interleaved over the accumulator tiles
         auto opf = [](const Frag4& f, int s) {
