@@ -47,7 +47,7 @@ int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
  *   "tn_x"  0|1|2   wgrad: input-resident (3 taps x 128 ci) x 128 co kernel off / phase form (default) / free-running form
  *   "tn_p8" 0|1     wgrad: LDS-DMA + transposing-read 256x256 kernel when tn_x does not apply (default 1)
  *   "tn_tile" 128|256, "gemm_kb" 64|128, "nt_glds", "nt_tepi", "nt_ring", "nt_order", "tn_xcd": the older variants
- *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "f1_blocks": launch geometry
+ *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "f1_blocks", "f1_fwd_blocks": launch geometry
  *   "nt_ablate": timing experiments that produce WRONG results (see conv_gemm.hip). */
 int vm_set_tuning(const char* key, int value);
 
@@ -85,9 +85,11 @@ int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L,
 /* Fused block 1 for bf16 storage (voicemap/models.py:13-19: Conv1D(F,32) -> BatchNormalization -> SpatialDropout1D ->
  * MaxPool1D(pool)): the full-resolution relu(conv) tensor is never written.
  *   training (inference = 0): out = e (n_windows, L/pool, F) bf16 = per-pool-window max (gamma >= 0) or min (gamma < 0) of
- *     bf16(relu(conv+b)) -- BN is a monotone per-channel affine, so pooling commutes with it; the affine + dropout are then
- *     applied to e by vm_bn_drop_pool_fwd(z = e, L = L/pool, pool = 1).  gamma_or_scale = gamma (F); shift ignored;
- *     stat_sum / stat_sq as for vm_conv1_fwd (over all L positions).
+ *     relu(conv+b), rounded to bf16 -- BN is a monotone per-channel affine, so pooling commutes with it; the affine +
+ *     dropout are then applied to e by vm_bn_drop_pool_fwd(z = e, L = L/pool, pool = 1).  gamma_or_scale = gamma (F);
+ *     shift ignored; stat_sum / stat_sq as for vm_conv1_fwd (over all L positions), taken from the fp32 accumulator:
+ *     relu(conv+b) itself is never stored, so it has no storage rounding -- the statistics, the pool arg-max and the
+ *     backward recompute all see the same fp32 values.
  *   inference (inference = 1): out = padded act (n_windows, L/pool + 2, F) bf16 = bf16(extreme * scale + shift);
  *     gamma_or_scale = scale, shift from vm_bn_infer_affine.
  * pool: 2 or 4. */

@@ -265,6 +265,34 @@ def _store(x, storage):
     return _StoreBf16.apply(x) if storage == "bf16" else x
 
 
+class _StoreAsBf16(torch.autograd.Function):
+    """Forward: the given (already rounded) value; backward: like _StoreBf16 (the gradient stored there is bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, value):
+        return value
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype), None
+
+
+class _Bf16GradOnly(torch.autograd.Function):
+    """A tensor that never reaches HBM (forward exact) but whose gradient is consumed as a bf16 matrix operand."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
 def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
                     drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None,
                     collect: Optional[dict] = None, storage: Optional[str] = None) -> torch.Tensor:
@@ -277,7 +305,12 @@ def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
         kern = p[f"conv{i+1}.kernel"]
         if storage == "bf16" and i > 0:  # GEMM operand copies of the k=3 kernels are bf16; block 1 stays fp32
             kern = kern + (kern.detach().to(torch.bfloat16).to(kern.dtype) - kern.detach())
-        z = _store(conv1d_same_relu(h, kern, p[f"conv{i+1}.bias"]), storage)
+        # bf16 emulation of block 1: the fused kernels never store z1 (statistics, arg-max and the backward recompute see
+        # the fp32 accumulator; only du1 becomes a bf16 MFMA operand); what IS stored is bf16(pooled extreme of z1), and the
+        # BN affine + dropout run over that -- so the pooled activation is rounded twice.
+        fused1 = storage == "bf16" and i == 0 and pool in (2, 4)
+        z = conv1d_same_relu(h, kern, p[f"conv{i+1}.bias"])
+        z = _Bf16GradOnly.apply(z) if fused1 else _store(z, storage)
         if training:
             y, mean, var = batchnorm_train(z, p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"], arch.bn_eps)
             if collect is not None:
@@ -289,7 +322,22 @@ def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
         else:
             y = batchnorm_infer(z, p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"], p[f"bn{i+1}.moving_mean"],
                                 p[f"bn{i+1}.moving_variance"], arch.bn_eps)
-        h = _store(maxpool1d(y, pool), storage)
+        if fused1:
+            with torch.no_grad():
+                gam, bet = p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"]
+                if training:
+                    inv = gam * torch.rsqrt(var + arch.bn_eps)
+                    sh = bet - mean * inv
+                    mult = 1.0 if (m is None or arch.dropout == 0.0) else m.to(z.dtype) / (1.0 - arch.dropout)
+                else:
+                    inv = gam * torch.rsqrt(p[f"bn{i+1}.moving_variance"] + arch.bn_eps)
+                    sh = bet - p[f"bn{i+1}.moving_mean"] * inv
+                    mult = 1.0
+                ext = torch.where(inv >= 0, maxpool1d(z, pool), -maxpool1d(-z, pool))
+                act = _bf16((_bf16(ext) * inv + sh) * mult)
+            h = _StoreAsBf16.apply(maxpool1d(y, pool), act)
+        else:
+            h = _store(maxpool1d(y, pool), storage)
         if collect is not None:
             collect.setdefault("z", []).append(z.detach())
             collect.setdefault("pooled", []).append(h.detach())

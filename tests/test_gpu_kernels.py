@@ -453,16 +453,33 @@ def test_nshot_distances(dist, k, n):
 
 
 # ----------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def f1_splits(request):
+    """Workgroups per window of the fused block-1 kernels: small test batches would otherwise always get one chunk per
+    workgroup and never walk the double-buffered multi-chunk loop that the full-size batch runs."""
+    per_window = request.param
+    if per_window:
+        n = request.node.callspec.params["n"]
+        L().call("vm_set_tuning", b"f1_fwd_blocks", per_window * n)
+        L().call("vm_set_tuning", b"f1_blocks", per_window * n)
+    yield per_window
+    L().call("vm_set_tuning", b"f1_fwd_blocks", 4096)
+    L().call("vm_set_tuning", b"f1_blocks", 2048)
+
+
+@pytest.mark.parametrize("f1_splits", [0, 1, 2], indirect=True)
+@pytest.mark.parametrize("neg", [0.25, 0.0])  # 0.0: every gamma positive -> the wave-uniform all-maximum paths (the training default)
 @pytest.mark.parametrize("n,wpt,l,f,pool,use_drop", [(4, 2, 700, 16, 4, True), (2, 1, 1200, 128, 4, False), (2, 2, 530, 40, 2, True),
-                                                     (2, 1, 300, 160, 4, False)])
-def test_conv1_fused_block(n, wpt, l, f, pool, use_drop):
+                                                     (2, 1, 300, 160, 4, False), (3, 3, 2100, 64, 4, False)])
+def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     """Fused bf16 block 1 (conv k=32 -> relu -> BN -> dropout -> maxpool) forward, inference forward and backward vs
-    the oracle with the same bf16 storage point (z rounded forward, du rounded backward)."""
+    the float64 oracle.  z1 never reaches HBM, so it has no storage rounding: statistics, arg-max routing and the
+    backward see the fp32 accumulator; the stored tensors are bf16(pooled extreme of z) and the bf16 activation."""
     r = rng(20)
     x = r.normal(0, 0.05, (n, l)).astype(np.float32)
     w = r.normal(0, 0.2, (32, 1, f)).astype(np.float32)
     b = r.normal(0, 0.05, (f,)).astype(np.float32)
-    gamma = (r.normal(1.0, 0.3, f) * np.where(r.random(f) < 0.25, -1, 1)).astype(np.float32)
+    gamma = (np.abs(r.normal(1.0, 0.3, f)) * np.where(r.random(f) < neg, -1, 1)).astype(np.float32)
     beta = r.normal(0, 0.3, f).astype(np.float32)
     drop = ((r.random((n, f)) > 0.3) / 0.7).astype(np.float32) if use_drop else None
     xp = np.zeros((n, l + 31), np.float32)
@@ -477,18 +494,18 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop):
     ss, sq = torch.zeros(n * rows, f, **f32), torch.zeros(n * rows, f, **f32)
     L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(gd), None, n, l, f, pool, 0, p(e), p(ss), p(sq), stream())
 
-    # ---- oracle: z with the bf16 storage point, BN per tower, dropout, pool
+    # ---- oracle: z (unrounded), BN per tower, dropout, pool
     T = lambda a: torch.tensor(a, dtype=torch.float64)
     wr, br = T(w).requires_grad_(True), T(b).requires_grad_(True)
     gr, btr = T(gamma).requires_grad_(True), T(beta).requires_grad_(True)
-    z = O._store(O.conv1d_same_relu(T(x)[:, :, None], wr, br), "bf16")
+    z = O.conv1d_same_relu(T(x)[:, :, None], wr, br)
     zz = z.detach()
     pooled_max = O.maxpool1d(zz, pool)
     pooled_min = -O.maxpool1d(-zz, pool)
-    e_ref = torch.where(T(gamma) >= 0, pooled_max, pooled_min)
+    e_ref = quant(torch.where(T(gamma) >= 0, pooled_max, pooled_min), "bf16")
     assert rel_err(e.float().cpu().numpy(), e_ref.numpy()) < 2e-3
-    assert rel_err(ss.cpu().numpy().reshape(n, rows, f).sum(1), zz.sum(1).numpy()) < 2e-4
-    assert rel_err(sq.cpu().numpy().reshape(n, rows, f).sum(1), (zz * zz).sum(1).numpy()) < 2e-4
+    assert rel_err(ss.cpu().numpy().reshape(n, rows, f).sum(1), zz.sum(1).numpy()) < 1e-4
+    assert rel_err(sq.cpu().numpy().reshape(n, rows, f).sum(1), (zz * zz).sum(1).numpy()) < 1e-4
 
     # ---- BN finalize + affine/dropout on the pooled tensor == pool(BN(z)*drop)
     mean, invstd, scale, shift = (torch.empty(towers, f, **f32) for _ in range(4))

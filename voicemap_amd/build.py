@@ -16,6 +16,9 @@ LIB = os.path.join(LIBDIR, "libvoicemap_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"] + os.environ.get("VM_EXTRA_HIPCC_FLAGS", "").split()
+# conv1_fused: its kernels read every MFMA result in a VALU epilogue and are VALU-bound; with the accumulators in VGPRs
+# (instead of AGPRs) the epilogue needs no v_accvgpr_read copies and the kernels fit one more wave per SIMD.
+FILE_FLAGS = {"conv1_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -34,7 +37,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(s)
             and os.path.getmtime(obj) >= _headers_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", s, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", s, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

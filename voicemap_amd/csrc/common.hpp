@@ -93,6 +93,7 @@ __device__ inline double wave_sum_d(double v) {
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int f1_set_blocks(int v);  // conv1_fused.hip tuning
+int f1_set_fwd_blocks(int v);
 
 // reduce.hip: out0[i] (i < n0) / out1[i - n0] = sum over `slabs` slabs of ws[k][i], two fixed-order stages.
 // `part` needs slab_sum_part_bytes(nel) bytes of scratch.

@@ -5,7 +5,7 @@
 // full resolution and streaming it three more times (BN+pool, BN-backward reduce, BN-backward apply) cost more
 // HBM time than the whole rest of the network.  Here the full-resolution tensor never exists in HBM:
 //
-//   forward : MFMA conv tile -> +bias, ReLU, bf16 round -> per-channel sum / sum-of-squares partials (BN statistics)
+//   forward : MFMA conv tile -> +bias, ReLU -> per-channel sum / sum-of-squares partials (BN statistics)
 //             -> MaxPool *in registers*.  BN is a per-channel affine applied after the statistics are known and
 //             max-pooling commutes with a monotone map:  max_j(a*z_j + b) = a*max_j z_j + b for a >= 0 and
 //             a*min_j z_j + b for a < 0 (sign(a) = sign(gamma), known before the launch).  So only the pooled
@@ -15,44 +15,71 @@
 //             B operand (the 32x32 accumulator layout of du IS a valid K-slot assignment for the next MFMA, as in
 //             flash-attention's P.V step), with the matching waveform samples gathered from LDS as the A operand.
 //
+// Both kernels are VALU-bound (the matrix pipe idles most of the time), so the per-element instruction count is what is
+// tuned here: packed fp32 adds/fmas, wave-uniform "every channel pools a maximum" paths without min/max selects, pair-wise
+// bf16 converts, scalar tile addressing, and accumulators kept in VGPRs (build.py: -amdgpu-mfma-vgpr-form) so the
+// epilogue reads them without v_accvgpr_read copies.
+//
 // MFMA operands are bf16, but the waveform and the filters are split hi+lo (x = xh + xl, both bf16) and the three
 // significant products accumulated (xh*wh + xl*wh + xh*wl), so block 1 keeps ~16 mantissa bits of its fp32 inputs.
 // The waveform tile lives in LDS as 8 sample-shifted copies so that every 8-sample (16-byte) fragment of the
 // sliding window  x[p+k .. p+k+8)  is an aligned ds_read_b128 whatever p is.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace vm {
 
 constexpr int F1_K = 32;       // taps
 constexpr int F1_CHUNK = 256;  // positions per chunk (8 MFMA row tiles of 32)
-constexpr int F1_CPL = 288;    // samples per shifted copy (>= 256 + 31, multiple of 8)
+constexpr int F1_CPL = 288;    // samples a shifted copy must hold (>= 256 + 31, multiple of 8)
+constexpr int F1_PAD = 8;      // slack either side of a copy: the 8 shifted stores of one sample need no range predicate
+constexpr int F1_ROW = F1_CPL + 2 * F1_PAD;  // 304 elements = 608 B: consecutive copies start 24 banks apart, so the 16-byte
+                                             // fragment reads of 8 lanes (8 copies, same offset) touch 32 distinct banks
 
-struct F1Smem {
-    bf16 xh[8][F1_CPL];
-    bf16 xl[8][F1_CPL];
-    float red[4][32][2];
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+struct F1Copies {
+    bf16 xh[8][F1_ROW];
+    bf16 xl[8][F1_ROW];
 };
 
 __device__ inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-__device__ inline float bf16_round(float v) { return (float)(bf16)v; }
-
-// x_pad row of window n (length L + 31) -> 8 shifted hi/lo copies of local samples [t0, t0 + 295)
-__device__ inline void f1_build_copies(F1Smem& sm, const float* __restrict__ xrow, int64_t t0, int64_t row_len, int tid) {
-    for (int j = tid; j < F1_CPL + 7; j += 256) {
-        const int64_t t = t0 + j;
-        const float v = t < row_len ? xrow[t] : 0.f;
-        const bf16 h = (bf16)v;
-        const bf16 l = (bf16)(v - (float)h);
+// x_pad row of window n (length L + 31) -> 8 shifted hi/lo copies of local samples [t0, t0 + 295): copy s holds sample
+// t0 + m + s at element F1_PAD + m.  Split in two so that the global loads of the next chunk are in flight while the
+// current chunk's tiles are computed: fetch (thread tid: samples tid and, for the first 39 threads, 256 + tid) ...
+struct F1Fetch {
+    float a, b;
+    bool va, vb;  // in range (the loads themselves are unconditional on a clamped index: a select in front of a load would
+                  // make the compiler wait for it at the join instead of at its first use)
+};
+__device__ inline F1Fetch f1_fetch(const float* __restrict__ xrow, int64_t t0, int64_t row_len, int tid) {
+    F1Fetch f;
+    const int64_t t = t0 + tid, last = row_len - 1;
+    f.va = t <= last;
+    f.vb = tid < F1_CPL + 7 - 256 && t + 256 <= last;
+    f.a = xrow[f.va ? t : last];
+    f.b = xrow[f.vb ? t + 256 : last];
+    return f;
+}
+// ... and stash: hi/lo split + the 8 shifted 2-byte stores per sample
+__device__ inline void f1_stash_one(F1Copies& sm, float v, int j) {
+    const bf16 h = (bf16)v;
+    const bf16 l = (bf16)(v - (float)h);
+    bf16* ph = &sm.xh[0][F1_PAD + j];
+    bf16* pl = &sm.xl[0][F1_PAD + j];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int m = j - s;
-            if (m >= 0 && m < F1_CPL) {
-                sm.xh[s][m] = h;
-                sm.xl[s][m] = l;
-            }
-        }
+    for (int s = 0; s < 8; ++s) {
+        ph[s * (F1_ROW - 1)] = h;  // element F1_PAD + j - s of copy s
+        pl[s * (F1_ROW - 1)] = l;
     }
+}
+__device__ inline void f1_stash(F1Copies& sm, const F1Fetch& f, int tid) {
+    f1_stash_one(sm, f.va ? f.a : 0.f, tid);
+    if (tid < F1_CPL + 7 - 256) f1_stash_one(sm, f.vb ? f.b : 0.f, 256 + tid);
 }
 
 struct F1Weights {
@@ -74,7 +101,7 @@ __device__ inline void f1_load_weights(F1Weights& w, const float* __restrict__ w
 }
 
 // u[p][c] for the 32 positions of row tile rt (local p = 32*rt + row) x the wave's 32 channels
-__device__ inline f32x16 f1_conv_tile(const F1Smem& sm, const F1Weights& w, int rt, int lane) {
+__device__ inline f32x16 f1_conv_tile(const F1Copies& sm, const F1Weights& w, int rt, int lane) {
     const int i = lane & 31, kh = lane >> 5;
     const int s = i & 7;
     f32x16 acc;
@@ -82,7 +109,7 @@ __device__ inline f32x16 f1_conv_tile(const F1Smem& sm, const F1Weights& w, int 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const int m0 = 32 * rt + (i & ~7) + 16 * ks + 8 * kh;
+        const int m0 = F1_PAD + 32 * rt + (i & ~7) + 16 * ks + 8 * kh;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sm.xh[s][m0]);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sm.xl[s][m0]);
         acc = mfma_bf16(ah, w.h[ks], acc);
@@ -113,103 +140,139 @@ __device__ inline F1Role f1_role(int wave, int CT) {
     return r;
 }
 
+// z = relu(conv + bias) of the 4 consecutive positions this lane holds in accumulator group g
+__device__ inline void f1_relu4(const f32x16& acc, int g, f32x2 bv2, f32x2& a, f32x2& b) {
+    a = f32x2{acc[4 * g], acc[4 * g + 1]} + bv2;  // v_pk_add_f32: the kernels are VALU-bound, so instructions are time
+    b = f32x2{acc[4 * g + 2], acc[4 * g + 3]} + bv2;
+    a[0] = __builtin_fmaxf(a[0], 0.f);  // the builtin, not fmaxf(): no canonicalising v_max x,x in front of every operand
+    a[1] = __builtin_fmaxf(a[1], 0.f);
+    b[0] = __builtin_fmaxf(b[0], 0.f);
+    b[1] = __builtin_fmaxf(b[1], 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------------
-// forward.  grid = (n_windows * chunks, ceil(F/128)).
-//   TRAIN: e[n][q][c] = pooled extreme of bf16(relu(conv+b)) (max if gamma >= 0 else min) + stat partials
+// forward.  grid = (n_windows * splits, ceil(F/128)); a block walks `cps` chunks of one window (weights and the per-channel
+// constants are loaded once, the waveform copies are double-buffered: one barrier per chunk).
+//   TRAIN: e[n][q][c] = bf16 pooled extreme of relu(conv+b) (max if gamma >= 0 else min) + stat partials of the fp32 z
 //   INFER: act[n][1+q][c] = bf16(pooled extreme * scale + shift), sign from scale (moving-statistics affine)
+// z itself is never stored, so it has no storage rounding: statistics, pooling and the backward recompute all see the
+// fp32 accumulator.
 template <int POOL, bool INFER>
 __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                               const float* __restrict__ bias, const float* __restrict__ sgn,
                                                               const float* __restrict__ shift, int64_t L, int F, int chunks,
-                                                              bf16* __restrict__ out, float* __restrict__ stat_sum,
-                                                              float* __restrict__ stat_sq) {
-    __shared__ __attribute__((aligned(16))) F1Smem sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n = blockIdx.x / chunks;
-    const int chunk = (int)(blockIdx.x % chunks);
-    const int64_t t0 = (int64_t)chunk * F1_CHUNK;
+                                                              int splits, int cps, bf16* __restrict__ out,
+                                                              float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+    __shared__ __attribute__((aligned(16))) F1Copies cp[2];
+    __shared__ float red[4][32][2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n = blockIdx.x / splits;
+    const int split = (int)(blockIdx.x % splits);
     const int cbase = blockIdx.y * 128;
     const int CT = (min(F - cbase, 128) + 31) / 32;
     const F1Role role = f1_role(wave, CT);
     const int64_t Lq = L / POOL;
-
-    f1_build_copies(sm, x + n * (L + F1_K - 1), t0, L + F1_K - 1, tid);
-    __syncthreads();
+    const int ch_lo = split * cps;
+    int ch_hi = ch_lo + cps;
+    if (ch_hi > chunks) ch_hi = chunks;
+    const float* xrow = x + n * (L + F1_K - 1);
 
     const int c = cbase + role.ct * 32 + (lane & 31);
     const bool cok = role.active && c < F;
     const int hi = lane >> 5;
+    F1Weights w;
+    f1_load_weights(w, wk, F, c, cok, hi);
+    const float bv = cok ? bias[c] : 0.f;
+    const float sg = cok ? sgn[c] : 1.f;  // gamma (TRAIN) or scale (INFER): only its sign selects max/min ...
+    const float sh = (INFER && cok) ? shift[c] : 0.f;
+    const bool use_min = sg < 0.f;
+    const bool all_max = __builtin_amdgcn_ballot_w64(use_min) == 0;  // wave-uniform: no channel of this wave pools a minimum
+    const f32x2 bv2 = {bv, bv};
+    const int lane_off = c + (4 / POOL) * hi * F;  // this lane's element inside a tile's pooled rows
     float csum = 0.f, csq = 0.f;
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
     f32x2 csum2 = {0.f, 0.f}, csq2 = {0.f, 0.f};
-    if (role.active) {
-        F1Weights w;
-        f1_load_weights(w, wk, F, c, cok, hi);
-        const float bv = cok ? bias[c] : 0.f;
-        const float sg = cok ? sgn[c] : 1.f;  // gamma (TRAIN) or scale (INFER): only its sign selects max/min ...
-        const float sh = (INFER && cok) ? shift[c] : 0.f;
-        const bool use_min = sg < 0.f;
-        for (int rt = role.rs; rt < 8; rt += role.RS) {
+
+    // all 32 positions of a tile pooled and in range (every tile at cfg-A): no per-element predicates, one scalar base
+    // pointer per tile.  ALLMAX (wave-uniform): plain maxima, no min/max selects.
+    auto fast_tile = [&](const f32x16& acc, bf16* ob, auto allmax) {
+        constexpr bool ALLMAX = decltype(allmax)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (INFER && ALLMAX) {
+                // no statistics: max-pooling commutes with the ReLU, so the four ReLUs collapse into the last max3
+                const f32x2 a = f32x2{acc[4 * g], acc[4 * g + 1]} + bv2, b = f32x2{acc[4 * g + 2], acc[4 * g + 3]} + bv2;
+                if (POOL == 4) {
+                    const float ext = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), b[0]), __builtin_fmaxf(b[1], 0.f));
+                    ob[(2 * g) * F] = (bf16)fmaf(ext, sg, sh);
+                } else {
+                    ob[(4 * g) * F] = (bf16)fmaf(__builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), 0.f), sg, sh);
+                    ob[(4 * g + 1) * F] = (bf16)fmaf(__builtin_fmaxf(__builtin_fmaxf(b[0], b[1]), 0.f), sg, sh);
+                }
+                continue;
+            }
+            f32x2 za, zb2;
+            f1_relu4(acc, g, bv2, za, zb2);
+            if (!INFER) {
+                csum2 += za;
+                csum2 += zb2;
+                csq2 = __builtin_elementwise_fma(za, za, csq2);
+                csq2 = __builtin_elementwise_fma(zb2, zb2, csq2);
+            }
+            const float z[4] = {za[0], za[1], zb2[0], zb2[1]};
+#pragma unroll
+            for (int pw = 0; pw < 4 / POOL; ++pw) {
+                float ext = z[pw * POOL];
+#pragma unroll
+                for (int j = 1; j < POOL; ++j) {
+                    const float v = z[pw * POOL + j];
+                    ext = ALLMAX ? __builtin_fmaxf(ext, v) : (use_min ? __builtin_fminf(ext, v) : __builtin_fmaxf(ext, v));
+                }
+                ob[((8 * g) / POOL + pw) * F] = INFER ? (bf16)fmaf(ext, sg, sh) : (bf16)ext;
+            }
+        }
+    };
+
+    F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
+    f1_stash(cp[0], nxt, tid);
+    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+        const int buf = (chunk - ch_lo) & 1;
+        // this chunk's copies are visible, and every wave is done reading the other buffer (previous chunk)
+        __syncthreads();
+        const bool more = chunk + 1 < ch_hi;
+        if (more) nxt = f1_fetch(xrow, (int64_t)(chunk + 1) * F1_CHUNK, L + F1_K - 1, tid);  // lands while the tiles run
+        const F1Copies& sm = cp[buf];
+        const int64_t t0 = (int64_t)chunk * F1_CHUNK;
+        for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
             if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
-                // Fast path (every tile at cfg-A): all 32 positions are pooled and in range -- no per-element predicates, no
-                // 64-bit index arithmetic, one base pointer per tile.  The kernel is VALU-bound, so instructions are time.
-                bf16* ob = INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F + c : out + (n * Lq + (t0 + 32 * rt) / POOL) * F + c;
-                const f32x2 bv2 = {bv, bv};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float zb[4];
-                    // two-wide fp32 arithmetic (v_pk_add_f32 / v_pk_fma_f32): half the VALU issue slots for bias and statistics
-#pragma unroll
-                    for (int j2 = 0; j2 < 2; ++j2) {
-                        f32x2 v = f32x2{acc[4 * g + 2 * j2], acc[4 * g + 2 * j2 + 1]} + bv2;
-                        v[0] = v[0] > 0.f ? v[0] : 0.f;
-                        v[1] = v[1] > 0.f ? v[1] : 0.f;
-                        const f32x2 zr = {bf16_round(v[0]), bf16_round(v[1])};
-                        zb[2 * j2] = zr[0];
-                        zb[2 * j2 + 1] = zr[1];
-                        if (!INFER) {
-                            csum2 += zr;
-                            csq2 = __builtin_elementwise_fma(zr, zr, csq2);
-                        }
-                    }
-#pragma unroll
-                    for (int pw = 0; pw < 4 / POOL; ++pw) {
-                        float ext = zb[pw * POOL];
-#pragma unroll
-                        for (int j = 1; j < POOL; ++j) {
-                            const float v = zb[pw * POOL + j];
-                            ext = use_min ? fminf(ext, v) : fmaxf(ext, v);
-                        }
-                        const int qo = ((8 * g) / POOL + pw) * F + (4 / POOL) * hi * F;  // pooled row offset inside the tile
-                        ob[qo] = INFER ? (bf16)fmaf(ext, sg, sh) : (bf16)ext;
-                    }
+                bf16* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F : out + (n * Lq + (t0 + 32 * rt) / POOL) * F) + lane_off;
+                if (all_max) {
+                    fast_tile(acc, ob, std::true_type{});
+                } else {
+                    fast_tile(acc, ob, std::false_type{});
                 }
                 continue;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t tg = t0 + 32 * rt + 8 * g + 4 * hi;  // first of 4 consecutive positions
-                float zb[4];
+                f32x2 za, zb2;
+                f1_relu4(acc, g, bv2, za, zb2);
+                const float z[4] = {za[0], za[1], zb2[0], zb2[1]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = acc[4 * g + j] + bv;
-                    v = v > 0.f ? v : 0.f;
-                    zb[j] = bf16_round(v);
                     if (!INFER && tg + j < L) {
-                        csum += zb[j];
-                        csq += zb[j] * zb[j];
+                        csum += z[j];
+                        csq += z[j] * z[j];
                     }
                 }
 #pragma unroll
                 for (int pw = 0; pw < 4 / POOL; ++pw) {
-                    float ext = zb[pw * POOL];
+                    float ext = z[pw * POOL];
 #pragma unroll
-                    for (int j = 1; j < POOL; ++j) {
-                        const float v = zb[pw * POOL + j];
-                        ext = use_min ? fminf(ext, v) : fmaxf(ext, v);
-                    }
+                    for (int j = 1; j < POOL; ++j) ext = use_min ? __builtin_fminf(ext, z[pw * POOL + j]) : __builtin_fmaxf(ext, z[pw * POOL + j]);
                     const int64_t q = tg / POOL + pw;
                     if (cok && q < Lq) {
                         if (INFER) {
@@ -221,15 +284,17 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 }
             }
         }
+        if (more) f1_stash(cp[buf ^ 1], nxt, tid);
     }
     if (!INFER) {
+        // one statistics row per chunk (vm_conv1_stat_rows): the block's sum goes to its first chunk's row, zeros to the rest
         csum += csum2[0] + csum2[1];
         csq += csq2[0] + csq2[1];
         csum += __shfl_xor(csum, 32, 64);
         csq += __shfl_xor(csq, 32, 64);
         if (lane < 32) {
-            sm.red[wave][lane][0] = role.active ? csum : 0.f;
-            sm.red[wave][lane][1] = role.active ? csq : 0.f;
+            red[wave][lane][0] = role.active ? csum : 0.f;
+            red[wave][lane][1] = role.active ? csq : 0.f;
         }
         __syncthreads();
         if (tid < CT * 32) {
@@ -240,13 +305,15 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 for (int w2 = 0; w2 < 4; ++w2) {
                     const F1Role r2 = f1_role(w2, CT);
                     if (r2.active && r2.ct == ct) {
-                        s += sm.red[w2][col][0];
-                        q += sm.red[w2][col][1];
+                        s += red[w2][col][0];
+                        q += red[w2][col][1];
                     }
                 }
-                const int64_t row = n * chunks + chunk;
-                stat_sum[row * F + cc] = s;
-                stat_sq[row * F + cc] = q;
+                for (int ch = ch_lo; ch < ch_hi; ++ch) {
+                    const int64_t row = n * chunks + ch;
+                    stat_sum[row * F + cc] = ch == ch_lo ? s : 0.f;
+                    stat_sq[row * F + cc] = ch == ch_lo ? q : 0.f;
+                }
             }
         }
     }
@@ -263,8 +330,9 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                                                               const float* __restrict__ c1, const float* __restrict__ c2,
                                                               int64_t wpt, int64_t L, int F, int chunks, int splits, int cps,
                                                               float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) F1Smem sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) F1Copies cp[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n = blockIdx.x / splits;
     const int split = (int)(blockIdx.x % splits);
     const int cbase = blockIdx.y * 128;
@@ -275,6 +343,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const int i = lane & 31, hi = lane >> 5;
     const int c = cbase + role.ct * 32 + i;
     const bool cok = role.active && c < F;
+    const float* xrow = x + n * (L + F1_K - 1);
 
     F1Weights w;
     f1_load_weights(w, wk, F, c, cok, hi);
@@ -286,11 +355,13 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const float k1 = cok ? c1[tw * F + c] : 0.f;
     const float k2 = cok ? c2[tw * F + c] : 0.f;
     const bool use_min = sc < 0.f;
+    const bool all_max = __builtin_amdgcn_ballot_w64(use_min) == 0;
     // du = [z>0] * (gc*z + gb0 + [arg] ga*dp)   (same folding as bn_pool_bwd_kernel)
     const float ga = sc * dr, gb0 = sc * (is * k2 * mu - k1), gc = -sc * is * k2;
+    const f32x2 bv2 = {bv, bv};
 
     f32x16 accw, accb;  // accb: the bias gradient sum_rows du[row][c], as one more MFMA with an all-ones A operand -- the
-                        // kernel is VALU-bound and the matrix pipe is 86 % idle, so the 32 converts + adds per tile move there
+                        // kernel is VALU-bound and the matrix pipe is mostly idle, so the converts + adds per tile move there
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[r] = accb[r] = 0.f;
     bf16x8 ones8;
@@ -300,90 +371,134 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const int ch_lo = split * cps;
     int ch_hi = ch_lo + cps;
     if (ch_hi > chunks) ch_hi = chunks;
-    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
-        const int64_t t0 = (int64_t)chunk * F1_CHUNK;
-        __syncthreads();  // previous chunk's fragment reads are done
-        f1_build_copies(sm, x + n * (L + F1_K - 1), t0, L + F1_K - 1, tid);
-        __syncthreads();
-        if (!role.active) continue;
-        for (int rt = role.rs; rt < 8; rt += role.RS) {
-            if (t0 + 32 * rt >= L) break;
-            const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
-            bf16 dub[16];
-            if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
-                // fast path (every tile at cfg-A): no per-element range predicates, one dp base pointer per tile
-                const bf16* dpb = dp + (n * Lq + (t0 + 32 * rt) / POOL) * F + c;
+    constexpr int PW = 4 / POOL;    // pool windows per group of 4 consecutive positions
+    constexpr int NDP = 4 * PW;     // pooled gradients one lane needs per tile
+    // du of a tile whose 32 positions are all pooled and in range (every tile at cfg-A), dpv = its pooled gradients
+    auto fast_tile = [&](const f32x16& acc, const bf16 (&dpv)[NDP], bf16x2 (&dub)[8], auto allmax) {
+        constexpr bool ALLMAX = decltype(allmax)::value;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float zb[4];
+        for (int g = 0; g < 4; ++g) {
+            f32x2 za, zb2;
+            f1_relu4(acc, g, bv2, za, zb2);
+            const float z[4] = {za[0], za[1], zb2[0], zb2[1]};
+            float gz[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[4 * g + j] + bv;
-                        v = v > 0.f ? v : 0.f;
-                        zb[j] = bf16_round(v);
+            for (int pw = 0; pw < 4 / POOL; ++pw) {
+                const float* zw = &z[pw * POOL];
+                const float gb1 = fmaf(ga, (float)dpv[PW * g + pw], gb0);
+                // The first extreme of the pool window takes the pooled gradient: its addend is gb1, the others' gb0; where
+                // z = 0 the product gc*z vanishes by itself, so only the addend needs the ReLU mask.
+                float a[POOL];
+                if (ALLMAX) {
+                    // running maximum by compare + select: the three compares ARE the "strictly greater than everything
+                    // before" flags, and the first-maximum one-hot follows from them on the scalar unit (lane masks)
+                    uint64_t cgt[POOL];
+                    float run = zw[0];
+#pragma unroll
+                    for (int j = 1; j < POOL; ++j) {
+                        const bool gt = zw[j] > run;
+                        cgt[j] = __builtin_amdgcn_ballot_w64(gt);
+                        if (j + 1 < POOL) run = gt ? zw[j] : run;
+                    }
+                    uint64_t later = 0;  // some later position is strictly greater than everything before it
+#pragma unroll
+                    for (int j = POOL - 1; j >= 1; --j) {
+                        a[j] = __builtin_amdgcn_inverse_ballot_w64(cgt[j] & ~later) ? gb1 : gb0;
+                        later |= cgt[j];
+                    }
+                    a[0] = __builtin_amdgcn_inverse_ballot_w64(later) ? gb0 : gb1;
+                } else {
+                    float ext = zw[0];
+                    int arg = 0;
+#pragma unroll
+                    for (int j = 1; j < POOL; ++j) {
+                        const bool better = use_min ? (zw[j] < ext) : (zw[j] > ext);  // strict: the first extreme keeps the gradient
+                        if (better) {
+                            ext = zw[j];
+                            arg = j;
+                        }
                     }
 #pragma unroll
+                    for (int j = 0; j < POOL; ++j) a[j] = j == arg ? gb1 : gb0;
+                }
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) gz[pw * POOL + j] = fmaf(gc, zw[j], zw[j] > 0.f ? a[j] : 0.f);
+            }
+            dub[2 * g] = __builtin_convertvector(f32x2{gz[0], gz[1]}, bf16x2);
+            dub[2 * g + 1] = __builtin_convertvector(f32x2{gz[2], gz[3]}, bf16x2);
+        }
+    };
+    // pooled gradients of the tile at row tile rt of the chunk starting at t0.  Unconditional loads: a tile that is not a
+    // fast-path one (or a lane without a channel) reads a valid dummy element instead, so the compiler keeps the loads in
+    // flight until their first use instead of waiting at a branch join.
+    const int csafe = cok ? c : 0;
+    auto load_dp = [&](bf16 (&dpv)[NDP], int64_t t0, int rt) {
+        const bool fast = rt < 8 && t0 + 32 * rt + 32 <= Lq * POOL;  // wave-uniform
+        const int64_t Fs = fast ? F : 0;
+        const bf16* dpb = dp + (fast ? (n * Lq + (t0 + 32 * rt) / POOL) * F : 0) + csafe + PW * hi * Fs;
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) dpv[k] = dpb[((8 * (k / PW)) / POOL + k % PW) * Fs];
+    };
+
+    F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
+    f1_stash(cp[0], nxt, tid);
+    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+        const int buf = (chunk - ch_lo) & 1;
+        const int64_t t0 = (int64_t)chunk * F1_CHUNK;
+        bf16 dpn[NDP];  // the next tile's pooled gradients, loaded one tile ahead (their latency hides behind a tile of VALU work)
+        load_dp(dpn, t0, role.rs);
+        __syncthreads();  // this chunk's copies are visible; the other buffer's readers (previous chunk) are done
+        const bool more = chunk + 1 < ch_hi;
+        if (more) nxt = f1_fetch(xrow, (int64_t)(chunk + 1) * F1_CHUNK, L + F1_K - 1, tid);  // lands while the tiles run
+        const F1Copies& sm = cp[buf];
+        for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
+            if (t0 + 32 * rt >= L) break;
+            const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            bf16 dpv[NDP];
+#pragma unroll
+            for (int k = 0; k < NDP; ++k) dpv[k] = dpn[k];
+            load_dp(dpn, t0, rt + role.RS);
+            bf16x2 dub[8];  // du of accumulator registers (2k, 2k+1), already packed as the next MFMA wants them
+            if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
+                if (all_max) {
+                    fast_tile(acc, dpv, dub, std::true_type{});
+                } else {
+                    fast_tile(acc, dpv, dub, std::false_type{});
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t tg = t0 + 32 * rt + 8 * g + 4 * hi;
+                    f32x2 za, zb2;
+                    f1_relu4(acc, g, bv2, za, zb2);
+                    const float z[4] = {za[0], za[1], zb2[0], zb2[1]};
+                    float gz[4];
+#pragma unroll
                     for (int pw = 0; pw < 4 / POOL; ++pw) {
-                        float ext = zb[pw * POOL];
+                        float ext = z[pw * POOL];
                         int arg = 0;
 #pragma unroll
                         for (int j = 1; j < POOL; ++j) {
-                            const float v = zb[pw * POOL + j];
+                            const float v = z[pw * POOL + j];
                             const bool better = use_min ? (v < ext) : (v > ext);
                             if (better) {
                                 ext = v;
                                 arg = j;
                             }
                         }
-                        const int qo = ((8 * g) / POOL + pw) * F + (4 / POOL) * hi * F;
-                        const float ady = ga * (float)dpb[qo];
+                        const int64_t q = tg / POOL + pw;
+                        float ady = 0.f;
+                        if (cok && q < Lq) ady = ga * (float)dp[(n * Lq + q) * F + c];
 #pragma unroll
                         for (int j = 0; j < POOL; ++j) {
-                            const float zz = zb[pw * POOL + j];
-                            float gz = fmaf(gc, zz, gb0) + (j == arg ? ady : 0.f);
-                            gz = zz > 0.f ? gz : 0.f;
-                            const bf16 gb = (bf16)gz;
-                            dub[4 * g + pw * POOL + j] = gb;
+                            const float zz = z[pw * POOL + j];
+                            const float v = fmaf(gc, zz, gb0) + (j == arg ? ady : 0.f);
+                            gz[pw * POOL + j] = (zz > 0.f && tg + pw * POOL + j < L) ? v : 0.f;
                         }
                     }
+                    dub[2 * g] = __builtin_convertvector(f32x2{gz[0], gz[1]}, bf16x2);
+                    dub[2 * g + 1] = __builtin_convertvector(f32x2{gz[2], gz[3]}, bf16x2);
                 }
-            } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t tg = t0 + 32 * rt + 8 * g + 4 * hi;
-                float zb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[4 * g + j] + bv;
-                    v = v > 0.f ? v : 0.f;
-                    zb[j] = bf16_round(v);
-                }
-#pragma unroll
-                for (int pw = 0; pw < 4 / POOL; ++pw) {
-                    float ext = zb[pw * POOL];
-                    int arg = 0;
-#pragma unroll
-                    for (int j = 1; j < POOL; ++j) {
-                        const float v = zb[pw * POOL + j];
-                        const bool better = use_min ? (v < ext) : (v > ext);  // strict: the first extreme keeps the gradient
-                        if (better) {
-                            ext = v;
-                            arg = j;
-                        }
-                    }
-                    const int64_t q = tg / POOL + pw;
-                    float ady = 0.f;
-                    if (cok && q < Lq) ady = ga * (float)dp[(n * Lq + q) * F + c];
-#pragma unroll
-                    for (int j = 0; j < POOL; ++j) {
-                        const float zz = zb[pw * POOL + j];
-                        float gz = fmaf(gc, zz, gb0) + (j == arg ? ady : 0.f);
-                        gz = (zz > 0.f && tg + pw * POOL + j < L) ? gz : 0.f;
-                        const bf16 gb = (bf16)gz;
-                        dub[4 * g + pw * POOL + j] = gb;
-                    }
-                }
-            }
             }
             // weight gradient: dW[tap i][c] += sum_rows x_loc[32*rt + row + i] * du[row][c].  K-slot e of half kh in
             // MFMA m <-> accumulator register 8m+e of this lane <-> row 16m + 8(e>>2) + 4kh + (e&3).
@@ -391,14 +506,13 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
             for (int m = 0; m < 2; ++m) {
                 bf16x8 bfrag;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bfrag[e] = dub[8 * m + e];
+                for (int e = 0; e < 8; ++e) bfrag[e] = dub[4 * m + (e >> 1)][e & 1];
                 const int s = i & 3;
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                 bf16x8 ah, al;
 #pragma unroll
                 for (int eh = 0; eh < 2; ++eh) {
                     const int S = 32 * rt + 16 * m + 8 * eh + 4 * hi + i;
-                    const int m0 = S - s;
+                    const int m0 = F1_PAD + S - s;
                     const bf16x4 vh = *reinterpret_cast<const bf16x4*>(&sm.xh[s][m0]);
                     const bf16x4 vl = *reinterpret_cast<const bf16x4*>(&sm.xl[s][m0]);
 #pragma unroll
@@ -412,6 +526,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                 accb = mfma_bf16(ones8, bfrag, accb);
             }
         }
+        if (more) f1_stash(cp[buf ^ 1], nxt, tid);
     }
     // one slab per block.x: (33, F) = 32 tap rows + the bias-gradient row.  Waves that share a column tile
     // (CT < 3: the row tiles are split over several waves) are summed through LDS in a fixed order.
@@ -445,10 +560,11 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     }
 }
 
-int g_f1_blocks = 2048;  // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
+int g_f1_blocks = 2048;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
+int g_f1_fwd_blocks = 4096;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n))
 
-static int f1_splits(int64_t n_windows, int chunks) {
-    int s = (int)((g_f1_blocks + n_windows - 1) / n_windows);  // aim for >= g_f1_blocks workgroups
+static int f1_splits(int64_t n_windows, int chunks, int target) {
+    int s = (int)((target + n_windows - 1) / n_windows);  // aim for >= target workgroups
     if (s < 1) s = 1;
     if (s > chunks) s = chunks;
     const int cps = (chunks + s - 1) / s;
@@ -457,6 +573,10 @@ static int f1_splits(int64_t n_windows, int chunks) {
 
 int f1_set_blocks(int v) {
     g_f1_blocks = v;
+    return 0;
+}
+int f1_set_fwd_blocks(int v) {
+    g_f1_fwd_blocks = v;
     return 0;
 }
 
@@ -472,12 +592,14 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
     VM_REQUIRE(pool == 2 || pool == 4, "vm_conv1_fused_fwd: pool must be 2 or 4 (got %d)", pool);
     VM_REQUIRE(inference ? shift != nullptr : (stat_sum && stat_sq), "vm_conv1_fused_fwd: missing shift / stat buffers");
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
-    const int64_t gx = n_windows * chunks;
+    const int splits = f1_splits(n_windows, chunks, g_f1_fwd_blocks);
+    const int cps = (chunks + splits - 1) / splits;
+    const int64_t gx = n_windows * splits;
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_fwd: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
 #define VM_F1_FWD(POOL, INF)                                                                                              \
     hipLaunchKernelGGL((conv1_fused_fwd_kernel<POOL, INF>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,           \
-                       gamma_or_scale, shift, L, F, chunks, (bf16*)out, stat_sum, stat_sq)
+                       gamma_or_scale, shift, L, F, chunks, splits, cps, (bf16*)out, stat_sum, stat_sq)
     if (pool == 2) {
         if (inference) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
     } else {
@@ -489,7 +611,7 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
 
 extern "C" int64_t vm_conv1_fused_bwd_workspace_bytes(int64_t n_windows, int64_t L, int F) {
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
-    const int64_t slabs = n_windows * f1_splits(n_windows, chunks);
+    const int64_t slabs = n_windows * f1_splits(n_windows, chunks, g_f1_blocks);
     return slabs * 33 * (int64_t)F * (int64_t)sizeof(float) + slab_sum_part_bytes(33LL * F);
 }
 
@@ -499,10 +621,10 @@ extern "C" int vm_conv1_fused_bwd(const float* x, const float* w, const float* b
                                   float* grad_w, float* grad_b, void* stream) {
     VM_REQUIRE(x && w && bias && dp && scale && mean && invstd && c1 && c2 && ws && grad_w && grad_b,
                "vm_conv1_fused_bwd: null pointer");
-    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L > 0 && F > 0 && F % 8 == 0, "vm_conv1_fused_bwd: bad sizes");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && F > 0 && F % 8 == 0, "vm_conv1_fused_bwd: bad sizes");
     VM_REQUIRE(pool == 2 || pool == 4, "vm_conv1_fused_bwd: pool must be 2 or 4 (got %d)", pool);
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
-    const int splits = f1_splits(n_windows, chunks);
+    const int splits = f1_splits(n_windows, chunks, g_f1_blocks);
     const int cps = (chunks + splits - 1) / splits;
     const int64_t gx = n_windows * splits;
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_bwd: grid too large");

@@ -2316,6 +2316,9 @@ extern "C" int vm_set_tuning(const char* key, int value) {
         g_gemm_kb = value;
         return VM_OK;
     }
+    if (key != nullptr && strcmp(key, "f1_fwd_blocks") == 0 && value > 0) {
+        return f1_set_fwd_blocks(value);
+    }
     if (key != nullptr && strcmp(key, "f1_blocks") == 0 && value > 0) {
         return f1_set_blocks(value);
     }
