@@ -464,7 +464,7 @@ def f1_splits(request):
         L().call("vm_set_tuning", b"f1_blocks", per_window * n)
     yield per_window
     L().call("vm_set_tuning", b"f1_fwd_blocks", 4096)
-    L().call("vm_set_tuning", b"f1_blocks", 2048)
+    L().call("vm_set_tuning", b"f1_blocks", 1024)
 
 
 @pytest.mark.parametrize("f1_splits", [0, 1, 2], indirect=True)

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     }
 }
 
-int g_f1_blocks = 2048;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
+int g_f1_blocks = 1024;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
 int g_f1_fwd_blocks = 4096;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n))
 
 static int f1_splits(int64_t n_windows, int chunks, int target) {
