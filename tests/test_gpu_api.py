@@ -176,6 +176,35 @@ def test_device_side_crop_equals_host_crop(tmp_path):
         assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,mode,dist", [(1, 5, "siamese", "euclidean"), (3, 4, "siamese", "cosine"), (2, 5, "classifier", "dot_product")])
+def test_device_resident_n_shot_equals_host_n_shot(tmp_path, n, k, mode, dist):
+    """n_shot_task_evaluation over a device-resident corpus (tasks = start offsets, crop in the preprocessing
+    kernel) returns the same n_correct as the host route fed with the same tasks (same RNG seed => same files and fragments)."""
+    from voicemap_amd import models, shards, utils
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    src = SyntheticSpeechDataset(num_speakers=9, files_per_speaker=5, seconds=3, seed=2)
+    shards.write_shards(src, str(tmp_path), shard_samples=600000)
+    sd = shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=True)
+    enc = models.get_baseline_convolutional_encoder(16, 24, dropout=0.0, dtype="f32")
+    if mode == "siamese":
+        net = models.build_siamese_net(enc, (sd.fragment_length // 4, 1))
+        net.compile(loss="binary_crossentropy", optimizer="adam")
+    else:
+        from voicemap_amd.keras_like import Dense
+        enc.add(Dense(sd.num_classes(), activation="softmax"))
+        enc.compile(loss="categorical_crossentropy", optimizer="adam")
+        net = enc
+    bp = utils.BatchPreProcessor(mode, utils.preprocess_instances(4))
+    tasks = 12
+    np.random.seed(21)
+    host = utils.n_shot_task_evaluation(net, sd, bp, tasks, n, k, network_type=mode, distance=dist)
+    sd.to_device("cuda")
+    np.random.seed(21)
+    dev = utils.n_shot_task_evaluation(net, sd, bp, tasks, n, k, network_type=mode, distance=dist)
+    assert 0 <= host <= tasks and dev == host
+
+
 def test_train_siamese_script_with_device_resident_data(tmp_path, monkeypatch):
     """experiments/train_siamese.py --device-data: the training windows exist only as offsets into an HBM-resident int16
     buffer; the script runs end to end (fit_generator, validation, n-shot callback, checkpoint) and the loss is finite."""

@@ -248,3 +248,18 @@ def test_sharded_dataset_round_trip_and_offsets(tmp_path):
     # the sampling API of the reference still works on top of the shards
     q, (sup, sup_labels) = sd.build_n_shot_task(4, 2)
     assert sup.shape == (8, sd.fragment_length) and q[1] == sup_labels[0] == sup_labels[1]
+    # ... and as offsets (the device route of the n-shot evaluation): same draws in the same order as the host method
+    np.random.seed(11)
+    q_host, (sup_host, lab_host) = sd.build_n_shot_task(4, 2)
+    np.random.seed(11)
+    (qo, ql), (so, sl) = sd.build_n_shot_task_offsets(4, 2)
+    T = sd.fragment_length
+    assert ql == q_host[1] and list(sl) == list(lab_host) and so.shape == (8,)
+    assert np.array_equal(shards.to_int16(q_host[0]), cat[qo:qo + T])
+    for j in range(8):
+        assert np.array_equal(shards.to_int16(sup_host[j]), cat[so[j]:so[j] + T])
+    with pytest.raises(ValueError):
+        sd.build_n_shot_task_offsets(1, 1)
+    with pytest.raises(ValueError):
+        sd.build_n_shot_task_offsets(sd.unique_speakers, 1)
+

@@ -573,6 +573,18 @@ class HipEncoderEngine:
             self.preprocess(pl, x, downsampling, whitening, windows_per_tower or n)
         return self.forward(pl, n, None)
 
+    def embed_from_offsets(self, audio: torch.Tensor, offsets: torch.Tensor, raw_len: int, downsampling: int = 4,
+                           whitening: bool = True, windows_per_tower: Optional[int] = None) -> torch.Tensor:
+        """``embed`` fed from a device-resident recording buffer: window i is the ``raw_len`` samples at audio[offsets[i]]
+        (voicemap_amd/shards.py); the crop happens inside the preprocessing kernel."""
+        n = int(offsets.numel())
+        l0 = (raw_len + downsampling - 1) // downsampling
+        pl = self.plan(n, l0, False)
+        self.last_infer_l0 = l0
+        self.preprocess(pl, audio, downsampling, whitening, windows_per_tower or n,
+                        offsets=offsets.to(self.device, torch.int64).contiguous(), raw_len=raw_len)
+        return self.forward(pl, n, None)
+
     def siamese_eval(self, x1, x2, y, loss: str = "contrastive", preprocessed: bool = True, downsampling: int = 4,
                      whitening: bool = True):
         """test_on_batch of the siamese model: inference-mode forward + loss / accuracy (no gradients are used; the

@@ -145,13 +145,14 @@ class LibriSpeechDataset(Sequence):
                 instance = np.pad(instance, (before, missing - before), 'constant')
             else:
                 instance = np.pad(instance, (0, missing), 'constant')
+        return instance, self._label(index)
+
+    def _label(self, index):
         if self.label == 'sex':
-            label = sex_to_label[self.datasetid_to_sex[index]]
+            return sex_to_label[self.datasetid_to_sex[index]]
         elif self.label == 'speaker':
-            label = self.datasetid_to_speaker_id[index]
-        else:
-            raise ValueError('Label type must be one of (\'sex\', \'speaker\')')
-        return instance, label
+            return self.datasetid_to_speaker_id[index]
+        raise ValueError('Label type must be one of (\'sex\', \'speaker\')')
 
     def __len__(self):
         return len(self.df)

@@ -168,3 +168,41 @@ class ShardedSpeechDataset(LibriSpeechDataset):
     def yield_verification_batches_device(self, batchsize):
         while True:
             yield self.build_verification_batch_device(batchsize)
+
+    def build_n_shot_task_offsets(self, k, n=1):
+        """The task of ``build_n_shot_task`` (librispeech.py:204-240 of the reference) as start offsets into the device
+        buffer: ((query_offset, query_label), (support_offsets (k*n,), support_labels (k*n,))), support laid out
+        [class_1]*n + ... + [class_k]*n with class_1 = the query's speaker.  Same draws in the same order as the host method
+        (query file, its fragment, n other files of that speaker, k-1 other speakers, n files each, their fragments)."""
+        if k >= self.unique_speakers:
+            raise ValueError('k must be smaller than the number of unique speakers in this dataset!')
+        if k <= 1:
+            raise ValueError('k must be greater than or equal to one!')
+        query = self.df.sample(1, weights='length')
+        query_index = query.index.values[0]
+        q_off = self.window_starts([query_index])[0]
+        same_speaker = self.df['speaker_id'] == query['speaker_id'].values[0]
+        correct = self.df[same_speaker & (self.df.index != query_index)].sample(n, weights='length')
+        others = np.random.choice(self.df[~same_speaker]['speaker_id'].unique(), k - 1, replace=False)
+        parts = [correct]
+        for speaker in others:
+            parts.append(self.df[self.df['speaker_id'] == speaker].sample(n, weights='length'))
+        support_index = pd.concat(parts).index.values
+        s_off = self.window_starts(support_index)
+        return (q_off, self._label(query_index)), (s_off, np.array([self._label(i) for i in support_index]))
+
+    def build_n_shot_tasks_device(self, num_tasks, k, n=1):
+        """``num_tasks`` tasks at once: (queries, supports, query_labels, support_labels) with queries a ``DeviceWindows`` of
+        num_tasks windows and supports one of num_tasks*k*n windows (task-major, then the layout above)."""
+        assert self.device_audio is not None, 'call to_device() first'
+        q, s, ql, sl = [], [], [], []
+        for _ in range(num_tasks):
+            (qo, qlab), (so, slab) = self.build_n_shot_task_offsets(k, n)
+            q.append(qo)
+            s.append(so)
+            ql.append(qlab)
+            sl.append(slab)
+        T = self.fragment_length
+        return (DeviceWindows(self.device_audio, np.array(q, dtype=np.int64), T),
+                DeviceWindows(self.device_audio, np.concatenate(s) if s else np.zeros(0, np.int64), T),
+                np.array(ql), np.array(sl))

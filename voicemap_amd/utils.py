@@ -137,13 +137,16 @@ def n_shot_task_evaluation(model, dataset, preprocessor, num_tasks, n, k, networ
         raise ValueError("Distance must be in (euclidean, cosine, dot_product)")
     inst = preprocessor.instance_preprocessor if hasattr(preprocessor, "instance_preprocessor") else None
 
+    if num_tasks == 0:
+        return 0
+    if getattr(dataset, "device_audio", None) is not None and hasattr(dataset, "build_n_shot_tasks_device"):
+        # device-resident corpus (shards.py): tasks are start offsets, windows are cropped by the preprocessing kernel
+        return _n_shot_device(model, dataset, preprocessor, num_tasks, n, k, network_type, distance)
     queries, supports = [], []
     for _ in range(num_tasks):
         query_sample, support_set_samples = dataset.build_n_shot_task(k, n)
         queries.append(np.asarray(query_sample[0]))
         supports.append(np.asarray(support_set_samples[0]))
-    if num_tasks == 0:
-        return 0
 
     n_correct = 0
     chunk = max(1, 256 // max(k * n, 1))  # tasks per launch
@@ -176,6 +179,50 @@ def n_shot_task_evaluation(model, dataset, preprocessor, num_tasks, n, k, networ
         ql, sl = inst(qraw), inst(sraw)
         qe = _embed_towers(eng, ql, tower=1)
         se = _embed_towers(eng, sl, tower=k * n)
+        pred = torch.empty(nt, k, dtype=torch.float32, device=eng.device)
+        am = torch.empty(nt, dtype=torch.int32, device=eng.device)
+        eng._call("vm_nshot_distances", qe.data_ptr(), se.data_ptr(), nt, k, n, eng.E, _DIST[distance], pred.data_ptr(),
+                  am.data_ptr(), eng.stream())
+        n_correct += int((am == 0).sum().item())
+    return n_correct
+
+
+def _n_shot_device(model, dataset, preprocessor, num_tasks, n, k, network_type, distance):
+    """n_shot_task_evaluation over ``ShardedSpeechDataset.build_n_shot_tasks_device``: identical task semantics and
+    whitening batches (query alone / repeated k times, support set of a task as one batch), windows addressed by offset."""
+    import torch
+    q, s, _, _ = dataset.build_n_shot_tasks_device(num_tasks, k, n)
+    lazy = preprocessor.instance_preprocessor(q) if hasattr(preprocessor, "instance_preprocessor") else None
+    if not isinstance(lazy, LazyWindows):
+        raise ValueError("the device n-shot path needs a BatchPreProcessor over preprocess_instances")
+    ds, wh, T = lazy.downsampling, lazy.whitening, q.length
+    n_correct = 0
+    chunk = max(1, 256 // max(k * n, 1))  # tasks per launch
+    siamese_1shot = n == 1 and network_type == "siamese"
+    if siamese_1shot:
+        eng = model._ensure_engine()
+    elif network_type == "siamese":
+        encoder = model.layers[2]
+        encoder.engine = model._ensure_engine()
+        eng = encoder._ensure_engine()
+    else:
+        encoder = model.clone()
+        encoder.set_weights(model.get_weights())
+        encoder.pop()
+        eng = encoder._ensure_engine()
+    for t0 in range(0, num_tasks, chunk):
+        nt = min(chunk, num_tasks - t0)
+        qo = q.offsets[t0:t0 + nt]
+        so = s.offsets[t0 * k * n:(t0 + nt) * k * n]
+        if siamese_1shot:
+            off = torch.cat([qo.repeat_interleave(k), so])  # input_1 = the query k times, input_2 = the k support windows
+            eng.embed_from_offsets(q.audio, off, T, ds, wh, windows_per_tower=k)
+            pl = eng.plan(2 * nt * k, eng.last_infer_l0, False)
+            pred = eng.siamese_head(pl, None).reshape(nt, k)
+            n_correct += int((pred.argmin(dim=1) == 0).sum().item())
+            continue
+        qe = eng.embed_from_offsets(q.audio, qo, T, ds, wh, windows_per_tower=1).clone()
+        se = eng.embed_from_offsets(q.audio, so, T, ds, wh, windows_per_tower=k * n).clone()
         pred = torch.empty(nt, k, dtype=torch.float32, device=eng.device)
         am = torch.empty(nt, dtype=torch.int32, device=eng.device)
         eng._call("vm_nshot_distances", qe.data_ptr(), se.data_ptr(), nt, k, n, eng.E, _DIST[distance], pred.data_ptr(),
