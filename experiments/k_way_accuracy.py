@@ -1,6 +1,6 @@
 """k-way n-shot accuracy sweep of trained models -- counterpart of the reference's experiments/k_way_accuracy.py
 (k = 2..20, n in {1, 5}, 1000 tasks each, distance 'dot_product'); results are appended to a CSV as they arrive.
-    python -m experiments.k_way_accuracy --siamese models/x.npz [--classifier models/y.npz] [--synthetic]"""
+    python -m experiments.k_way_accuracy --siamese models/x.hdf5 [--classifier models/y.hdf5] [--synthetic]"""
 import argparse
 
 import pandas as pd

@@ -21,7 +21,7 @@ def main(argv=None):
     key = "val_{}-shot_acc".format(a.n_shot)
     cbs = [NShotEvaluationCallback(a.num_evaluation_tasks, a.n_shot, a.k_way, valid, preprocessor=whiten_downsample),
            CSVLogger(PATH + "/logs/convnet_contrastive_loss.csv"),
-           ModelCheckpoint(PATH + "/models/convnet_contrastive_loss.npz", monitor=key, mode="max", save_best_only=True, verbose=True)]
+           ModelCheckpoint(PATH + "/models/convnet_contrastive_loss.hdf5", monitor=key, mode="max", save_best_only=True, verbose=True)]
     return siamese.fit_generator(generator=stream(train), steps_per_epoch=a.steps_per_epoch, validation_data=stream(valid),
                                  validation_steps=a.validation_steps, epochs=a.epochs, workers=a.workers,
                                  use_multiprocessing=True, callbacks=cbs)

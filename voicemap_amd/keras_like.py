@@ -273,7 +273,8 @@ class CSVLogger(Callback):
 
 class ModelCheckpoint(Callback):
     """keras.callbacks.ModelCheckpoint(filepath, monitor, mode, save_best_only, verbose).  Saves the full model
-    (weights + Adam slots + BN moving statistics) with ``model.save`` -- an ``.npz`` container; see models.save_model."""
+    (weights + Adam slots + BN moving statistics) with ``model.save``: a Keras-2.2.2 HDF5 file for ``*.hdf5`` / ``*.h5`` names
+    (voicemap_amd/keras_hdf5.py), this package's ``.npz`` container otherwise."""
 
     def __init__(self, filepath, monitor="val_loss", verbose=0, save_best_only=False, save_weights_only=False, mode="auto",
                  period=1):

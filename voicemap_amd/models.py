@@ -36,6 +36,7 @@ class _TrainableModel:
         self.metrics: List[str] = []
         self.stop_training = False
         self._pending_weights = None
+        self._pending_adam = None
         self.history = None
 
     # ---- engine lifecycle -------------------------------------------------------------------------------
@@ -49,6 +50,9 @@ class _TrainableModel:
             if self._pending_weights is not None:
                 self.engine.set_params(self._pending_weights)
                 self._pending_weights = None
+            if self._pending_adam is not None:
+                self._set_adam_state(self._pending_adam)
+                self._pending_adam = None
             if self.optimizer is not None:
                 self.optimizer.apply_to(self.engine)
         return self.engine
@@ -98,14 +102,59 @@ class _TrainableModel:
     def count_params(self) -> int:
         return self._ensure_engine().n_params
 
-    # ---- persistence: one .npz with weights, Adam slots, moving statistics and the model config ------------
-    def save(self, filepath: str):
+    # ---- persistence ------------------------------------------------------------------------------------
+    def _set_adam_state(self, st: dict):
+        import torch
+        eng = self.engine
+        eng.iterations = int(st.get("iterations", 0))
+        for slot, buf in (("m", eng.M), ("v", eng.V)):
+            for name, val in (st.get(slot) or {}).items():
+                v = eng.view(name, buf)
+                v.copy_(torch.as_tensor(np.asarray(val, dtype=np.float32)).to(eng.device).reshape(v.shape))
+
+    def _keras_state(self):
+        """(kind, geometry, params, optimizer, training) in keras_hdf5's vocabulary."""
+        from . import keras_hdf5 as KH
         import torch
         eng = self._ensure_engine()
         torch.cuda.synchronize()
+        cfg = self.get_config()
+        enc = cfg["encoder"] if cfg["class_name"] == "SiameseNet" else cfg
+        kind = "siamese" if cfg["class_name"] == "SiameseNet" else ("classifier" if enc["classifier_units"] else "encoder")
+        shape = cfg.get("input_shape") if kind == "siamese" else enc.get("input_shape")
+        geo = {"filters": enc["filters"], "embedding_dimension": enc["embedding_dimension"], "dropout": enc["dropout"],
+               "first_pool": enc["first_pool"], "input_shape": tuple(shape) if shape else (None, 1),  # Conv1D takes any length
+               "dtype": enc["dtype"],
+               "classifier_units": enc["classifier_units"], "distance_metric": cfg.get("distance_metric")}
+        names = KH.trainable_names(kind != "encoder")
+        opt = {"config": {"lr": eng.lr, "beta_1": eng.beta_1, "beta_2": eng.beta_2, "epsilon": eng.adam_eps, "decay": eng.decay,
+                          "amsgrad": False}, "iterations": int(eng.iterations),
+               "m": {n: eng.view(n, eng.M).detach().cpu().numpy() for n in names},
+               "v": {n: eng.view(n, eng.V).detach().cpu().numpy() for n in names}}
+        if eng.clipnorm:
+            opt["config"]["clipnorm"] = float(eng.clipnorm)
+        loss = self.loss if isinstance(self.loss, str) or self.loss is None else getattr(self.loss, "__name__", str(self.loss))
+        return kind, geo, eng.get_params(), opt, {"loss": loss, "metrics": list(self.metrics)}
+
+    def save(self, filepath: str):
+        """``model.save``: a Keras-2.2.2 HDF5 file for ``*.hdf5`` / ``*.h5`` names (what the reference's ModelCheckpoint
+        writes, keras_hdf5.py), otherwise one .npz with weights, Adam slots, moving statistics and the model config."""
+        import torch
+        if str(filepath).lower().endswith((".hdf5", ".h5")):
+            from . import keras_hdf5 as KH
+            kind, geo, params, opt, training = self._keras_state()
+            KH.write_checkpoint(filepath, kind, geo, params, opt, training)
+            return
+        eng = self._ensure_engine()
+        torch.cuda.synchronize()
+        cfg = dict(self.get_config())
+        loss = self.loss if isinstance(self.loss, str) or self.loss is None else getattr(self.loss, "__name__", str(self.loss))
+        cfg["training"] = {"loss": loss, "metrics": list(self.metrics),
+                           "optimizer": {"lr": eng.lr, "beta_1": eng.beta_1, "beta_2": eng.beta_2, "epsilon": eng.adam_eps,
+                                         "decay": eng.decay, "clipnorm": float(eng.clipnorm) if eng.clipnorm else None}}
         blob = {"P": eng.P.cpu().numpy(), "M": eng.M.cpu().numpy(), "V": eng.V.cpu().numpy(), "NT": eng.NT.cpu().numpy(),
                 "iterations": np.int64(eng.iterations),
-                "config": np.frombuffer(json.dumps(self.get_config()).encode(), dtype=np.uint8)}
+                "config": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
         with open(filepath, "wb") as f:
             np.savez(f, **blob)
 
@@ -116,6 +165,24 @@ class _TrainableModel:
             getattr(eng, name).copy_(torch.from_numpy(blob[name]).to(eng.device))
         eng.iterations = int(blob["iterations"])
         eng.refresh_weights()
+
+    def save_weights(self, filepath: str):
+        """``model.save_weights``: HDF5 in Keras' layout (weights only; the model_weights group of ``save``)."""
+        from . import keras_hdf5 as KH
+        kind, geo, params, _, _ = self._keras_state()
+        KH.write_checkpoint(filepath, kind, geo, params, None, None)
+
+    def load_weights(self, filepath: str, by_name: bool = False):
+        """``model.load_weights`` from a Keras HDF5 file (full model or weights only)."""
+        from . import keras_hdf5 as KH
+        w = KH.read_weights(filepath)
+        want = set(self.weight_names()) if self.engine is not None else None
+        if want is not None:
+            w = OrderedDict((k, v) for k, v in w.items() if k in want)
+        if self.engine is not None:
+            self.engine.set_params(w)
+        else:
+            self._pending_weights = w
 
     def get_config(self) -> dict:
         raise NotImplementedError
@@ -481,8 +548,12 @@ def clone_model(model):
     return model.clone()
 
 
-def load_model(filepath: str, custom_objects=None):
-    """Load a model written by ``model.save`` (experiments/k_way_accuracy.py:45-46 uses keras.models.load_model)."""
+def load_model(filepath: str, custom_objects=None, dtype=None):
+    """Load a model written by ``model.save`` (experiments/k_way_accuracy.py:45-46 uses keras.models.load_model): a Keras
+    2.2.2 HDF5 checkpoint -- the reference's own files included -- or this package's .npz container."""
+    from . import keras_hdf5 as KH
+    if KH.is_hdf5(filepath):
+        return _load_keras_hdf5(filepath, dtype)
     blob = np.load(filepath, allow_pickle=False)
     cfg = json.loads(bytes(blob["config"]).decode())
 
@@ -497,9 +568,41 @@ def load_model(filepath: str, custom_objects=None):
         m = build_siamese_net(enc_from(cfg["encoder"]), cfg["input_shape"], cfg["distance_metric"])
     else:
         m = enc_from(cfg)
-    m.compile(optimizer=Adam())
+    tr = cfg.get("training") or {}
+    m.compile(loss=tr.get("loss"), optimizer=Adam(**tr["optimizer"]) if tr.get("optimizer") else Adam(), metrics=tr.get("metrics"))
     m._load_state(blob)
     return m
+
+
+def _load_keras_hdf5(filepath: str, dtype=None):
+    """``dtype``: activation storage mode of the loaded model; default = what the file records (files written here) or
+    "bf16" (files written by Keras carry no such thing)."""
+    from . import keras_hdf5 as KH
+    ck = KH.read_checkpoint(filepath)
+    g = ck["config"]
+    dtype = dtype or g.get("dtype") or "bf16"
+    enc = get_baseline_convolutional_encoder(g["filters"], g["embedding_dimension"], input_shape=g["input_shape"],
+                                             dropout=g["dropout"], dtype=dtype, first_pool=g["first_pool"])
+    if ck["kind"] == "classifier":
+        enc.add(Dense(g["classifier_units"], activation="softmax"))
+    m = build_siamese_net(enc, g["input_shape"], g["distance_metric"]) if ck["kind"] == "siamese" else enc
+    m._pending_weights = ck["params"]
+    opt, tr = ck["optimizer"], ck["training"]
+    if opt is not None:
+        c = opt["config"]
+        adam = Adam(lr=c.get("lr", 0.001), beta_1=c.get("beta_1", 0.9), beta_2=c.get("beta_2", 0.999), epsilon=c.get("epsilon"),
+                    decay=c.get("decay", 0.0), clipnorm=c.get("clipnorm"))
+        loss = tr["loss"] if tr else None
+        m.compile(loss=contrastive_loss_by_name(loss), optimizer=adam, metrics=(tr or {}).get("metrics"))
+        if opt.get("m") is not None:
+            m._pending_adam = {"iterations": opt["iterations"], "m": opt["m"], "v": opt["v"]}
+    m._ensure_engine()  # like the .npz path: a loaded model is live (weights, Adam slots and counters are on the device)
+    return m
+
+
+def contrastive_loss_by_name(loss):
+    """training_config stores a custom loss by its function name; the reference's only one is utils.contrastive_loss."""
+    return "contrastive_loss" if loss == "contrastive_loss" else loss
 
 
 def load_keras_checkpoint_npz(weights_npz: str, dtype="bf16"):
