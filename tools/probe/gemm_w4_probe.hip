@@ -35,6 +35,7 @@ struct Args {
     bf16* c;
     int M, N, K;
     int tilesN;
+    unsigned long long* stall;  // MODE & 64: per wave {prologue wait, sum of vmcnt waits, sum of barrier waits, whole kernel}
 };
 
 template <int MODE>
@@ -98,6 +99,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         const char* base = lds + (t < 4 ? sa * OPB + a_rows : B0 + sb * OPB + b_rows) + foff[s] + (t & 3) * 32 * ROWB;
         if (t < 4) f.a[t] = *reinterpret_cast<const bf16x8*>(base); else f.b[t - 4] = *reinterpret_cast<const bf16x8*>(base);
     };
+    unsigned long long st_wait = 0, st_bar = 0;
     // DMA of one K tile: B pieces of K tile kt+1 first, then A pieces of K tile kt+2, so that the counted wait vmcnt(8) in
     // the middle of k-step 3 covers B(kt+1) and the older A(kt+1) while the 8 newest pieces, A(kt+2), stay in flight.
     auto kstep = [&](const Frag& cur, Frag& nxt, int rsa, int rsb, int rs, int rslot0, int dma_op, int dstage, int dkt, bool sync_mid) {
@@ -106,8 +108,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
             const int i = t >> 2, j = t & 3;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
             if (sync_mid && t == 7) {
+                unsigned long long t0 = 0, t1 = 0;
+                if (MODE & 64) t0 = __builtin_amdgcn_s_memtime();
                 if (MODE & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (MODE & 64) t1 = __builtin_amdgcn_s_memtime();
                 __builtin_amdgcn_s_barrier();
+                if (MODE & 64) {
+                    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                    st_wait += t1 - t0;
+                    st_bar += t2 - t1;
+                }
             }
             if (t >= rslot0 && t < rslot0 + 8) one_read(nxt, rsa, rsb, rs, t - rslot0);
             if (dma_op >= 0 && !(MODE & 1) && t >= 8) stage_piece(dstage, dkt, t - 8, dma_op);
@@ -115,6 +125,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         }
     };
 
+    const unsigned long long t_begin = (MODE & 64) ? __builtin_amdgcn_s_memtime() : 0;
     // ---- prologue: A(0), B(0), then A(1); wait for the first two ----
 #pragma unroll
     for (int q = 0; q < 8; ++q) stage_piece(0, 0, q, 0);
@@ -128,6 +139,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    const unsigned long long t_pro = (MODE & 64) ? __builtin_amdgcn_s_memtime() : 0;
     Frag f0, f1;
     if (MODE & 2) {
 #pragma unroll
@@ -154,6 +166,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         sa = sa1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy re-stages past the end must not outlive the workgroup
+    const unsigned long long t_loop = (MODE & 64) ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- epilogue: D = B.A^T puts 4 consecutive output columns in 4 consecutive registers: 8-byte stores ----
     if (MODE & 4) {
@@ -166,6 +179,40 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         return;
     }
     bf16* cbase = p.c + (int64_t)(tm * TM + wm * 128) * p.N + tn * TN + wn * 128;
+    if (MODE & 32) {
+        // through LDS: the wave's 128 x 128 bf16 tile (32 KB, rows of 256 B, 16-byte chunk c of row R kept at c ^ (R & 15)) is
+        // written from the accumulator layout (8 bytes per lane) and leaves as whole rows: 16 bytes per lane, 4 rows per store
+        __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages (all DMA was drained above)
+        char* scr = lds + w * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16 o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][4 * g + e];
+                    const int row = i * 32 + r, cb = (j * 32 + 8 * g + 4 * kh) * 2;
+                    *reinterpret_cast<u32x2*>(scr + row * 256 + (((cb >> 4) ^ (row & 15)) << 4) + (cb & 15)) = *reinterpret_cast<const u32x2*>(o);
+                }
+            }
+        }
+        // wave-private region: no barrier needed, only this wave's own LDS writes must have landed (lgkmcnt, compiler-tracked)
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#pragma unroll 8
+        for (int it = 0; it < 32; ++it) {
+            const int row = it * 4 + (lane >> 4), c = lane & 15;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4));
+            *reinterpret_cast<u32x4*>(cbase + (int64_t)row * p.N + c * 8) = v;
+        }
+        if ((MODE & 64) && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* o = p.stall + ((int64_t)blockIdx.x * 4 + w) * 5;
+            o[0] = t_pro - t_begin; o[1] = st_wait; o[2] = st_bar; o[3] = t_loop - t_pro; o[4] = __builtin_amdgcn_s_memtime() - t_loop;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -216,10 +263,12 @@ int main() {
         hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
         hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
         hipMemset(dc, 0xff, (size_t)M * N * 2);
-        Args a{da, db, dc, M, N, K, N / TN};
+        unsigned long long* dst;
+        hipMalloc(&dst, (size_t)((M / TM + 8) * (N / TN)) * 4 * 5 * 8);
+        Args a{da, db, dc, M, N, K, N / TN, dst};
         const int grid = (M / TM) * (N / TN);
         const int grid16 = ((M / TM + 7) / 8) * 8 * (N / TN);
-        hipLaunchKernelGGL(gemm_w4<0>, dim3(grid), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(gemm_w4<32>, dim3(grid), dim3(256), 0, 0, a);
         if (hipDeviceSynchronize() != hipSuccess) {
             printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
             return 1;
@@ -250,6 +299,9 @@ int main() {
                 case 3: hipLaunchKernelGGL(gemm_w4<3>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 5: hipLaunchKernelGGL(gemm_w4<5>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 4: hipLaunchKernelGGL(gemm_w4<4>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 96: hipLaunchKernelGGL(gemm_w4<96>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 32: hipLaunchKernelGGL(gemm_w4<32>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 48: hipLaunchKernelGGL(gemm_w4<48>, dim3(grid16), dim3(256), 0, 0, a); break;
                 case 16: hipLaunchKernelGGL(gemm_w4<16>, dim3(grid16), dim3(256), 0, 0, a); break;
                 case 20: hipLaunchKernelGGL(gemm_w4<20>, dim3(grid16), dim3(256), 0, 0, a); break;
                 case 8: hipLaunchKernelGGL(gemm_w4<8>, dim3(grid), dim3(256), 0, 0, a); break;
@@ -257,7 +309,16 @@ int main() {
                 default: hipLaunchKernelGGL(gemm_w4<7>, dim3(grid), dim3(256), 0, 0, a); break;
             }
         };
-        for (int mode : {0, 4, 16, 20}) {
+        {
+            hipLaunchKernelGGL(gemm_w4<96>, dim3(grid), dim3(256), 0, 0, a);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> hs((size_t)grid * 20);
+            hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost);
+            double s5[5] = {0, 0, 0, 0, 0};
+            for (int b = 0; b < grid; ++b) for (int k = 0; k < 5; ++k) s5[k] += (double)hs[(size_t)b * 20 + k];  // wave 0 of every workgroup
+            printf("   cycles per tile (wave 0, mean over %d tiles): prologue wait %.0f | K loop %.0f of which DMA waits %.0f, barriers %.0f | epilogue %.0f\n", grid, s5[0] / grid, s5[3] / grid, s5[1] / grid, s5[2] / grid, s5[4] / grid);
+        }
+        for (int mode : {32, 4}) {
             for (int i = 0; i < 3; ++i) launch(mode);
             hipEventRecord(e0);
             const int reps = 10;
@@ -267,8 +328,8 @@ int main() {
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
             const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-            printf("   mode %2d (%s%s%s%s%s)  %8.1f us  %7.1f TFLOP/s\n", mode, mode & 1 ? "no-DMA " : "", mode & 2 ? "no-frag-reads " : "",
-                   mode & 4 ? "no-stores " : "", mode & 8 ? "A-from-tile-0 " : "", mode & 16 ? "xcd-order" : (mode ? "" : "full"), us, tf);
+            printf("   mode %2d (%s%s%s%s%s%s)  %8.1f us  %7.1f TFLOP/s\n", mode, mode & 1 ? "no-DMA " : "", mode & 2 ? "no-frag-reads " : "",
+                   mode & 4 ? "no-stores " : "", mode & 8 ? "A-from-tile-0 " : "", mode & 16 ? "xcd-order " : "", mode & 32 ? "lds-epilogue" : (mode ? "" : "full"), us, tf);
         }
         hipFree(da);
         hipFree(db);
