@@ -102,7 +102,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     unsigned long long st_wait = 0, st_bar = 0;
     // DMA of one K tile: B pieces of K tile kt+1 first, then A pieces of K tile kt+2, so that the counted wait vmcnt(8) in
     // the middle of k-step 3 covers B(kt+1) and the older A(kt+1) while the 8 newest pieces, A(kt+2), stay in flight.
-    auto kstep = [&](const Frag& cur, Frag& nxt, int rsa, int rsb, int rs, int rslot0, int dma_op, int dstage, int dkt, bool sync_mid) {
+    auto kstep = [&](const Frag& cur, Frag& nxt, int rsa, int rsb, int rs, int rslot0, int dma_op, int dstage, int dkt, bool sync_mid, int dpiece0 = 0) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int i = t >> 2, j = t & 3;
@@ -119,8 +119,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                     st_bar += t2 - t1;
                 }
             }
-            if (t >= rslot0 && t < rslot0 + 8) one_read(nxt, rsa, rsb, rs, t - rslot0);
-            if (dma_op >= 0 && !(MODE & 1) && t >= 8) stage_piece(dstage, dkt, t - 8, dma_op);
+            if (MODE & 128) {
+                // spread form: reads in the even slots (or 8-15 after the barrier), DMA pieces in odd slots -- never two DMA
+                // instructions back to back, so a backed-up request queue delays one MFMA, not a run of them
+                if (rslot0 == 0) {
+                    if ((t & 1) == 0) one_read(nxt, rsa, rsb, rs, t >> 1);
+                } else if (t >= 8) {
+                    one_read(nxt, rsa, rsb, rs, t - 8);
+                }
+                if (dma_op == 1 && !(MODE & 1) && (t & 1)) stage_piece(dstage, dkt, t >> 1, 1);            // 8 B pieces: k-step 0
+                if (dma_op == 0 && !(MODE & 1) && (t & 3) == 1) stage_piece(dstage, dkt, dpiece0 + (t >> 2), 0);  // 4 A pieces per k-step
+            } else {
+                if (t >= rslot0 && t < rslot0 + 8) one_read(nxt, rsa, rsb, rs, t - rslot0);
+                if (dma_op >= 0 && !(MODE & 1) && t >= 8) stage_piece(dstage, dkt, t - 8, dma_op);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -160,8 +172,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         const int sa1 = sa == NA - 1 ? 0 : sa + 1, sa2 = sa1 == NA - 1 ? 0 : sa1 + 1;
         const int kt1 = kt + 1 < nk ? kt + 1 : 0, kt2 = kt + 2 < nk ? kt + 2 : 0;  // branch-free: past the end re-stage tile 0
         kstep(f0, f1, sa, sb, 1, 0, 1, sb ^ 1, kt1, false);   // B pieces of K tile kt+1 (B stage last read in K tile kt-1)
-        kstep(f1, f0, sa, sb, 2, 0, 0, sa2, kt2, false);      // A pieces of K tile kt+2 (A stage last read in K tile kt-1)
-        kstep(f0, f1, sa, sb, 3, 0, -1, 0, 0, false);
+        kstep(f1, f0, sa, sb, 2, 0, 0, sa2, kt2, false, 0);   // A pieces of K tile kt+2 (A stage last read in K tile kt-1)
+        kstep(f0, f1, sa, sb, 3, 0, (MODE & 128) ? 0 : -1, sa2, kt2, false, 4);  // spread form: its second half
         kstep(f1, f0, sa1, sb ^ 1, 0, 8, -1, 0, 0, true);     // counted wait + barrier after MFMA 7, then the next tile's first reads
         sa = sa1;
     }
@@ -268,7 +280,7 @@ int main() {
         Args a{da, db, dc, M, N, K, N / TN, dst};
         const int grid = (M / TM) * (N / TN);
         const int grid16 = ((M / TM + 7) / 8) * 8 * (N / TN);
-        hipLaunchKernelGGL(gemm_w4<32>, dim3(grid), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(gemm_w4<160>, dim3(grid), dim3(256), 0, 0, a);
         if (hipDeviceSynchronize() != hipSuccess) {
             printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
             return 1;
@@ -299,6 +311,9 @@ int main() {
                 case 3: hipLaunchKernelGGL(gemm_w4<3>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 5: hipLaunchKernelGGL(gemm_w4<5>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 4: hipLaunchKernelGGL(gemm_w4<4>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 160: hipLaunchKernelGGL(gemm_w4<160>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 132: hipLaunchKernelGGL(gemm_w4<132>, dim3(grid), dim3(256), 0, 0, a); break;
+                case 224: hipLaunchKernelGGL(gemm_w4<224>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 96: hipLaunchKernelGGL(gemm_w4<96>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 32: hipLaunchKernelGGL(gemm_w4<32>, dim3(grid), dim3(256), 0, 0, a); break;
                 case 48: hipLaunchKernelGGL(gemm_w4<48>, dim3(grid16), dim3(256), 0, 0, a); break;
@@ -310,7 +325,7 @@ int main() {
             }
         };
         {
-            hipLaunchKernelGGL(gemm_w4<96>, dim3(grid), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL(gemm_w4<224>, dim3(grid), dim3(256), 0, 0, a);
             hipDeviceSynchronize();
             std::vector<unsigned long long> hs((size_t)grid * 20);
             hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost);
@@ -318,7 +333,7 @@ int main() {
             for (int b = 0; b < grid; ++b) for (int k = 0; k < 5; ++k) s5[k] += (double)hs[(size_t)b * 20 + k];  // wave 0 of every workgroup
             printf("   cycles per tile (wave 0, mean over %d tiles): prologue wait %.0f | K loop %.0f of which DMA waits %.0f, barriers %.0f | epilogue %.0f\n", grid, s5[0] / grid, s5[3] / grid, s5[1] / grid, s5[2] / grid, s5[4] / grid);
         }
-        for (int mode : {32, 4}) {
+        for (int mode : {32, 160, 4, 132, 32, 160}) {
             for (int i = 0; i < 3; ++i) launch(mode);
             hipEventRecord(e0);
             const int reps = 10;
@@ -328,8 +343,8 @@ int main() {
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
             const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-            printf("   mode %2d (%s%s%s%s%s%s)  %8.1f us  %7.1f TFLOP/s\n", mode, mode & 1 ? "no-DMA " : "", mode & 2 ? "no-frag-reads " : "",
-                   mode & 4 ? "no-stores " : "", mode & 8 ? "A-from-tile-0 " : "", mode & 16 ? "xcd-order " : "", mode & 32 ? "lds-epilogue" : (mode ? "" : "full"), us, tf);
+            printf("   mode %3d (%s%s%s%s%s%s%s)  %8.1f us  %7.1f TFLOP/s\n", mode, mode & 1 ? "no-DMA " : "", mode & 2 ? "no-frag-reads " : "",
+                   mode & 4 ? "no-stores " : "", mode & 8 ? "A-from-tile-0 " : "", mode & 16 ? "xcd-order " : "", mode & 32 ? "lds-epilogue " : "", mode & 128 ? "spread-dma" : (mode ? "" : "full"), us, tf);
         }
         hipFree(da);
         hipFree(db);
