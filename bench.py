@@ -244,11 +244,25 @@ def main():
             eng.backward(pl)
             eng.optimizer_step()
         t_h2d = timed(step_h2d)
+        # device-resident corpus (voicemap_amd/shards.py): the 256 windows are start offsets into an int16 buffer in HBM and
+        # the crop happens inside the preprocessing kernel -- the data path of experiments/train_siamese.py --device-data
+        corpus = (torch.randn(64 * 1024 * 1024, device=dev) * 0.05 * 32767.0).clamp(-32767, 32767).to(torch.int16)
+        offs = torch.randint(0, corpus.numel() - 48000, (2 * pairs,), device=dev, dtype=torch.int64)
+
+        def step_offsets():
+            eng.preprocess(pl, corpus, 4, True, pairs, offsets=offs, raw_len=48000)
+            eng.forward(pl, pairs, None)
+            eng.siamese_head(pl, y, a.loss)
+            eng.backward(pl)
+            eng.optimizer_step()
+        t_off = timed(step_offsets)
+        del corpus
         eng.P.copy_(snap[0]); eng.M.copy_(snap[1]); eng.V.copy_(snap[2]); eng.iterations = snap[3]
         eng.refresh_weights()
         out["extras"] = {"%s_loss_ms_per_step" % other: t_other * 1e3,
                          "embed_only_audio_s_per_s": 2 * pairs * 3.0 / t_embed, "embed_only_ms_per_256_windows": t_embed * 1e3,
-                         "pcie_inclusive_ms_per_step_int16_host_windows": t_h2d * 1e3}
+                         "pcie_inclusive_ms_per_step_int16_host_windows": t_h2d * 1e3,
+                         "device_resident_corpus_ms_per_step_int16_offsets": t_off * 1e3}
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         from oracle import voicemap_oracle as O
