@@ -126,6 +126,30 @@ class LibriSpeechDataset(Sequence):
         self.datasetid_to_filepath = d['filepath']
         self.datasetid_to_speaker_id = d['speaker_id']
         self.datasetid_to_sex = d['sex']
+        self._build_sampling_index()
+
+    def _build_sampling_index(self):
+        """Arrays behind the numpy restatement of the pair / task sampling below.  The reference does these draws with
+        ``DataFrame.sample`` / ``pd.merge`` per batch (librispeech.py:145-240), which costs 6-9 ms for one 128-pair batch on a
+        4000-file index -- twice the GPU's step time.  pandas' ``sample`` is ``np.random.choice(len, size, replace=False,
+        p=weights/weights.sum())`` on the global RandomState, an inner ``merge`` keeps the left rows' order and, inside a key,
+        the right rows' order: so the same ``np.random`` calls in the same order on plain arrays give the SAME pairs and tasks
+        (tests/test_host_api.py compares the two under one seed)."""
+        spk = self.df['speaker_id'].values
+        self._len = self.df['length'].values.astype(np.float64)
+        self._uniq, self._code = np.unique(spk, return_inverse=True)          # speaker codes 0..S-1 (sorted ids)
+        order = np.argsort(self._code, kind='stable')                         # files grouped by speaker, df order inside
+        self._cnt = np.bincount(self._code, minlength=len(self._uniq))
+        self._start = np.concatenate([[0], np.cumsum(self._cnt)[:-1]])
+        self._files = order
+        first = np.full(len(self._uniq), len(spk), dtype=np.int64)
+        np.minimum.at(first, self._code, np.arange(len(spk)))
+        self._appear = np.argsort(first, kind='stable')                       # speaker codes in order of first appearance
+
+    @staticmethod
+    def _weighted(n, weights):
+        """``DataFrame.sample(n, weights=...)`` on row positions."""
+        return np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum())
 
     # ---- Sequence ------------------------------------------------------------------------------------------
     def _load(self, index):
@@ -164,16 +188,33 @@ class LibriSpeechDataset(Sequence):
     def get_alike_pairs(self, num_pairs):
         """List of (id, id) pairs from the same speaker: 2*num_pairs anchors drawn with probability ~ file length, joined
         with every file of the same speaker (a file may pair with itself), num_pairs rows of the join kept."""
-        anchors = self.df.sample(num_pairs * 2, weights='length')
-        joined = pd.merge(anchors, self.df, on='speaker_id').sample(num_pairs)
-        return list(zip(joined['id_x'].values, joined['id_y'].values))
+        if not getattr(self, 'fast_sampling', True):
+            anchors = self.df.sample(num_pairs * 2, weights='length')
+            joined = pd.merge(anchors, self.df, on='speaker_id').sample(num_pairs)
+            return list(zip(joined['id_x'].values, joined['id_y'].values))
+        anchors = self._weighted(num_pairs * 2, self._len)
+        cnt = self._cnt[self._code[anchors]]                  # rows each anchor contributes to the join
+        ends = np.cumsum(cnt)
+        rows = np.random.choice(int(ends[-1]), size=num_pairs, replace=False)   # .sample(num_pairs) of the joined frame
+        a = np.searchsorted(ends, rows, side='right')         # which anchor a joined row belongs to
+        k = rows - (ends[a] - cnt[a])                         # ... and which file of that anchor's speaker (df order)
+        left = anchors[a]
+        right = self._files[self._start[self._code[left]] + k]
+        return list(zip(left, right))
 
     def get_differing_pairs(self, num_pairs):
         """List of (id, id) pairs from different speakers: num_pairs files ~ length, then num_pairs files ~ length from
         the speakers NOT in the first draw."""
-        first = self.df.sample(num_pairs, weights='length')
-        rest = self.df[~self.df['speaker_id'].isin(first['speaker_id'])].sample(num_pairs, weights='length')
-        return list(zip(first['id'].values, rest['id'].values))
+        if not getattr(self, 'fast_sampling', True):
+            first = self.df.sample(num_pairs, weights='length')
+            rest = self.df[~self.df['speaker_id'].isin(first['speaker_id'])].sample(num_pairs, weights='length')
+            return list(zip(first['id'].values, rest['id'].values))
+        first = self._weighted(num_pairs, self._len)
+        taken = np.zeros(len(self._uniq), dtype=bool)
+        taken[self._code[first]] = True
+        others = np.flatnonzero(~taken[self._code])            # files of the speakers not in the first draw, df order
+        rest = others[self._weighted(num_pairs, self._len[others])]
+        return list(zip(first, rest))
 
     def build_verification_batch(self, batchsize):
         """([input_1, input_2], outputs): batchsize//2 same-speaker pairs then batchsize//2 different-speaker pairs;
@@ -201,18 +242,37 @@ class LibriSpeechDataset(Sequence):
             raise ValueError('k must be smaller than the number of unique speakers in this dataset!')
         if k <= 1:
             raise ValueError('k must be greater than or equal to one!')
-        query = self.df.sample(1, weights='length')
-        query_index = query.index.values[0]
-        query_sample = self[query_index]
-        same_speaker = self.df['speaker_id'] == query['speaker_id'].values[0]
-        correct = self.df[same_speaker & (self.df.index != query_index)].sample(n, weights='length')
-        others = np.random.choice(self.df[~same_speaker]['speaker_id'].unique(), k - 1, replace=False)
-        parts = [correct]
-        for speaker in others:
-            parts.append(self.df[self.df['speaker_id'] == speaker].sample(n, weights='length'))
-        support = pd.concat(parts)
-        samples = [self[i] for i in support.index]
+        if not getattr(self, 'fast_sampling', True):
+            query = self.df.sample(1, weights='length')
+            query_index = query.index.values[0]
+            query_sample = self[query_index]
+            same_speaker = self.df['speaker_id'] == query['speaker_id'].values[0]
+            correct = self.df[same_speaker & (self.df.index != query_index)].sample(n, weights='length')
+            others = np.random.choice(self.df[~same_speaker]['speaker_id'].unique(), k - 1, replace=False)
+            parts = [correct]
+            for speaker in others:
+                parts.append(self.df[self.df['speaker_id'] == speaker].sample(n, weights='length'))
+            support_index = pd.concat(parts).index.values
+        else:
+            query_index = int(self._weighted(1, self._len)[0])
+            query_sample = self[query_index]
+            support_index = self._n_shot_support(query_index, k, n)
+        samples = [self[i] for i in support_index]
         return query_sample, (np.stack([s[0] for s in samples]), np.stack([s[1] for s in samples]))
+
+    def _n_shot_support(self, query_index, k, n):
+        """File ids of the support set of ``build_n_shot_task`` for a drawn query: n other files of its speaker, then n files
+        of each of k-1 other speakers (drawn uniformly without replacement, in order of first appearance like ``unique()``)."""
+        q = self._code[query_index]
+        mine = self._files[self._start[q]:self._start[q] + self._cnt[q]]
+        mine = mine[mine != query_index]
+        parts = [mine[self._weighted(n, self._len[mine])]]
+        pool = self._appear[self._appear != q]
+        for sp in np.random.choice(self._uniq[pool], k - 1, replace=False):
+            c = np.searchsorted(self._uniq, sp)
+            files = self._files[self._start[c]:self._start[c] + self._cnt[c]]
+            parts.append(files[self._weighted(n, self._len[files])])
+        return np.concatenate(parts)
 
     @staticmethod
     def index_subset(subset):

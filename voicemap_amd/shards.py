@@ -142,7 +142,7 @@ class ShardedSpeechDataset(LibriSpeechDataset):
             raise ValueError('the device path cannot pad: a file is shorter than the fragment length')
         if self.stochastic:
             span = np.maximum(lengths - self.fragment_length, 1)
-            start = np.array([np.random.randint(0, s) for s in span], dtype=np.int64)
+            start = np.random.randint(0, span).astype(np.int64)  # one draw per file, same stream as a loop of scalar draws
         else:
             start = np.zeros(len(indices), dtype=np.int64)
         return self.global_offset[indices] + start
@@ -178,16 +178,9 @@ class ShardedSpeechDataset(LibriSpeechDataset):
             raise ValueError('k must be smaller than the number of unique speakers in this dataset!')
         if k <= 1:
             raise ValueError('k must be greater than or equal to one!')
-        query = self.df.sample(1, weights='length')
-        query_index = query.index.values[0]
+        query_index = int(self._weighted(1, self._len)[0])
         q_off = self.window_starts([query_index])[0]
-        same_speaker = self.df['speaker_id'] == query['speaker_id'].values[0]
-        correct = self.df[same_speaker & (self.df.index != query_index)].sample(n, weights='length')
-        others = np.random.choice(self.df[~same_speaker]['speaker_id'].unique(), k - 1, replace=False)
-        parts = [correct]
-        for speaker in others:
-            parts.append(self.df[self.df['speaker_id'] == speaker].sample(n, weights='length'))
-        support_index = pd.concat(parts).index.values
+        support_index = self._n_shot_support(query_index, k, n)
         s_off = self.window_starts(support_index)
         return (q_off, self._label(query_index)), (s_off, np.array([self._label(i) for i in support_index]))
 
