@@ -29,6 +29,8 @@ import torch
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+MFMA_BF16_SUSTAINED_TF = 1880.0  # what the matrix pipes sustain from registers: the chip clocks at 1.79 GHz with every SIMD issuing
+                                 # MFMAs back to back (tools/probe/mfma_valu_probe.hip, profiles/r01_mfma_valu_issue_probe.txt)
 TRAIN_BYTES_PER_WINDOW = 44.02e6   # algorithmic HBM bytes per 3 s window, training, S4k, bf16
 TRAIN_FLOPS_PER_WINDOW = 7.373e9
 
@@ -155,6 +157,9 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": nflops / t_avg / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    if roof["bound"] == "mfma":  # side figure: against the measured sustained matrix rate instead of the nominal peak
+        roof["sustained_peak_measured"] = MFMA_BF16_SUSTAINED_TF
+        roof["frac_of_sustained"] = roof["achieved"] / MFMA_BF16_SUSTAINED_TF
     roof["algorithmic_bytes"] = nbytes
     roof["traffic"] = None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), if this shape was profiled
