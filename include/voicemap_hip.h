@@ -44,6 +44,8 @@ int vm_check_device(void);
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
 /* Tuning hook for A/B measurements (process-global, benchmarking only; not part of the drop-in surface).  Kernel selection:
  *   "nt_p8" 0|1|2   forward/dgrad: 256x256 phase-interleaved kernel off / every eligible shape / K >= 1152 only (default 2)
+ *   "nt_w4" 0|1|2   forward/dgrad: one-wave-per-SIMD 254x256 kernel with an input-resident A (conv_w4_kernel) off (default) /
+ *                   every eligible shape / K >= 1152 only
  *   "tn_x"  0|1|2   wgrad: input-resident (3 taps x 128 ci) x 128 co kernel off / phase form (default) / free-running form
  *   "tn_p8" 0|1     wgrad: LDS-DMA + transposing-read 256x256 kernel when tn_x does not apply (default 1)
  *   "tn_tile" 128|256, "gemm_kb" 64|128, "nt_glds", "nt_tepi", "nt_ring", "nt_order", "tn_xcd": the older variants

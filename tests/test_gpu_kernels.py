@@ -47,7 +47,7 @@ def _conv_ref(x, w, b):
 
 
 GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "nt_korder": 0, "tn_p8": 1, "tn_x": 1,
-                 "nt_p8_blocks": 256}
+                 "nt_p8_blocks": 256, "nt_w4": 0}
 
 
 @pytest.fixture
@@ -72,6 +72,21 @@ def gemm_kb(request):
                                           (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),
                                           (16, 1030, 256, 256)])
 def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kb):
+    _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
+
+
+@pytest.mark.parametrize("gemm_kb", [{"nt_w4": 1}], indirect=True, ids=["w4"])
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
+                                          (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),
+                                          (16, 1030, 256, 256), (2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512)])
+def test_conv_one_wave_per_simd_variant(n, l, cin, cout, gemm_kb):
+    """conv_w4_kernel (opt-in, vm_set_tuning("nt_w4", 1); bf16): forward with fused statistics where L fills the statistics rows
+    (700, 760, 650 here), dgrad wherever C_in % 256 == 0 and C_out % 64 == 0 (520 and 1030: ragged last tiles of 254 positions);
+    every other launch of the test falls back to the default kernels."""
+    _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)
+
+
+def _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
     vm, tdt = DTYPES[dt]
     r = rng(2)
     x = quant(r.normal(0, 1.0, (n, l, cin)), dt)

@@ -1186,6 +1186,214 @@ __global__ __launch_bounds__(512) void conv_nt8_kernel(NtArgs<bf16> p, int n_gro
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT conv GEMM with ONE wave per SIMD (bf16, opt-in: vm_set_tuning("nt_w4", 1 | 2); the round-2 direction of DESIGN.md 8.1,
+// developed as tools/probe/conv_w4_probe.hip).  256-thread workgroup, every wave owns a 128 x 128 output tile in 256
+// accumulator registers (0.5 KB of fragment reads per MFMA against 0.75 KB in conv_nt8_kernel); tile = 254 output positions x
+// 256 channels; the K walk is (channel chunk, tap) with an INPUT-RESIDENT A: the 256 padded rows of a 64-channel chunk are
+// staged once and read at row offsets 0 / 1 / 2 for the three taps (a third of the A pieces to issue).
+// LDS: 2 A blocks + 2 B stages of 32 KB = 128 KB; the epilogue reuses it as one 32 KB transpose region per wave.
+// Every MFMA is followed by one filler in its issue shadow (fragment read of the next k-step, or a DMA piece);
+// per K tile g = 3*chunk + tap there is one counted DMA wait + one s_barrier in the middle of its last k-step:
+//   tap 0: k-step 0 issues B(g+1) [8 pieces], k-step 1 the first half of A(chunk+1) [4] -> wait vmcnt(4): B(g+1) landed
+//   tap 1: likewise with the second half of A(chunk+1)                                 -> wait vmcnt(4)
+//   tap 2: k-step 0 issues B(g+1) [8]                                                  -> wait vmcnt(0): B(g+1) and A(chunk+1)
+// (loads complete in order, and inside a K tile every B piece precedes the A pieces).  WAR: a B stage / A block is re-staged
+// only after the barrier that follows its last fragment reads.  Requires Ktot == 3*a_c, a_c % 64 == 0, N % 256 == 0.
+// ------------------------------------------------------------------------------------------------
+namespace w4 {
+constexpr int TROWS = 254;
+constexpr int ROWB = 128;
+constexpr int OPB = 256 * ROWB;
+constexpr int B0 = 2 * OPB;
+constexpr int LDS_BYTES = 4 * OPB;
+struct Frag {
+    bf16x8 a[4], b[4];
+};
+}  // namespace w4
+
+template <int EPI>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void conv_w4_kernel(NtArgs<bf16> p) {
+    using namespace w4;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int tn = __builtin_amdgcn_readfirstlane((int)blockIdx.x % p.tilesN);
+    const int grp = (int)blockIdx.x / p.tilesN;
+    const int tl = __builtin_amdgcn_readfirstlane(grp % p.tilesL), n = __builtin_amdgcn_readfirstlane(grp / p.tilesL);
+    const int t0 = tl * TROWS;
+    const int chunks = p.a_c / 64, nk = chunks * 3;
+    const int a_pitch = p.a_c * 2, b_pitch = p.Ktot * 2;
+
+    // ---- DMA geometry: a piece = 8 rows x 128 B, lane-linear in LDS; wave w stages rows [64w, 64w+64) of a block; LDS row R
+    // keeps 16-byte chunk c at position c ^ ((R >> 1) & 7), so the source chunk of a lane is permuted accordingly ----
+    const int prow = lane >> 3;
+    const char* a_win = reinterpret_cast<const char*>(p.a) + (int64_t)n * p.a_win_stride * 2;
+    const char* b_base = reinterpret_cast<const char*>(p.bt) + (int64_t)(tn * 256 + w * 64) * b_pitch;
+    unsigned a_off[8], b_off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int key = (4 * q + (prow >> 1)) & 7;
+        int pr = t0 + w * 64 + q * 8 + prow;  // padded row of the window; the tail tile reads its last halo row again
+        pr = pr < p.L + 2 ? pr : p.L + 1;
+        a_off[q] = (unsigned)(pr * a_pitch + (((lane & 7) ^ key) * 16));
+        b_off[q] = (unsigned)((q * 8 + prow) * b_pitch + (((lane & 7) ^ key) * 16));
+    }
+    auto stage_a = [&](int blk, int chunk, int q) { glds16(a_win + (int64_t)chunk * ROWB + a_off[q], lds + blk * OPB + (w * 64 + q * 8) * ROWB); };
+    auto stage_b = [&](int stg, int g, int q) {  // K tile g = 3*chunk + tap -> weight columns tap*a_c + 64*chunk
+        const int chunk = g / 3, tap = g - 3 * chunk;
+        glds16(b_base + (int64_t)(tap * p.a_c + chunk * 64) * 2 + b_off[q], lds + B0 + stg * OPB + (w * 64 + q * 8) * ROWB);
+    };
+
+    // ---- fragment geometry: lane (r, kh) reads 16 B of row r (+ tap for A), k-chunk 2s + kh ----
+    const int r = lane & 31, kh = lane >> 5;
+    int foff_b[4], foff_a[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        foff_b[s] = r * ROWB + (((2 * s + kh) ^ ((r >> 1) & 7)) * 16);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) foff_a[tap][s] = (r + tap) * ROWB + (((2 * s + kh) ^ (((r + tap) >> 1) & 7)) * 16);
+    }
+    const int a_rows = wm * 128 * ROWB, b_rows = wn * 128 * ROWB;
+    auto one_read = [&](Frag& f, int blk, int stg, int tap, int s, int t) {  // t in 0..7: a[0..3], b[0..3]
+        if (t < 4) {
+            f.a[t] = *reinterpret_cast<const bf16x8*>(lds + blk * OPB + a_rows + t * 32 * ROWB + foff_a[tap][s]);
+        } else {
+            f.b[t - 4] = *reinterpret_cast<const bf16x8*>(lds + B0 + stg * OPB + b_rows + (t - 4) * 32 * ROWB + foff_b[s]);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto kstep = [&](const Frag& cur, Frag& nxt, int rblk, int rstg, int rtap, int rs, int rslot0, int bstg, int bg, int ablk, int achunk, int aq0,
+                     int wait_n) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = t >> 2, j = t & 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+            if (wait_n >= 0 && t == 7) {
+                if (wait_n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (rslot0 == 0) {
+                if ((t & 1) == 0) one_read(nxt, rblk, rstg, rtap, rs, t >> 1);
+            } else if (t >= 8) {
+                one_read(nxt, rblk, rstg, rtap, rs, t - 8);
+            }
+            if (bg >= 0 && (t & 1)) stage_b(bstg, bg, t >> 1);                        // k-step 0: the 8 B pieces, odd slots
+            if (achunk >= 0 && (t & 3) == 1) stage_a(ablk, achunk, aq0 + (t >> 2));  // k-step 1: 4 A pieces, slots 1, 5, 9, 13
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: A(0), B(0) ----
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_a(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_b(0, 0, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) one_read(f0, 0, 0, 0, 0, t);
+
+    // ---- K-tile stream; past the end the DMAs re-stage K tile 0 / chunk 0 into memory nobody reads ----
+    for (int c = 0; c < chunks; ++c) {
+        const int ablk = c & 1;
+        const int cn = c + 1 < chunks ? c + 1 : 0;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int g = 3 * c + tap, sb = g & 1;
+            const int gn = g + 1 < nk ? g + 1 : 0;
+            const int ntap = tap == 2 ? 0 : tap + 1, nblk = tap == 2 ? (ablk ^ 1) : ablk;  // where the next K tile reads
+            kstep(f0, f1, ablk, sb, tap, 1, 0, sb ^ 1, gn, 0, -1, 0, -1);
+            kstep(f1, f0, ablk, sb, tap, 2, 0, 0, -1, ablk ^ 1, tap == 2 ? -1 : cn, tap == 0 ? 0 : 4, -1);
+            kstep(f0, f1, ablk, sb, tap, 3, 0, 0, -1, 0, -1, 0, -1);
+            kstep(f1, f0, nblk, sb ^ 1, ntap, 0, 8, 0, -1, 0, -1, 0, tap == 2 ? 0 : 4);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the operand memory: it becomes the epilogue scratch
+
+    // ---- epilogue: (bias + ReLU,) bf16, through LDS (the wave's 128 x 128 tile, rows of 256 B, 16-byte chunk c of row R at
+    // c ^ (R & 15)) to whole-row 16-byte stores; forward: statistics of the stored (rounded) values ----
+    char* scr = lds + w * 32768;
+    const int col0 = tn * 256 + wn * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cc = j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels in the wave tile
+                bf16 o[4];
+                if (EPI == EPI_FWD) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col0 + cc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[i][j][4 * g + e] + bv[e];
+                        o[e] = (bf16)(x > 0.f ? x : 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][4 * g + e];
+                }
+                const int row = i * 32 + r, cb = cc * 2;
+                *reinterpret_cast<u32x2*>(scr + row * 256 + (((cb >> 4) ^ (row & 15)) << 4) + (cb & 15)) = *reinterpret_cast<const u32x2*>(o);
+            }
+        }
+    }
+    float s8[8], q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+    bf16* zbase = p.out + ((int64_t)n * p.L + t0 + wm * 128) * p.N + col0;
+    const int c16 = lane & 15;
+    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int trow = wm * 128 + row;  // row inside the 256-row MFMA tile
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(scr + row * 256 + ((c16 ^ (row & 15)) << 4));
+        if (trow < TROWS && t0 + trow < p.L) {
+            *reinterpret_cast<bf16x8*>(zbase + (int64_t)row * p.N + c16 * 8) = v;
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (float)v[e];
+                    s8[e] += x;
+                    q8[e] = fmaf(x, x, q8[e]);
+                }
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s8[e] += __shfl_xor(s8[e], 16, 64);
+            s8[e] += __shfl_xor(s8[e], 32, 64);
+            q8[e] += __shfl_xor(q8[e], 16, 64);
+            q8[e] += __shfl_xor(q8[e], 32, 64);
+        }
+        if (lane < 16) {
+            // statistics rows per window = (L + 127) / 128 (vm_conv_stat_rows); the launch guarantees 2 * tilesL of them
+            const int64_t srow = (int64_t)n * ((p.L + 127) / 128) + tl * 2 + wm;
+            float* ps = p.stat_sum + srow * p.N + col0 + c16 * 8;
+            float* pq = p.stat_sq + srow * p.N + col0 + c16 * 8;
+            *reinterpret_cast<f32x4*>(ps) = f32x4{s8[0], s8[1], s8[2], s8[3]};
+            *reinterpret_cast<f32x4*>(ps + 4) = f32x4{s8[4], s8[5], s8[6], s8[7]};
+            *reinterpret_cast<f32x4*>(pq) = f32x4{q8[0], q8[1], q8[2], q8[3]};
+            *reinterpret_cast<f32x4*>(pq + 4) = f32x4{q8[4], q8[5], q8[6], q8[7]};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
 // of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
 // 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
@@ -2078,11 +2286,32 @@ int g_nt_p8_skew = 0;
 int g_nt_korder = 0;  // K walk of the 128^2 LDS-DMA kernels: 0 (tap, chunk), 1 (chunk, tap)
 int g_nt_p8_korder = 1;  // -0.5 % step (interleaved A/B): the same cache lines are re-read one K tile later instead of six
 int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tuning("nt_p8_phases", 2 | 4)
+// conv_w4_kernel (one wave per SIMD, input-resident A): vm_set_tuning("nt_w4", 0 | 1 | 2): 0 off (default in round 1: it was
+// finished after the last evidence run), 1 every eligible shape, 2 only K >= 1152.  Stand-alone form measured at 226 us on the
+// block-4 forward against 265 us for conv_nt8_kernel (profiles/r01_conv_w4_probe.txt).
+int g_nt_w4 = 0;
+
+template <int EPI>
+static bool launch_w4(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
+    const int tl254 = (a.L + w4::TROWS - 1) / w4::TROWS;
+    if (!g_nt_w4 || (g_nt_w4 == 2 && a.Ktot < 1152) || a.N % 256 != 0 || a.a_c % 64 != 0 || a.Ktot != 3 * a.a_c || a.ablate != 0) return false;
+    // forward statistics: one partial row per (tile, row half) must fill exactly the (L + 127) / 128 rows per window (checked
+    // for the inference launch as well, so that a layer runs the same kernel -- the same summation order -- in both modes)
+    if (EPI == EPI_FWD && 2 * tl254 != (a.L + 127) / 128) return false;
+    const int64_t grid = n_windows * tl254 * (a.N / 256);
+    if (grid >= (1LL << 31)) return false;
+    NtArgs<bf16> b = a;
+    b.tilesL = tl254;
+    b.tilesN = a.N / 256;
+    hipLaunchKernelGGL((conv_w4_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b);
+    return true;
+}
 
 template <typename T, int EPI>
 static bool launch_nt8(const NtArgs<T>&, int64_t, hipStream_t) { return false; }
 template <int EPI>
 static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
+    if (launch_w4<EPI>(a, n_windows, stream)) return true;
     if (!g_nt_p8 || (g_nt_p8 == 2 && a.Ktot < 1152) || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
         n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
     NtArgs<bf16> b = a;
@@ -2364,6 +2593,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_korder") == 0) {
         g_nt_p8_korder = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_w4") == 0 && value >= 0 && value <= 2) {
+        g_nt_w4 = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_p8_skew") == 0 && value >= 0 && value <= 64) {
