@@ -188,3 +188,68 @@ print("LIBHDF5_OK")
 '''
     out = subprocess.run([H5PY_PYTHON, "-c", code, p, str(tmp_path / "want.npz")], capture_output=True, text=True, timeout=120)
     assert "LIBHDF5_OK" in out.stdout, out.stderr[-2000:]
+
+
+def _random_tree(seed):
+    r = np.random.default_rng(seed)
+    root = H.NodeSpec()
+    want, attrs = {}, {}
+    dtypes = [np.float32, np.float64, np.int32, np.int64, np.uint8, np.int16]
+
+    def name():
+        return "".join(r.choice(list("abcdefghijklmnopqrstuvwxyz_0123456789:"), size=int(r.integers(1, 14))))
+
+    def fill(node, path, depth):
+        for _ in range(int(r.integers(1, 12 if depth == 0 else 6))):
+            nm = name()
+            if nm in node.children:
+                continue
+            full = path + "/" + nm if path else nm
+            if depth < 3 and r.random() < 0.35:
+                g = node.require_group(nm)
+                if r.random() < 0.5:
+                    g.attrs["note"] = ("group " + full).encode()
+                    attrs[full] = ("note", ("group " + full).encode())
+                fill(g, full, depth + 1)
+            else:
+                shape = tuple(int(x) for x in r.integers(0, 5, size=int(r.integers(0, 4))))
+                dt = dtypes[int(r.integers(len(dtypes)))]
+                a = (r.normal(size=shape) * 50).astype(dt)
+                d = node.create_dataset(nm, a)
+                want[full] = a
+                if r.random() < 0.4:
+                    v = r.integers(-5, 5, size=int(r.integers(1, 6))).astype(np.int64)
+                    d.attrs["tags"] = v
+                    attrs[full] = ("tags", v)
+    fill(root, "", 0)
+    return root, want, attrs
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hdf5_lite_random_trees_round_trip(tmp_path, seed):
+    root, want, attrs = _random_tree(seed)
+    p = str(tmp_path / "r.h5")
+    H.write_file(p, root)
+    f = H.File(p)
+    got = dict(f.visit_datasets())
+    assert sorted(got) == sorted(want)
+    for k, a in want.items():
+        b = np.asarray(got[k])
+        assert b.shape == a.shape and b.dtype == a.dtype and np.array_equal(a, b), k
+    for k, (an, av) in attrs.items():
+        v = f[k].attrs[an]
+        assert (v == av) if isinstance(av, bytes) else np.array_equal(v, av), k
+    if os.path.exists(H5PY_PYTHON) and seed < 3:  # libhdf5 reads the same values
+        np.savez(str(tmp_path / "want.npz"), **{k.replace("/", "|"): v for k, v in want.items()})
+        code = r'''
+import sys, h5py, numpy as np
+f = h5py.File(sys.argv[1], "r"); want = np.load(sys.argv[2])
+n = 0
+for k in want.files:
+    d = f[k.replace("|", "/")]
+    assert d.shape == want[k].shape and d.dtype == want[k].dtype and np.array_equal(d[()], want[k]), k
+    n += 1
+print("LIBHDF5_OK", n)
+'''
+        out = subprocess.run([H5PY_PYTHON, "-c", code, p, str(tmp_path / "want.npz")], capture_output=True, text=True, timeout=120)
+        assert "LIBHDF5_OK" in out.stdout, out.stderr[-2000:]
