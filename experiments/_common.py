@@ -76,4 +76,8 @@ def standard_callbacks(a, valid, preprocessor, mode, param_str, plateau_patience
 
 
 def seed_everything(seed=0):
+    """np.random drives the pair / task sampling; torch's global generator seeds the weight initialisers and, through the
+    engine's own generator, the SpatialDropout1D masks (HipEncoderEngine.init_params)."""
+    import torch
     np.random.seed(seed)
+    torch.manual_seed(seed)

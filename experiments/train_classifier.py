@@ -1,6 +1,8 @@
 """Speaker-identification classifier on the same encoder (+ Dense(num_classes, softmax), categorical cross-entropy) --
 counterpart of the reference's experiments/train_classifier.py; its bottleneck layer is evaluated with the same
 n-shot tasks (mode='classifier').     python -m experiments.train_classifier [--synthetic] ..."""
+import sys
+
 import numpy as np
 
 from experiments import _common as C
@@ -37,7 +39,11 @@ def main(argv=None):
     index_of = {s: i for i, s in enumerate(ids)}
     one_hot = lambda y: to_categorical(np.array([index_of[s] for s in y[:, 0]]), train.num_classes())
     pre = BatchPreProcessor("classifier", preprocess_instances(a.downsampling), one_hot)
-    classifier = get_baseline_convolutional_encoder(a.filters, a.embedding_dimension, (C.input_length(a), 1), dropout=a.dropout,
+    # the reference defines dropout = 0.0 (train_classifier.py:28) but never passes it to the build function (:110), so its
+    # classifier trains at the function's default SpatialDropout1D rate 0.05 while the run is NAMED drop_0.0 (:40).  Same here
+    # unless --dropout is given explicitly.
+    rate = a.dropout if "--dropout" in (argv if argv is not None else sys.argv[1:]) else 0.05
+    classifier = get_baseline_convolutional_encoder(a.filters, a.embedding_dimension, (C.input_length(a), 1), dropout=rate,
                                                     dtype=a.dtype)
     classifier.add(Dense(train.num_classes(), activation="softmax"))
     classifier.compile(loss="categorical_crossentropy", optimizer=Adam(clipnorm=1.), metrics=["accuracy"])

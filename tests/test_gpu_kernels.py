@@ -607,3 +607,120 @@ def test_bn_pool_bwd_sparse_gmax_form_equals_dense(dt):
     for a, b in zip(outs[0][:2], outs[1][:2]):
         wa, wb = a.view(n, rows, c).sum(1), b.view(n, rows, c).sum(1)
         assert torch.allclose(wa, wb, rtol=2e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# cfg-A's own GEMM geometries (experiments/train_siamese.py:20-25: filters 128 -> blocks 2..4 are 128->256 @ L=3000,
+# 256->384 @ L=1500, 384->512 @ L=750) under the DEFAULT dispatch -- no vm_set_tuning call in these tests, so they
+# exercise exactly the kernels the bench line runs (conv_nt8 / conv_w4 for the K >= 1152 launches, the three-chunk
+# c_in = 384 walk of conv_tn8x, ...).  Reference arithmetic: voicemap/models.py:22-35.
+CFG_A_GEMMS = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("l,cin,cout", CFG_A_GEMMS)
+def test_conv_cfgA_geometry_default_dispatch(dt, l, cin, cout):
+    _conv_fwd_dgrad_wgrad(dt, 4, l, cin, cout)
+
+
+def _window_slices(n):
+    return sorted({0, 1, n // 2 - 1, n // 2, n - 1})
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("l,cin,cout", CFG_A_GEMMS)
+def test_conv_cfgA_full_batch_sampled_windows(dt, l, cin, cout):
+    """The bench launch itself (256 windows = 128 pairs): forward + statistics and dgrad are per-window independent, so the
+    oracle is run on a handful of sampled windows of the very same launch; wgrad sums over windows, so it is checked (a)
+    by linearity -- du non-zero in the sampled windows only must give the oracle's wgrad of those windows, with the other
+    251 windows' inputs random (they walk every split/slab of the launch) -- and (b) with a dense du against a float64
+    torch.matmul restatement of the same sum on the device."""
+    vm, tdt = DTYPES[dt]
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(77)
+    xq = torch.randn(n, l, cin, device="cuda", generator=g).to(tdt)
+    duq = torch.randn(n, l, cout, device="cuda", generator=g).to(tdt)
+    r = rng(5)
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt)
+    b = torch.tensor(r.normal(0, 0.3, (cout,)).astype(np.float32), dtype=torch.float64)
+    wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
+    wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
+    xp = torch.zeros(n, l + 2, cin, dtype=tdt, device="cuda")
+    xp[:, 1:l + 1] = xq
+    dup = torch.zeros(n, l + 2, cout, dtype=tdt, device="cuda")
+    dup[:, 1:l + 1] = duq
+    rows = L().query("vm_conv_stat_rows", l)
+    z = torch.empty(n, l, cout, dtype=tdt, device="cuda")
+    ss = torch.zeros(n * rows, cout, device="cuda")
+    sq = torch.zeros(n * rows, cout, device="cuda")
+    L().call("vm_conv_fwd", p(xp), p(wf), p(dev(b)), n, l, cin, cout, vm, p(z), p(ss), p(sq), stream())
+    dx = torch.empty(n, l, cin, dtype=tdt, device="cuda")
+    L().call("vm_conv_dgrad", p(dup), p(wd), n, l, cin, cout, vm, p(dx), stream())
+    sel = _window_slices(n)
+    pl_, pr_ = O.same_padding(3)
+    for i in sel:
+        xi = xq[i:i + 1].double().cpu()
+        ref = _conv_ref(xi, w, b).numpy()
+        zz = z[i:i + 1].float().cpu().numpy()
+        assert rel_err(zz, ref) < TOL[dt], i
+        assert rel_err(ss.view(n, rows, cout)[i].sum(0).cpu().numpy(), zz.astype(np.float64).sum((0, 1))) < 1e-5
+        assert rel_err(sq.view(n, rows, cout)[i].sum(0).cpu().numpy(), (zz.astype(np.float64) ** 2).sum((0, 1))) < 1e-5
+        dui = duq[i:i + 1].double().cpu()
+        xr = xi.clone().requires_grad_(True)
+        y = torch.nn.functional.conv1d(torch.nn.functional.pad(xr.transpose(1, 2), (pl_, pr_)), w.permute(2, 1, 0)).transpose(1, 2)
+        gx, = torch.autograd.grad((y * dui).sum(), [xr])
+        assert rel_err(dx[i:i + 1].float().cpu().numpy(), gx.numpy()) < TOL[dt], i
+    # the statistics of the whole launch against the stored z (every window)
+    zd = z.double()
+    assert rel_err(ss.view(n, rows, cout).sum(1).cpu().numpy(), zd.sum(1).cpu().numpy()) < 1e-5
+    assert rel_err(sq.view(n, rows, cout).sum(1).cpu().numpy(), (zd * zd).sum(1).cpu().numpy()) < 1e-5
+    del zd
+    # wgrad (a): linearity against the oracle
+    ws = torch.empty(L().query("vm_conv_wgrad_workspace_bytes", n, l, cin, cout) // 4 + 16, device="cuda")
+    gwd = torch.empty(3, cin, cout, device="cuda")
+    dus = torch.zeros_like(dup)
+    dus[sel] = dup[sel]
+    L().call("vm_conv_wgrad", p(xp), p(dus), n, l, cin, cout, vm, p(ws), p(gwd), stream())
+    xs = xq[sel].double().cpu()
+    wr = w.clone().requires_grad_(True)
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(xs.transpose(1, 2), (pl_, pr_)), wr.permute(2, 1, 0)).transpose(1, 2)
+    gw, = torch.autograd.grad((y * duq[sel].double().cpu()).sum(), [wr])
+    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < 2e-5
+    # wgrad (b): dense du, float64 restatement of the sum on the device (torch.matmul, not a kernel of this repo)
+    L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gwd), stream())
+    ref = torch.empty(3, cin, cout, dtype=torch.float64, device="cuda")
+    dd = duq.double().reshape(n * l, cout)
+    for k in range(3):
+        ref[k] = xp[:, k:k + l].double().reshape(n * l, cin).t() @ dd
+    assert rel_err(gwd.cpu().numpy(), ref.cpu().numpy()) < (2e-5 if dt == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("i16", [False, True])
+def test_crop_decimate_whiten_vs_oracle(i16):
+    """vm_crop_decimate_whiten (device-side crop of voicemap/librispeech.py:103-137 + utils.py:22-34, 88-101) compared
+    DIRECTLY with O.preprocess_instances on numpy-cropped windows (not via the host-crop kernel)."""
+    r = rng(13)
+    n, wpt, raw_len, ds = 6, 3, 4801, 4
+    total = 60000
+    audio = r.normal(0, 0.05, total) + 0.01 * np.sin(np.arange(total) / 900.0)
+    if i16:
+        a16 = np.clip(np.round(audio * 32768), -32768, 32767).astype(np.int16)
+        audio = a16.astype(np.float64) / 32768.0
+        ad = dev(a16, torch.int16)
+    else:
+        audio = audio.astype(np.float32)
+        ad = dev(audio)
+    offs = r.integers(0, total - raw_len, n).astype(np.int64)
+    offs[0], offs[-1] = 0, total - raw_len
+    l0 = (raw_len + ds - 1) // ds
+    out = torch.zeros(n, l0 + 31, device="cuda")
+    ws = torch.empty(L().query("vm_decimate_whiten_workspace_bytes", n) // 8, dtype=torch.float64, device="cuda")
+    L().call("vm_crop_decimate_whiten", p(ad), int(i16), p(dev(offs, torch.int64)), n, raw_len, ds, 1, 0.038021, wpt, p(out),
+             p(ws), stream())
+    win = np.stack([audio[o:o + raw_len] for o in offs]).astype(np.float64)
+    pre = O.preprocess_instances(ds)
+    ref = np.concatenate([pre(win[t:t + wpt, :, None]) for t in range(0, n, wpt)])[:, :, 0]
+    o = out.cpu().numpy()
+    assert np.all(o[:, :15] == 0) and np.all(o[:, 15 + l0:] == 0)
+    assert max_err(o[:, 15:15 + l0], ref) < 1e-7

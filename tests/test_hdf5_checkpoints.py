@@ -175,12 +175,12 @@ import sys, json, h5py, numpy as np
 f = h5py.File(sys.argv[1], "r"); want = np.load(sys.argv[2])
 assert json.loads(f.attrs["model_config"])["class_name"] == "Model" and f.attrs["keras_version"] == b"2.2.2"
 mw = f["model_weights"]
-assert [n.decode() for n in mw.attrs["layer_names"]] == ["input_1", "input_2", "sequential_1", "subtract_1", "lambda_1", "dense_2"]
+assert [n.decode() for n in mw.attrs["layer_names"]] == ["input_1", "input_2", "sequential_1", "subtract_embeddings", "euclidean_distance", "dense_2"]
 names = [n.decode() for n in mw["sequential_1"].attrs["weight_names"]]
 assert len(names) == 26 and names[0] == "sequential_1/conv1d_1/kernel:0" and names[-1].endswith("batch_normalization_4/moving_variance:0")
 assert np.array_equal(mw["sequential_1"][names[0]][()], want["conv1__kernel"])
 assert np.array_equal(mw["sequential_1/sequential_1/batch_normalization_3/beta:0"][()], want["bn3__beta"])
-assert np.array_equal(mw["dense_2/dense_2/kernel:0"][()], want["head__kernel"]) and len(mw["lambda_1"].attrs["weight_names"]) == 0
+assert np.array_equal(mw["dense_2/dense_2/kernel:0"][()], want["head__kernel"]) and len(mw["euclidean_distance"].attrs["weight_names"]) == 0
 ow = f["optimizer_weights"]; wn = [n.decode() for n in ow.attrs["weight_names"]]
 assert len(wn) == 61 and ow["Adam/iterations:0"][()] == 123 and ow[wn[-1]].shape == (1,)
 assert np.allclose(ow[wn[1]][()], want["conv1__kernel"] * 1e-3)

@@ -267,27 +267,30 @@ def test_sharded_dataset_round_trip_and_offsets(tmp_path):
 
 def test_numpy_sampling_reproduces_the_pandas_draws():
     """The pair / task sampling is restated on plain arrays (librispeech._build_sampling_index): under one np.random seed it must
-    return exactly what the reference's DataFrame.sample / pd.merge formulation returns (librispeech.py:145-240) -- same files,
-    same order -- because pandas' sample IS np.random.choice on row positions."""
+    return exactly what the reference's DataFrame.sample / pd.merge formulation (tests/pandas_sampling.py, restating
+    librispeech.py:145-240) returns -- same files, same fragments, same order -- because pandas' sample IS np.random.choice on
+    row positions; build_verification_batch must also cut its fragments in the reference's statement order."""
+    from tests import pandas_sampling as PS
     from voicemap_amd.librispeech import SyntheticSpeechDataset
     for ds in (SyntheticSpeechDataset(num_speakers=40, files_per_speaker=7, seconds=0.3, seed=5),
                SyntheticSpeechDataset(num_speakers=9, files_per_speaker=3, seconds=0.2, seed=1, stochastic=False)):
         for seed in range(6):
             for fn, args in (("get_alike_pairs", (8,)), ("get_differing_pairs", (4,))):
-                out = []
-                for fast in (False, True):
-                    ds.fast_sampling = fast
-                    np.random.seed(seed)
-                    out.append([(int(a), int(b)) for a, b in getattr(ds, fn)(*args)])
-                assert out[0] == out[1], (fn, seed)
-            tasks = []
-            for fast in (False, True):
-                ds.fast_sampling = fast
-                np.random.seed(100 + seed)
-                tasks.append(ds.build_n_shot_task(4, 2))
-            (qa, (sa, la)), (qb, (sb, lb)) = tasks
+                np.random.seed(seed)
+                a = [(int(x), int(y)) for x, y in getattr(PS, fn)(ds, *args)]
+                np.random.seed(seed)
+                b = [(int(x), int(y)) for x, y in getattr(ds, fn)(*args)]
+                assert a == b, (fn, seed)
+            np.random.seed(100 + seed)
+            qa, (sa, la) = PS.build_n_shot_task(ds, 4, 2)
+            np.random.seed(100 + seed)
+            qb, (sb, lb) = ds.build_n_shot_task(4, 2)
             assert qa[1] == qb[1] and np.array_equal(qa[0], qb[0]) and np.array_equal(sa, sb) and list(la) == list(lb)
-        ds.fast_sampling = True
+            np.random.seed(200 + seed)
+            (a1, a2), ya = PS.build_verification_batch(ds, 8)
+            np.random.seed(200 + seed)
+            (b1, b2), yb = ds.build_verification_batch(8)
+            assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(ya, yb)
     # one vectorised randint draw per file == the reference's loop of scalar draws (librispeech.py:113)
     r = np.random.default_rng(0)
     for trial in range(50):

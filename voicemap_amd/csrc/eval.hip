@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void nshot_kernel(const float* __restrict__ que
     const float* q = query + task * E;
     const float* s = support + task * (int64_t)k * n * E;
     double best = INFINITY;
-    int besti = 0x7fffffff;
+    int besti = 0x7fffffff, bestn = 0;
     for (int cb = 0; cb < k; cb += 64) {
         const int cls = cb + (int)threadIdx.x;
         double d = INFINITY;
@@ -57,20 +57,25 @@ __global__ __launch_bounds__(64) void nshot_kernel(const float* __restrict__ que
             }
             pred[task * k + cls] = (float)d;
         }
-        // wave argmin, first minimum wins
-        double dv = d;
+        // wave argmin, first minimum wins; a NaN distance orders below everything, like numpy.argmin (utils.py:200 takes
+        // np.argmin of the distances: the first NaN if there is one)
+        double dv = (cls < k && d != d) ? -INFINITY : d;
+        int dn = (cls < k && d != d) ? 1 : 0;
         int di = cls < k ? cls : 0x7fffffff;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double od = __shfl_xor(dv, o, 64);
+            const int on = __shfl_xor(dn, o, 64);
             const int oi = __shfl_xor(di, o, 64);
-            if (od < dv || (od == dv && oi < di)) {
+            if (on > dn || (on == dn && (od < dv || (od == dv && oi < di)))) {
                 dv = od;
+                dn = on;
                 di = oi;
             }
         }
-        if (dv < best || (dv == best && di < besti)) {
+        if (dn > bestn || (dn == bestn && (dv < best || (dv == best && di < besti)))) {
             best = dv;
+            bestn = dn;
             besti = di;
         }
     }

@@ -161,7 +161,17 @@ class HipEncoderEngine:
 
     def init_params(self, seed: Optional[int] = None):
         """Keras default initialisers (glorot_uniform kernels, zero biases, gamma 1, beta 0, moving 0 / 1)."""
-        g = torch.Generator().manual_seed(0 if seed is None else int(seed))
+        if seed is None:
+            # like Keras' unseeded initialisers: a fresh draw per model, reproducible through torch.manual_seed
+            # (experiments/_common.seed_everything sets it)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self.seed = int(seed)
+        g = torch.Generator().manual_seed(self.seed)
+        # SpatialDropout1D masks come from an engine-owned generator: reproducible under the same seed, decorrelated across
+        # data-parallel ranks (every rank holds the same weights but must drop different channels)
+        import os as _os
+        self._drop_gen = torch.Generator(device=self.device)
+        self._drop_gen.manual_seed(self.seed * 1000003 + 7919 * (int(_os.environ.get("RANK", "0")) + 1))
         self.P.zero_()
         for name, (o, n, shape) in self.offsets.items():
             if name.endswith(".kernel"):
@@ -487,7 +497,7 @@ class HipEncoderEngine:
             return None
         out = []
         for (_, c, _) in self.blocks:
-            u = torch.rand(n_windows, c, device=self.device, generator=generator)
+            u = torch.rand(n_windows, c, device=self.device, generator=generator if generator is not None else self._drop_gen)
             out.append((u >= self.dropout).to(torch.float32) / (1.0 - self.dropout))
         return out
 

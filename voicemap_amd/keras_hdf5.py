@@ -249,6 +249,14 @@ def encoder_layer_configs(filters, embedding_dimension, dropout, first_pool, inp
     return layers
 
 
+def head_layer_names(distance_metric):
+    """Names Keras gives the two weight-less head layers of build_siamese_net: auto-named for 'weighted_l1'
+    (voicemap/models.py:58-59), explicit for 'uniform_euclidean' (voicemap/models.py:64-68)."""
+    if distance_metric == "uniform_euclidean":
+        return "subtract_embeddings", "euclidean_distance"
+    return "subtract_1", "lambda_1"
+
+
 def _model_config(kind, geo):
     enc = encoder_layer_configs(geo["filters"], geo["embedding_dimension"], geo["dropout"], geo["first_pool"],
                                 geo["input_shape"], geo.get("classifier_units", 0))
@@ -257,18 +265,21 @@ def _model_config(kind, geo):
     shape = [None] + list(geo["input_shape"])
     inp = lambda n: {"name": n, "class_name": "InputLayer", "inbound_nodes": [],
                      "config": {"batch_input_shape": shape, "dtype": "float32", "sparse": False, "name": n}}
+    sub, lam = head_layer_names(geo["distance_metric"])
     layers = [inp("input_1"), inp("input_2"),
               {"name": "sequential_1", "class_name": "Sequential", "config": enc,
                "inbound_nodes": [[["input_1", 0, 0, {}]], [["input_2", 0, 0, {}]]]},
-              {"name": "subtract_1", "class_name": "Subtract", "config": {"name": "subtract_1", "trainable": True},
+              {"name": sub, "class_name": "Subtract", "config": {"name": sub, "trainable": True},
                "inbound_nodes": [[["sequential_1", 1, 0, {}], ["sequential_1", 2, 0, {}]]]},
-              # Keras stores a Lambda as marshalled Python bytecode; this writer records WHICH of the reference's two lambdas
-              # it is (voicemap/models.py:55-69) instead -- rebuild with build_siamese_net and load the weights by name
-              {"name": "lambda_1", "class_name": "Lambda", "inbound_nodes": [[["subtract_1", 0, 0, {}]]],
-               "config": {"name": "lambda_1", "trainable": True, "function": geo["distance_metric"],
+              # Keras stores a Lambda as marshalled Python-2 bytecode; this writer records WHICH of the reference's two lambdas
+              # it is (voicemap/models.py:55-69) instead.  Consequence: keras.models.load_model cannot deserialize THIS layer
+              # of a file written here (model_weights / optimizer_weights / training_config are plain Keras); rebuild the
+              # model with build_siamese_net and model.load_weights(file), or use this package's load_model
+              {"name": lam, "class_name": "Lambda", "inbound_nodes": [[[sub, 0, 0, {}]]],
+               "config": {"name": lam, "trainable": True, "function": geo["distance_metric"],
                           "function_type": "voicemap_distance_metric", "output_shape": None, "output_shape_type": "raw",
                           "arguments": {}}},
-              dict(_dense_cfg("dense_2", 1, "sigmoid"), name="dense_2", inbound_nodes=[[["lambda_1", 0, 0, {}]]])]
+              dict(_dense_cfg("dense_2", 1, "sigmoid"), name="dense_2", inbound_nodes=[[[lam, 0, 0, {}]]])]
     return {"class_name": "Model", "config": {"name": "model_1", "layers": layers,
                                               "input_layers": [["input_1", 0, 0], ["input_2", 0, 0]],
                                               "output_layers": [["dense_2", 0, 0]]}}
@@ -312,12 +323,13 @@ def write_checkpoint(path: str, kind: str, geo: dict, params: Dict[str, np.ndarr
 
     if kind == "siamese":
         tr, nt = encoder_weights("sequential_1/")
-        layer_names = ["input_1", "input_2", "sequential_1", "subtract_1", "lambda_1", "dense_2"]
+        sub, lam = head_layer_names(geo.get("distance_metric"))
+        layer_names = ["input_1", "input_2", "sequential_1", sub, lam, "dense_2"]
         put("input_1", [])
         put("input_2", [])
         put("sequential_1", tr + nt)
-        put("subtract_1", [])
-        put("lambda_1", [])
+        put(sub, [])
+        put(lam, [])
         put("dense_2", [("dense_2/kernel:0", params["head.kernel"]), ("dense_2/bias:0", params["head.bias"])])
     else:
         # a Sequential saved on its own: one group per layer, weights named "<layer>/<weight>:0"

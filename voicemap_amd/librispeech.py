@@ -134,7 +134,7 @@ class LibriSpeechDataset(Sequence):
         4000-file index -- twice the GPU's step time.  pandas' ``sample`` is ``np.random.choice(len, size, replace=False,
         p=weights/weights.sum())`` on the global RandomState, an inner ``merge`` keeps the left rows' order and, inside a key,
         the right rows' order: so the same ``np.random`` calls in the same order on plain arrays give the SAME pairs and tasks
-        (tests/test_host_api.py compares the two under one seed)."""
+        (tests/test_host_api.py compares the two under one seed; the pandas formulation lives in tests/pandas_sampling.py)."""
         spk = self.df['speaker_id'].values
         self._len = self.df['length'].values.astype(np.float64)
         self._uniq, self._code = np.unique(spk, return_inverse=True)          # speaker codes 0..S-1 (sorted ids)
@@ -188,10 +188,6 @@ class LibriSpeechDataset(Sequence):
     def get_alike_pairs(self, num_pairs):
         """List of (id, id) pairs from the same speaker: 2*num_pairs anchors drawn with probability ~ file length, joined
         with every file of the same speaker (a file may pair with itself), num_pairs rows of the join kept."""
-        if not getattr(self, 'fast_sampling', True):
-            anchors = self.df.sample(num_pairs * 2, weights='length')
-            joined = pd.merge(anchors, self.df, on='speaker_id').sample(num_pairs)
-            return list(zip(joined['id_x'].values, joined['id_y'].values))
         anchors = self._weighted(num_pairs * 2, self._len)
         cnt = self._cnt[self._code[anchors]]                  # rows each anchor contributes to the join
         ends = np.cumsum(cnt)
@@ -205,10 +201,6 @@ class LibriSpeechDataset(Sequence):
     def get_differing_pairs(self, num_pairs):
         """List of (id, id) pairs from different speakers: num_pairs files ~ length, then num_pairs files ~ length from
         the speakers NOT in the first draw."""
-        if not getattr(self, 'fast_sampling', True):
-            first = self.df.sample(num_pairs, weights='length')
-            rest = self.df[~self.df['speaker_id'].isin(first['speaker_id'])].sample(num_pairs, weights='length')
-            return list(zip(first['id'].values, rest['id'].values))
         first = self._weighted(num_pairs, self._len)
         taken = np.zeros(len(self._uniq), dtype=bool)
         taken[self._code[first]] = True
@@ -220,10 +212,14 @@ class LibriSpeechDataset(Sequence):
         """([input_1, input_2], outputs): batchsize//2 same-speaker pairs then batchsize//2 different-speaker pairs;
         inputs (batchsize, T, 1) float, outputs (batchsize, 1) = zeros (same) then ones (different)."""
         half = batchsize // 2
+        # np.random is consumed in the reference's order (librispeech.py:179-189): alike pairs, their input_1 fragments, their
+        # input_2 fragments, THEN the differing pairs and their fragments
         alike = self.get_alike_pairs(half)
+        left = [self[i][0] for i, _ in alike]
+        right = [self[j][0] for _, j in alike]
         differing = self.get_differing_pairs(half)
-        left = [self[i][0] for i, _ in alike] + [self[i][0] for i, _ in differing]
-        right = [self[j][0] for _, j in alike] + [self[j][0] for _, j in differing]
+        left += [self[i][0] for i, _ in differing]
+        right += [self[j][0] for _, j in differing]
         input_1 = np.stack(left)[:, :, np.newaxis]
         input_2 = np.stack(right)[:, :, np.newaxis]
         outputs = np.append(np.zeros(half), np.ones(half))[:, np.newaxis]
@@ -242,21 +238,9 @@ class LibriSpeechDataset(Sequence):
             raise ValueError('k must be smaller than the number of unique speakers in this dataset!')
         if k <= 1:
             raise ValueError('k must be greater than or equal to one!')
-        if not getattr(self, 'fast_sampling', True):
-            query = self.df.sample(1, weights='length')
-            query_index = query.index.values[0]
-            query_sample = self[query_index]
-            same_speaker = self.df['speaker_id'] == query['speaker_id'].values[0]
-            correct = self.df[same_speaker & (self.df.index != query_index)].sample(n, weights='length')
-            others = np.random.choice(self.df[~same_speaker]['speaker_id'].unique(), k - 1, replace=False)
-            parts = [correct]
-            for speaker in others:
-                parts.append(self.df[self.df['speaker_id'] == speaker].sample(n, weights='length'))
-            support_index = pd.concat(parts).index.values
-        else:
-            query_index = int(self._weighted(1, self._len)[0])
-            query_sample = self[query_index]
-            support_index = self._n_shot_support(query_index, k, n)
+        query_index = int(self._weighted(1, self._len)[0])
+        query_sample = self[query_index]
+        support_index = self._n_shot_support(query_index, k, n)
         samples = [self[i] for i in support_index]
         return query_sample, (np.stack([s[0] for s in samples]), np.stack([s[1] for s in samples]))
 

@@ -290,6 +290,14 @@ class ConvolutionalEncoder(_TrainableModel):
         self.layers += [K.GlobalMaxPool1D("global_max_pooling1d_1"), Dense(self.embedding_dimension, name="dense_1")]
         self.classifier_units = 0  # > 0 after .add(Dense(num_classes, activation='softmax'))
 
+    def weight_names(self) -> List[str]:
+        """The encoder's own weights: once it shares a siamese engine (SiameseNet._ensure_engine) that engine also holds the
+        siamese Dense(1) head, which is not a layer of this Sequential."""
+        names = super().weight_names()
+        if not self.classifier_units:
+            names = [n for n in names if not n.startswith("head.")]
+        return names
+
     # ---- Sequential surface ------------------------------------------------------------------------------
     def add(self, layer):
         """Only what the reference does with it: append ``Dense(num_classes, activation='softmax')``
@@ -444,6 +452,22 @@ class SiameseNet(_TrainableModel):
                     dtype=e.dtype)
 
     def _ensure_engine(self):
+        if self.engine is None:
+            # Keras shares the encoder's variables with the siamese model (voicemap/models.py:52-53): weights the encoder
+            # already holds -- set_weights / load_weights before wrapping, a trained classifier after .pop()
+            # (voicemap/utils.py:143-145) -- are what the siamese model starts from; weights loaded into the siamese model
+            # itself (load_model) take precedence
+            enc = self.encoder
+            inherited = None
+            if enc.engine is not None:
+                inherited = enc.engine.get_params()
+            elif enc._pending_weights is not None:
+                inherited = enc._pending_weights
+                enc._pending_weights = None
+            if inherited is not None:
+                merged = OrderedDict((k, v) for k, v in inherited.items() if not k.startswith("head."))
+                merged.update(self._pending_weights or {})
+                self._pending_weights = merged
         eng = super()._ensure_engine()
         # the encoder object shares the siamese engine: encoder.predict() embeds with the trained weights
         self.encoder.engine = eng

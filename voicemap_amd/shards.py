@@ -151,12 +151,15 @@ class ShardedSpeechDataset(LibriSpeechDataset):
         """(offsets_1, offsets_2, outputs): the pairs of ``build_verification_batch`` (batchsize//2 same-speaker pairs, then
         batchsize//2 different-speaker pairs; outputs (batchsize, 1) zeros then ones) as start offsets into the device buffer."""
         half = batchsize // 2
+        # same np.random consumption order as build_verification_batch (reference librispeech.py:179-189)
         alike = self.get_alike_pairs(half)
+        l_a = self.window_starts([i for i, _ in alike])
+        r_a = self.window_starts([j for _, j in alike])
         differing = self.get_differing_pairs(half)
-        left = [i for i, _ in alike] + [i for i, _ in differing]
-        right = [j for _, j in alike] + [j for _, j in differing]
+        l_d = self.window_starts([i for i, _ in differing])
+        r_d = self.window_starts([j for _, j in differing])
         outputs = np.append(np.zeros(half), np.ones(half))[:, np.newaxis]
-        return self.window_starts(left), self.window_starts(right), outputs
+        return np.concatenate([l_a, l_d]), np.concatenate([r_a, r_d]), outputs
 
     def build_verification_batch_device(self, batchsize):
         """``build_verification_batch`` with the two inputs as ``DeviceWindows`` (needs ``to_device()`` first)."""
