@@ -29,8 +29,6 @@ import torch
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
-MFMA_BF16_SUSTAINED_TF = 1880.0  # what the matrix pipes sustain from registers: the chip clocks at 1.79 GHz with every SIMD issuing
-                                 # MFMAs back to back (tools/probe/mfma_valu_probe.hip, profiles/r01_mfma_valu_issue_probe.txt)
 TRAIN_BYTES_PER_WINDOW = 44.02e6   # algorithmic HBM bytes per 3 s window, training, S4k, bf16
 TRAIN_FLOPS_PER_WINDOW = 7.373e9
 
@@ -108,19 +106,17 @@ def main():
         eng.preprocess(pl, xcat, 4, True, pairs)
         eng.forward(pl, pairs, None)
         eng.siamese_head(pl, y, a.loss)
-        eng.backward(pl)
+        eng.backward(pl, sync_tail=True)   # N > 1: the large gradient all-reduce starts before block 1's backward
         eng.optimizer_step()
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     parallel.barrier()
-    # With the side-stream wgrad the backward kernels run concurrently and their durations are not attributable; the forward
-    # GEMMs never overlap anything and are the largest family of the serial breakdown as well (profiles/*breakdown*).
-    if a.dominant == "auto":
-        families = ["vm_conv_fwd"] if eng.overlap_wgrad else ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
-    else:
-        families = [a.dominant]
+    # Inside the timed region only the forward GEMMs are event-bracketed when the weight-gradient GEMMs run on the side stream
+    # (the backward kernels then overlap and their durations are not attributable); all three GEMM families are attributed by
+    # a SERIAL pass after the timed region (below) and the roofline object describes the family that is largest there.
+    families = ["vm_conv_fwd"] if eng.overlap_wgrad else ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
     eng.timed = {nm: [] for nm in families}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -130,9 +126,7 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
-    totals = {nm: sum(e0.elapsed_time(e1) for e0, e1, _ in eng.timed[nm]) for nm in families}
-    a.dominant = max(totals, key=totals.get)
-    recs = eng.timed[a.dominant]
+    in_region = {nm: sum(e0.elapsed_time(e1) for e0, e1, _ in eng.timed[nm]) / a.steps for nm in families}
     eng.timed = {}
     loss = float(pl["loss_acc"][0].item())
     assert np.isfinite(loss) or a.tune, "training diverged"
@@ -141,15 +135,39 @@ def main():
     value = windows * 3.0 / dt
     ms = dt / a.steps * 1e3
 
-    # ---- roofline of the dominant kernel: slowest launch family of that entry point ----------------------------
+    # ---- serial attribution pass (untimed, after the timed region): the same step with the weight-gradient GEMMs on the main
+    # stream, every GEMM launch bracketed by HIP events on its launch stream; median over the repetitions per launch shape ----
     esize = 2 if a.dtype == "bf16" else 4
-    by_shape = {}
-    for e0, e1, args in recs:
-        key = tuple(conv_launch_work(a.dominant, args, esize)[2].values())
-        by_shape.setdefault(key, []).append((e0.elapsed_time(e1) * 1e-3, args))
-    worst = max(by_shape.values(), key=lambda v: sum(t for t, _ in v))
-    t_avg = sum(t for t, _ in worst) / len(worst)
-    nbytes, nflops, shape = conv_launch_work(a.dominant, worst[0][1], esize)
+    gemm = ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
+    was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False
+    snap0 = (eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.NT.clone(), eng.iterations)
+    eng.timed = {nm: [] for nm in gemm}
+    att_reps = max(5, min(a.steps, 20))
+    for _ in range(att_reps):
+        step()
+    torch.cuda.synchronize()
+    fam = {}
+    for nm in gemm:
+        by_shape = {}
+        for e0, e1, args in eng.timed[nm]:
+            nb_, nf_, shp = conv_launch_work(nm, args, esize)
+            by_shape.setdefault(tuple(shp.values()), []).append(e0.elapsed_time(e1) * 1e-3)
+        launches = []
+        for key, ts in by_shape.items():
+            t_med = float(np.median(ts))
+            nb_, nf_, shp = conv_launch_work(nm, (None,) * {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[nm] + key, esize)
+            launches.append({"shape": shp, "ms": t_med * 1e3, "tflops": nf_ / t_med / 1e12, "gbs": nb_ / t_med / 1e9,
+                             "algorithmic_bytes": nb_, "flops": nf_})
+        fam[nm] = {"ms_per_step": sum(l["ms"] for l in launches), "launches": launches}
+    eng.timed = {}
+    eng.overlap_wgrad = was_overlap
+    eng.P.copy_(snap0[0]); eng.M.copy_(snap0[1]); eng.V.copy_(snap0[2]); eng.NT.copy_(snap0[3]); eng.iterations = snap0[4]
+    eng.refresh_weights()
+    if a.dominant == "auto":
+        a.dominant = max(fam, key=lambda k: fam[k]["ms_per_step"])
+    worst = max(fam[a.dominant]["launches"], key=lambda l: l["ms"])
+    t_avg = worst["ms"] * 1e-3
+    nbytes, nflops, shape = worst["algorithmic_bytes"], worst["flops"], worst["shape"]
     ai = nflops / nbytes
     ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
     if ai < ridge:
@@ -157,9 +175,6 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": nflops / t_avg / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    if roof["bound"] == "mfma":  # side figure: against the measured sustained matrix rate instead of the nominal peak
-        roof["sustained_peak_measured"] = MFMA_BF16_SUSTAINED_TF
-        roof["frac_of_sustained"] = roof["achieved"] / MFMA_BF16_SUSTAINED_TF
     roof["algorithmic_bytes"] = nbytes
     roof["traffic"] = None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), if this shape was profiled
@@ -169,9 +184,17 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     roof["kernel"] = a.dominant
-    roof["family_ms_per_step"] = {nm: totals[nm] / a.steps for nm in families}
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
+    # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense bf16 peak) and algorithmic GB/s
+    roof["families_serial"] = {nm: {"ms_per_step": round(f["ms_per_step"], 4),
+                                    "frac_of_mfma_peak": round(sum(l["flops"] for l in f["launches"]) / (f["ms_per_step"] * 1e-3) / 1e12
+                                                               / MFMA_BF16_PEAK_TF, 4),
+                                    "launches": [{"L": l["shape"]["L"], "c_in": l["shape"]["c_in"], "c_out": l["shape"]["c_out"],
+                                                  "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
+                                                  "algorithmic_gbs": round(l["gbs"], 1)} for l in f["launches"]]}
+                               for nm, f in fam.items()}
+    roof["family_ms_per_step_in_timed_region"] = in_region
     roof["step_hbm_frac"] = TRAIN_BYTES_PER_WINDOW * (2 * pairs * a.steps / dt) / (HBM_PEAK_GBS * 1e9)
     roof["step_mfma_frac"] = TRAIN_FLOPS_PER_WINDOW * (2 * pairs * a.steps / dt) / (MFMA_BF16_PEAK_TF * 1e12)
 
@@ -274,10 +297,14 @@ def main():
         arch = O.EncoderArch.baseline(F, E, dropout=0.0)
         cpu_pairs, cpu_steps = 8, 4
         sec, threads = O.time_cpu_train_steps(arch, cpu_pairs, cpu_steps, loss=a.loss, threads=None)
+        trials = getattr(O.time_cpu_train_steps, "last_trials", {})
         out["cpu_baseline"] = {"value": 2 * cpu_pairs * 3.0 / sec, "unit": "audio-s/s", "cores": threads, "kind": "port",
-                               "sample": "<=%d steps of %d pairs, cfg-A, same step definition (fp32 torch-CPU oracle, best of a "
-                                         "few intra-op thread counts on a %d-cpu host, %.0f ms/step)"
-                                         % (cpu_steps, cpu_pairs, os.cpu_count() or 1, sec * 1e3)}
+                               "host_cpu_count": os.cpu_count() or 1,
+                               "threads_tried_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(trials.items())},
+                               "sample": "<=%d steps of %d pairs, cfg-A, same step definition (fp32 torch-CPU oracle, best of the "
+                                         "intra-op thread counts listed in threads_tried on a %d-cpu host: a batch of %d pairs does "
+                                         "not scale to every core; %.0f ms/step)"
+                                         % (cpu_steps, cpu_pairs, os.cpu_count() or 1, cpu_pairs, sec * 1e3)}
     if rank == 0:
         print(json.dumps(out))
 

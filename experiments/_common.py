@@ -75,9 +75,23 @@ def standard_callbacks(a, valid, preprocessor, mode, param_str, plateau_patience
             ReduceLROnPlateau(monitor=key, mode="max", verbose=1, patience=plateau_patience)]
 
 
-def seed_everything(seed=0):
-    """np.random drives the pair / task sampling; torch's global generator seeds the weight initialisers and, through the
-    engine's own generator, the SpatialDropout1D masks (HipEncoderEngine.init_params)."""
+def seed_everything(seed=0, rank=0):
+    """np.random drives the pair / task sampling (a different stream per data-parallel rank: every rank draws its own
+    batches); torch's global generator seeds the weight initialisers and, through the engine's own generator, the
+    SpatialDropout1D masks (HipEncoderEngine.init_params) -- the same on every rank, and rank 0's state is broadcast anyway."""
     import torch
-    np.random.seed(seed)
+    np.random.seed(seed + 100003 * rank)
     torch.manual_seed(seed)
+
+
+def setup(seed=0):
+    """First call of every script: join the torchrun process group if there is one (one process per GPU; `python -m
+    torch.distributed.run --nproc-per-node N -m experiments.train_siamese ...`), bind this process to its GPU, seed.
+    Returns (rank, world)."""
+    import torch
+    from voicemap_amd import parallel
+    rank, world, local = parallel.init_distributed()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    seed_everything(seed, rank)
+    return rank, world

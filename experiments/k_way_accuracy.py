@@ -24,6 +24,9 @@ def main(argv=None):
     p.add_argument("--distance", default="dot_product", choices=["euclidean", "cosine", "dot_product"])
     p.add_argument("--synthetic", action="store_true")
     a = p.parse_args(argv)
+    # under torchrun the tasks of every (k, n) cell are sharded over the ranks (BASELINE.json config 5); rank 0 writes the CSV
+    from experiments._common import setup
+    rank, _ = setup()
     if a.synthetic:
         valid = SyntheticSpeechDataset(num_speakers=40, files_per_speaker=12, seconds=a.n_seconds, stochastic=False, seed=1)
     else:
@@ -34,15 +37,17 @@ def main(argv=None):
         nets.append(("classifier", "classifier", load_model(a.classifier)))
     out = PATH + "/logs/k-way_n-shot_accuracy_{}_{}.csv".format(a.validation_set, a.distance)
     rows = []
-    with open(out, "w") as f:
-        f.write("method,n_correct,n_tasks,n_shot,k_way\n")
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("method,n_correct,n_tasks,n_shot,k_way\n")
     for k in a.k_way:
         for n in a.n_shot:
             for method, kind, net in nets:
                 correct = n_shot_task_evaluation(net, valid, pre, a.num_tasks, n, k, network_type=kind, distance=a.distance)
                 rows.append({"method": method, "n_correct": correct, "n_tasks": a.num_tasks, "n": n, "k": k})
-                with open(out, "a") as f:
-                    f.write("{},{},{},{},{}\n".format(method, correct, a.num_tasks, n, k))
+                if rank == 0:
+                    with open(out, "a") as f:
+                        f.write("{},{},{},{},{}\n".format(method, correct, a.num_tasks, n, k))
     return pd.DataFrame(rows)
 
 

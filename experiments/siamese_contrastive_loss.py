@@ -11,7 +11,7 @@ from voicemap_amd.utils import BatchPreProcessor, NShotEvaluationCallback, contr
 def main(argv=None):
     p = C.base_parser(__doc__, batchsize=32, filters=32, embedding_dimension=128, dropout=0.05, epochs=25, pad=False)
     a = p.parse_args(argv)
-    C.seed_everything()
+    C.setup()
     train, valid = C.datasets(a, pad=False)
     whiten_downsample = BatchPreProcessor("siamese", preprocess_instances(a.downsampling, whitening=True))
     stream = lambda ds: (whiten_downsample(b) for b in ds.yield_verification_batches(a.batchsize))

@@ -33,7 +33,7 @@ class ShuffledBatches(Sequence):
 
 def main(argv=None):
     a = C.base_parser(__doc__, pad=False).parse_args(argv)
-    C.seed_everything()
+    C.setup()
     train, valid = C.datasets(a, pad=False)
     ids = sorted(train.df["speaker_id"].unique())
     index_of = {s: i for i, s in enumerate(ids)}

@@ -9,7 +9,7 @@ from voicemap_amd.utils import BatchPreProcessor, preprocess_instances
 
 def main(argv=None):
     a = C.base_parser(__doc__).parse_args(argv)
-    C.seed_everything()
+    C.setup()
     train, valid = C.datasets(a, pad=a.pad)
     pre = BatchPreProcessor("siamese", preprocess_instances(a.downsampling))
     batches = lambda ds: (pre(b) for b in ds.yield_verification_batches(a.batchsize))

@@ -592,9 +592,10 @@ def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contra
     backward + clip + Adam) on a bounded sample, on the host cores.  With ``threads=None`` a few intra-op
     thread counts are tried for one step each (a small batch does not scale to hundreds of cores; the best
     count is what a user of the CPU path would run) and the best is used for the timed steps.
-    Returns (seconds_per_step, threads_used)."""
+    Returns (seconds_per_step, threads_used); ``time_cpu_train_steps.last_trials`` holds {threads: seconds of the trial step}."""
     import os
     import time
+    time_cpu_train_steps.last_trials = {}
     x1, x2, y = synthetic_pairs(batch_pairs, seed)
     pre = preprocess_instances(downsampling)
     yt = torch.tensor(y)
@@ -624,6 +625,7 @@ def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contra
                 break
             torch.set_num_threads(c)
             t = run(1, time.perf_counter() + budget_s * 0.15)
+            time_cpu_train_steps.last_trials[c] = t
             if best_t is None or t < best_t:
                 best, best_t = c, t
         threads = best

@@ -1394,6 +1394,251 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT GEMM, 256 (positions) x 128 (channels) output tile, 4 waves (2 x 2, 128 x 64 each), TWO workgroups per CU (bf16).
+//
+// Why this shape (round 2).  At cfg-A an output tile sees only K = 384..1536, i.e. a 256 x 256 tile is 6..24 K tiles of 64 and
+// then an epilogue that has to push 128 KB through a store path that issues ~7..10 B/clk/CU: in the one-workgroup-per-CU
+// kernels (conv_nt8_kernel, conv_w4_kernel) that epilogue and the cold start of the next tile are a quarter of the tile time
+// with the matrix pipes idle (profiles/r01_gemm_w4_structure_probe.txt: cold start 6.5k + epilogue 10.5k of 69k cycles), and
+// making the K stream persistent inside a workgroup did not help (tools/probe/conv_w4p_probe: 364 us against 280 us).  The
+// 128^2 kernels do overlap epilogues with other workgroups' main loops (2-3 per CU) but their 64 x 64 wave tiles need 1 KB of
+// fragment reads per MFMA and 2 x 128 rows of DMA per 4 MFMA-steps: LDS-bound outright.  This kernel keeps the 128 x 64 wave
+// tile of conv_nt8_kernel (0.75 KB of fragment reads per MFMA, 128 accumulator registers -> 256 registers per wave -> two
+// waves per SIMD) but gives each group of four waves its OWN output tile and its own 72 KB of LDS, as an independent workgroup:
+// two of them share a CU, drift apart, and one's epilogue / cold start runs under the other's MFMAs.  Per MFMA the DMA bytes
+// are (256 + 128) / (256 * 128) against (128 + 128) / (128 * 128) of the 128^2 kernels: -25 %.
+//
+// K slices of 64 bytes (32 bf16) in a ring of three 24 KB stages (A 256 rows + B 128 rows, unpadded, 16-byte chunk c of row R at
+// c ^ ((R >> 2) & 3): swizzle applied to the per-lane SOURCE address of the LDS-DMA and again by the fragment reads); K is
+// walked (channel chunk, tap) so that consecutive slices re-read the same input cache lines one row later.  One counted
+// s_waitcnt vmcnt(6) (= the 6 pieces of the slice that may still fly) + one raw s_barrier per slice.
+//   RAW: a wave waits for its own pieces of slice kt, then the barrier: after it every wave's pieces of slice kt have landed.
+//   WAR: slice kt+2 is staged into the stage read in iteration kt-1, after barrier kt, which every wave reaches only with all
+//        its fragment reads of iteration kt-1 issued and consumed by its MFMAs.
+// Epilogue: (bias + ReLU,) bf16 in registers, tile through LDS ([256][272 B]), whole-row 16-byte stores, forward statistics of
+// the stored (rounded) values as two partial rows per tile (one per 128 positions: the layout of vm_conv_stat_rows).
+// Requires a_c % 32 == 0, Ktot == 3 * a_c, N % 128 == 0.
+// ------------------------------------------------------------------------------------------------
+namespace n2 {
+constexpr int TM = 256, TN = 128, KB = 64, RING = 3;
+constexpr int A_BYTES = TM * KB, B_BYTES = TN * KB, STAGE = A_BYTES + B_BYTES;
+constexpr int TP = TN * 2 + 16;
+constexpr int LDS_BYTES = (RING * STAGE > TM * TP + 8192) ? RING * STAGE : TM * TP + 8192;  // tile + 8 KB of statistics partials
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+}  // namespace n2
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_t n_groups) {
+    using namespace n2;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int chunks = p.a_c / 32, nk = chunks * 3;
+    const int row_bytes = p.a_c * 2;
+
+    // tile of this workgroup; the n-tiles of one (window, t-tile) group go to workgroups 8 apart (same XCD, dispatched together)
+    int64_t group;
+    int tn;
+    {
+        const int64_t v = blockIdx.x;
+        if (p.order == 1 && (n_groups & 7) == 0) {
+            const int64_t j = v >> 3;
+            tn = (int)(j % p.tilesN);
+            group = (j / p.tilesN) * 8 + (v & 7);
+        } else {
+            group = v / p.tilesN;
+            tn = (int)(v % p.tilesN);
+        }
+    }
+    const int tl = (int)(group % p.tilesL);
+    const int64_t n = group / p.tilesL;
+    const int t0 = tl * TM, n0 = tn * TN;
+
+    // ---- DMA sources: one instruction = 16 rows x 64 B, lane -> (row lane/4, physical chunk lane%4) ----
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const char* a_src[4];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w + 4 * i) * 16 + lrow;
+        int t = t0 + row;
+        t = t < p.L ? t : p.L - 1;
+        a_src[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)t * p.a_c) + ((lchunk ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (w + 4 * i) * 16 + lrow;
+        b_src[i] = reinterpret_cast<const char*>(p.bt + (int64_t)(n0 + row) * p.Ktot) + ((lchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    auto issue = [&](int stage, int ko) {
+        char* base = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(a_src[i] + ko, base + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(b_src[i] + ko, base + A_BYTES + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
+    };
+
+    // ---- fragment geometry: lane (r, kh) reads chunk 2s + kh of its row ----
+    const int r = lane & 31, kh = lane >> 5;
+    int fa[4], fb[2], key_a[4], key_b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + 32 * i + r;
+        fa[i] = row * KB;
+        key_a[i] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + 32 * j + r;
+        fb[j] = A_BYTES + row * KB;
+        key_b[j] = (row >> 2) & 3;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // K walk (chunk, tap): slice kt -> byte offset tap * row_bytes + chunk * 64 in an im2col / weight row
+    int i_tap = 0, i_ko = 0, i_chunk_off = 0;  // of the next slice to ISSUE
+    auto advance = [&]() {
+        ++i_tap;
+        i_ko += row_bytes;
+        if (i_tap == 3) {
+            i_tap = 0;
+            i_chunk_off += KB;
+            i_ko = i_chunk_off;
+        }
+    };
+    issue(0, i_ko);
+    advance();
+    if (nk > 1) {
+        issue(1, i_ko);
+        advance();
+    }
+    int stage = 0, istage = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) {
+            issue(istage, i_ko);
+            advance();
+            istage = istage == 2 ? 0 : istage + 1;
+        }
+        const char* base = lds + stage * STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+        // all 12 fragment reads of the slice are issued up front, in the order the MFMAs consume them (the compiler then waits with
+        // counted lgkmcnt): the k-step-1 reads land under the 8 MFMAs of k-step 0, and what is exposed of the first reads is covered
+        // by the other workgroup's wave on this SIMD
+        bf16x8 a0[4], b0[2], a1[4], b1[2];
+        b0[0] = *reinterpret_cast<const bf16x8*>(base + fb[0] + ((kh ^ key_b[0]) << 4));
+        a0[0] = *reinterpret_cast<const bf16x8*>(base + fa[0] + ((kh ^ key_a[0]) << 4));
+        b0[1] = *reinterpret_cast<const bf16x8*>(base + fb[1] + ((kh ^ key_b[1]) << 4));
+#pragma unroll
+        for (int i = 1; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8*>(base + fa[i] + ((kh ^ key_a[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const bf16x8*>(base + fb[j] + (((2 + kh) ^ key_b[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(base + fa[i] + (((2 + kh) ^ key_a[i]) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
+
+    // ---- epilogue: registers -> bf16 tile in LDS ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_FWD) b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm * 128 + i * 32 + r;
+                bf16 o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * g + e] + b4[e];
+                    if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
+                    o[e] = (bf16)x;
+                }
+                *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = *reinterpret_cast<const u32x2*>(o);
+            }
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;
+    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
+    float* red = reinterpret_cast<float*>(lds + TM * TP);  // [half][wave][sum | square][128] floats = 8 KB
+    bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float s8[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int row = h * 128 + rg + 16 * jj;
+            if (t0 + row < p.L) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row * TP + c8 * 16);
+                *reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N) = v;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)v[e];
+                        s8[e] += x;
+                        q8[e] = fmaf(x, x, q8[e]);
+                    }
+                }
+            }
+        }
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s8[e] += __shfl_xor(s8[e], 16, 64);
+                s8[e] += __shfl_xor(s8[e], 32, 64);
+                q8[e] += __shfl_xor(q8[e], 16, 64);
+                q8[e] += __shfl_xor(q8[e], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[((h * 4 + w) * 2 + 0) * 128 + c8 * 8 + e] = s8[e];
+                    red[((h * 4 + w) * 2 + 1) * 128 + c8 * 8 + e] = q8[e];
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        const int h = tid >> 7, c = tid & 127;
+        const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
+        if (2 * tl + h < srows) {
+            const float* rr = red + h * 4 * 2 * 128;
+            const int64_t srow = n * srows + 2 * tl + h;
+            p.stat_sum[srow * p.N + n0 + c] = (rr[0 * 128 + c] + rr[2 * 128 + c]) + (rr[4 * 128 + c] + rr[6 * 128 + c]);
+            p.stat_sq[srow * p.N + n0 + c] = (rr[1 * 128 + c] + rr[3 * 128 + c]) + (rr[5 * 128 + c] + rr[7 * 128 + c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
 // of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
 // 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
@@ -2291,6 +2536,21 @@ int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tu
 // block-4 forward against 265 us for conv_nt8_kernel (profiles/r01_conv_w4_probe.txt).
 int g_nt_w4 = 0;
 
+// conv_nt2_kernel (256 x 128 tiles, two workgroups per CU): vm_set_tuning("nt_n2", 0 | 1 | 2 | 3): 0 off, 1 forward, 2 dgrad, 3 both
+int g_nt_n2 = 0;
+template <int EPI>
+static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
+    if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c || a.ablate != 0) return false;
+    NtArgs<bf16> b = a;
+    b.tilesL = (a.L + n2::TM - 1) / n2::TM;
+    b.tilesN = a.N / n2::TN;
+    const int64_t n_groups = n_windows * b.tilesL;
+    const int64_t grid = n_groups * b.tilesN;
+    if (grid >= (1LL << 31)) return false;
+    hipLaunchKernelGGL((conv_nt2_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b, n_groups);
+    return true;
+}
+
 template <int EPI>
 static bool launch_w4(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
     const int tl254 = (a.L + w4::TROWS - 1) / w4::TROWS;
@@ -2311,6 +2571,7 @@ template <typename T, int EPI>
 static bool launch_nt8(const NtArgs<T>&, int64_t, hipStream_t) { return false; }
 template <int EPI>
 static bool launch_nt8_bf16(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
+    if (launch_n2<EPI>(a, n_windows, stream)) return true;
     if (launch_w4<EPI>(a, n_windows, stream)) return true;
     if (!g_nt_p8 || (g_nt_p8 == 2 && a.Ktot < 1152) || a.N % 256 != 0 || a.Ktot % 64 != 0 || a.Ktot < 192 || a.a_c % 8 != 0 ||
         n_windows * ((a.L + 255) / 256) * (a.N / 256) >= (1LL << 30)) return false;
@@ -2593,6 +2854,10 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_korder") == 0) {
         g_nt_p8_korder = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_n2") == 0 && value >= 0 && value <= 3) {
+        g_nt_n2 = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_w4") == 0 && value >= 0 && value <= 2) {

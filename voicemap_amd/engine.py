@@ -34,6 +34,68 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def flat_layout(blocks: Sequence[Tuple[int, int, int]], embedding_dimension: int, head: Optional[str], num_classes: int = 0):
+    """Layout of the flat fp32 buffers (parameters / gradients / Adam slots share it): tensors in Keras ``trainable_weights``
+    order, each starting on a 64-element boundary, and the non-trainable BatchNorm moving statistics in a second buffer.
+    Returns (spec, offsets {name: (offset, size, shape)}, n_flat, nt_off {name: (offset, size)}, n_nt).  Pure host code:
+    parallel.py's collectives and the CPU tests use the same layout the engine does."""
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+    for i, (k, c, _) in enumerate(blocks):
+        cin = 1 if i == 0 else blocks[i - 1][1]
+        spec += [(f"conv{i+1}.kernel", (k, cin, c)), (f"conv{i+1}.bias", (c,)),
+                 (f"bn{i+1}.gamma", (c,)), (f"bn{i+1}.beta", (c,))]
+    cl = blocks[-1][1]
+    E = int(embedding_dimension)
+    spec += [("dense.kernel", (cl, E)), ("dense.bias", (E,))]
+    if head == "uniform_euclidean":
+        spec += [("head.kernel", (1, 1)), ("head.bias", (1,))]
+    elif head == "weighted_l1":
+        spec += [("head.kernel", (E, 1)), ("head.bias", (1,))]
+    elif head == "classifier":
+        spec += [("head.kernel", (E, num_classes)), ("head.bias", (num_classes,))]
+    elif head is not None:
+        raise NotImplementedError(head)
+    offsets: Dict[str, Tuple[int, int, Tuple[int, ...]]] = OrderedDict()
+    off = 0
+    for name, shape in spec:
+        n = int(np.prod(shape))
+        offsets[name] = (off, n, shape)
+        off += _align(n)
+    n_flat = off
+    nt_off: Dict[str, Tuple[int, int]] = OrderedDict()
+    off = 0
+    for i, (_, c, _) in enumerate(blocks):
+        nt_off[f"bn{i+1}.moving_mean"] = (off, c)
+        off += _align(c)
+        nt_off[f"bn{i+1}.moving_variance"] = (off, c)
+        off += _align(c)
+    return spec, offsets, n_flat, nt_off, off
+
+
+class FlatState:
+    """The flat buffers themselves (P parameters, G gradients, M / V Adam slots, NT moving statistics) on ``device``."""
+
+    def __init__(self, blocks, embedding_dimension, head, num_classes, device):
+        self.spec, self.offsets, self.n_flat, self.nt_off, n_nt = flat_layout(blocks, embedding_dimension, head, num_classes)
+        self.n_params = sum(n for _, n, _ in self.offsets.values())
+        self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.NT = torch.zeros(n_nt, dtype=torch.float32, device=device)
+        self.iterations = 0
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if name in self.nt_off:
+            o, n = self.nt_off[name]
+            return self.NT[o:o + n]
+        o, n, shape = self.offsets[name]
+        return (self.P if buf is None else buf)[o:o + n].view(shape)
+
+    def refresh_weights(self):  # the engine re-derives its GEMM-layout weight copies here
+        pass
+
+
 class HipEncoderEngine:
     """The voicemap encoder (voicemap/models.py:6-41) + optional head on one MI355X.
 
@@ -70,44 +132,14 @@ class HipEncoderEngine:
         self.fuse_block1 = self.dtype == VM_BF16 and self.blocks[0][2] in (2, 4)
 
         # ---- flat parameter store, Keras trainable_weights order -------------------------------------
-        spec: List[Tuple[str, Tuple[int, ...]]] = []
-        for i, (k, c, _) in enumerate(self.blocks):
-            cin = 1 if i == 0 else self.blocks[i - 1][1]
-            spec += [(f"conv{i+1}.kernel", (k, cin, c)), (f"conv{i+1}.bias", (c,)),
-                     (f"bn{i+1}.gamma", (c,)), (f"bn{i+1}.beta", (c,))]
-        cl = self.blocks[-1][1]
-        spec += [("dense.kernel", (cl, self.E)), ("dense.bias", (self.E,))]
-        if head == "uniform_euclidean":
-            spec += [("head.kernel", (1, 1)), ("head.bias", (1,))]
-        elif head == "weighted_l1":
-            spec += [("head.kernel", (self.E, 1)), ("head.bias", (1,))]
-        elif head == "classifier":
-            assert num_classes > 0
-            spec += [("head.kernel", (self.E, num_classes)), ("head.bias", (num_classes,))]
-        elif head is not None:
+        if head not in (None, "uniform_euclidean", "weighted_l1", "classifier"):
             raise NotImplementedError(head)
-        self.spec = spec
-        self.offsets: Dict[str, Tuple[int, int, Tuple[int, ...]]] = OrderedDict()
-        off = 0
-        for name, shape in spec:
-            n = int(np.prod(shape))
-            self.offsets[name] = (off, n, shape)
-            off += _align(n)
-        self.n_flat = off
-        self.n_params = sum(n for _, n, _ in self.offsets.values())
+        assert head != "classifier" or num_classes > 0
+        st = FlatState(self.blocks, self.E, head, self.num_classes, self.device)
+        self.spec, self.offsets, self.n_flat, self.n_params = st.spec, st.offsets, st.n_flat, st.n_params
+        self.P, self.G, self.M, self.V = st.P, st.G, st.M, st.V
+        self.nt_off, self.NT = st.nt_off, st.NT
         dev = self.device
-        self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
-        self.G = torch.zeros_like(self.P)
-        self.M = torch.zeros_like(self.P)
-        self.V = torch.zeros_like(self.P)
-        self.nt_off: Dict[str, Tuple[int, int]] = OrderedDict()
-        off = 0
-        for i, (_, c, _) in enumerate(self.blocks):
-            self.nt_off[f"bn{i+1}.moving_mean"] = (off, c)
-            off += _align(c)
-            self.nt_off[f"bn{i+1}.moving_variance"] = (off, c)
-            off += _align(c)
-        self.NT = torch.zeros(off, dtype=torch.float32, device=dev)
         self.wf: Dict[int, torch.Tensor] = {}
         self.wd: Dict[int, torch.Tensor] = {}
         for i in range(1, self.nb):
@@ -381,9 +413,13 @@ class HipEncoderEngine:
                  _p(pl["emb"]), st)
         return pl["emb"]
 
-    def backward(self, pl: dict):
-        """pl['demb'] -> gradients of every encoder tensor in self.G (fixed summation order throughout)."""
+    def backward(self, pl: dict, sync_tail: bool = False):
+        """pl['demb'] -> gradients of every encoder tensor in self.G (fixed summation order throughout).  ``sync_tail``
+        (data parallelism, set by the train steps that go on to ``optimizer_step``): as soon as the gradients of blocks 2..n,
+        the dense layer and the head are enqueued, hand G[conv2.kernel:] to ``grad_sync.begin_tail`` so that its all-reduce
+        overlaps the block-2 dgrad and the whole block-1 backward (voicemap_amd/parallel.py)."""
         assert pl["training"]
+        sync_tail = sync_tail and self.grad_sync is not None and hasattr(self.grad_sync, "begin_tail")
         lib, st, n, dt, wpt = self.lib, self.stream(), pl["n"], self.dtype, pl["wpt"]
         drop = pl["drop"]
         cl, Ll = self.blocks[-1][1], pl["L"][-1]
@@ -440,6 +476,11 @@ class HipEncoderEngine:
                                    self.stream())
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, st)
+                if i == 1 and sync_tail:
+                    if "sync_ev" not in pl:
+                        pl["sync_ev"] = torch.cuda.Event()
+                    pl["sync_ev"].record()  # main stream: every gradient of G[conv2.kernel:] that is not on the side stream
+                    self.grad_sync.begin_tail(self, pl["sync_ev"])
                 self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(pl[i - 1]["dp"]), st)
         if self.overlap_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
@@ -521,7 +562,7 @@ class HipEncoderEngine:
         yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
         self.forward(pl, pairs, drop_masks)
         self.siamese_head(pl, yd, loss)
-        self.backward(pl)
+        self.backward(pl, sync_tail=apply_update)
         if apply_update:
             self.optimizer_step()
         return pl
@@ -541,7 +582,7 @@ class HipEncoderEngine:
         yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
         self.forward(pl, pairs, drop_masks)
         self.siamese_head(pl, yd, loss)
-        self.backward(pl)
+        self.backward(pl, sync_tail=apply_update)
         if apply_update:
             self.optimizer_step()
         return pl
@@ -563,7 +604,7 @@ class HipEncoderEngine:
         lab = torch.as_tensor(labels).reshape(n).to(self.device, torch.int32).contiguous()
         self.forward(pl, n, drop_masks)
         self.classifier_head(pl, lab)
-        self.backward(pl)
+        self.backward(pl, sync_tail=apply_update)
         if apply_update:
             self.optimizer_step()
         return pl

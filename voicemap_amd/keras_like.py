@@ -196,6 +196,8 @@ class BatchFeeder:
 # callbacks
 # ---------------------------------------------------------------------------------------------------------
 class Callback:
+    rank0_only = False  # data-parallel fit_generator: callbacks that write files run on rank 0 only
+
     def __init__(self):
         self.model = None
         self.params = {}
@@ -239,6 +241,7 @@ class History(Callback):
 class CSVLogger(Callback):
     """keras.callbacks.CSVLogger: one row per epoch, columns = 'epoch' + sorted log keys
     (epoch, acc, loss, lr, val_1-shot_acc, val_acc, val_loss for the siamese script)."""
+    rank0_only = True
 
     def __init__(self, filename, separator=",", append=False):
         super().__init__()
@@ -275,6 +278,7 @@ class ModelCheckpoint(Callback):
     """keras.callbacks.ModelCheckpoint(filepath, monitor, mode, save_best_only, verbose).  Saves the full model
     (weights + Adam slots + BN moving statistics) with ``model.save``: a Keras-2.2.2 HDF5 file for ``*.hdf5`` / ``*.h5`` names
     (voicemap_amd/keras_hdf5.py), this package's ``.npz`` container otherwise."""
+    rank0_only = True
 
     def __init__(self, filepath, monitor="val_loss", verbose=0, save_best_only=False, save_weights_only=False, mode="auto",
                  period=1):

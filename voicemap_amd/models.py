@@ -198,8 +198,8 @@ class _TrainableModel:
         x0 = x[0] if isinstance(x, (list, tuple)) else x
         return int(x0.shape[0])
 
-    def evaluate_generator(self, generator, steps, workers=1, max_queue_size=10, use_multiprocessing=False):
-        feeder = generator if isinstance(generator, K.BatchFeeder) else K.BatchFeeder(generator, workers, max_queue_size)
+    def _evaluate_sums(self, feeder, steps):
+        """(samples, sum of loss x batch size, sum of acc x batch size) over ``steps`` batches of a BatchFeeder."""
         tot, wl, wa = 0, 0.0, 0.0
         for _ in range(steps):
             x, y = feeder.get()[:2]
@@ -208,9 +208,19 @@ class _TrainableModel:
             tot += n
             wl += l * n
             wa += a * n
+        return tot, wl, wa
+
+    def evaluate_generator(self, generator, steps, workers=1, max_queue_size=10, use_multiprocessing=False):
+        """Under torchrun every rank evaluates ceil(steps / world) batches of ITS generator and the sample-weighted means are
+        taken over all ranks (one small all-reduce)."""
+        from . import parallel
+        _, world = parallel.rank_world()
+        feeder = generator if isinstance(generator, K.BatchFeeder) else K.BatchFeeder(generator, workers, max_queue_size)
+        tot, wl, wa = self._evaluate_sums(feeder, -(-steps // world))
         if not isinstance(generator, K.BatchFeeder):
             feeder.close()
-        return [wl / max(tot, 1), wa / max(tot, 1)]
+        m = parallel.weighted_mean_logs({"loss": wl, "acc": wa}, tot)
+        return [m["loss"], m["acc"]]
 
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
                       validation_steps=None, class_weight=None, max_queue_size=10, workers=1, use_multiprocessing=False,
@@ -218,12 +228,24 @@ class _TrainableModel:
         """keras fit_generator as the scripts call it (experiments/train_siamese.py:65-94): `steps_per_epoch` training
         batches, then `validation_steps` validation batches with inference-mode BatchNorm, then the callbacks IN LIST
         ORDER (the n-shot callback must write logs['val_1-shot_acc'] before CSVLogger / ModelCheckpoint /
-        ReduceLROnPlateau read it).  Running means of loss / acc are weighted by batch size like Keras."""
-        self._ensure_engine()
+        ReduceLROnPlateau read it).  Running means of loss / acc are weighted by batch size like Keras.
+
+        Data parallel (new; the reference is single-device): launched under torchrun (one process per GPU, after
+        ``parallel.init_distributed()``) every rank runs this same loop on its OWN generator -- global batch = world x
+        batchsize -- with the gradient all-reduce hooked into the engine (voicemap_amd/parallel.py); replicas start from
+        rank 0's weights.  Epoch metrics are reduced over ranks, so every rank's callbacks see identical logs: callbacks that
+        write files (``rank0_only``: CSVLogger, ModelCheckpoint) run on rank 0 only, the others (ReduceLROnPlateau, the n-shot
+        evaluation, which shards its tasks over ranks) on every rank."""
+        from . import parallel
+        eng = self._ensure_engine()
+        rank, world = parallel.attach_if_distributed(eng)
+        if rank != 0:
+            verbose = 0
         if steps_per_epoch is None:
             steps_per_epoch = len(generator)
         history = K.History()
         cbs = list(callbacks or []) + [history]  # Keras appends History last: it sees what the other callbacks logged
+        cbs = [cb for cb in cbs if rank == 0 or not getattr(cb, "rank0_only", False)]
         for cb in cbs:
             cb.set_model(self)
             cb.set_params({"epochs": epochs, "steps": steps_per_epoch, "verbose": verbose})
@@ -246,7 +268,8 @@ class _TrainableModel:
                     wl += loss * n
                     wa += acc * n
                     K.run_callbacks(cbs, "on_batch_end", step, {"loss": loss, "acc": acc, "size": n})
-                logs = {"loss": wl / max(tot, 1), "acc": wa / max(tot, 1)}
+                logs = parallel.weighted_mean_logs({"loss": wl, "acc": wa}, tot)
+                logs = {"loss": logs["loss"], "acc": logs["acc"]}
                 if validation_data is not None:
                     if isinstance(validation_data, tuple):
                         vl, va = self.test_on_batch(validation_data[0], validation_data[1])

@@ -127,7 +127,23 @@ def n_shot_task_evaluation(model, dataset, preprocessor, num_tasks, n, k, networ
       batch (:153-154), class prototypes + distance (:159-206) on the GPU (vm_nshot_distances), correct iff argmin == 0.
 
     Tasks are sampled one by one with ``dataset.build_n_shot_task(k, n)`` exactly like the reference, but embedded in
-    batched launches (the per-task whitening batches are kept as towers of the preprocessing kernel)."""
+    batched launches (the per-task whitening batches are kept as towers of the preprocessing kernel).
+
+    Under torchrun (BASELINE.json config 5) the ``num_tasks`` tasks are sharded over the ranks: every rank samples and
+    evaluates its own ``parallel.shard_range`` share (tasks are independent draws) and the counts are summed with one
+    all-reduce, so every rank returns the global ``n_correct``."""
+    import torch
+    from . import parallel
+    rank, world = parallel.rank_world()
+    if world > 1:
+        lo, hi = parallel.shard_range(num_tasks, rank, world)
+        local = _n_shot_local(model, dataset, preprocessor, hi - lo, n, k, network_type, distance)
+        return int(round(parallel.sum_over_ranks(float(local))))
+    return _n_shot_local(model, dataset, preprocessor, num_tasks, n, k, network_type, distance)
+
+
+def _n_shot_local(model, dataset, preprocessor, num_tasks, n, k, network_type="siamese", distance="euclidean"):
+    """This rank's share of ``n_shot_task_evaluation``."""
     import torch
     if n < 1:
         raise ValueError("n must be >= 1")
