@@ -46,9 +46,9 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-NT_N2_DEFAULT = 0  # library default of vm_set_tuning("nt_n2", ..) -- keep in step with conv_gemm.hip g_nt_n2
+NT_N2_DEFAULT = 3  # library default of vm_set_tuning("nt_n2", ..) -- keep in step with conv_gemm.hip g_nt_n2
 GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "nt_korder": 0, "tn_p8": 1, "tn_x": 1,
-                 "nt_p8_blocks": 256, "nt_w4": 0, "nt_n2": NT_N2_DEFAULT}
+                 "nt_p8_blocks": 256, "nt_w4": 0, "nt_n2": NT_N2_DEFAULT, "nt_n2r": 1}
 
 
 @pytest.fixture
@@ -87,12 +87,13 @@ def test_conv_one_wave_per_simd_variant(n, l, cin, cout, gemm_kb):
     _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)
 
 
-@pytest.mark.parametrize("gemm_kb", [{"nt_n2": 3}, {"nt_n2": 0}], indirect=True, ids=["n2", "n2-off"])
+@pytest.mark.parametrize("gemm_kb", [{"nt_n2": 3}, {"nt_n2": 3, "nt_n2r": 0}, {"nt_n2": 0}], indirect=True, ids=["n2r", "n2", "n2-off"])
 @pytest.mark.parametrize("n,l,cin,cout", [(2, 300, 128, 256), (3, 520, 256, 512), (8, 300, 64, 256), (16, 1030, 256, 256), (8, 140, 64, 384),
                                           (2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512), (1, 129, 32, 128), (2, 5, 128, 128),
                                           (4, 3000, 128, 256), (4, 1500, 256, 384), (4, 750, 384, 512), (3, 131, 96, 32)])
 def test_conv_256x128_two_workgroups_per_cu_variant(n, l, cin, cout, gemm_kb):
-    """conv_nt2_kernel (bf16; vm_set_tuning("nt_n2", 1 forward | 2 dgrad | 3 both)): every shape with a channel count that is a
+    """conv_nt2r_kernel (input-resident A, 254-position tiles; where its statistics tiling fits) / conv_nt2_kernel (bf16;
+    vm_set_tuning("nt_n2", 1 forward | 2 dgrad | 3 both), "nt_n2r" 0 forces the plain form): every shape with a channel count that is a
     multiple of 32 on the K side and of 128 on the N side -- ragged last t-tiles (300, 520, 1030 ..., 5 < one tile), windows whose
     second statistics row of the last tile does not exist (129, 140, 650), cfg-A's own geometries; (131, 96, 32) falls back."""
     _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)

@@ -83,7 +83,8 @@ class OracleBackedSiamese:
                     st.grad_sync.begin_tail(st, None)   # HipEncoderEngine.backward, after block 2's gradients
                     st.grad_sync(st.G)                  # HipEncoderEngine.optimizer_step
                 g = {k: st.view(k, st.G).to(torch.float64) * st.grad_prescale for k in self.names}
-                new = O.adam_step(self.adam, {k: p[k] for k in self.names}, g, lr=st.lr, clipnorm=1.0)
+                self.adam.lr, self.adam.clipnorm = st.lr, 1.0
+                new = O.adam_step(self.adam, {k: p[k] for k in self.names}, g)
                 for k in self.names:
                     st.view(k).copy_(new[k].to(torch.float32).reshape(st.view(k).shape))
                 st.iterations += 1
@@ -91,8 +92,8 @@ class OracleBackedSiamese:
 
             def test_on_batch(self, x, y):
                 O = self.O
-                out = O.siamese_forward(self.arch, self._params(), torch.tensor(x[0]), torch.tensor(x[1]), training=False)
-                pr = out["p"].reshape(-1)
+                pr, _, _ = O.siamese_forward(self.arch, self._params(), torch.tensor(x[0]), torch.tensor(x[1]), training=False)
+                pr = pr.reshape(-1)
                 yt = torch.tensor(y).reshape(-1)
                 return float(O.contrastive_loss(yt, pr)), float(O.binary_accuracy(yt, pr))
 

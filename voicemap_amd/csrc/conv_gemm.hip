@@ -1427,6 +1427,116 @@ constexpr int LDS_BYTES = (RING * STAGE > TM * TP + 8192) ? RING * STAGE : TM * 
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 }  // namespace n2
 
+// accumulators start at the bias of their channel (forward) or 0 (dgrad): register 4g + e of block j <-> channel c0 + 32j + 8g + e
+template <int EPI>
+__device__ inline void n2_init_acc(const NtArgs<bf16>& p, f32x16 (&acc)[4][2], int c0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_FWD) b4 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[e];
+        }
+}
+
+// Shared epilogue of the 256 x 128 kernels below.  ``trows``: valid MFMA-tile rows (256, or 254 for the input-resident kernel).
+template <int EPI>
+__device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x16 (&acc)[4][2], int64_t n, int tl, int t0, int n0, int trows,
+                                   int tid, int lane, int w, int wm, int wn) {
+    using namespace n2;
+    const int r = lane & 31, kh = lane >> 5;
+    __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
+
+    // ---- epilogue: registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with
+    // it) and ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0
+    // included; rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm * 128 + i * 32 + r;
+                bf16 o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][4 * g + e];
+                u32x2 pk = *reinterpret_cast<const u32x2*>(o);
+                if (EPI == EPI_FWD) {
+                    uint32_t lo = pk[0], hi = pk[1];
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
+                    pk[0] = lo;
+                    pk[1] = hi;
+                }
+                *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;
+    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
+    float* red = reinterpret_cast<float*>(lds + TM * TP);  // [half][wave][sum | square][128] floats = 8 KB
+    bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float s8[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int row = h * 128 + rg + 16 * jj;
+            if (row < trows && t0 + row < p.L) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row * TP + c8 * 16);
+                if (p.ablate & 16) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N));
+                } else if (!(p.ablate & 1) && !((p.ablate & 32) && (jj & 1))) {
+                    *reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N) = v;
+                }
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)v[e];
+                        s8[e] += x;
+                        q8[e] = fmaf(x, x, q8[e]);
+                    }
+                }
+            }
+        }
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s8[e] += __shfl_xor(s8[e], 16, 64);
+                s8[e] += __shfl_xor(s8[e], 32, 64);
+                q8[e] += __shfl_xor(q8[e], 16, 64);
+                q8[e] += __shfl_xor(q8[e], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[((h * 4 + w) * 2 + 0) * 128 + c8 * 8 + e] = s8[e];
+                    red[((h * 4 + w) * 2 + 1) * 128 + c8 * 8 + e] = q8[e];
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        const int h = tid >> 7, c = tid & 127;
+        const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
+        if (2 * tl + h < srows) {
+            const float* rr = red + h * 4 * 2 * 128;
+            const int64_t srow = n * srows + 2 * tl + h;
+            p.stat_sum[srow * p.N + n0 + c] = (rr[0 * 128 + c] + rr[2 * 128 + c]) + (rr[4 * 128 + c] + rr[6 * 128 + c]);
+            p.stat_sq[srow * p.N + n0 + c] = (rr[1 * 128 + c] + rr[3 * 128 + c]) + (rr[5 * 128 + c] + rr[7 * 128 + c]);
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_t n_groups) {
     using namespace n2;
@@ -1495,12 +1605,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_
     }
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    n2_init_acc<EPI>(p, acc, n0 + wn * 64 + 4 * (lane >> 5));
 
     // K walk (chunk, tap): slice kt -> byte offset tap * row_bytes + chunk * 64 in an im2col / weight row
     int i_tap = 0, i_ko = 0, i_chunk_off = 0;  // of the next slice to ISSUE
@@ -1527,7 +1632,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) {
+        if (kt + 2 < nk && !(p.ablate & 8)) {
             issue(istage, i_ko);
             advance();
             istage = istage == 2 ? 0 : istage + 1;
@@ -1558,84 +1663,210 @@ __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
+    if (p.ablate & 2) {  // timing experiments: no epilogue at all (one store keeps the accumulators live)
+        if (acc[0][0][0] == 123.456f) p.out[0] = (bf16)acc[3][1][15];
+        return;
+    }
+    n2_epilogue<EPI>(p, lds, acc, n, tl, t0, n0, TM, tid, lane, w, wm, wn);
+}
 
-    // ---- epilogue: registers -> bf16 tile in LDS ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_FWD) b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = wm * 128 + i * 32 + r;
-                bf16 o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * g + e] + b4[e];
-                    if (EPI == EPI_FWD) x = x > 0.f ? x : 0.f;
-                    o[e] = (bf16)x;
-                }
-                *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = *reinterpret_cast<const u32x2*>(o);
-            }
+// ------------------------------------------------------------------------------------------------
+// conv_nt2_kernel with an INPUT-RESIDENT A operand (the structure of conv_w4_kernel / conv_tn8x_kernel applied to the
+// two-workgroups-per-CU tile).  Ablation of conv_nt2_kernel at cfg-A (us; forward 256->384 / dgrad 384->512): full 278 / 244,
+// no epilogue 204 / 196, no in-loop DMA 197 / 153, neither 142 / 136, DMA + fragment reads alone (no MFMA, no epilogue) 179 /
+// 175: the global -> LDS stream is the longest pole -- it moves 24 KB per 64 MFMAs, 85 FLOP per byte of L2 -> LDS traffic.
+// The A row of tap k at position t is input row t + k, so ONE staged block of 256 input rows x 32 channels serves the three
+// taps of a channel chunk: per chunk 16 KB of A + 3 x 8 KB of B instead of 3 x 24 KB (153 FLOP/B).  An output tile is 254
+// positions (MFMA rows 254, 255 are computed and dropped) so that a block is exactly 16 DMA instructions.
+//
+// Stream: K tile kt = 3 * chunk + tap.  B slices in a ring of three 8 KB stages (two ahead), A blocks in a ring of three 16 KB
+// blocks (block chunk+2 is issued during taps 0 and 1 of `chunk`: four slices of lead for the HBM-streamed operand).  Per wave
+// and iteration kt the issue order is  B(kt+2) [2 pieces], then half of A(chunk+2) [2 pieces, taps 0 and 1 only].
+//   RAW: iteration kt needs B(kt) (first issue of iteration kt-2; kt = 0, 1: prologue) and, at tap 0, A(chunk) (issued four or
+//        more slices earlier).  Loads complete in order, so s_waitcnt vmcnt(N) with N = pieces issued after B(kt), then the
+//        barrier.  N is computed from the schedule (tail iterations issue less).
+//   WAR: B(kt+2) overwrites the stage read in iteration kt-1, A(chunk+2) the block read during chunk-1; both are issued after
+//        barrier kt, which every wave reaches only when its reads of iteration kt-1 have been consumed.
+// Requires a_c % 32 == 0, Ktot == 3 * a_c, N % 128 == 0; forward with statistics: 2 * ceil(L / 254) == ceil(L / 128).
+// ------------------------------------------------------------------------------------------------
+namespace n2r {
+constexpr int TROWS = 254;
+constexpr int A_BLK = 256 * 64, B_STG = 128 * 64;
+constexpr int B0 = 3 * A_BLK;
+constexpr int OPER = 3 * A_BLK + 3 * B_STG;  // 72 KB
+static_assert(OPER <= n2::LDS_BYTES, "operand rings fit under the epilogue tile");
+}  // namespace n2r
+
+__device__ inline void wait_vm_0246(int n) {
+    if (n >= 6) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (n == 4) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (n == 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64_t n_groups) {
+    using namespace n2;
+    using namespace n2r;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int chunks = p.a_c / 32, nk = chunks * 3;
+    const int row_bytes = p.a_c * 2;
+
+    int64_t group;
+    int tn;
+    {
+        const int64_t v = blockIdx.x;
+        if (p.order == 1 && (n_groups & 7) == 0) {
+            const int64_t j = v >> 3;
+            tn = (int)(j % p.tilesN);
+            group = (j / p.tilesN) * 8 + (v & 7);
+        } else {
+            group = v / p.tilesN;
+            tn = (int)(v % p.tilesN);
         }
     }
-    __syncthreads();
-    const int c8 = tid & 15, rg = tid >> 4;
-    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
-    float* red = reinterpret_cast<float*>(lds + TM * TP);  // [half][wave][sum | square][128] floats = 8 KB
-    bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
+    const int tl = (int)(group % p.tilesL);
+    const int64_t n = group / p.tilesL;
+    const int t0 = tl * TROWS, n0 = tn * TN;
+
+    // ---- DMA sources: one instruction = 16 rows x 64 B; A block row R <-> padded input row t0 + R (clamped to the L + 2 rows) ----
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const char* a_src[4];
+    const char* b_src[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float s8[8], q8[8];
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w + 4 * i) * 16 + lrow;
+        int pr = t0 + row;
+        pr = pr < p.L + 2 ? pr : p.L + 1;
+        a_src[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)pr * p.a_c) + ((lchunk ^ ((row >> 2) & 3)) << 4);
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int row = (w + 4 * i) * 16 + lrow;
+        b_src[i] = reinterpret_cast<const char*>(p.bt + (int64_t)(n0 + row) * p.Ktot) + ((lchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    auto issue_a = [&](int blk, int chunk, int i0) {  // pieces i0, i0 + 1 of this wave's four
+        char* base = lds + blk * A_BLK;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int row = h * 128 + rg + 16 * jj;
-            if (t0 + row < p.L) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row * TP + c8 * 16);
-                *reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N) = v;
-                if (stats) {
+        for (int i = 0; i < 2; ++i) glds16(a_src[i0 + i] + chunk * KB, base + __builtin_amdgcn_readfirstlane((w + 4 * (i0 + i)) * 1024));
+    };
+    auto issue_b = [&](int stg, int ko) {
+        char* base = lds + B0 + stg * B_STG;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (float)v[e];
-                        s8[e] += x;
-                        q8[e] = fmaf(x, x, q8[e]);
+        for (int i = 0; i < 2; ++i) glds16(b_src[i] + ko, base + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
+    };
+
+    // ---- fragment geometry: A row of tap k = block row m + k.  The four 32-row blocks of a wave are 2048 bytes apart and share the
+    // swizzle key ((row >> 2) & 3 is unchanged by +32), so one address per (tap, k-step) serves them through the ds_read offset
+    // field; rows 256 / 257 (taps 1, 2 of the dropped outputs 254, 255) read whatever follows the block -- valid LDS, results unused ----
+    const int r = lane & 31, kh = lane >> 5;
+    int a_addr[3][2], b_addr[2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int row = wm * 128 + r + tap;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_addr[tap][ks] = row * KB + (((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
+    }
+    {
+        const int row = wn * 64 + r;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_addr[ks] = B0 + row * KB + (((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[4][2];
+    n2_init_acc<EPI>(p, acc, n0 + wn * 64 + 4 * (lane >> 5));
+
+    // ---- prologue: A(0), B(0), A(1), B(1) in that order ----
+    issue_a(0, 0, 0);
+    issue_a(0, 0, 2);
+    issue_b(0, 0);
+    if (chunks > 1) {
+        issue_a(1, 1, 0);
+        issue_a(1, 1, 2);
+    }
+    issue_b(1, row_bytes);  // K tile 1 = (chunk 0, tap 1)
+    int n_wait = (chunks > 1 ? 4 : 0) + 2;  // pieces issued after B(0)
+    int ia_prev = 0;                        // A pieces issued in the previous iteration (after its B pieces)
+    // of the next B slice to issue (K tile kt + 2)
+    int b_tap = 2, b_chunk_off = 0, b_stage = 2;
+    int a_blk = 0, b_cur = 0;  // ring slots read by the current K tile
+    // the other workgroup of this CU is usually in a different phase: its VALU-dense epilogue must not starve this wave's MFMA
+    // issue (two waves per SIMD share one issue port), so the K loop runs at raised priority
+    if (p.skew & 1) __builtin_amdgcn_s_setprio(2);
+    if ((p.skew >> 1) > 0 && blockIdx.x < 512) {
+        // experiment: de-synchronise the chip.  Every first-round workgroup starts ((blockIdx >> 3) & 7) x (skew >> 1) x 1016 clocks
+        // late, so that the epilogue store bursts of the 512 resident workgroups do not all fall into the same time window.
+        if (w == 0) {
+            const int units = (int)((blockIdx.x >> 3) & 7) * (p.skew >> 1);
+            for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int c = 0; c < chunks; ++c) {
+        const bool more_a = c + 2 < chunks;
+        const int a_next_blk = a_blk == 0 ? 2 : a_blk - 1;  // (c + 2) % 3
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int kt = 3 * c + tap;
+            wait_vm_0246(n_wait);
+            __builtin_amdgcn_s_barrier();
+            int ib = 0, ia = 0;
+            if (!(p.ablate & 8)) {
+                if (kt + 2 < nk) {
+                    issue_b(b_stage, b_tap * row_bytes + b_chunk_off);
+                    b_stage = b_stage == 2 ? 0 : b_stage + 1;
+                    if (++b_tap == 3) {
+                        b_tap = 0;
+                        b_chunk_off += KB;
                     }
+                    ib = 2;
+                }
+                if (tap < 2 && more_a) {
+                    issue_a(a_next_blk, c + 2, 2 * tap);
+                    ia = 2;
                 }
             }
-        }
-        if (stats) {
+            n_wait = ia_prev + ib + ia;  // pieces issued after B(kt + 1): the A pieces of kt - 1, then everything of kt
+            ia_prev = ia;
+            const char* abase = lds + a_blk * A_BLK;
+            const char* bbase = lds + b_cur * B_STG;  // b_addr already contains the B0 offset
+            b_cur = b_cur == 2 ? 0 : b_cur + 1;
+            bf16x8 a0[4], b0[2], a1[4], b1[2];
+            b0[0] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[0]);
+            a0[0] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][0]);
+            b0[1] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[0] + 2048);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s8[e] += __shfl_xor(s8[e], 16, 64);
-                s8[e] += __shfl_xor(s8[e], 32, 64);
-                q8[e] += __shfl_xor(q8[e], 16, 64);
-                q8[e] += __shfl_xor(q8[e], 32, 64);
-            }
-            if (lane < 16) {
+            for (int i = 1; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][0] + i * 2048);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[((h * 4 + w) * 2 + 0) * 128 + c8 * 8 + e] = s8[e];
-                    red[((h * 4 + w) * 2 + 1) * 128 + c8 * 8 + e] = q8[e];
-                }
-            }
+            for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[1] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][1] + i * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        a_blk = a_blk == 2 ? 0 : a_blk + 1;
     }
-    if (stats) {
-        __syncthreads();
-        const int h = tid >> 7, c = tid & 127;
-        const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
-        if (2 * tl + h < srows) {
-            const float* rr = red + h * 4 * 2 * 128;
-            const int64_t srow = n * srows + 2 * tl + h;
-            p.stat_sum[srow * p.N + n0 + c] = (rr[0 * 128 + c] + rr[2 * 128 + c]) + (rr[4 * 128 + c] + rr[6 * 128 + c]);
-            p.stat_sq[srow * p.N + n0 + c] = (rr[1 * 128 + c] + rr[3 * 128 + c]) + (rr[5 * 128 + c] + rr[7 * 128 + c]);
-        }
+    if (p.skew & 1) __builtin_amdgcn_s_setprio(0);
+    if (p.ablate & 2) {
+        if (acc[0][0][0] == 123.456f) p.out[0] = (bf16)acc[3][1][15];
+        return;
     }
+    n2_epilogue<EPI>(p, lds, acc, n, tl, t0, n0, TROWS, tid, lane, w, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2537,13 +2768,27 @@ int g_nt_p8_phases = 2;  // MFMA clusters per K tile: 2 x 16 or 4 x 8; vm_set_tu
 int g_nt_w4 = 0;
 
 // conv_nt2_kernel (256 x 128 tiles, two workgroups per CU): vm_set_tuning("nt_n2", 0 | 1 | 2 | 3): 0 off, 1 forward, 2 dgrad, 3 both
-int g_nt_n2 = 0;
+int g_nt_n2 = 3;
+int g_nt_n2_prio = 0;  // experiment: s_setprio(2) around the K loop of conv_nt2r_kernel
+int g_nt_n2r = 1;  // prefer the input-resident form (conv_nt2r_kernel) where its tiling fits; vm_set_tuning("nt_n2r", 0 | 1)
 template <int EPI>
 static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
-    if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c || a.ablate != 0) return false;
+    if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c) return false;
     NtArgs<bf16> b = a;
-    b.tilesL = (a.L + n2::TM - 1) / n2::TM;
+    b.skew = g_nt_n2_prio;
     b.tilesN = a.N / n2::TN;
+    const int t254 = (a.L + n2r::TROWS - 1) / n2r::TROWS;
+    // input-resident variant: its statistics rows (two per 254-position tile) must be exactly the (L + 127) / 128 rows of
+    // vm_conv_stat_rows -- checked for the inference launch as well so that a layer runs the same kernel in both modes
+    if (g_nt_n2r && (EPI != EPI_FWD || 2 * t254 == (a.L + 127) / 128)) {
+        b.tilesL = t254;
+        const int64_t n_groups = n_windows * b.tilesL;
+        const int64_t grid = n_groups * b.tilesN;
+        if (grid >= (1LL << 31)) return false;
+        hipLaunchKernelGGL((conv_nt2r_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b, n_groups);
+        return true;
+    }
+    b.tilesL = (a.L + n2::TM - 1) / n2::TM;
     const int64_t n_groups = n_windows * b.tilesL;
     const int64_t grid = n_groups * b.tilesN;
     if (grid >= (1LL << 31)) return false;
@@ -2854,6 +3099,14 @@ extern "C" int vm_set_tuning(const char* key, int value) {
     }
     if (key != nullptr && strcmp(key, "nt_p8_korder") == 0) {
         g_nt_p8_korder = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_n2_prio") == 0) {
+        g_nt_n2_prio = value;
+        return VM_OK;
+    }
+    if (key != nullptr && strcmp(key, "nt_n2r") == 0 && value >= 0 && value <= 1) {
+        g_nt_n2r = value;
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_n2") == 0 && value >= 0 && value <= 3) {
