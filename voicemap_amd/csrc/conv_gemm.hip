@@ -1478,36 +1478,45 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
         }
     }
     __syncthreads();
+    // ---- read-back: 8 rows per thread and half, ALL tile reads first, then the 8 whole-row stores back to back (a predicated
+    // read -> wait -> store chain per row left the store path idle between rows); interior tiles take a predicate-free path ----
     const int c8 = tid & 15, rg = tid >> 4;
     const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
     float* red = reinterpret_cast<float*>(lds + TM * TP);  // [half][wave][sum | square][128] floats = 8 KB
     bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
+    const bool interior = t0 + trows <= p.L;  // every valid MFMA row of the tile is a position of the window
+    const bool no_store = (p.ablate & 1) != 0;
+    auto half = [&](int h, auto interior_c) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;
+        bf16x8 v[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float s8[8], q8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+        for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const bf16x8*>(lds + (h * 128 + rg + 16 * jj) * TP + c8 * 16);
+        bool ok[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int row = h * 128 + rg + 16 * jj;
-            if (row < trows && t0 + row < p.L) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row * TP + c8 * 16);
-                if (p.ablate & 16) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N));
-                } else if (!(p.ablate & 1) && !((p.ablate & 32) && (jj & 1))) {
-                    *reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N) = v;
-                }
-                if (stats) {
+            // rows >= trows exist only in the last 16 rows of the tile (trows >= 240)
+            ok[jj] = INTERIOR ? (h == 0 || jj < 7 || row < trows) : (row < trows && t0 + row < p.L);
+        }
+        if (!no_store) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (ok[jj]) *reinterpret_cast<bf16x8*>(obase + (int64_t)(h * 128 + rg + 16 * jj) * p.N) = v[jj];
+        }
+        if (stats) {
+            float s8[8], q8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (ok[jj]) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float x = (float)v[e];
+                        const float x = (float)v[jj][e];
                         s8[e] += x;
                         q8[e] = fmaf(x, x, q8[e]);
                     }
                 }
-            }
-        }
-        if (stats) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s8[e] += __shfl_xor(s8[e], 16, 64);
@@ -1523,6 +1532,13 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
                 }
             }
         }
+    };
+    if (interior) {
+        half(0, std::true_type{});
+        half(1, std::true_type{});
+    } else {
+        half(0, std::false_type{});
+        half(1, std::false_type{});
     }
     if (stats) {
         __syncthreads();
@@ -1688,6 +1704,10 @@ __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_
 //   WAR: B(kt+2) overwrites the stage read in iteration kt-1, A(chunk+2) the block read during chunk-1; both are issued after
 //        barrier kt, which every wave reaches only when its reads of iteration kt-1 have been consumed.
 // Requires a_c % 32 == 0, Ktot == 3 * a_c, N % 128 == 0; forward with statistics: 2 * ceil(L / 254) == ceil(L / 128).
+// Tried on this kernel without gain (round 2, interleaved A/B on the six cfg-A launches): s_setprio(2) around the K loop (+1 %
+// time), a start offset between the two workgroups of a CU or across the chip (0 .. +3 %), the two operand streams issued by
+// different waves so that vmcnt's in-order retirement does not tie the input blocks to the weight slices (+3 %), non-temporal
+// output stores (-1.5 %, not kept: the next kernel reads the tensor).  Ablations: see DESIGN.md 4.2.
 // ------------------------------------------------------------------------------------------------
 namespace n2r {
 constexpr int TROWS = 254;
@@ -2775,7 +2795,7 @@ template <int EPI>
 static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
     if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c) return false;
     NtArgs<bf16> b = a;
-    b.skew = g_nt_n2_prio;
+    b.skew = g_nt_n2_prio & 63;
     b.tilesN = a.N / n2::TN;
     const int t254 = (a.L + n2r::TROWS - 1) / n2r::TROWS;
     // input-resident variant: its statistics rows (two per 254-position tile) must be exactly the (L + 127) / 128 rows of
@@ -2785,7 +2805,8 @@ static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stre
         const int64_t n_groups = n_windows * b.tilesL;
         const int64_t grid = n_groups * b.tilesN;
         if (grid >= (1LL << 31)) return false;
-        hipLaunchKernelGGL((conv_nt2r_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b, n_groups);
+        // experiment (nt_n2_prio & 64): 8 KB of unused dynamic LDS -> one workgroup per CU instead of two
+        hipLaunchKernelGGL((conv_nt2r_kernel<EPI>), dim3((unsigned)grid), dim3(256), (g_nt_n2_prio & 64) ? 8192 : 0, stream, b, n_groups);
         return true;
     }
     b.tilesL = (a.L + n2::TM - 1) / n2::TM;
