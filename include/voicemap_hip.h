@@ -247,6 +247,38 @@ int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, f
 int vm_nshot_distances(const float* query, const float* support, int64_t tasks, int k, int n, int E, int dist_kind,
                        float* pred, int32_t* argmin, void* stream);
 
+/* ---- a10 / f4: log-mel front-end and the 2-D CNN encoder variant (BASELINE.json config 4) -------------------
+ * NOT in the reference (nothing to cite under /root/reference); the specification is DESIGN.md section 9 and the
+ * CPU oracle is oracle/voicemap_oracle.py (logmel_features, encoder2d_forward): parity unpinned by construction.
+ *
+ * vm_stft_logmel: raw (n_clips, raw_len) fp32 or int16 16 kHz windows -> frames of win_length samples every `hop` samples
+ * (T = vm_stft_frames: no centre padding), 512-point DFT of the windowed frame, power of bins 0..255, mel projection, log:
+ *   out[(b * n_mels + m)][1 + t] = log(sum_k melw[k][m] * |X_t[k]|^2 + log_floor)
+ * written in `dtype` as the block-1 input of the 2-D encoder: n_clips * n_mels windows of T + 2 rows (halo rows are not
+ * written: the caller zeroes the buffer once), 1 channel.  basis: (win_length, 512) fp32 = the analysis window times
+ * [cos(2 pi k n / 512) for k < 256 | -sin(2 pi k n / 512) for k < 256]; melw: (256, n_mels) fp32; both built by the host side
+ * (voicemap_amd/spectro.py).  n_mels in {32, 64, 96, 128}. */
+int64_t vm_stft_frames(int64_t raw_len, int win_length, int hop);
+int vm_stft_logmel(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const float* basis,
+                   const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
+/* Conv2D(3 x 3, SAME) over (T, M) = the k = 3 convolution along T (vm_conv_fwd / _dgrad / _wgrad) of the band-stacked tensor:
+ * x: (n_clips * M windows, rows, C) with rows = T + 2 (halo rows included: they are copied, so they stay zero);
+ * out: (n_clips * M, rows, Cs), out[(b, m)][row][dm * C + c] = x[(b, m + dm - 1)][row][c] (0 outside the clip's M bands),
+ * channels [3 C, Cs) = 0 (Cs >= 3 C, a multiple of 8 for the convolution kernels).  W2d[kt][km][ci][co] = W1d[kt][km * C + ci][co]. */
+int vm_stack_windows(const void* x, int64_t n_clips, int M, int64_t rows, int C, int Cs, int dtype, void* out, void* stream);
+/* adjoint of vm_stack_windows on un-padded rows: dxs (n_clips * M, L, Cs) -> dx (n_clips * M, L, C),
+ * dx[(b, m)][t][c] = sum_dm dxs[(b, m - dm + 1)][t][dm * C + c]. */
+int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int dtype, void* dx, void* stream);
+/* mel half of MaxPool2D(2, 2): out[(b, m')][row][c] = max(q[(b, 2m')], q[(b, 2m'+1)]) over (n_clips * M, rows, C) -> (n_clips *
+ * (M / 2), rows, C) (floor: an odd last band is dropped); backward: q as in the forward (rows = L + 2 with halo), dout (n_clips *
+ * (M / 2), L, C), dq (n_clips * M, L, C) = dout routed to the first maximum of each pair. */
+int vm_pool_windows_fwd(const void* q, int64_t n_clips, int M, int64_t rows, int C, int dtype, void* out, void* stream);
+int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M, int64_t L, int C, int dtype, void* dq, void* stream);
+/* mel half of GlobalMaxPool2D: out[b][c] = max over m < M_valid of gmax[(b, m)][c] (fp32; first maximum -> widx[b][c]);
+ * backward: dg[(b, m)][c] = dout[b][c] if m == widx[b][c] else 0. */
+int vm_clip_max_fwd(const float* gmax, int64_t n_clips, int M, int M_valid, int C, float* out, int32_t* widx, void* stream);
+int vm_clip_max_bwd(const float* dout, const int32_t* widx, int64_t n_clips, int M, int C, float* dg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -586,6 +586,147 @@ def synthetic_pairs(batch_pairs: int, seed: int = 1234, samples: int = 48000):
     return x1, x2, y
 
 
+
+# ---------------------------------------------------------------------------------------------
+# log-mel front-end + 2-D CNN encoder variant (BASELINE.json config 4).  NOT in the reference
+# (SURVEY.md D9): the specification is DESIGN.md section 9 / voicemap_amd/spectro.py and this is
+# its float64 restatement -- PARITY UNPINNED by construction (there is nothing in the reference
+# tree to pin it on); the HIP path (vm_stft_logmel, the band-stacked Conv2D lowering) is checked
+# against this code, and this code against numpy.fft on the same frames.
+# ---------------------------------------------------------------------------------------------
+
+
+def logmel_features(raw: np.ndarray, win_length: int = 400, hop: int = 160, n_fft: int = 512, n_mels: int = 64,
+                    sample_rate: int = 16000, log_floor: float = 1e-6) -> np.ndarray:
+    """raw (B, n) -> (B, T, n_mels) float64: frames of win_length samples every hop samples (no centre padding), periodic
+    Hann window, n_fft-point DFT (frame zero-extended at the END), power of bins 0..n_fft/2-1, triangular HTK-mel filters with
+    unit peak between 0 Hz and Nyquist, natural log(mel + log_floor).  Written with numpy.fft, independently of the DFT-basis
+    GEMM the HIP kernel uses."""
+    raw = np.asarray(raw, dtype=np.float64)
+    if raw.ndim == 3:
+        raw = raw[:, :, 0]
+    B, n = raw.shape
+    T = 1 + (n - win_length) // hop
+    idx = np.arange(T)[:, None] * hop + np.arange(win_length)[None, :]
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    frames = raw[:, idx] * win[None, None, :]
+    spec = np.fft.rfft(frames, n=n_fft, axis=-1)
+    power = (spec.real ** 2 + spec.imag ** 2)[..., :n_fft // 2]
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    edges = 700.0 * (10.0 ** (np.linspace(mel(0.0), mel(sample_rate / 2.0), n_mels + 2) / 2595.0) - 1.0)
+    f = (np.arange(n_fft // 2) * sample_rate / n_fft)[:, None]
+    lo, mid, hi = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
+    w = np.maximum(0.0, np.minimum((f - lo) / (mid - lo), (hi - f) / (hi - mid)))
+    return np.log(power @ w + log_floor)
+
+
+@dataclass
+class Encoder2dArch:
+    """The 2-D variant of get_baseline_convolutional_encoder over a (T, M) log-mel image: 4 x [Conv2D 3x3 SAME + bias -> ReLU
+    -> BatchNorm -> SpatialDropout2D -> MaxPool2D(2, 2)] -> GlobalMaxPool2D -> Dense(E); channels F, 2F, 3F, 4F like the 1-D
+    encoder (voicemap/models.py:13-35)."""
+
+    filters: int
+    embedding_dimension: int
+    dropout: float = 0.05
+    bn_eps: float = 1e-3
+    bn_momentum: float = 0.99
+
+    @property
+    def channels(self) -> List[int]:
+        return [self.filters * (i + 1) for i in range(4)]
+
+
+def init_params2d(arch: Encoder2dArch, head: Optional[str] = "uniform_euclidean", seed: int = 1234, dtype=torch.float64):
+    """Keras defaults [3P]: glorot_uniform Conv2D kernels (fan = 9 * C), zero biases, gamma 1, beta 0, moving 0 / 1."""
+    g = torch.Generator().manual_seed(seed)
+    p: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def glorot(shape, fan_in, fan_out):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(dtype)
+
+    cin = 1
+    for i, c in enumerate(arch.channels):
+        p[f"conv{i+1}.kernel"] = glorot((3, 3, cin, c), 9 * cin, 9 * c)
+        p[f"conv{i+1}.bias"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.gamma"] = torch.ones(c, dtype=dtype)
+        p[f"bn{i+1}.beta"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.moving_mean"] = torch.zeros(c, dtype=dtype)
+        p[f"bn{i+1}.moving_variance"] = torch.ones(c, dtype=dtype)
+        cin = c
+    e = arch.embedding_dimension
+    p["dense.kernel"] = glorot((cin, e), cin, e)
+    p["dense.bias"] = torch.zeros(e, dtype=dtype)
+    if head == "uniform_euclidean":
+        p["head.kernel"] = glorot((1, 1), 1, 1)
+        p["head.bias"] = torch.zeros(1, dtype=dtype)
+    elif head == "weighted_l1":
+        p["head.kernel"] = glorot((e, 1), e, 1)
+        p["head.bias"] = torch.zeros(1, dtype=dtype)
+    elif head is not None:
+        raise ValueError(head)
+    return p
+
+
+def encoder2d_forward(arch: Encoder2dArch, p, feats: torch.Tensor, training: bool, drop_masks=None, collect: Optional[dict] = None):
+    """feats (B, T, M) log-mel -> (B, E).  Conv2D kernels are Keras-shaped (kT, kM, C_in, C_out) over a channels-last (B, T, M, C)
+    image; BatchNorm statistics over (B, T, M) of THIS call (one tower); SpatialDropout2D masks are (B, C) keep masks."""
+    h = feats[:, None, :, :]  # (B, C=1, T, M)
+    for i, c in enumerate(arch.channels):
+        w = p[f"conv{i+1}.kernel"].permute(3, 2, 0, 1)  # (C_out, C_in, kT, kM)
+        z = torch.relu(F.conv2d(h, w, p[f"conv{i+1}.bias"], padding=1))
+        gam, bet = p[f"bn{i+1}.gamma"], p[f"bn{i+1}.beta"]
+        if training:
+            mean = z.mean(dim=(0, 2, 3))
+            var = z.var(dim=(0, 2, 3), unbiased=False)
+            y = (z - mean[None, :, None, None]) * torch.rsqrt(var + arch.bn_eps)[None, :, None, None] * gam[None, :, None, None] \
+                + bet[None, :, None, None]
+            if collect is not None:
+                collect.setdefault("bn_mean", []).append(mean.detach())
+                collect.setdefault("bn_var", []).append(var.detach())
+                collect.setdefault("bn_count", []).append(z.shape[0] * z.shape[2] * z.shape[3])
+            if drop_masks is not None and drop_masks[i] is not None and arch.dropout > 0.0:
+                y = y * (drop_masks[i].to(y.dtype) / (1.0 - arch.dropout))[:, :, None, None]
+        else:
+            inv = gam * torch.rsqrt(p[f"bn{i+1}.moving_variance"] + arch.bn_eps)
+            y = z * inv[None, :, None, None] + (bet - p[f"bn{i+1}.moving_mean"] * inv)[None, :, None, None]
+        h = F.max_pool2d(y, 2, 2)
+        if collect is not None:
+            collect.setdefault("z", []).append(z.detach())
+            collect.setdefault("pooled", []).append(h.detach())
+    g = h.amax(dim=(2, 3))
+    return g @ p["dense.kernel"] + p["dense.bias"]
+
+
+def siamese2d_train_step(arch: Encoder2dArch, p, state: Optional["AdamState"], f1, f2, y, loss: str = "contrastive",
+                         distance_metric: str = "uniform_euclidean", drop_masks1=None, drop_masks2=None,
+                         unbiased_moving_variance: bool = True):
+    """siamese_train_step for the 2-D variant on log-mel features f1, f2 (B, T, M): same loss / clip / Adam / moving-statistics
+    arithmetic as the 1-D step."""
+    names = [k for k in p if "moving" not in k]
+    q = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
+    c1, c2 = {}, {}
+    e1 = encoder2d_forward(arch, q, f1, True, drop_masks1, c1)
+    e2 = encoder2d_forward(arch, q, f2, True, drop_masks2, c2)
+    pred = siamese_head(q, e1, e2, distance_metric)
+    l = contrastive_loss(y, pred) if loss in ("contrastive", "contrastive_loss") else binary_crossentropy(y, pred)
+    acc = binary_accuracy(y, pred)
+    grads = dict(zip(names, torch.autograd.grad(l, [q[k] for k in names])))
+    new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
+    for c in (c1, c2):
+        for i in range(4):
+            n = c["bn_count"][i]
+            var = bn_unbiased_variance(c["bn_var"][i], n, arch.bn_eps) if unbiased_moving_variance else c["bn_var"][i]
+            new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
+            new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    if state is not None:
+        upd = adam_step(state, {k: new_p[k] for k in names}, grads)
+        new_p.update(upd)
+    return {"loss": l.detach(), "acc": acc.detach(), "pred": pred.detach(), "e1": e1.detach(), "e2": e2.detach(), "grads": grads,
+            "params": new_p, "z1": c1["z"], "pooled1": c1["pooled"]}
+
+
 def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contrastive", threads: Optional[int] = None,
                          seed: int = 1234, downsampling: int = 4, budget_s: float = 25.0):
     """bench.py cpu_baseline leg: the oracle's fp32 training step (preprocess + twin forward + loss +

@@ -1,0 +1,206 @@
+"""-m gpu parity tests of the log-mel front-end and the 2-D CNN encoder variant (BASELINE.json config 4):
+HIP entry points vs the float64 oracle (oracle.voicemap_oracle.logmel_features / encoder2d_forward / siamese2d_train_step).  The
+variant is not in the reference, so the oracle is this repository's own specification restated (parity unpinned by construction).
+Tolerances: fp32 storage 2e-5 relative unless stated (the DFT runs on exact-fp32 MFMAs); bf16 storage 1e-2 per rounding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voicemap_oracle as O
+from tests.gpu_util import DTYPES, L, cosine, dev, grad_close, max_err, p, quant, rel_err, report, stream
+from voicemap_amd import spectro as S
+
+pytestmark = pytest.mark.gpu
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+@pytest.mark.parametrize("i16", [False, True])
+@pytest.mark.parametrize("n,raw_len,n_mels", [(3, 48000, 64), (2, 4000, 32), (1, 400 + 160 * 32, 128), (2, 5003, 96)])
+def test_stft_logmel(i16, n, raw_len, n_mels):
+    r = rng(1)
+    t = np.arange(raw_len) / 16000.0
+    raw = 0.05 * r.normal(0, 1, (n, raw_len)) + 0.2 * np.sin(2 * np.pi * 440.0 * t)[None, :] * r.uniform(0.2, 1.0, (n, 1))
+    if i16:
+        q = np.clip(np.round(raw * 32768), -32768, 32767).astype(np.int16)
+        raw = q.astype(np.float64) / 32768.0
+        rd = dev(q, torch.int16)
+    else:
+        raw = raw.astype(np.float32).astype(np.float64)
+        rd = dev(raw)
+    T = L().query("vm_stft_frames", raw_len, S.WIN_LENGTH, S.HOP)
+    assert T == S.n_frames(raw_len) == 1 + (raw_len - 400) // 160
+    basis, melw = dev(S.dft_basis()), dev(S.mel_filterbank(n_mels))
+    ref = O.logmel_features(raw, n_mels=n_mels)                       # (n, T, n_mels)
+    for dt, tol in (("f32", 2e-4), ("bf16", 3e-2)):
+        vm, tdt = DTYPES[dt]
+        out = torch.zeros(n * n_mels, T + 2, 1, dtype=tdt, device="cuda")
+        L().call("vm_stft_logmel", p(rd), int(i16), n, raw_len, S.WIN_LENGTH, S.HOP, p(basis), p(melw), n_mels, S.LOG_FLOOR, vm, p(out),
+                 stream())
+        o = out.float().cpu().numpy().reshape(n, n_mels, T + 2)
+        assert np.all(o[:, :, 0] == 0) and np.all(o[:, :, -1] == 0)      # halo rows untouched
+        got = o[:, :, 1:-1].transpose(0, 2, 1)
+        assert max_err(got, ref) < tol * max(1.0, np.abs(ref).max()), dt    # log domain: absolute error
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,M,rows,C,Cs", [(2, 5, 7, 1, 8), (3, 4, 6, 8, 24), (2, 8, 5, 32, 96), (1, 3, 4, 4, 16), (2, 2, 3, 16, 48)])
+def test_stack_fold_windows(dt, n, M, rows, C, Cs):
+    vm, tdt = DTYPES[dt]
+    r = rng(2)
+    x = quant(r.normal(0, 1, (n, M, rows, C)), dt).numpy()
+    out = torch.full((n * M, rows, Cs), 7.0, dtype=tdt, device="cuda")
+    L().call("vm_stack_windows", p(dev(x, tdt)), n, M, rows, C, Cs, vm, p(out), stream())
+    ref = np.zeros((n, M, rows, Cs))
+    for dm in range(3):
+        for m in range(M):
+            if 0 <= m + dm - 1 < M:
+                ref[:, m, :, dm * C:(dm + 1) * C] = x[:, m + dm - 1]
+    assert np.array_equal(out.float().cpu().numpy().reshape(n, M, rows, Cs), ref)
+    # adjoint on un-padded rows
+    Lr = rows
+    g = quant(r.normal(0, 1, (n, M, Lr, Cs)), dt).numpy()
+    dx = torch.empty(n * M, Lr, C, dtype=tdt, device="cuda")
+    L().call("vm_fold_windows", p(dev(g, tdt)), n, M, Lr, C, Cs, vm, p(dx), stream())
+    fref = np.zeros((n, M, Lr, C))
+    for dm in range(3):
+        for m in range(M):
+            if 0 <= m - dm + 1 < M:
+                fref[:, m] += g[:, m - dm + 1, :, dm * C:(dm + 1) * C]
+    assert rel_err(dx.float().cpu().numpy().reshape(n, M, Lr, C), fref) < (1e-6 if dt == "f32" else 5e-3)
+    assert abs((ref * g).sum() - (x * fref).sum()) < 1e-9 * max(1.0, abs((ref * g).sum()))   # <stack x, g> == <x, fold g>
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,M,Lq,C", [(2, 4, 5, 8), (3, 5, 4, 16), (1, 2, 3, 4), (2, 8, 9, 32)])
+def test_pool_windows(dt, n, M, Lq, C):
+    vm, tdt = DTYPES[dt]
+    r = rng(3)
+    q = quant(np.round(r.normal(0, 1, (n, M, Lq + 2, C)) * 4) / 4, dt).numpy()   # coarse values: ties occur
+    q[:, :, 0] = 0
+    q[:, :, -1] = 0
+    Mo = M // 2
+    out = torch.empty(n * Mo, Lq + 2, C, dtype=tdt, device="cuda")
+    qd = dev(q, tdt)
+    L().call("vm_pool_windows_fwd", p(qd), n, M, Lq + 2, C, vm, p(out), stream())
+    ref = np.maximum(q[:, 0:2 * Mo:2], q[:, 1:2 * Mo:2])
+    assert np.array_equal(out.float().cpu().numpy().reshape(n, Mo, Lq + 2, C), ref)
+    g = quant(r.normal(0, 1, (n, Mo, Lq, C)), dt).numpy()
+    dq = torch.full((n * M, Lq, C), 9.0, dtype=tdt, device="cuda")
+    L().call("vm_pool_windows_bwd", p(qd), p(dev(g, tdt)), n, M, Lq, C, vm, p(dq), stream())
+    first = q[:, 0:2 * Mo:2, 1:-1] >= q[:, 1:2 * Mo:2, 1:-1]
+    dref = np.zeros((n, M, Lq, C))
+    dref[:, 0:2 * Mo:2] = np.where(first, g, 0)
+    dref[:, 1:2 * Mo:2] = np.where(first, 0, g)
+    assert np.array_equal(dq.float().cpu().numpy().reshape(n, M, Lq, C), dref)
+
+
+def test_clip_max():
+    r = rng(4)
+    n, M, Mv, C = 3, 5, 4, 24
+    g = np.round(r.normal(0, 1, (n, M, C)) * 2).astype(np.float32) / 2
+    out = torch.empty(n, C, device="cuda")
+    widx = torch.empty(n, C, dtype=torch.int32, device="cuda")
+    L().call("vm_clip_max_fwd", p(dev(g)), n, M, Mv, C, p(out), p(widx), stream())
+    assert np.array_equal(out.cpu().numpy(), g[:, :Mv].max(1)) and np.array_equal(widx.cpu().numpy(), g[:, :Mv].argmax(1))
+    d = r.normal(0, 1, (n, C)).astype(np.float32)
+    dg = torch.empty(n * M, C, device="cuda")
+    L().call("vm_clip_max_bwd", p(dev(d)), p(widx), n, M, C, p(dg), stream())
+    ref = np.zeros((n, M, C), np.float32)
+    for b in range(n):
+        for c in range(C):
+            ref[b, g[b, :Mv, c].argmax(), c] = d[b, c]
+    assert np.array_equal(dg.cpu().numpy().reshape(n, M, C), ref)
+
+
+def _clips(n, raw_len, seed):
+    r = rng(seed)
+    t = np.arange(raw_len) / 16000.0
+    f0 = r.uniform(100, 400, (n, 1))
+    x = 0.1 * np.sin(2 * np.pi * f0 * t[None, :]) * (0.5 + 0.5 * np.sin(2 * np.pi * 3.0 * t[None, :] + r.uniform(0, 6, (n, 1)))) \
+        + 0.02 * r.normal(0, 1, (n, raw_len))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("dt,drop", [("f32", 0.0), ("f32", 0.25), ("bf16", 0.0)])
+def test_spectrogram_siamese_step_vs_oracle(dt, drop):
+    """One train_on_batch of the 2-D variant: embeddings, loss, every gradient (in Keras' Conv2D shapes), the parameters after the
+    Adam step and the moving statistics, against the float64 oracle on the same clips."""
+    from voicemap_amd.spectro_engine import HipSpectrogramEncoderEngine
+    pairs, raw_len, F_, E = 4, 400 + 160 * 63, 8, 8     # 64 frames x 64 mels -> 4 x 4 before the global max
+    arch = O.Encoder2dArch(F_, E, dropout=drop)
+    pr = O.init_params2d(arch, head="uniform_euclidean", seed=5)
+    x1, x2 = _clips(pairs, raw_len, 6), _clips(pairs, raw_len, 7)
+    y = np.array([[0.0], [0.0], [1.0], [1.0]])
+    eng = HipSpectrogramEncoderEngine(F_, E, dropout=drop, head="uniform_euclidean", dtype=dt)
+    eng.set_params({k: v.numpy() for k, v in pr.items()})
+    masks = None
+    m1 = m2 = None
+    if drop > 0:
+        g = torch.Generator(device="cuda").manual_seed(11)
+        masks = eng.make_drop_masks(2 * pairs, g)
+        keep = [(m > 0).cpu() for m in masks]
+        m1, m2 = [k[:pairs] for k in keep], [k[pairs:] for k in keep]
+    f1, f2 = torch.tensor(O.logmel_features(x1.astype(np.float64))), torch.tensor(O.logmel_features(x2.astype(np.float64)))
+    ref = O.siamese2d_train_step(arch, pr, O.AdamState(), f1, f2, torch.tensor(y), drop_masks1=m1, drop_masks2=m2)
+    pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=masks, apply_update=False)
+    torch.cuda.synchronize()
+    emb = pl["emb"].cpu().numpy()
+    e_ref = np.concatenate([ref["e1"].numpy(), ref["e2"].numpy()])
+    tol = 2e-4 if dt == "f32" else 6e-2
+    report("spectro_step_%s_drop%g" % (dt, drop), "emb_rel_err", rel_err(emb, e_ref))
+    assert rel_err(emb, e_ref) < tol
+    assert abs(pl["loss_acc"][0].item() - ref["loss"].item()) < tol * max(1.0, abs(ref["loss"].item()))
+    grads = eng.get_grads()
+    worst = 0.0
+    for k, gref in ref["grads"].items():
+        if dt == "f32":
+            assert grad_close(grads[k], gref.numpy(), 2e-3, 1e-7), (k, rel_err(grads[k], gref.numpy()))
+        else:
+            assert cosine(grads[k], gref.numpy()) > 0.9 or max_err(grads[k], gref.numpy()) < 1e-5, k
+        worst = max(worst, rel_err(grads[k], gref.numpy()))
+    report("spectro_step_%s_drop%g" % (dt, drop), "worst_grad_rel_err", worst)
+    if dt == "f32":
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        got = eng.get_params()
+        for k, v in ref["params"].items():
+            assert max_err(got[k], v.numpy()) < 5e-5, k
+
+
+def test_spectrogram_encoder_api_and_full_size():
+    """The Keras-like surface over the variant (build function -> build_siamese_net -> train / predict / save / load) and one
+    full-size batch (BASELINE.json config 4: 3 s clips) in bf16: finite loss, embeddings of the inference pass close to the fp32
+    engine's on the same weights."""
+    import os
+    import tempfile
+    from voicemap_amd.keras_like import Adam
+    from voicemap_amd.models import build_siamese_net, get_spectrogram_convolutional_encoder, load_model
+    from voicemap_amd.utils import contrastive_loss
+    pairs = 8
+    x1, x2 = _clips(pairs, 48000, 21)[:, :, None], _clips(pairs, 48000, 22)[:, :, None]
+    y = np.concatenate([np.zeros(pairs // 2), np.ones(pairs // 2)])[:, None]
+    nets = {}
+    for dt in ("bf16", "f32"):
+        torch.manual_seed(3)
+        enc = get_spectrogram_convolutional_encoder(32, 64, (48000, 1), dropout=0.0, dtype=dt)
+        net = build_siamese_net(enc, (48000, 1))
+        net.compile(loss=contrastive_loss, optimizer=Adam(clipnorm=1.0), metrics=["accuracy"])
+        nets[dt] = net
+    nets["f32"].set_weights(nets["bf16"].get_weights())
+    e16 = nets["bf16"].layers[2].predict(x1)
+    e32 = nets["f32"].layers[2].predict(x1)
+    assert e16.shape == (pairs, 64) and rel_err(e16, e32) < 6e-2
+    losses = [nets["bf16"].train_on_batch([x1, x2], y)[0] for _ in range(5)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    pr = nets["bf16"].predict([x1, x2])
+    assert pr.shape == (pairs, 1) and np.all((pr >= 0) & (pr <= 1))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "spectro.npz")
+        nets["bf16"].save(path)
+        again = load_model(path)
+        assert np.array_equal(again.predict([x1, x2]), pr)
+        with pytest.raises(NotImplementedError):
+            nets["bf16"].save(os.path.join(d, "x.hdf5"))

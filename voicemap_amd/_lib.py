@@ -73,6 +73,14 @@ SIGNATURES = {
     "vm_grad_sqnorm": (I, [P, L, P, P, P]),
     "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P]),
     "vm_nshot_distances": (I, [P, P, L, I, I, I, I, P, P, P]),
+    "vm_stft_frames": (L, [L, I, I]),
+    "vm_stft_logmel": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
+    "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),
+    "vm_fold_windows": (I, [P, L, I, L, I, I, I, P, P]),
+    "vm_pool_windows_fwd": (I, [P, L, I, L, I, I, P, P]),
+    "vm_pool_windows_bwd": (I, [P, P, L, I, L, I, I, P, P]),
+    "vm_clip_max_fwd": (I, [P, L, I, I, I, P, P, P]),
+    "vm_clip_max_bwd": (I, [P, P, L, I, I, P, P]),
 }
 
 

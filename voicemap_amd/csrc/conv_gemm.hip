@@ -2794,6 +2794,11 @@ int g_nt_n2r = 1;  // prefer the input-resident form (conv_nt2r_kernel) where it
 template <int EPI>
 static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
     if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c) return false;
+    // short windows (the 2-D variant runs L = 298 .. 37): a 256-row tile that is mostly padding loses to the 128-row kernels
+    {
+        const double u256 = (double)a.L / (256.0 * ((a.L + 255) / 256)), u128 = (double)a.L / (128.0 * ((a.L + 127) / 128));
+        if (u256 + 0.10 < u128) return false;
+    }
     NtArgs<bf16> b = a;
     b.skew = g_nt_n2_prio & 63;
     b.tilesN = a.N / n2::TN;

@@ -1,0 +1,369 @@
+// Log-mel front-end and the window-axis helpers of the 2-D CNN encoder variant (BASELINE.json config 4).
+// NOT in the reference: the specification is this repository's own and the CPU oracle is
+// oracle/voicemap_oracle.py (logmel_features, encoder2d_*), parity unpinned by construction.
+//
+//   vm_stft_logmel      raw 16 kHz windows -> log(mel(|STFT|^2) + floor), written as the block-1 input of the 2-D encoder
+//   vm_stack_windows    Conv2D(3x3) lowering, forward:  X'[(b,m)][t][(dm, c)] = x[(b, m+dm-1)][t][c]   (zero outside the clip)
+//   vm_fold_windows     ... and its adjoint:            dx[(b,m)][t][c]      = sum_dm dX'[(b, m-dm+1)][t][(dm, c)]
+//   vm_pool_windows_*   the mel half of MaxPool2D(2, 2): max over window pairs (2m', 2m'+1) / gradient routing (first maximum wins)
+//   vm_clip_max_*       the mel half of GlobalMaxPool2D: max over the windows of a clip / gradient routing
+//
+// Layout: a clip of the 2-D encoder is M "windows" (one per mel band, then per pooled band) of T positions each, window index
+// (b, m) = b * M + m, channels last, and -- like every tensor that feeds a k = 3 convolution in this library -- T + 2 rows with
+// a zero halo row at both ends.  A Conv2D(3 x 3, SAME) over (T, M) is then the library's k = 3 implicit-GEMM convolution along T
+// (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) applied to the band-stacked tensor X' with 3 * C channels: the weights
+// W2d[kt][km][ci][co] are W1d[kt][(km, ci)][co], no reshuffling.  BatchNorm, dropout and the time half of the pooling are the
+// 1-D kernels' as they are.
+#include "common.hpp"
+
+namespace vm {
+
+// ------------------------------------------------------------------------------------------------
+// STFT -> power -> mel -> log as two chained fp32 MFMA GEMMs per tile of 32 frames (exact fp32 products: a bf16 DFT would cost
+// the log-mel its dynamic range):
+//   GEMM 1   D1[bin][frame] = sum_n basis[n][bin] * frame_samples[frame][n]     K = win_length, 256 bins x (re | im) = 512 rows
+//            (the analysis window is folded into the basis; bins 0..255 only: with fmin = 0 and fmax = Nyquist the triangular
+//             mel filters give bin 0 and bin 256 zero weight)
+//   power    P = re^2 + im^2 in the accumulator registers
+//   GEMM 2   D2[mel][frame] = sum_bin melw[bin][mel] * P[bin][frame]: the accumulator layout of GEMM 1 (lane <-> frame, register
+//            <-> bin) IS a valid K-slot assignment of the B operand of the next MFMA (the P.V trick of attention kernels), so
+//            the power spectrum never leaves the registers; the four waves' partial sums over their 64 bins meet in LDS.
+// Workgroup = 4 waves = 32 frames of one clip; wave w owns bins [64 w, 64 w + 64).  The 32 frames are staged as an LDS matrix
+// [32][win + 1] (odd pitch: the B operand read, one frame per lane, is conflict-free).
+// ------------------------------------------------------------------------------------------------
+constexpr int SF_FRAMES = 32;
+
+template <typename TOUT, int NMB>  // NMB = n_mels / 32
+__global__ __launch_bounds__(256) void stft_logmel_kernel(const void* __restrict__ raw, int is_int16, int64_t raw_len, int win, int hop,
+                                                          int T, const float* __restrict__ basis,  // [win][512]: re bins | im bins
+                                                          const float* __restrict__ melw,          // [256][32 * NMB]
+                                                          float log_floor, TOUT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);  // [32][win + 1]; later [4][32 * NMB][32] partial mel sums
+    const int pitch = win + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t clip = blockIdx.y;
+    const int f0 = blockIdx.x * SF_FRAMES;
+    const float* rf = reinterpret_cast<const float*>(raw) + clip * raw_len;
+    const int16_t* ri = reinterpret_cast<const int16_t*>(raw) + clip * raw_len;
+    for (int i = tid; i < SF_FRAMES * win; i += 256) {
+        const int f = i / win, n = i - f * win;
+        float v = 0.f;
+        if (f0 + f < T) {
+            const int64_t s = (int64_t)(f0 + f) * hop + n;
+            v = is_int16 ? (float)ri[s] * (1.0f / 32768.0f) : rf[s];
+        }
+        xs[f * pitch + n] = v;
+    }
+    __syncthreads();
+
+    const int col = lane & 31, kh = lane >> 5;
+    f32x16 re[2], im[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) re[c][e] = im[c][e] = 0.f;
+    const float* bre = basis + 64 * w + col;  // + n * 512 (+ 32 for the second bin block, + 256 for the imaginary part)
+    const float* xrow = xs + col * pitch;
+    for (int n0 = 0; n0 + 1 < win + 1; n0 += 2) {
+        const int n = n0 + kh;
+        const bool ok = n < win;  // odd window lengths: the last k-step has one term
+        const float x = ok ? xrow[n] : 0.f;
+        const float* bn = bre + (int64_t)(ok ? n : 0) * 512;
+        const float a0 = bn[0], a1 = bn[32], a2 = bn[256], a3 = bn[288];
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x, re[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x, re[1], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, x, im[0], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, x, im[1], 0, 0, 0);
+    }
+    // power spectrum in place; then the mel GEMM over this wave's 64 bins
+    f32x16 mel[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mel[mb][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pw = re[c][r] * re[c][r] + im[c][r] * im[c][r];
+            const int bin = 64 * w + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;  // the bin this lane's register r holds
+            const float* wrow = melw + (int64_t)bin * (32 * NMB) + col;
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) mel[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * mb], pw, mel[mb], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the frame matrix
+    float* red = xs;  // [4][32 * NMB][32]
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            red[(w * 32 * NMB + m) * 32 + col] = mel[mb][r];
+        }
+    __syncthreads();
+    const int n_mels = 32 * NMB;
+    for (int i = tid; i < n_mels * 32; i += 256) {
+        const int m = i >> 5, f = i & 31;
+        if (f0 + f < T) {
+            const float s = (red[(0 * n_mels + m) * 32 + f] + red[(1 * n_mels + m) * 32 + f]) +
+                            (red[(2 * n_mels + m) * 32 + f] + red[(3 * n_mels + m) * 32 + f]);
+            out[((int64_t)clip * n_mels + m) * (T + 2) + 1 + f0 + f] = Elem<TOUT>::from_f(logf(s + log_floor));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise helpers; V = elements per thread access (16 bytes when the channel count allows, else 1)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void stack_windows_kernel(const T* __restrict__ x, int64_t n_clips, int M, int rows, int C, int Cs,
+                                                            T* __restrict__ out) {
+    const int64_t per_row = Cs / V;
+    const int64_t total = n_clips * M * rows * per_row;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cs = (int)(i % per_row) * V;
+        const int64_t rw = i / per_row;  // (window, row)
+        const int row = (int)(rw % rows);
+        const int64_t win = rw / rows;
+        const int m = (int)(win % M);
+        const int dm = cs / C, c = cs - dm * C;  // V divides C on the vector path: a vector never straddles two bands
+        const int ms = m + dm - 1;
+        T v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = Elem<T>::from_f(0.f);
+        if (dm < 3 && ms >= 0 && ms < M) {
+            const T* src = x + ((win - m + ms) * rows + row) * (int64_t)C + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = src[e];
+        }
+        T* dst = out + rw * (int64_t)Cs + cs;
+#pragma unroll
+        for (int e = 0; e < V; ++e) dst[e] = v[e];
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void fold_windows_kernel(const T* __restrict__ dxs, int64_t n_clips, int M, int L, int C, int Cs,
+                                                           T* __restrict__ dx) {
+    const int64_t per_row = C / V;
+    const int64_t total = n_clips * M * L * per_row;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % per_row) * V;
+        const int64_t rw = i / per_row;
+        const int t = (int)(rw % L);
+        const int64_t win = rw / L;
+        const int m = (int)(win % M);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dm = 0; dm < 3; ++dm) {
+            const int md = m - dm + 1;  // the window whose stacked band dm is this window
+            if (md >= 0 && md < M) {
+                const T* src = dxs + ((win - m + md) * L + t) * (int64_t)Cs + dm * C + c;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(src[e]);
+            }
+        }
+        T* dst = dx + rw * (int64_t)C + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) dst[e] = Elem<T>::from_f(acc[e]);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_windows_fwd_kernel(const T* __restrict__ q, int64_t n_clips, int M, int rows, int C,
+                                                               T* __restrict__ out) {
+    const int Mo = M / 2;
+    const int64_t per_win = (int64_t)rows * C / V;
+    const int64_t total = n_clips * Mo * per_win;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t e0 = (i % per_win) * V;
+        const int64_t wo = i / per_win;
+        const int64_t b = wo / Mo;
+        const int mo = (int)(wo % Mo);
+        const T* a = q + ((b * M + 2 * mo) * (int64_t)rows * C) + e0;
+        const T* c2 = a + (int64_t)rows * C;
+        T* dst = out + wo * (int64_t)rows * C + e0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float x0 = Elem<T>::to_f(a[e]), x1 = Elem<T>::to_f(c2[e]);
+            dst[e] = x0 >= x1 ? a[e] : c2[e];
+        }
+    }
+}
+
+// q: the forward input (n_clips * M windows, L + 2 rows with halo); dout: (n_clips * (M/2), L, C); dq: (n_clips * M, L, C)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_windows_bwd_kernel(const T* __restrict__ q, const T* __restrict__ dout, int64_t n_clips, int M,
+                                                               int L, int C, T* __restrict__ dq) {
+    const int Mo = M / 2;
+    const int64_t per_win = (int64_t)L * C / V;
+    const int64_t total = n_clips * M * per_win;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t e0 = (i % per_win) * V;
+        const int64_t win = i / per_win;
+        const int64_t b = win / M;
+        const int m = (int)(win % M);
+        T* dst = dq + win * (int64_t)L * C + e0;
+        if (m >= 2 * Mo) {  // odd band count: the last band is dropped by the floor pooling
+#pragma unroll
+            for (int e = 0; e < V; ++e) dst[e] = Elem<T>::from_f(0.f);
+            continue;
+        }
+        const int64_t pair = b * M + (m & ~1);
+        const T* q0 = q + (pair * (L + 2) + 1) * (int64_t)C + e0;  // skip the halo row
+        const T* q1 = q0 + (int64_t)(L + 2) * C;
+        const T* g = dout + (b * Mo + (m >> 1)) * (int64_t)L * C + e0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const bool first = Elem<T>::to_f(q0[e]) >= Elem<T>::to_f(q1[e]);
+            dst[e] = (first == ((m & 1) == 0)) ? g[e] : Elem<T>::from_f(0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_max_fwd_kernel(const float* __restrict__ gmax, int64_t n_clips, int M, int Mv, int C,
+                                                           float* __restrict__ out, int32_t* __restrict__ widx) {
+    const int64_t i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n_clips * C) return;
+    const int64_t b = i / C;
+    const int c = (int)(i % C);
+    float best = gmax[(b * M) * (int64_t)C + c];
+    int bi = 0;
+    for (int m = 1; m < Mv; ++m) {
+        const float v = gmax[(b * M + m) * (int64_t)C + c];
+        if (v > best) {  // first maximum wins
+            best = v;
+            bi = m;
+        }
+    }
+    out[i] = best;
+    widx[i] = bi;
+}
+
+__global__ __launch_bounds__(256) void clip_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ widx,
+                                                           int64_t n_clips, int M, int C, float* __restrict__ dg) {
+    const int64_t i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n_clips * M * C) return;
+    const int c = (int)(i % C);
+    const int64_t win = i / C;
+    const int64_t b = win / M;
+    const int m = (int)(win % M);
+    dg[i] = widx[b * C + c] == m ? dout[b * C + c] : 0.f;
+}
+
+static unsigned ew_grid(int64_t total) {
+    const int64_t g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+}  // namespace vm
+
+using namespace vm;
+
+extern "C" int64_t vm_stft_frames(int64_t raw_len, int win_length, int hop) {
+    if (raw_len < win_length || hop <= 0) return 0;
+    return 1 + (raw_len - win_length) / hop;
+}
+
+extern "C" int vm_stft_logmel(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
+                              const float* basis, const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream) {
+    VM_REQUIRE(raw && basis && melw && out, "vm_stft_logmel: null pointer");
+    VM_REQUIRE(n_clips > 0 && n_clips < 65536 && win_length >= 2 && win_length <= 512 && hop > 0 && raw_len >= win_length,
+               "vm_stft_logmel: bad sizes (n_fft is 512: win_length <= 512)");
+    VM_REQUIRE(n_mels == 32 || n_mels == 64 || n_mels == 96 || n_mels == 128, "vm_stft_logmel: n_mels must be 32, 64, 96 or 128");
+    VM_REQUIRE(log_floor > 0.f, "vm_stft_logmel: log_floor must be positive");
+    const int n_frames = (int)vm_stft_frames(raw_len, win_length, hop);
+    const dim3 grid((unsigned)((n_frames + SF_FRAMES - 1) / SF_FRAMES), (unsigned)n_clips);
+    size_t lds = (size_t)SF_FRAMES * (win_length + 1) * 4;
+    const size_t red = (size_t)4 * n_mels * 32 * 4;
+    if (red > lds) lds = red;
+#define VM_LAUNCH_SF(TT, NMB)                                                                                                    \
+    hipLaunchKernelGGL((stft_logmel_kernel<TT, NMB>), grid, dim3(256), lds, (hipStream_t)stream, raw, is_int16, raw_len, win_length, \
+                       hop, n_frames, basis, melw, log_floor, (TT*)out)
+    VM_DISPATCH_DTYPE(dtype, {
+        switch (n_mels / 32) {
+            case 1: VM_LAUNCH_SF(T, 1); break;
+            case 2: VM_LAUNCH_SF(T, 2); break;
+            case 3: VM_LAUNCH_SF(T, 3); break;
+            default: VM_LAUNCH_SF(T, 4); break;
+        }
+    });
+#undef VM_LAUNCH_SF
+    return check_launch("vm_stft_logmel");
+}
+
+#define VM_DISPATCH_VEC(T, C, ...)                       \
+    do {                                                 \
+        if ((C) % Elem<T>::kVec == 0) {                  \
+            constexpr int V = Elem<T>::kVec;             \
+            __VA_ARGS__;                                 \
+        } else {                                         \
+            constexpr int V = 1;                         \
+            __VA_ARGS__;                                 \
+        }                                                \
+    } while (0)
+
+extern "C" int vm_stack_windows(const void* x, int64_t n_clips, int M, int64_t rows, int C, int Cs, int dtype, void* out, void* stream) {
+    VM_REQUIRE(x && out, "vm_stack_windows: null pointer");
+    VM_REQUIRE(n_clips > 0 && M > 0 && rows > 0 && C > 0 && Cs >= 3 * C, "vm_stack_windows: bad sizes (Cs >= 3 C)");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
+        const int64_t total = n_clips * M * rows * (Cs / V);
+        hipLaunchKernelGGL((stack_windows_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, n_clips, M,
+                           (int)rows, C, Cs, (T*)out);
+    }));
+    return check_launch("vm_stack_windows");
+}
+
+extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int dtype, void* dx, void* stream) {
+    VM_REQUIRE(dxs && dx, "vm_fold_windows: null pointer");
+    VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && C > 0 && Cs >= 3 * C, "vm_fold_windows: bad sizes (Cs >= 3 C)");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
+        const int64_t total = n_clips * M * L * (C / V);
+        hipLaunchKernelGGL((fold_windows_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dxs, n_clips, M,
+                           (int)L, C, Cs, (T*)dx);
+    }));
+    return check_launch("vm_fold_windows");
+}
+
+extern "C" int vm_pool_windows_fwd(const void* q, int64_t n_clips, int M, int64_t rows, int C, int dtype, void* out, void* stream) {
+    VM_REQUIRE(q && out, "vm_pool_windows_fwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M >= 2 && rows > 0 && C > 0, "vm_pool_windows_fwd: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, (rows * C), {
+        const int64_t total = n_clips * (M / 2) * (rows * C / V);
+        hipLaunchKernelGGL((pool_windows_fwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)q, n_clips, M,
+                           (int)rows, C, (T*)out);
+    }));
+    return check_launch("vm_pool_windows_fwd");
+}
+
+extern "C" int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M, int64_t L, int C, int dtype, void* dq,
+                                   void* stream) {
+    VM_REQUIRE(q && dout && dq, "vm_pool_windows_bwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M >= 2 && L > 0 && C > 0, "vm_pool_windows_bwd: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, C, {
+        const int64_t total = n_clips * M * (L * C / V);
+        hipLaunchKernelGGL((pool_windows_bwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)q,
+                           (const T*)dout, n_clips, M, (int)L, C, (T*)dq);
+    }));
+    return check_launch("vm_pool_windows_bwd");
+}
+
+extern "C" int vm_clip_max_fwd(const float* gmax, int64_t n_clips, int M, int M_valid, int C, float* out, int32_t* widx, void* stream) {
+    VM_REQUIRE(gmax && out && widx, "vm_clip_max_fwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M > 0 && M_valid > 0 && M_valid <= M && C > 0, "vm_clip_max_fwd: bad sizes");
+    hipLaunchKernelGGL(clip_max_fwd_kernel, dim3((unsigned)((n_clips * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gmax, n_clips,
+                       M, M_valid, C, out, widx);
+    return check_launch("vm_clip_max_fwd");
+}
+
+extern "C" int vm_clip_max_bwd(const float* dout, const int32_t* widx, int64_t n_clips, int M, int C, float* dg, void* stream) {
+    VM_REQUIRE(dout && widx && dg, "vm_clip_max_bwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M > 0 && C > 0, "vm_clip_max_bwd: bad sizes");
+    hipLaunchKernelGGL(clip_max_bwd_kernel, dim3((unsigned)((n_clips * M * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, widx,
+                       n_clips, M, C, dg);
+    return check_launch("vm_clip_max_bwd");
+}

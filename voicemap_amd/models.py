@@ -43,10 +43,13 @@ class _TrainableModel:
     def _engine_args(self):
         raise NotImplementedError
 
+    def _make_engine(self):
+        from .engine import HipEncoderEngine
+        return HipEncoderEngine(**self._engine_args())
+
     def _ensure_engine(self):
         if self.engine is None:
-            from .engine import HipEncoderEngine
-            self.engine = HipEncoderEngine(**self._engine_args())
+            self.engine = self._make_engine()
             if self._pending_weights is not None:
                 self.engine.set_params(self._pending_weights)
                 self._pending_weights = None
@@ -141,6 +144,9 @@ class _TrainableModel:
         writes, keras_hdf5.py), otherwise one .npz with weights, Adam slots, moving statistics and the model config."""
         import torch
         if str(filepath).lower().endswith((".hdf5", ".h5")):
+            enc = getattr(self, "encoder", self)
+            if type(enc).__name__ == "SpectrogramEncoder":
+                raise NotImplementedError("Keras HDF5 checkpoints describe the reference's 1-D encoder; save the spectrogram variant as .npz")
             from . import keras_hdf5 as KH
             kind, geo, params, opt, training = self._keras_state()
             KH.write_checkpoint(filepath, kind, geo, params, opt, training)
@@ -358,6 +364,15 @@ class ConvolutionalEncoder(_TrainableModel):
         return dict(blocks=self.blocks, embedding_dimension=self.embedding_dimension, dropout=self.dropout,
                     head="classifier" if self.classifier_units else None, num_classes=self.classifier_units, dtype=self.dtype)
 
+    def _make_engine(self, head="__own__"):
+        """The engine of this encoder on its own (``head='__own__'``: classifier head if one was added) or as the shared encoder of
+        a siamese model (``head`` = its distance metric)."""
+        from .engine import HipEncoderEngine
+        args = self._engine_args()
+        if head != "__own__":
+            args.update(head=head, num_classes=0)
+        return HipEncoderEngine(**args)
+
     def get_config(self):
         return {"class_name": "ConvolutionalEncoder", "filters": self.filters, "embedding_dimension": self.embedding_dimension,
                 "input_shape": self.input_shape, "dropout": self.dropout, "dtype": self.dtype, "first_pool": self.blocks[0][2],
@@ -446,6 +461,58 @@ class ConvolutionalEncoder(_TrainableModel):
         return float(la[0]), float(la[1])
 
 
+class SpectrogramEncoder(ConvolutionalEncoder):
+    """The log-mel + 2-D CNN variant of the encoder (BASELINE.json config 4; not in the reference -- DESIGN.md section 9): the same
+    Sequential surface, 4 x [Conv2D 3x3 -> BatchNorm -> SpatialDropout2D -> MaxPool2D] -> GlobalMaxPool2D -> Dense over the log-mel
+    image that ``vm_stft_logmel`` computes from the RAW 16 kHz window (so the batch pre-processor must not decimate or whiten:
+    ``preprocess_instances(1, whitening=False)``)."""
+
+    def __init__(self, filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16", n_mels=64):
+        super().__init__(filters, embedding_dimension, input_shape, dropout, dtype)
+        from . import spectro
+        self.n_mels = int(n_mels)
+        f = self.filters
+        self.blocks = [(3, f, 2), (3, 2 * f, 2), (3, 3 * f, 2), (3, 4 * f, 2)]
+        self.name = "sequential_1"
+        self.layers = [K.Lambda("log_mel_spectrogram", function="log(mel(|stft|^2) + %g): win %d hop %d n_fft %d mels %d"
+                                % (spectro.LOG_FLOOR, spectro.WIN_LENGTH, spectro.HOP, spectro.N_FFT, self.n_mels))]
+        for i, (k, c, p) in enumerate(self.blocks):
+            self.layers += [K.Layer(f"conv2d_{i+1}", filters=c, kernel_size=(3, 3), padding="same", activation="relu"),
+                            K.BatchNormalization(f"batch_normalization_{i+1}", epsilon=1e-3, momentum=0.99),
+                            K.Layer(f"spatial_dropout2d_{i+1}", rate=self.dropout),
+                            K.Layer(f"max_pooling2d_{i+1}", pool_size=(2, 2), strides=(2, 2))]
+        self.layers += [K.Layer("global_max_pooling2d_1"), Dense(self.embedding_dimension, name="dense_1")]
+
+    def add(self, layer):
+        raise NotImplementedError("the spectrogram variant is an embedding encoder only (no classification layer)")
+
+    def clone(self):
+        return SpectrogramEncoder(self.filters, self.embedding_dimension, self.input_shape, self.dropout, self.dtype, self.n_mels)
+
+    def _make_engine(self, head="__own__"):
+        from .spectro_engine import HipSpectrogramEncoderEngine
+        return HipSpectrogramEncoderEngine(self.filters, self.embedding_dimension, dropout=self.dropout,
+                                           head=None if head == "__own__" else head, dtype=self.dtype, n_mels=self.n_mels)
+
+    def get_config(self):
+        return {"class_name": "SpectrogramEncoder", "filters": self.filters, "embedding_dimension": self.embedding_dimension,
+                "input_shape": self.input_shape, "dropout": self.dropout, "dtype": self.dtype, "n_mels": self.n_mels,
+                "first_pool": 2, "classifier_units": 0}
+
+    def summary(self, print_fn=print):
+        print_fn("log-mel front-end (25 ms / 10 ms frames, %d mel bands) + 2-D CNN encoder: Conv2D 3x3 channels %s, embedding %d, %d parameters"
+                 % (self.n_mels, [b[1] for b in self.blocks], self.embedding_dimension, self.count_params()))
+
+    def _keras_state(self):
+        raise NotImplementedError("Keras HDF5 checkpoints describe the reference's 1-D encoder; save the spectrogram variant as .npz")
+
+
+def get_spectrogram_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16", n_mels=64):
+    """The build function of the log-mel / 2-D CNN variant, same signature as ``get_baseline_convolutional_encoder``
+    (voicemap/models.py:6); ``input_shape`` = (samples, 1) of the RAW window."""
+    return SpectrogramEncoder(filters, embedding_dimension, input_shape, dropout, dtype=dtype, n_mels=n_mels)
+
+
 def eng_last_l0(eng) -> int:
     """length of the most recent inference plan (set by HipEncoderEngine.embed)."""
     return eng.last_infer_l0
@@ -473,6 +540,9 @@ class SiameseNet(_TrainableModel):
         e = self.encoder
         return dict(blocks=e.blocks, embedding_dimension=e.embedding_dimension, dropout=e.dropout, head=self.distance_metric,
                     dtype=e.dtype)
+
+    def _make_engine(self):
+        return self.encoder._make_engine(head=self.distance_metric)
 
     def _ensure_engine(self):
         if self.engine is None:
@@ -605,6 +675,8 @@ def load_model(filepath: str, custom_objects=None, dtype=None):
     cfg = json.loads(bytes(blob["config"]).decode())
 
     def enc_from(c):
+        if c.get("class_name") == "SpectrogramEncoder":
+            return SpectrogramEncoder(c["filters"], c["embedding_dimension"], c["input_shape"], c["dropout"], c["dtype"], c["n_mels"])
         e = ConvolutionalEncoder(c["filters"], c["embedding_dimension"], c["input_shape"], c["dropout"], c["dtype"],
                                  c["first_pool"])
         if c["classifier_units"]:
