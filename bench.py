@@ -287,10 +287,67 @@ def main():
         del corpus
         eng.P.copy_(snap[0]); eng.M.copy_(snap[1]); eng.V.copy_(snap[2]); eng.iterations = snap[3]
         eng.refresh_weights()
+        # BASELINE.json config 4: the log-mel + 2-D CNN variant (not in the reference): one siamese training step
+        # of 128 pairs of RAW 3 s clips -- vm_stft_logmel + four Conv2D 3x3 blocks (filters 32) + loss + backward + Adam
+        spectro_extras = {}
+        try:
+            from voicemap_amd.spectro_engine import HipSpectrogramEncoderEngine
+            seng = HipSpectrogramEncoderEngine(32, 64, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
+            spl = seng.plan(2 * pairs, 48000, True)
+
+            def spectro_step():
+                seng.features(spl, xcat)
+                seng.forward(spl, pairs, None)
+                seng.siamese_head(spl, y, a.loss)
+                seng.backward(spl)
+                seng.optimizer_step()
+
+            def spectro_features():
+                seng.features(spl, xcat)
+            t_sp = timed(spectro_step)
+            t_ft = timed(spectro_features)
+            spectro_extras = {"logmel_2dcnn_train_ms_per_step": t_sp * 1e3, "logmel_2dcnn_audio_s_per_s": 2 * pairs * 3.0 / t_sp,
+                              "logmel_frontend_ms_per_256_clips": t_ft * 1e3,
+                              "logmel_2dcnn_config": "log-mel 298 x 64 (25 ms / 10 ms frames), Conv2D 3x3 channels 32-64-96-128, embedding 64, "
+                                                     "%d pairs, %s storage" % (pairs, a.dtype)}
+            del seng, spl
+        except Exception as e:  # the side figure must never take the headline line down
+            spectro_extras = {"logmel_2dcnn_error": repr(e)}
         out["extras"] = {"%s_loss_ms_per_step" % other: t_other * 1e3,
                          "embed_only_audio_s_per_s": 2 * pairs * 3.0 / t_embed, "embed_only_ms_per_256_windows": t_embed * 1e3,
                          "pcie_inclusive_ms_per_step_int16_host_windows": t_h2d * 1e3,
                          "device_resident_corpus_ms_per_step_int16_offsets": t_off * 1e3}
+        out["extras"].update(spectro_extras)
+        if a.dtype == "bf16":
+            # the exact-parity storage mode (fp32 activations, split-precision MFMAs) on the same windows: its step time and how far the
+            # bf16 embeddings / gradients of THIS run are from it (north star: embeddings within 1e-3 of the reference arithmetic)
+            try:
+                e32 = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype="f32", device=dev, seed=1234)
+                e32.set_params({k: v for k, v in eng.get_params().items()})
+                p32 = e32.plan(2 * pairs, l0, True)
+
+                def step32(update=True):
+                    e32.preprocess(p32, xcat, 4, True, pairs)
+                    e32.forward(p32, pairs, None)
+                    e32.siamese_head(p32, y, a.loss)
+                    e32.backward(p32)
+                    if update:
+                        e32.optimizer_step()
+                step32(False)
+                eng.preprocess(pl, xcat, 4, True, pairs)
+                eng.forward(pl, pairs, None)
+                eng.siamese_head(pl, y, a.loss)
+                eng.backward(pl)
+                torch.cuda.synchronize()
+                rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-30))
+                cos = lambda u, v: float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30))
+                out["extras"].update({"bf16_vs_f32_embedding_rel_err": rel(pl["emb"], p32["emb"]),
+                                      "bf16_vs_f32_gradient_rel_err": rel(eng.G, e32.G), "bf16_vs_f32_gradient_cosine": cos(eng.G, e32.G)})
+                t32 = timed(step32, reps=5)
+                out["extras"]["f32_storage_ms_per_step"] = t32 * 1e3
+                del e32, p32
+            except Exception as e:
+                out["extras"]["f32_storage_error"] = repr(e)
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         from oracle import voicemap_oracle as O

@@ -759,7 +759,9 @@ def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contra
     t_start = time.perf_counter()
     if threads is None:
         cores = os.cpu_count() or 1
-        cands = sorted({max(1, min(cores, c)) for c in (8, 16, 32, 64, cores)})
+        # a batch of 8 pairs stops scaling well below 64 threads (256 threads: 50 s per step on the GPU node's host); the counts tried
+        # and their step times go into the bench line next to os.cpu_count()
+        cands = sorted({max(1, min(cores, c)) for c in (8, 16, 32, 64)})
         best, best_t = None, None
         for c in cands:
             if time.perf_counter() - t_start > budget_s * 0.5 and best is not None:
