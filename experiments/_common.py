@@ -71,7 +71,9 @@ def standard_callbacks(a, valid, preprocessor, mode, param_str, plateau_patience
     key = "val_{}-shot_acc".format(a.n_shot)
     return [NShotEvaluationCallback(a.num_evaluation_tasks, a.n_shot, a.k_way, valid, preprocessor=preprocessor, mode=mode),
             CSVLogger(PATH + "/logs/{}.csv".format(param_str)),
-            ModelCheckpoint(PATH + "/models/{}.hdf5".format(param_str), monitor=key, mode="max", save_best_only=True, verbose=True),
+            # Keras HDF5 for the reference's architectures; the log-mel variant (not a Keras model of the reference) saves as .npz
+            ModelCheckpoint(PATH + "/models/{}.{}".format(param_str, "npz" if getattr(a, "frontend", "waveform") == "logmel" else "hdf5"),
+                            monitor=key, mode="max", save_best_only=True, verbose=True),
             ReduceLROnPlateau(monitor=key, mode="max", verbose=1, patience=plateau_patience)]
 
 
