@@ -11,8 +11,11 @@
  *   - plain pointers are DEVICE pointers unless named host_*; sizes are explicit; no torch types.
  *   - `dtype` selects the storage type of activations / GEMM operands: VM_F32 or VM_BF16.  Accumulation,
  *     batch statistics, the tail (global max -> dense -> head -> loss) and the optimizer are always fp32.
- *   - enqueue-only on `stream` (a hipStream_t passed as void*); no host sync, no allocation, no global
- *     mutable state; re-entrant per stream.
+ *   - enqueue-only on `stream` (a hipStream_t passed as void*); no host sync, no allocation; re-entrant per
+ *     stream.  The ONE piece of process-global mutable state is the kernel-selection table behind vm_set_tuning
+ *     (below): every selectable kernel computes the same result (each is parity-tested against the oracle), so
+ *     the table changes speed, never values; it is read at launch time and is not thread-safe -- set it before
+ *     work is enqueued from other threads, or leave the defaults (what the drop-in surface does).
  *   - returns 0 on success, <0 on error (VM_ERR_*); vm_last_error() gives a thread-local message.
  *   - activation layout is Keras' channels-last.  "padded" tensors are (N, L+2, C) with one zero halo
  *     row before and after each window so that a k=3 SAME convolution reads rows t..t+2 with no branch;
@@ -42,15 +45,23 @@ int vm_abi_version(void);
 int vm_check_device(void);
 
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
-/* Tuning hook for A/B measurements (process-global, benchmarking only; not part of the drop-in surface).  Kernel selection:
- *   "nt_p8" 0|1|2   forward/dgrad: 256x256 phase-interleaved kernel off / every eligible shape / K >= 1152 only (default 2)
+/* Kernel-selection table for A/B measurements and for the tests that pin a kernel variant (process-global, see the conventions
+ * above; not part of the drop-in surface: voicemap_amd never calls it outside bench.py --tune).  Unknown keys / values out of
+ * range return VM_ERR_ARG.
+ *   "nt_n2" 0..3    forward / dgrad: the 256 x 128, two-workgroups-per-CU kernels (bit 0 forward, bit 1 dgrad; default 3);
+ *   "nt_n2r" 0|1    ... prefer their input-resident form conv_nt2r_kernel where its tiling fits (default 1)
+ *   "nt_p8" 0|1|2   forward/dgrad: 256x256 phase-interleaved kernel off / every eligible shape / K >= 1152 only (default 2; only
+ *                   reached when nt_n2 does not take the launch)
  *   "nt_w4" 0|1|2   forward/dgrad: one-wave-per-SIMD 254x256 kernel with an input-resident A (conv_w4_kernel) off (default) /
  *                   every eligible shape / K >= 1152 only
  *   "tn_x"  0|1|2   wgrad: input-resident (3 taps x 128 ci) x 128 co kernel off / phase form (default) / free-running form
  *   "tn_p8" 0|1     wgrad: LDS-DMA + transposing-read 256x256 kernel when tn_x does not apply (default 1)
  *   "tn_tile" 128|256, "gemm_kb" 64|128, "nt_glds", "nt_tepi", "nt_ring", "nt_order", "tn_xcd": the older variants
- *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "f1_blocks", "f1_fwd_blocks": launch geometry
- *   "nt_ablate": timing experiments that produce WRONG results (see conv_gemm.hip). */
+ *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "nt_n2_prio", "f1_blocks", "f1_fwd_blocks":
+ *                   launch geometry / scheduling experiments (results unchanged)
+ *   "nt_ablate"     timing experiments that switch parts of a kernel OFF and therefore produce WRONG results: compiled in only
+ *                   when the library is built with -DVM_ENABLE_ABLATION (VM_EXTRA_HIPCC_FLAGS, tools/); the shipped build answers
+ *                   VM_ERR_UNSUPPORTED to any non-zero value. */
 int vm_set_tuning(const char* key, int value);
 
 /* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------

@@ -44,3 +44,13 @@ def test_engine_refuses_to_run_without_gpu():
     from voicemap_amd.engine import HipEncoderEngine
     with pytest.raises(RuntimeError):
         HipEncoderEngine([(32, 16, 4), (3, 32, 2)], 8)
+
+
+def test_shipped_build_refuses_result_changing_tuning():
+    """vm_set_tuning only selects among kernels that compute the same result; the ablation switches (wrong results, timing
+    experiments) exist only in -DVM_ENABLE_ABLATION builds (include/voicemap_hip.h).  Host-only call: no GPU needed."""
+    from voicemap_amd import _lib
+    lib = _lib.lib()
+    assert lib.cdll.vm_set_tuning(b"nt_ablate", 0) == 0
+    assert lib.cdll.vm_set_tuning(b"nt_ablate", 2) == -3 and b"VM_ENABLE_ABLATION" in lib.cdll.vm_last_error()
+    assert lib.cdll.vm_set_tuning(b"no_such_knob", 1) != 0

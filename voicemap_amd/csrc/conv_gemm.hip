@@ -1802,6 +1802,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
 
     f32x16 acc[4][2];
     n2_init_acc<EPI>(p, acc, n0 + wn * 64 + 4 * (lane >> 5));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#else
+    const uint32_t lds0 = 0;
+#endif
 
     // ---- prologue: A(0), B(0), A(1), B(1) in that order ----
     issue_a(0, 0, 0);
@@ -1855,28 +1860,61 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
             }
             n_wait = ia_prev + ib + ia;  // pieces issued after B(kt + 1): the A pieces of kt - 1, then everything of kt
             ia_prev = ia;
-            const char* abase = lds + a_blk * A_BLK;
-            const char* bbase = lds + b_cur * B_STG;  // b_addr already contains the B0 offset
+            // ---- fragments: 12 x ds_read_b128 issued up front in consumption order, then COUNTED lgkmcnt waits (LDS returns in order):
+            // the first MFMAs start when 3 reads have landed, the k-step-1 reads land under the MFMAs of k-step 0.  The reads are
+            // inline asm because hipcc waits lgkmcnt(0) before the first use of any of them; every wait names the registers it
+            // releases as in/out operands, which orders the MFMAs behind it ----
+            const uint32_t aa0 = lds0 + a_blk * A_BLK + a_addr[tap][0], aa1 = lds0 + a_blk * A_BLK + a_addr[tap][1];
+            const uint32_t bb0 = lds0 + b_cur * B_STG + b_addr[0], bb1 = lds0 + b_cur * B_STG + b_addr[1];  // b_addr contains B0
             b_cur = b_cur == 2 ? 0 : b_cur + 1;
-            bf16x8 a0[4], b0[2], a1[4], b1[2];
-            b0[0] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[0]);
-            a0[0] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][0]);
-            b0[1] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[0] + 2048);
-#pragma unroll
-            for (int i = 1; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][0] + i * 2048);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const bf16x8*>(bbase + b_addr[1] + j * 2048);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(abase + a_addr[tap][1] + i * 2048);
+            u32x4 a0[4], b0[2], a1[4], b1[2];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b0[0]) : "v"(bb0));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a0[0]) : "v"(aa0));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b0[1]) : "v"(bb0));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a0[1]) : "v"(aa0));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a0[2]) : "v"(aa0));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a0[3]) : "v"(aa0));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b1[0]) : "v"(bb1));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b1[1]) : "v"(bb1));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a1[0]) : "v"(aa1));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[1]) : "v"(aa1));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[2]) : "v"(aa1));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a1[3]) : "v"(aa1));
+#define VM_MM(A, B, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, B), __builtin_bit_cast(bf16x8, A), acc[I][J], 0, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(a0[0]), "+v"(b0[1]));
+            VM_MM(a0[0], b0[0], 0, 0);
+            VM_MM(a0[0], b0[1], 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[1]));
+            VM_MM(a0[1], b0[0], 1, 0);
+            VM_MM(a0[1], b0[1], 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a0[2]));
+            VM_MM(a0[2], b0[0], 2, 0);
+            VM_MM(a0[2], b0[1], 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[3]));
+            VM_MM(a0[3], b0[0], 3, 0);
+            VM_MM(a0[3], b0[1], 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b1[0]), "+v"(b1[1]), "+v"(a1[0]));
+            VM_MM(a1[0], b1[0], 0, 0);
+            VM_MM(a1[0], b1[1], 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[1]));
+            VM_MM(a1[1], b1[0], 1, 0);
+            VM_MM(a1[1], b1[1], 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a1[2]));
+            VM_MM(a1[2], b1[0], 2, 0);
+            VM_MM(a1[2], b1[1], 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[3]));
+            VM_MM(a1[3], b1[0], 3, 0);
+            VM_MM(a1[3], b1[1], 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#undef VM_MM
             __builtin_amdgcn_sched_barrier(0);
         }
         a_blk = a_blk == 2 ? 0 : a_blk + 1;
@@ -3153,6 +3191,12 @@ extern "C" int vm_set_tuning(const char* key, int value) {
         return VM_OK;
     }
     if (key != nullptr && strcmp(key, "nt_ablate") == 0) {
+#ifndef VM_ENABLE_ABLATION
+        if (value != 0) {
+            vm::set_error("vm_set_tuning: nt_ablate produces wrong results and is only available in builds with -DVM_ENABLE_ABLATION");
+            return VM_ERR_UNSUPPORTED;
+        }
+#endif
         g_nt_ablate = value;
         return VM_OK;
     }
