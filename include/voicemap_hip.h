@@ -144,12 +144,16 @@ int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* w
  * and applies the moving-average updates tower by tower:  moving -= (moving - batch) * (1 - momentum), with the
  * batch variance multiplied by n/(n-(1+eps)) first when unbiased_moving_var != 0 (Keras 2.2.x). */
 /* ws (all three reducers below): >= vm_colreduce_workspace_bytes(n_segments, C) bytes of scratch for the first of the
- * two deterministic reduction stages (n_segments = n_towers; 1 for vm_colsum). */
+ * two deterministic reduction stages (n_segments = n_towers; 1 for vm_colsum).  * zd_biased (n_towers, 2, C) fp32 or NULL: Keras 2.2.2's moving_average_update is TF 1.10's assign_moving_average with
+ * zero_debias=True -- per encoder call a zero-initialised biased accumulator b -= (b - value)(1 - momentum) and
+ * moving = b * zd_correction with zd_correction = 1 / (1 - momentum^t), t = number of training steps so far (host side); the
+ * towers are applied in order.  NULL = the plain exponential average moving -= (moving - value)(1 - momentum). */
 int64_t vm_colreduce_workspace_bytes(int n_segments, int C);
 int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                    double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                    int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                   float* scale, float* shift, void* ws, void* stream);
+                   float* scale, float* shift, void* ws, float* zd_biased, float zd_correction,
+                   void* stream);
 /* inference affine from moving statistics (one "tower"). */
 int vm_bn_infer_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                        float eps, int C, float* scale, float* shift, void* stream);

@@ -221,6 +221,38 @@ def moving_update(moving, batch_value, momentum: float):
     return moving - (moving - batch_value) * (1.0 - momentum)
 
 
+def apply_moving_updates(new_p, collects, n_blocks: int, eps: float, momentum: float, unbiased_moving_variance: bool = True,
+                         bn_state="fresh"):
+    """The BatchNorm moving-statistic updates of one training step for the encoder calls in ``collects`` (one dict per tower,
+    in call order).  Keras 2.2.2: ``K.moving_average_update(x, value, momentum)`` is
+    ``tf.train.assign_moving_average(x, value, momentum, zero_debias=True)`` and TF 1.10's ``_zero_debias`` keeps, PER UPDATE OP
+    (= per encoder call and statistic), a zero-initialised ``biased`` accumulator and a ``local_step`` [3P]:
+        biased -= (biased - value) * (1 - momentum);  local_step += 1;  x = biased / (1 - momentum ** local_step)
+    ``bn_state``: dict carried from step to step ({"step": t, ("m" | "v", tower, block): biased}); "fresh" = a new one (what a
+    freshly built or freshly LOADED Keras model has: the accumulators are not weights and are not in a checkpoint);
+    None = the plain exponential average x -= (x - value)(1 - momentum) (TF's zero_debias=False).  With two towers the reference
+    runs the two update ops of a layer in an unspecified order; here they are applied in call order, so the moving statistic
+    ends as the LAST tower's de-biased average.  Returns the state."""
+    if bn_state == "fresh":
+        bn_state = {}
+    if bn_state is not None:
+        bn_state["step"] = bn_state.get("step", 0) + 1
+    for tw, c in enumerate(collects):
+        for i in range(n_blocks):
+            var = c["bn_var"][i]
+            if unbiased_moving_variance:
+                var = bn_unbiased_variance(var, c["bn_count"][i], eps)
+            for key, name, value in (("m", f"bn{i+1}.moving_mean", c["bn_mean"][i]), ("v", f"bn{i+1}.moving_variance", var)):
+                if bn_state is None:
+                    new_p[name] = moving_update(new_p[name], value, momentum)
+                else:
+                    b = bn_state.get((key, tw, i), torch.zeros_like(value))
+                    b = b - (b - value) * (1.0 - momentum)
+                    bn_state[(key, tw, i)] = b
+                    new_p[name] = b / (1.0 - momentum ** bn_state["step"])
+    return bn_state
+
+
 def bn_unbiased_variance(var, n: int, eps: float):
     """Keras 2.2.x multiplies the batch variance by n / (n - (1 + eps)) before the moving update
     (normalization.py, 'sample variance - unbiased estimator of population variance') [3P].  Not
@@ -477,7 +509,7 @@ def adam_step(state: AdamState, params, grads: Dict[str, torch.Tensor]):
 
 def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str = "contrastive",
                        distance_metric: str = "uniform_euclidean", drop_masks1=None, drop_masks2=None,
-                       unbiased_moving_variance: bool = True, storage: Optional[str] = None):
+                       unbiased_moving_variance: bool = True, storage: Optional[str] = None, bn_state="fresh"):
     """train_on_batch of experiments/siamese_contrastive_loss.py:70 (loss='contrastive') or
     experiments/train_siamese.py:57 (loss='bce'): forward both towers in training mode, loss, grads
     wrt the 20 trainable tensors, global-norm clip + Adam, two sequential BN moving-stat updates
@@ -497,13 +529,7 @@ def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str
     gl = torch.autograd.grad(l, [leaf[k] for k in names])
     grads = OrderedDict((k, g.detach()) for k, g in zip(names, gl))
     new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
-    for c in (c1, c2):
-        for i in range(len(arch.blocks)):
-            var = c["bn_var"][i]
-            if unbiased_moving_variance:
-                var = bn_unbiased_variance(var, c["bn_count"][i], arch.bn_eps)
-            new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
-            new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    bn_state = apply_moving_updates(new_p, (c1, c2), len(arch.blocks), arch.bn_eps, arch.bn_momentum, unbiased_moving_variance, bn_state)
     gnorm = global_norm(grads)
     if state is not None:
         tr = OrderedDict((k, new_p[k]) for k in names)
@@ -511,11 +537,11 @@ def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str
         for k in names:
             new_p[k] = tr[k]
     return {"loss": l.detach(), "acc": acc.detach(), "pred": pred.detach(), "e1": e1.detach(), "e2": e2.detach(),
-            "grads": grads, "grad_norm": gnorm, "params": new_p, "collect1": c1, "collect2": c2}
+            "grads": grads, "grad_norm": gnorm, "params": new_p, "collect1": c1, "collect2": c2, "bn_state": bn_state}
 
 
 def classifier_train_step(arch, p, state: Optional[AdamState], x, y_onehot, drop_masks=None,
-                          unbiased_moving_variance: bool = True):
+                          unbiased_moving_variance: bool = True, bn_state="fresh"):
     """train_on_batch of experiments/train_classifier.py:110-115 (categorical CE + Adam(clipnorm 1))."""
     names = param_names(arch)
     leaf = OrderedDict((k, (v.detach().clone().requires_grad_(k in names))) for k, v in p.items())
@@ -526,18 +552,13 @@ def classifier_train_step(arch, p, state: Optional[AdamState], x, y_onehot, drop
     gl = torch.autograd.grad(l, [leaf[k] for k in names])
     grads = OrderedDict((k, g.detach()) for k, g in zip(names, gl))
     new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
-    for i in range(len(arch.blocks)):
-        var = c["bn_var"][i]
-        if unbiased_moving_variance:
-            var = bn_unbiased_variance(var, c["bn_count"][i], arch.bn_eps)
-        new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
-        new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    bn_state = apply_moving_updates(new_p, (c,), len(arch.blocks), arch.bn_eps, arch.bn_momentum, unbiased_moving_variance, bn_state)
     if state is not None:
         tr = adam_step(state, OrderedDict((k, new_p[k]) for k in names), grads)
         for k in names:
             new_p[k] = tr[k]
     return {"loss": l.detach(), "acc": acc.detach(), "prob": prob.detach(), "e": e.detach(), "grads": grads,
-            "grad_norm": global_norm(grads), "params": new_p, "collect": c}
+            "grad_norm": global_norm(grads), "params": new_p, "collect": c, "bn_state": bn_state}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -701,7 +722,7 @@ def encoder2d_forward(arch: Encoder2dArch, p, feats: torch.Tensor, training: boo
 
 def siamese2d_train_step(arch: Encoder2dArch, p, state: Optional["AdamState"], f1, f2, y, loss: str = "contrastive",
                          distance_metric: str = "uniform_euclidean", drop_masks1=None, drop_masks2=None,
-                         unbiased_moving_variance: bool = True):
+                         unbiased_moving_variance: bool = True, bn_state="fresh"):
     """siamese_train_step for the 2-D variant on log-mel features f1, f2 (B, T, M): same loss / clip / Adam / moving-statistics
     arithmetic as the 1-D step."""
     names = [k for k in p if "moving" not in k]
@@ -714,17 +735,12 @@ def siamese2d_train_step(arch: Encoder2dArch, p, state: Optional["AdamState"], f
     acc = binary_accuracy(y, pred)
     grads = dict(zip(names, torch.autograd.grad(l, [q[k] for k in names])))
     new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
-    for c in (c1, c2):
-        for i in range(4):
-            n = c["bn_count"][i]
-            var = bn_unbiased_variance(c["bn_var"][i], n, arch.bn_eps) if unbiased_moving_variance else c["bn_var"][i]
-            new_p[f"bn{i+1}.moving_mean"] = moving_update(new_p[f"bn{i+1}.moving_mean"], c["bn_mean"][i], arch.bn_momentum)
-            new_p[f"bn{i+1}.moving_variance"] = moving_update(new_p[f"bn{i+1}.moving_variance"], var, arch.bn_momentum)
+    bn_state = apply_moving_updates(new_p, (c1, c2), 4, arch.bn_eps, arch.bn_momentum, unbiased_moving_variance, bn_state)
     if state is not None:
         upd = adam_step(state, {k: new_p[k] for k in names}, grads)
         new_p.update(upd)
     return {"loss": l.detach(), "acc": acc.detach(), "pred": pred.detach(), "e1": e1.detach(), "e2": e2.detach(), "grads": grads,
-            "params": new_p, "z1": c1["z"], "pooled1": c1["pooled"]}
+            "params": new_p, "z1": c1["z"], "pooled1": c1["pooled"], "bn_state": bn_state}
 
 
 def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contrastive", threads: Optional[int] = None,

@@ -68,7 +68,12 @@ def _dev_masks(arch, m1, m2):
 def _check_params_after_adam(newp, ref_params, ref_grads, atol, steps=1, lr=1e-3):
     for k, v in ref_params.items():
         got, want = np.asarray(newp[k], dtype=np.float64), v.numpy()
-        if "moving" in k or k not in ref_grads:
+        if "moving" in k:
+            # zero-debiased: after a few steps the moving statistic is (nearly) the last batch statistic, which from step 2 on
+            # inherits the <= steps * lr freedom Adam leaves parameters whose gradient is ~0 (next comment)
+            assert max_err(got, want) < max(atol, (2.0 * (steps - 1) * lr)) * max(1.0, np.abs(want).max()), k
+            continue
+        if k not in ref_grads:
             assert max_err(got, want) < max(atol, 1e-5), k
             continue
         g = np.abs(ref_grads[k].numpy())
@@ -116,7 +121,10 @@ def test_siamese_train_step_matches_oracle(dtype, loss):
             report(tag, "grad_rel_err_vs_fp64[%s]" % k, rel_err(grads[k], ref["grads"][k].numpy()))
             assert grad_close(grads[k], g.numpy(), 0.12, atol=1e-5), k
         for k, v in ref["params"].items():
-            assert max_err(newp[k], v.numpy()) < 2.1e-3, k   # one Adam step moves a parameter by at most ~lr
+            if "moving" in k:   # after one step the (zero-debiased) moving statistic IS the last tower's batch statistic: bf16 activations
+                assert rel_err(newp[k], v.numpy()) < 2e-2, k
+            else:
+                assert max_err(newp[k], v.numpy()) < 2.1e-3, k   # one Adam step moves a parameter by at most ~lr
     assert eng.iterations == 1
 
 
@@ -126,10 +134,11 @@ def test_two_steps_fp32_keep_tracking_oracle():
     eng = _engine(arch, p, "uniform_euclidean", "f32")
     st = O.AdamState()
     pr = p
+    bn = "fresh"   # the zero-debias accumulators of the moving statistics are carried from step to step (Keras 2.2.2 / TF 1.10)
     for step in range(2):
         pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None)
-        ref = O.siamese_train_step(arch, pr, st, torch.tensor(x1), torch.tensor(x2), torch.tensor(y), loss="contrastive")
-        pr = ref["params"]
+        ref = O.siamese_train_step(arch, pr, st, torch.tensor(x1), torch.tensor(x2), torch.tensor(y), loss="contrastive", bn_state=bn)
+        pr, bn = ref["params"], ref["bn_state"]
         assert abs(pl["loss_acc"][0].item() - ref["loss"].item()) < 1e-4
     _check_params_after_adam(eng.get_params(), pr, ref["grads"], 3e-5, steps=2)
 

@@ -198,7 +198,7 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
     mv = torch.ones(c, **f32)
     crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, c) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
-             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), p(crws), stream())
+             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, stream())
     zr = z.clone().requires_grad_(True)
     gr = gamma.clone().requires_grad_(True)
     br = beta.clone().requires_grad_(True)
@@ -213,6 +213,20 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
         mv_ref = O.moving_update(mv_ref, O.bn_unbiased_variance(v_.detach(), wpt * l, 1e-3), 0.99)
     assert max_err(mm.cpu().numpy(), mm_ref.numpy()) < 1e-6
     assert max_err(mv.cpu().numpy(), mv_ref.numpy()) < 1e-6
+    # the same two calls with Keras 2.2.2 / TF 1.10 zero-debias accumulators (two consecutive training steps on the same batch)
+    zdb = torch.zeros(towers * 2 * c, **f32)
+    mm2, mv2 = torch.zeros(c, **f32), torch.ones(c, **f32)
+    state = "fresh"
+    newp = {"bn1.moving_mean": torch.zeros(c, dtype=torch.float64), "bn1.moving_variance": torch.ones(c, dtype=torch.float64)}
+    for step in (1, 2):
+        L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
+                 p(mm2), p(mv2), p(mean), p(invstd), p(scale), p(shift), p(crws), p(zdb), 1.0 / (1.0 - 0.99 ** step), stream())
+        collects = [{"bn_mean": [m_.detach()], "bn_var": [v_.detach()], "bn_count": [wpt * l]} for (m_, v_) in stats]
+        state = O.apply_moving_updates(newp, collects, 1, 1e-3, 0.99, True, state)
+        assert rel_err(mm2.cpu().numpy(), newp["bn1.moving_mean"].numpy()) < 1e-5
+        assert rel_err(mv2.cpu().numpy(), newp["bn1.moving_variance"].numpy()) < 1e-5
+    # after one or two steps on the same batch the de-biased average IS the last tower's batch statistic
+    assert rel_err(mm2.cpu().numpy(), stats[-1][0].detach().numpy()) < 1e-5
 
     dropd = dev(drop) if drop is not None else None
     out = torch.zeros(n, lq + 2, c, dtype=tdt, device="cuda")
@@ -539,7 +553,7 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     mean, invstd, scale, shift = (torch.empty(towers, f, **f32) for _ in range(4))
     crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, f) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, f, float(wpt * l), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
-             p(mean), p(invstd), p(scale), p(shift), p(crws), stream())
+             p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, stream())
     act = torch.zeros(n, lq + 2, f, dtype=torch.bfloat16, device="cuda")
     L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(dropd), n, wpt, lq, f, 1, 1, p(act), stream())
     out_ref, _ = _bn_block_oracle(z, gr, btr, T(drop) if drop is not None else None, pool, wpt)

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float momentum, int unbiased, float* moving_mean,
                                                            float* moving_var, float* mean, float* invstd, float* scale,
-                                                           float* shift) {
+                                                           float* shift, float* zd_biased, float zd_correction) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= C) return;
     float mm = 0.f, mv = 0.f;
@@ -133,8 +133,24 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
         if (moving_mean != nullptr) {
             double vv = var;
             if (unbiased) vv = var * (count / (count - (1.0 + (double)eps)));
-            mm = mm - (mm - (float)m) * (1.0f - momentum);
-            mv = mv - (mv - (float)vv) * (1.0f - momentum);
+            if (zd_biased != nullptr) {
+                // Keras 2.2.2 K.moving_average_update = tf.train.assign_moving_average(..., zero_debias=True) (TF 1.10
+                // moving_averages._zero_debias): every encoder CALL (tower) keeps its own zero-initialised "biased" accumulator,
+                //   biased -= (biased - value) * (1 - momentum);   moving = biased / (1 - momentum^local_step)
+                // (zd_correction = 1 / (1 - momentum^t) from the host).  The towers' updates are applied in order: the moving
+                // statistic ends up as the last tower's de-biased average.
+                float* bm = zd_biased + ((int64_t)tw * 2 + 0) * C + c;
+                float* bv = zd_biased + ((int64_t)tw * 2 + 1) * C + c;
+                const float nbm = *bm - (*bm - (float)m) * (1.0f - momentum);
+                const float nbv = *bv - (*bv - (float)vv) * (1.0f - momentum);
+                *bm = nbm;
+                *bv = nbv;
+                mm = nbm * zd_correction;
+                mv = nbv * zd_correction;
+            } else {
+                mm = mm - (mm - (float)m) * (1.0f - momentum);
+                mv = mv - (mv - (float)vv) * (1.0f - momentum);
+            }
         }
     }
     if (moving_mean != nullptr && k == 0) {
@@ -708,15 +724,16 @@ extern "C" int64_t vm_colreduce_workspace_bytes(int n_segments, int C) {
 extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                               double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                               int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                              float* scale, float* shift, void* ws, void* stream) {
+                              float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, void* stream) {
     VM_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && invstd && scale && shift && ws, "vm_bn_finalize: null pointer");
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
+    VM_REQUIRE(zd_biased == nullptr || (moving_mean != nullptr && zd_correction >= 1.0f), "vm_bn_finalize: zero-debias needs the moving statistics and a correction >= 1");
     hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
                        stat_sum, stat_sq, rows_per_tower, C, (double*)ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                       mean, invstd, scale, shift);
+                       mean, invstd, scale, shift, zd_biased, zd_correction);
     return check_launch("vm_bn_finalize");
 }
 

@@ -140,6 +140,7 @@ class HipEncoderEngine:
         self.P, self.G, self.M, self.V = st.P, st.G, st.M, st.V
         self.nt_off, self.NT = st.nt_off, st.NT
         dev = self.device
+        self._init_zero_debias()
         self.wf: Dict[int, torch.Tensor] = {}
         self.wd: Dict[int, torch.Tensor] = {}
         for i in range(1, self.nb):
@@ -166,6 +167,29 @@ class HipEncoderEngine:
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
         self.init_params(seed)
+
+    def _init_zero_debias(self):
+        """Keras 2.2.2 BatchNormalization updates its moving statistics with TF 1.10's assign_moving_average(zero_debias=True)
+        (keras/backend/tensorflow_backend.py moving_average_update [3P]): per encoder call (tower) and statistic a zero-initialised
+        "biased" accumulator and a step counter, moving = biased / (1 - momentum^step).  ZD holds the accumulators of every
+        BatchNorm layer as (2 towers, 2 statistics, C) blocks; they are NOT Keras weights (a Keras checkpoint does not carry them:
+        after load_model the first update overwrites the moving statistics with the de-biased batch statistics, here as there).
+        ``bn_zero_debias = False`` gives the plain exponential average."""
+        self.bn_zero_debias = True
+        self.zd_off = OrderedDict()
+        off = 0
+        for i, (_, c, _) in enumerate(self.blocks):
+            self.zd_off[i] = (off, c)
+            off += 4 * _align(c)
+        self.ZD = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.bn_steps = 0
+
+    def _zd(self, i: int):
+        """(pointer to the block's accumulators, 1 / (1 - momentum^t)) for the training forward in progress, or (None, 0)."""
+        if not self.bn_zero_debias:
+            return None, 0.0
+        o, c = self.zd_off[i]
+        return self.ZD[o:o + 4 * c].data_ptr(), 1.0 / (1.0 - self.bn_momentum ** self._bn_t)
 
     # ------------------------------------------------------------------------------------------------
     def stream(self):
@@ -221,6 +245,9 @@ class HipEncoderEngine:
         self.M.zero_()
         self.V.zero_()
         self.iterations = 0
+        if hasattr(self, "ZD"):
+            self.ZD.zero_()
+            self.bn_steps = 0
         self.refresh_weights()
 
     def set_params(self, params: Dict[str, "np.ndarray"]):
@@ -360,6 +387,9 @@ class HipEncoderEngine:
         wpt = windows_per_tower if training else n
         pl["wpt"], pl["drop"] = wpt, drop_masks
         fused_tail = False
+        if training:
+            self.bn_steps += 1
+            self._bn_t = self.bn_steps
         for i, (k, c, pool) in enumerate(self.blocks):
             b, L = pl[i], pl["L"][i]
             ssum = _p(b["ssum"]) if training else None
@@ -372,9 +402,10 @@ class HipEncoderEngine:
                 if training:
                     self._call("vm_conv1_fused_fwd", _p(pl["x0"]), w1, bias, gam, None, n, L, c, pool, 0, _p(b["e"]), ssum, ssq,
                                st)
+                    zd, zc = self._zd(i)
                     self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
                                self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
-                               _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), st)
+                               _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), zd, zc, st)
                     dm = drop_masks[i] if drop_masks is not None else None
                     self._call("vm_bn_drop_pool_fwd", _p(b["e"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt,
                                pl["L"][1], c, 1, dt, _p(b["act"]), st)
@@ -391,9 +422,10 @@ class HipEncoderEngine:
                 self._call("vm_conv_fwd", _p(pl[i - 1]["act"]), _p(self.wf[i]), bias, n, L, cin, c, dt, _p(b["z"]), ssum, ssq,
                          st)
             if training:
+                zd, zc = self._zd(i)
                 self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
                          self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
-                         _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), st)
+                         _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), zd, zc, st)
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
             dm = drop_masks[i] if (drop_masks is not None and training) else None

@@ -159,6 +159,7 @@ class _TrainableModel:
                            "optimizer": {"lr": eng.lr, "beta_1": eng.beta_1, "beta_2": eng.beta_2, "epsilon": eng.adam_eps,
                                          "decay": eng.decay, "clipnorm": float(eng.clipnorm) if eng.clipnorm else None}}
         blob = {"P": eng.P.cpu().numpy(), "M": eng.M.cpu().numpy(), "V": eng.V.cpu().numpy(), "NT": eng.NT.cpu().numpy(),
+                "ZD": eng.ZD.cpu().numpy(), "bn_steps": np.int64(eng.bn_steps),   # zero-debias accumulators of the moving statistics
                 "iterations": np.int64(eng.iterations),
                 "config": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
         with open(filepath, "wb") as f:
@@ -169,6 +170,9 @@ class _TrainableModel:
         eng = self._ensure_engine()
         for name in ("P", "M", "V", "NT"):
             getattr(eng, name).copy_(torch.from_numpy(blob[name]).to(eng.device))
+        if "ZD" in blob:
+            eng.ZD.copy_(torch.from_numpy(blob["ZD"]).to(eng.device))
+            eng.bn_steps = int(blob["bn_steps"])
         eng.iterations = int(blob["iterations"])
         eng.refresh_weights()
 

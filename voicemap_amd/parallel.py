@@ -142,9 +142,13 @@ def broadcast_state(engine, src: int = 0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in (engine.P, engine.M, engine.V, engine.NT):
             dist.broadcast(t, src)
-        it = torch.tensor([int(engine.iterations)], dtype=torch.int64, device=engine.P.device)
+        if hasattr(engine, "ZD"):   # zero-debias accumulators of the BatchNorm moving statistics + their step counter
+            dist.broadcast(engine.ZD, src)
+        it = torch.tensor([int(engine.iterations), int(getattr(engine, "bn_steps", 0))], dtype=torch.int64, device=engine.P.device)
         dist.broadcast(it, src)
-        engine.iterations = int(it.item())
+        engine.iterations = int(it[0].item())
+        if hasattr(engine, "ZD"):
+            engine.bn_steps = int(it[1].item())
         engine.refresh_weights()
 
 

@@ -100,6 +100,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.grad_sync = None
         self.grad_prescale = 1.0
         self._plans: Dict[tuple, dict] = {}
+        self._init_zero_debias()
         self.basis = torch.from_numpy(spectro.dft_basis(self.win_length)).to(dev)
         self.melw = torch.from_numpy(spectro.mel_filterbank(self.n_mels)).to(dev)
         self.init_params(seed)
@@ -139,6 +140,9 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.M.zero_()
         self.V.zero_()
         self.iterations = 0
+        if hasattr(self, "ZD"):
+            self.ZD.zero_()
+            self.bn_steps = 0
         self.set_params(params)
 
     def set_params(self, params):
@@ -265,6 +269,9 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         cpt = clips_per_tower if training else n
         pl["cpt"] = cpt
         pl["drop_w"] = [None] * 4
+        if training:
+            self.bn_steps += 1
+            self._bn_t = self.bn_steps
         for i, c in enumerate(self.chan):
             b, L, Mi = pl[i], pl["T"][i], pl["M"][i]
             nw, wpt = b["nw"], cpt * Mi
@@ -276,9 +283,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
             mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
             if training:
+                zd, zc = self._zd(i)
                 self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet, self.bn_eps,
                            self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]), _p(b["scale"]), _p(b["shift"]),
-                           _p(pl["cr_ws"]), st)
+                           _p(pl["cr_ws"]), zd, zc, st)
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
             dm = None
