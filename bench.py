@@ -82,6 +82,8 @@ def main():
             eng.overlap_wgrad = bool(int(v))
         elif k == "pooled_reduce":
             eng.pooled_reduce = bool(int(v))
+        elif k == "split_towers":
+            eng.split_towers = bool(int(v))
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
     if a.nt_blocks:
@@ -140,6 +142,7 @@ def main():
     esize = 2 if a.dtype == "bf16" else 4
     gemm = ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
     was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False
+    was_split, eng.split_towers = eng.split_towers, False   # one launch per GEMM of the step, nothing else in flight
     snap0 = (eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.NT.clone(), eng.iterations)
     eng.timed = {nm: [] for nm in gemm}
     att_reps = max(5, min(a.steps, 20))
@@ -161,6 +164,7 @@ def main():
         fam[nm] = {"ms_per_step": sum(l["ms"] for l in launches), "launches": launches}
     eng.timed = {}
     eng.overlap_wgrad = was_overlap
+    eng.split_towers = was_split
     eng.P.copy_(snap0[0]); eng.M.copy_(snap0[1]); eng.V.copy_(snap0[2]); eng.NT.copy_(snap0[3]); eng.iterations = snap0[4]
     eng.refresh_weights()
     if a.dominant == "auto":
@@ -214,6 +218,7 @@ def main():
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]
         eng.timed = {nm: [] for nm in names}
         was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False  # serial, so that every entry point is attributable
+        was_split2, eng.split_towers = eng.split_towers, False
         reps = 3
         for _ in range(reps):
             step()
@@ -225,6 +230,7 @@ def main():
             rows.append((nm, len(r_) // reps, tot))
         eng.timed = {}
         eng.overlap_wgrad = was_overlap
+        eng.split_towers = was_split2
         with open(a.breakdown, "w") as f:
             f.write("entry_point,launches_per_step,ms_per_step\n")
             for nm, cnt, tot in sorted(rows, key=lambda r: -r[2]):

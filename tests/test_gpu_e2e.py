@@ -238,6 +238,20 @@ def test_full_size_properties_cfgA_bf16():
                                     apply_update=False)
         torch.cuda.synchronize()
         assert torch.equal(g1, eng.G), "side-stream wgrad must not change the gradients"
+        # the second tower's forward on its own stream (default) or both towers in one launch per stage: the same arithmetic per
+        # tower up to the order of a few fp32 partial sums (the block-1 kernel's chunking depends on the launch size)
+        nt1 = eng.NT.clone()
+        eng.split_towers = not eng.split_towers
+        eng.init_params(1234)
+        pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,
+                                    apply_update=False)
+        torch.cuda.synchronize()
+        d_emb = rel_err(pl["emb"].cpu().numpy(), emb.cpu().numpy())
+        d_g = rel_err(eng.G.cpu().numpy(), g1.cpu().numpy())
+        d_nt = rel_err(eng.NT.cpu().numpy(), nt1.cpu().numpy())
+        report("full_size_cfgA", "tower_split_vs_one_launch_%s_emb" % dtype, d_emb)
+        report("full_size_cfgA", "tower_split_vs_one_launch_%s_grad" % dtype, d_g)
+        assert d_emb < (1e-5 if dtype == "f32" else 3e-3) and d_nt < 1e-5 and d_g < (1e-4 if dtype == "f32" else 5e-2), (d_emb, d_g, d_nt)
         assert torch.isfinite(eng.G).all() and torch.isfinite(loss1).all()
         res[dtype] = (emb.cpu().numpy(), loss1.cpu().numpy(), g1.cpu().numpy())
         del eng, pl

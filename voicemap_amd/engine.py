@@ -163,6 +163,9 @@ class HipEncoderEngine:
         # bf16), so it is on for bf16 storage (the throughput mode) and off for fp32 (the exact-parity mode).
         self.pooled_reduce = (self.dtype == _lib.VM_BF16)
         self.side_stream = torch.cuda.Stream(device=self.device)
+        # training forward: the second tower on its own stream (see forward())
+        self.split_towers = True
+        self.tower_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
@@ -378,72 +381,113 @@ class HipEncoderEngine:
 
     def forward(self, pl: dict, windows_per_tower: int, drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """x0 -> embeddings (pl['emb']).  Training plans use batch statistics per tower and update the moving
-        statistics; inference plans use the moving statistics (Keras learning phase 0)."""
-        lib, st, n, dt = self.lib, self.stream(), pl["n"], self.dtype
+        statistics; inference plans use the moving statistics (Keras learning phase 0).
+
+        ``split_towers`` (training, two towers): the two encoder calls of the siamese model (voicemap/models.py:52-53) are
+        independent until the head, so tower 2's kernel sequence is enqueued on a second stream over the second half of the
+        same buffers: a GEMM of one tower then runs next to a streaming BatchNorm pass of the other (8.6 % off the forward at
+        cfg-A forward alone, 1.5 % off the step, tools/tower_pipeline_probe.py).  Every launch computes what its half of the
+        one-launch form computes; the only difference is the order of a few fp32 partial sums whose chunking depends on the launch
+        size (block 1), i.e. results agree to rounding and stay run-to-run bit-identical (tests/test_gpu_e2e.py)."""
+        n = pl["n"]
         training = pl["training"]
         n_towers = n // windows_per_tower if training else 1
         assert (not training) or n % windows_per_tower == 0
         assert n_towers <= 2 or not training, "at most two towers per call"
         wpt = windows_per_tower if training else n
         pl["wpt"], pl["drop"] = wpt, drop_masks
-        fused_tail = False
         if training:
             self.bn_steps += 1
             self._bn_t = self.bn_steps
+        if training and n_towers == 2 and self.split_towers:
+            if "cr_ws_t2" not in pl:
+                pl["cr_ws_t2"] = torch.empty_like(pl["cr_ws"])
+                pl["gmax_ws_t2"] = torch.empty_like(pl["gmax_ws"])
+                pl["mov_scratch"] = torch.empty(2 * max(b[1] for b in self.blocks), dtype=torch.float32, device=self.device)
+                pl["tower_ev"] = [torch.cuda.Event() for _ in self.blocks]
+            cur = torch.cuda.current_stream(self.device)
+            self.tower_stream.wait_stream(cur)   # the pre-processed windows are ready
+            self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True)
+            with torch.cuda.stream(self.tower_stream):
+                self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True)
+            cur.wait_stream(self.tower_stream)
+        else:
+            self._forward_range(pl, 0, n, 0, n_towers, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"])
+        cl = self.blocks[-1][1]
+        self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
+                   _p(pl["emb"]), self.stream())
+        return pl["emb"]
+
+    def _forward_range(self, pl: dict, w0: int, nw: int, tw0: int, ntw: int, wpt: int, drop_masks, cr_ws, gmax_ws,
+                       first_of_two: bool = False, second_of_two: bool = False):
+        """The encoder blocks for windows [w0, w0 + nw) = towers [tw0, tw0 + ntw) on the current stream."""
+        st, dt, training = self.stream(), self.dtype, pl["training"]
+
+        def W(t, per_window=1):   # rows of a per-window tensor that belong to this range
+            return t[w0 * per_window:(w0 + nw) * per_window].data_ptr()
+
+        def T(t):                 # rows of a per-tower (2, C) tensor
+            return t[tw0:].data_ptr()
+
+        fused_tail = False
         for i, (k, c, pool) in enumerate(self.blocks):
             b, L = pl[i], pl["L"][i]
-            ssum = _p(b["ssum"]) if training else None
-            ssq = _p(b["ssq"]) if training else None
+            rows = b["stat_rows"]
+            ssum = W(b["ssum"], rows) if training else None
+            ssq = W(b["ssq"], rows) if training else None
             bias = _p(self.view(f"conv{i+1}.bias"))
             gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
             mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
+            dm = W(drop_masks[i]) if (training and drop_masks is not None and drop_masks[i] is not None) else None
+
+            def finalize():
+                zd, zc = self._zd(i)
+                m_, v_ = mm, mv
+                if zd is not None:
+                    zd += tw0 * 2 * c * 4   # this tower's accumulators
+                    if first_of_two:        # the moving statistic ends as the LAST tower's de-biased average: tower 1 of 2 only
+                        m_ = pl["mov_scratch"].data_ptr()   # updates its accumulators
+                        v_ = m_ + 4 * c
+                elif second_of_two:         # plain average: the two updates are sequential -- after tower 1's
+                    self.tower_stream.wait_event(pl["tower_ev"][i])
+                self._call("vm_bn_finalize", ssum, ssq, wpt * rows, ntw, c, float(wpt * L), gam, bet, self.bn_eps, self.bn_momentum,
+                           int(self.unbiased), m_, v_, T(b["mean"]), T(b["invstd"]), T(b["scale"]), T(b["shift"]), _p(cr_ws), zd, zc, st)
+                if zd is None and first_of_two:
+                    pl["tower_ev"][i].record()
+
             if i == 0 and self.fuse_block1:
                 w1 = _p(self.view("conv1.kernel"))
                 if training:
-                    self._call("vm_conv1_fused_fwd", _p(pl["x0"]), w1, bias, gam, None, n, L, c, pool, 0, _p(b["e"]), ssum, ssq,
-                               st)
-                    zd, zc = self._zd(i)
-                    self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
-                               self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
-                               _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), zd, zc, st)
-                    dm = drop_masks[i] if drop_masks is not None else None
-                    self._call("vm_bn_drop_pool_fwd", _p(b["e"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt,
-                               pl["L"][1], c, 1, dt, _p(b["act"]), st)
+                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 0, W(b["e"]), ssum, ssq, st)
+                    finalize()
+                    self._call("vm_bn_drop_pool_fwd", W(b["e"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, pl["L"][1], c, 1, dt,
+                               W(b["act"]), st)
                 else:
                     self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
-                    self._call("vm_conv1_fused_fwd", _p(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), n, L, c, pool, 1,
-                               _p(b["act"]), None, None, st)
+                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), nw, L, c, pool, 1,
+                               W(b["act"]), None, None, st)
                 continue
             if i == 0:
-                self._call("vm_conv1_fwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), bias, n, L, c, dt, _p(b["z"]), ssum,
-                         ssq, st)
+                self._call("vm_conv1_fwd", W(pl["x0"]), _p(self.view("conv1.kernel")), bias, nw, L, c, dt, W(b["z"]), ssum, ssq, st)
             else:
                 cin = self.blocks[i - 1][1]
-                self._call("vm_conv_fwd", _p(pl[i - 1]["act"]), _p(self.wf[i]), bias, n, L, cin, c, dt, _p(b["z"]), ssum, ssq,
-                         st)
+                self._call("vm_conv_fwd", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, nw, L, cin, c, dt, W(b["z"]), ssum, ssq, st)
             if training:
-                zd, zc = self._zd(i)
-                self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet,
-                         self.bn_eps, self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]),
-                         _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), zd, zc, st)
+                finalize()
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
-            dm = drop_masks[i] if (drop_masks is not None and training) else None
+            sc, sh = (T(b["scale"]), T(b["shift"])) if training else (_p(b["scale"]), _p(b["shift"]))
             if i == self.nb - 1:
                 # last block: BN apply + dropout + max-pool + GlobalMaxPool1D in one pass; its pooled tensor has no other
                 # consumer and is never written
-                self._call("vm_bn_drop_pool_gmax_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt, L, c, pool,
-                           dt, _p(pl["gmax"]), _p(pl["gidx"]), _p(pl["gmax_ws"]), st)
+                self._call("vm_bn_drop_pool_gmax_fwd", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt, W(pl["gmax"]), W(pl["gidx"]),
+                           _p(gmax_ws), st)
                 fused_tail = True
                 continue
-            self._call("vm_bn_drop_pool_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, wpt, L, c, pool, dt,
-                     _p(b["act"]), st)
-        cl, Ll = self.blocks[-1][1], pl["L"][-1]
+            self._call("vm_bn_drop_pool_fwd", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt, W(b["act"]), st)
         if not fused_tail:
-            self._call("vm_global_maxpool_fwd", _p(pl[self.nb - 1]["act"]), n, Ll, cl, dt, _p(pl["gmax"]), _p(pl["gidx"]), st)
-        self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
-                 _p(pl["emb"]), st)
-        return pl["emb"]
+            cl, Ll = self.blocks[-1][1], pl["L"][-1]
+            self._call("vm_global_maxpool_fwd", W(pl[self.nb - 1]["act"]), nw, Ll, cl, dt, W(pl["gmax"]), W(pl["gidx"]), st)
 
     def backward(self, pl: dict, sync_tail: bool = False):
         """pl['demb'] -> gradients of every encoder tensor in self.G (fixed summation order throughout).  ``sync_tail``
