@@ -131,7 +131,10 @@ def main():
     in_region = {nm: sum(e0.elapsed_time(e1) for e0, e1, _ in eng.timed[nm]) / a.steps for nm in families}
     eng.timed = {}
     loss = float(pl["loss_acc"][0].item())
-    assert np.isfinite(loss) or a.tune, "training diverged"
+    # a tuning set may switch kernels, never results: a non-finite loss is an error there too, except for the ablation switches of
+    # -DVM_ENABLE_ABLATION builds (wrong results by design; note that corrupted tensors also make every later launch FASTER -- the
+    # chip clocks higher on NaN / zero operands -- so their timings overstate what removing the ablated part would save)
+    assert np.isfinite(loss) or "ablate" in a.tune, "training diverged"
 
     windows = 2 * pairs * n_gpus * a.steps
     value = windows * 3.0 / dt

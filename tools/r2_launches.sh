@@ -7,7 +7,7 @@ for t in "$@"; do
   python - "$O/launch_${TAG}_$t.json" "$t" <<'PY'
 import sys, json
 d = json.load(open(sys.argv[1])); r = d["roofline"]
-print("== %s: %.4f ms/step  hbm_frac %.3f" % (sys.argv[2], d["ms_per_step"], r["step_hbm_frac"]))
+print("== %s: %.4f ms/step  hbm_frac %.3f  final_loss %r" % (sys.argv[2], d["ms_per_step"], r["step_hbm_frac"], d["config"]["final_loss"]))
 for nm, f in r["families_serial"].items():
     print("  %-14s %.4f ms  (%.3f of peak)  " % (nm, f["ms_per_step"], f["frac_of_mfma_peak"]) + "  ".join("L%d %d->%d: %.1f us %.0f TF" % (l["L"], l["c_in"], l["c_out"], l["ms"] * 1e3, l["tflops"]) for l in f["launches"]))
 PY

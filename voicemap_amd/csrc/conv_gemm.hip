@@ -1423,7 +1423,7 @@ namespace n2 {
 constexpr int TM = 256, TN = 128, KB = 64, RING = 3;
 constexpr int A_BYTES = TM * KB, B_BYTES = TN * KB, STAGE = A_BYTES + B_BYTES;
 constexpr int TP = TN * 2 + 16;
-constexpr int LDS_BYTES = (RING * STAGE > TM * TP + 8192) ? RING * STAGE : TM * TP + 8192;  // tile + 8 KB of statistics partials
+constexpr int LDS_BYTES = (RING * STAGE > TM * TP) ? RING * STAGE : TM * TP;  // operand rings / the epilogue tile
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 }  // namespace n2
 
@@ -1444,24 +1444,39 @@ __device__ inline void n2_init_acc(const NtArgs<bf16>& p, f32x16 (&acc)[4][2], i
 }
 
 // Shared epilogue of the 256 x 128 kernels below.  ``trows``: valid MFMA-tile rows (256, or 254 for the input-resident kernel).
+//
+// Forward statistics ON THE MATRIX PIPE.  The BatchNorm partial sums (sum z, sum z^2 per channel over the tile's positions) used
+// to be 3 VALU instructions per output element in the read-back loop -- 37..47 us of a 205..237 us launch at cfg-A, un-hidden
+// (ablation: forward 0.662 -> 0.540 ms per step without them).  They are column sums of the bf16 tile Z that sits in LDS anyway:
+//     sum_r Z[r][c]        = (1^T Z)[c]                    sum_r Z[r][c]^2 = diag(Z^T Z)[c]
+// so wave w takes channels [32 w, 32 w + 32), reads the K-major fragment X (lane <-> channel, 8 consecutive positions per lane)
+// of 16 positions with two transposing LDS reads (ds_read_b64_tr_b16, the wgrad kernels' read) and issues
+//     D2 += X X^T  (32 x 32 block of Z^T Z: its diagonal are the squares)     D1 += 1 X^T  (every row = the column sums)
+// -- the SAME registers serve as both operands of the first MFMA.  32 transposing reads + 32 MFMAs per wave replace 384 VALU
+// instructions per thread; products of bf16 values are exact in fp32, so the sums are those of the stored (rounded) values as
+// before, in a different (fixed) order.  Rows that are not positions of the window (254 / 255 of the input-resident tile, the
+// tail of the last tile) are written to LDS as zeros so that they drop out.
 template <int EPI>
 __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x16 (&acc)[4][2], int64_t n, int tl, int t0, int n0, int trows,
                                    int tid, int lane, int w, int wm, int wn) {
     using namespace n2;
     const int r = lane & 31, kh = lane >> 5;
+    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr && !(p.ablate & 64);
+    const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
 
-    // ---- epilogue: registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with
-    // it) and ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0
-    // included; rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
+    // ---- registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with it) and
+    // ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0 included;
+    // rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int i = 0; i < 4; ++i) {
+        const int m = wm * 128 + i * 32 + r;
+        const bool partial = wm * 128 + i * 32 + 32 > valid;  // wave-uniform: this 32-row block has rows outside the window
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = wm * 128 + i * 32 + r;
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
                 bf16 o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][4 * g + e];
@@ -1472,17 +1487,16 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
                     pk[0] = lo;
                     pk[1] = hi;
+                    if (partial && m >= valid) pk[0] = pk[1] = 0u;
                 }
                 *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
             }
         }
     }
     __syncthreads();
-    // ---- read-back: 8 rows per thread and half, ALL tile reads first, then the 8 whole-row stores back to back (a predicated
-    // read -> wait -> store chain per row left the store path idle between rows); interior tiles take a predicate-free path ----
+    // ---- read-back: 8 rows per thread and half, ALL tile reads first, then the 8 whole-row stores back to back; interior tiles
+    // take a predicate-free path ----
     const int c8 = tid & 15, rg = tid >> 4;
-    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
-    float* red = reinterpret_cast<float*>(lds + TM * TP);  // [half][wave][sum | square][128] floats = 8 KB
     bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
     const bool interior = t0 + trows <= p.L;  // every valid MFMA row of the tile is a position of the window
     const bool no_store = (p.ablate & 1) != 0;
@@ -1491,45 +1505,13 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
         bf16x8 v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const bf16x8*>(lds + (h * 128 + rg + 16 * jj) * TP + c8 * 16);
-        bool ok[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int row = h * 128 + rg + 16 * jj;
-            // rows >= trows exist only in the last 16 rows of the tile (trows >= 240)
-            ok[jj] = INTERIOR ? (h == 0 || jj < 7 || row < trows) : (row < trows && t0 + row < p.L);
-        }
         if (!no_store) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                if (ok[jj]) *reinterpret_cast<bf16x8*>(obase + (int64_t)(h * 128 + rg + 16 * jj) * p.N) = v[jj];
-        }
-        if (stats) {
-            float s8[8], q8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                if (ok[jj]) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (float)v[jj][e];
-                        s8[e] += x;
-                        q8[e] = fmaf(x, x, q8[e]);
-                    }
-                }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s8[e] += __shfl_xor(s8[e], 16, 64);
-                s8[e] += __shfl_xor(s8[e], 32, 64);
-                q8[e] += __shfl_xor(q8[e], 16, 64);
-                q8[e] += __shfl_xor(q8[e], 32, 64);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[((h * 4 + w) * 2 + 0) * 128 + c8 * 8 + e] = s8[e];
-                    red[((h * 4 + w) * 2 + 1) * 128 + c8 * 8 + e] = q8[e];
-                }
+            for (int jj = 0; jj < 8; ++jj) {
+                const int row = h * 128 + rg + 16 * jj;
+                // rows >= trows exist only in the last 16 rows of the tile (trows >= 240)
+                const bool ok = INTERIOR ? (h == 0 || jj < 7 || row < trows) : row < valid;
+                if (ok) *reinterpret_cast<bf16x8*>(obase + (int64_t)row * p.N) = v[jj];
             }
         }
     };
@@ -1541,14 +1523,67 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
         half(1, std::false_type{});
     }
     if (stats) {
-        __syncthreads();
-        const int h = tid >> 7, c = tid & 127;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#else
+        const uint32_t lds0 = 0;
+#endif
+        // fragment geometry of the transposing read: lane (kh, lg, li) supplies the 8-byte word of row kh * 8 + (li >> 2), channels
+        // 16 lg + 4 (li & 3) .. + 3 and receives channel 16 lg + li, rows kh * 8 .. + 3 (second read: + 4 rows)
+        const int li = lane & 15, lg = (lane >> 4) & 1;
+        const uint32_t xoff = lds0 + (kh * 8 + (li >> 2)) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+        const u32x4 ones4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones4);
         const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
-        if (2 * tl + h < srows) {
-            const float* rr = red + h * 4 * 2 * 128;
-            const int64_t srow = n * srows + 2 * tl + h;
-            p.stat_sum[srow * p.N + n0 + c] = (rr[0 * 128 + c] + rr[2 * 128 + c]) + (rr[4 * 128 + c] + rr[6 * 128 + c]);
-            p.stat_sq[srow * p.N + n0 + c] = (rr[1 * 128 + c] + rr[3 * 128 + c]) + (rr[5 * 128 + c] + rr[7 * 128 + c]);
+        const int cn = lane & 31;             // the channel (of this wave's 32) whose sums this lane extracts
+        const int rsel = (cn & 3) + 4 * (cn >> 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x16 d1, d2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d1[e] = d2[e] = 0.f;
+            u32x2 lo[8], hi[8];   // all 16 transposing reads of the half first, then the 16 MFMAs (one latency, not eight)
+#pragma unroll
+            for (int rs = 0; rs < 8; ++rs) {
+                const uint32_t a = xoff + (h * 128 + rs * 16) * TP;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[rs]) : "v"(a));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1088" : "=v"(hi[rs]) : "v"(a));  // + 4 rows of 272 bytes
+            }
+#pragma unroll
+            for (int rs = 0; rs < 8; ++rs) {
+                if (rs == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(lo[0]), "+v"(hi[0]));
+                } else if (rs == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(lo[1]), "+v"(hi[1]));
+                } else if (rs == 2) {
+                    asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(lo[2]), "+v"(hi[2]));
+                } else if (rs == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lo[3]), "+v"(hi[3]));
+                } else if (rs == 4) {
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo[4]), "+v"(hi[4]));
+                } else if (rs == 5) {
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo[5]), "+v"(hi[5]));
+                } else if (rs == 6) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo[6]), "+v"(hi[6]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[7]), "+v"(hi[7]));
+                }
+                const u32x4 xv = {lo[rs][0], lo[rs][1], hi[rs][0], hi[rs][1]};
+                const bf16x8 x = __builtin_bit_cast(bf16x8, xv);
+                d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, d2, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, x, d1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // D1[m][n] = sum over the 16 x 8 rows of Z[row][32 w + n] for every m: register 0 of lane n.  D2[m][n] with
+            // m = (r & 3) + 8 (r >> 2) + 4 kh: the diagonal element of channel n is register rsel(n) of the lane with kh == (n >> 2) & 1.
+            float dq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dq = e == rsel ? d2[e] : dq;
+            if (2 * tl + h < srows) {
+                const int64_t srow = n * srows + 2 * tl + h;
+                if (kh == 0) p.stat_sum[srow * p.N + n0 + 32 * w + cn] = d1[0];
+                if (kh == ((cn >> 2) & 1)) p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
+            }
         }
     }
 }
@@ -1707,7 +1742,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt2_kernel(NtArgs<bf16> p, int64_
 // Tried on this kernel without gain (round 2, interleaved A/B on the six cfg-A launches): s_setprio(2) around the K loop (+1 %
 // time), a start offset between the two workgroups of a CU or across the chip (0 .. +3 %), the two operand streams issued by
 // different waves so that vmcnt's in-order retirement does not tie the input blocks to the weight slices (+3 %), non-temporal
-// output stores (-1.5 %, not kept: the next kernel reads the tensor).  Ablations: see DESIGN.md 4.2.
+// output stores (-1.5 %, not kept: the next kernel reads the tensor).  Ablations: see DESIGN.md 4.2 -- and read them with care:
+// an ablation that corrupts the DATA (NaN / zero tensors downstream) makes every later launch faster by itself, the chip clocks
+// higher on such operands (a build whose statistics were broken ran the whole step 6 % faster, wgrad included).
 // ------------------------------------------------------------------------------------------------
 namespace n2r {
 constexpr int TROWS = 254;
