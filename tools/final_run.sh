@@ -7,15 +7,14 @@ mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_$TAG.log 2>&1; echo "pytest rc=$?"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"
-timeout 300 python bench.py --steps 20 --warmup 5 --breakdown $O/breakdown_$TAG.csv > $O/bench_$TAG.log 2>&1; echo "bench rc=$?"
-timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-wgrad > $O/bench_${TAG}_serial.log 2>&1
+timeout 400 python bench.py --steps 20 --warmup 5 --breakdown $O/breakdown_$TAG.csv > $O/bench_$TAG.log 2>&1; echo "bench rc=$?"
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > $O/bench_${TAG}_serial.log 2>&1
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$TAG -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$TAG -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > /dev/null 2>&1
 python $R/tools/trace_kernels.py $O/trace_$TAG conv_ 3 > $O/conv_kernels_by_layer_$TAG.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $O/pmc_${C}
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${C}_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_${C}_$TAG.log 2>&1; echo "pmc $C rc=$?"
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${C}_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > $O/pmc_${C}_$TAG.log 2>&1; echo "pmc $C rc=$?"
 done
 cd $R
 DB=$(find $O/prof_$TAG -name "*_results.db" | head -1); python tools/rocpd_summary.py $DB $O/kernel_stats_$TAG.csv
