@@ -84,6 +84,8 @@ def main():
             eng.pooled_reduce = bool(int(v))
         elif k == "split_towers":
             eng.split_towers = bool(int(v))
+        elif k == "fused_bn_reduce":
+            eng.fused_bn_reduce = bool(int(v))
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
     if a.nt_blocks:
@@ -216,7 +218,7 @@ def main():
     if a.breakdown and rank == 0:
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
-                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
+                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
                  "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights"]
         eng.timed = {nm: [] for nm in names}

@@ -129,6 +129,19 @@ int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_win
  * wd: (c_in, 3*c_out) `dtype` tap-flipped copy from vm_prep_conv_weights; dx: (n_windows, L, c_in). */
 int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
                   void* dx, void* stream);
+/* vm_conv_dgrad that also forms, from the output tile it holds on chip, the two sums the BatchNorm backward of the layer BELOW
+ * needs (that layer's output gradient is exactly this dx; keras BatchNormalization backward, voicemap/models.py:23,28,33):
+ *   red_s0[row][ci] = sum_t dx[n][t][ci],   red_s1[row][ci] = sum_t dx[n][t][ci] * red_a[n][t][ci]
+ * as vm_conv_dgrad_bnred_rows(L) partial rows per window (fp32, (n_windows * rows, c_in), every row written).  red_a: a
+ * (n_windows, L, c_in) tensor of `dtype` -- the pooled output of the layer below (red_a_padded = 1: stored (L + 2) rows with a
+ * halo row either side, as vm_bn_drop_pool_fwd writes it) or its pool-window extreme (red_a_padded = 0).  dx is written as by
+ * vm_conv_dgrad (the sums use dx as rounded to `dtype`).  Served by the 256 x 128 input-resident kernel only:
+ * vm_conv_dgrad_bnred_supported() says whether the shape / dtype / current tuning is, VM_ERR_UNSUPPORTED otherwise.
+ * vm_bn_bwd_from_sums turns the rows into the partials vm_bn_bwd_finalize takes, replacing vm_bn_pool_bwd_reduce[_pooled]. */
+int64_t vm_conv_dgrad_bnred_rows(int64_t L);
+int vm_conv_dgrad_bnred_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
+int vm_conv_dgrad_bnred(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                        void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, void* stream);
 /* wgrad: dW[k][ci][co] = sum_{n,t} in[n][t+k][ci] * du[n][t+1][co] (both padded).  Split over windows into
  * vm_conv_wgrad_splits() slabs in ws (fp32), then summed in fixed order into grad_w (3, c_in, c_out). */
 int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out);
@@ -184,6 +197,14 @@ int vm_bn_pool_bwd_reduce_pooled(const void* z, const void* act, const void* dp,
                                  const float* mean, const float* invstd, const float* drop, int64_t n_windows,
                                  int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_dy,
                                  float* part_dyz, void* stream);
+/* the same partials from the sums vm_conv_dgrad_bnred left behind (s0, sa: (n_windows * rows_per_window, C)).  a_is_act = 1:
+ * sa was taken against the pooled output, the extreme is recovered as in vm_bn_pool_bwd_reduce_pooled (z is read only for
+ * channels with scale == 0); a_is_act = 0: sa was taken against the extreme itself (z may be NULL).  L, pool: this block's
+ * pre-pool length and pool size (dp is (n_windows, L / pool, C)). */
+int vm_bn_bwd_from_sums(const float* s0, const float* sa, int64_t rows_per_window, const void* z, const void* dp,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, const float* drop,
+                        int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, int a_is_act,
+                        float* part_dy, float* part_dyz, void* stream);
 /* backward, pass 2: du[n][1+t][c] = [z>0] * scale * (dy - c1 - zhat*c2)  (padded (n_windows, L+2, C) out), plus
  * partial column sums of du -> part_du (n_windows * vm_bn_part_rows(), C) for the conv bias gradient. */
 int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,

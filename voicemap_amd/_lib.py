@@ -45,6 +45,9 @@ SIGNATURES = {
     "vm_conv_stat_rows": (L, [L]),
     "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
+    "vm_conv_dgrad_bnred_rows": (L, [L]),
+    "vm_conv_dgrad_bnred_supported": (I, [L, L, I, I, I]),
+    "vm_conv_dgrad_bnred": (I, [P, P, L, L, I, I, I, P, P, I, P, P, P]),
     "vm_conv_wgrad_splits": (I, [L, L, I, I]),
     "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),
     "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),
@@ -56,6 +59,7 @@ SIGNATURES = {
     "vm_bn_part_rows": (I, []),
     "vm_bn_pool_bwd_reduce": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_pooled": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_bn_bwd_from_sums": (I, [P, P, L, P, P, P, P, P, P, P, L, L, L, I, I, I, I, P, P, P]),
     "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P, P]),
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),

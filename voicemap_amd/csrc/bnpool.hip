@@ -638,6 +638,56 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
     }
 }
 
+// The two BatchNorm-backward sums when S0 = sum dp and SA = sum dp * A were already formed per (window, channel) by the dgrad
+// epilogue of the layer above (vm_conv_dgrad_bnred: `rows` partial rows per window).  A is either this block's pooled output
+// (a_is_act: ext = A / (scale*drop) - shift/scale as in bn_pool_bwd_reduce_kernel, so S1 = ra*SA + rb*S0) or the pool extreme
+// itself (block 1: S1 = SA).  One thread per (window, channel); writes all BN_SEG partial rows of the window (row 0 = value).
+// A channel whose scale is exactly 0 has no invertible map: its S1 is re-derived from z here (one slow thread, never in practice).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_from_sums_kernel(const float* __restrict__ s0p, const float* __restrict__ sap, int rows,
+                                                               const T* __restrict__ z, const T* __restrict__ dp,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ drop, int64_t n_windows, int64_t wpt, int64_t L,
+                                                               int C, int pool, int a_is_act, float* __restrict__ part_a,
+                                                               float* __restrict__ part_b) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_windows * C) return;
+    const int64_t n = idx / C;
+    const int c = (int)(idx - n * C);
+    const int64_t tw = n / wpt;
+    float S0 = 0.f, SA = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        S0 += s0p[(n * rows + r) * C + c];
+        SA += sap[(n * rows + r) * C + c];
+    }
+    const float sc = scale[tw * C + c], dr = drop ? drop[n * C + c] : 1.f;
+    float S1 = SA;
+    if (a_is_act) {
+        if (sc != 0.f && dr != 0.f) {
+            S1 = fmaf(SA, 1.0f / (sc * dr), (-shift[tw * C + c] / sc) * S0);
+        } else if (dr != 0.f) {  // scale == 0: the forward kept the maximum of z
+            const int64_t Lq = L / pool;
+            S1 = 0.f;
+            for (int64_t q = 0; q < Lq; ++q) {
+                float m = Elem<T>::to_f(z[(n * L + q * pool) * C + c]);
+                for (int j = 1; j < pool; ++j) {
+                    const float y = Elem<T>::to_f(z[(n * L + q * pool + j) * C + c]);
+                    m = y > m ? y : m;
+                }
+                S1 = fmaf(Elem<T>::to_f(dp[(n * Lq + q) * C + c]), m, S1);
+            }
+        } else {
+            S1 = 0.f;
+        }
+    }
+    const float a = dr * S0, b = dr * invstd[tw * C + c] * (S1 - mean[tw * C + c] * S0);
+    for (int s = 0; s < BN_SEG; ++s) {
+        part_a[(n * BN_SEG + s) * C + c] = s == 0 ? a : 0.f;
+        part_b[(n * BN_SEG + s) * C + c] = s == 0 ? b : 0.f;
+    }
+}
+
 // Reduce pass when dp is the sparse GlobalMaxPool1D-backward form: dy is non-zero at ONE pool group per (window, channel),
 // so the two sums need z at that group only -- a gather of n*C*POOL elements instead of a pass over z.
 // Writes all BN_SEG partial rows of a window (row 0 = the value, the others 0).
@@ -841,6 +891,23 @@ extern "C" int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const 
                            part_dyz);
     }));
     return check_launch("vm_bn_pool_bwd_reduce_gmax");
+}
+
+extern "C" int vm_bn_bwd_from_sums(const float* s0, const float* sa, int64_t rows_per_window, const void* z, const void* dp,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   const float* drop, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool,
+                                   int dtype, int a_is_act, float* part_dy, float* part_dyz, void* stream) {
+    VM_REQUIRE(s0 && sa && dp && scale && shift && mean && invstd && part_dy && part_dyz, "vm_bn_bwd_from_sums: null pointer");
+    VM_REQUIRE(!a_is_act || z, "vm_bn_bwd_from_sums: z is needed next to the pooled output (channels with scale == 0)");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && rows_per_window > 0 && pool >= 1 && L >= pool && C > 0,
+               "vm_bn_bwd_from_sums: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, {
+        const int64_t blocks = (n_windows * C + 255) / 256;
+        hipLaunchKernelGGL((bn_bwd_from_sums_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s0, sa,
+                           (int)rows_per_window, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop, n_windows,
+                           windows_per_tower, L, C, pool, a_is_act, part_dy, part_dyz);
+    });
+    return check_launch("vm_bn_bwd_from_sums");
 }
 
 extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,

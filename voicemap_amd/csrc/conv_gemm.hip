@@ -129,6 +129,11 @@ struct NtArgs {
     int skew;    // conv_nt8_kernel: start delay (units of 127*64 clocks) per workgroup phase (blockIdx >> 3) & 3
     int ablate;  // timing experiments only (results are wrong when != 0): 1 no epilogue stores, 2 no epilogue,
                  // 4 no MFMA, 8 no K-loop global loads after the first slice
+    // dgrad + BatchNorm-backward reduce (conv_nt2r_kernel only; vm_conv_dgrad_bnred): red_a = the tensor A whose rows line up with
+    // the output rows (window stride / first row in elements / rows), stat_sum / stat_sq then receive sum(out) and sum(out * A)
+    const T* red_a = nullptr;
+    int64_t red_a_win_stride = 0;
+    int red_a_row0 = 0;
 };
 
 template <int KB>
@@ -1462,6 +1467,7 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
     using namespace n2;
     const int r = lane & 31, kh = lane >> 5;
     const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr && !(p.ablate & 64);
+    const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
 
@@ -1487,8 +1493,8 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
                     pk[0] = lo;
                     pk[1] = hi;
-                    if (partial && m >= valid) pk[0] = pk[1] = 0u;
                 }
+                if ((EPI == EPI_FWD || red) && partial && m >= valid) pk[0] = pk[1] = 0u;
                 *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
             }
         }
@@ -1584,6 +1590,90 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
                 if (kh == 0) p.stat_sum[srow * p.N + n0 + 32 * w + cn] = d1[0];
                 if (kh == ((cn >> 2) & 1)) p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
             }
+        }
+    }
+    if (red) {
+        // ---- BatchNorm-backward partial sums of the layer below, from the tile that is in LDS anyway (vm_conv_dgrad_bnred):
+        //   S0[c] = sum_r dp[r][c] = (1^T DP)[c],   S1[c] = sum_r dp[r][c] * A[r][c] = diag(DP^T A)[c]
+        // with the statistics machinery above.  The K-major fragments of dp are kept in registers while the A tile (the pooled
+        // activation / pooled extreme of the layer below: same rows, same channels) replaces the dp tile in LDS by LDS-DMA. ----
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#else
+        const uint32_t lds0 = 0;
+#endif
+        const int li = lane & 15, lg = (lane >> 4) & 1;
+        const uint32_t xoff = lds0 + (kh * 8 + (li >> 2)) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+        const u32x4 ones4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones4);
+        u32x2 dlo[16], dhi[16];
+        f32x16 d1[2], d2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d1[h][e] = d2[h][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t a = xoff + (q * 16) * TP;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dlo[q]) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1088" : "=v"(dhi[q]) : "v"(a));
+            if (q == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]),
+                                     "+v"(dlo[3]), "+v"(dhi[3]), "+v"(dlo[4]), "+v"(dhi[4]), "+v"(dlo[5]), "+v"(dhi[5]), "+v"(dlo[6]), "+v"(dhi[6]),
+                                     "+v"(dlo[7]), "+v"(dhi[7]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[8]), "+v"(dhi[8]), "+v"(dlo[9]), "+v"(dhi[9]), "+v"(dlo[10]), "+v"(dhi[10]), "+v"(dlo[11]),
+                     "+v"(dhi[11]), "+v"(dlo[12]), "+v"(dhi[12]), "+v"(dlo[13]), "+v"(dhi[13]), "+v"(dlo[14]), "+v"(dhi[14]), "+v"(dlo[15]),
+                     "+v"(dhi[15]));
+        __syncthreads();  // every wave has its dp fragments and has issued its output stores: the tile memory is free
+        // A tile: 256 rows x 128 channels, 256-byte rows (unpadded: the LDS-DMA destination is lane-linear), 64 pieces of 4 rows
+        {
+            const int arow = lane >> 4, achunk = lane & 15;
+            const bf16* abase = p.red_a + n * p.red_a_win_stride + (int64_t)(t0 + p.red_a_row0) * p.N + n0 + achunk * 8;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int pi = w + 4 * k;
+                int R = pi * 4 + arow;
+                R = R < valid ? R : valid - 1;  // rows outside the window: any finite value (their dp rows are zero)
+                glds16(reinterpret_cast<const char*>(abase + (int64_t)R * p.N), lds + __builtin_amdgcn_readfirstlane(pi * 1024));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const u32x4 xv = {dlo[q][0], dlo[q][1], dhi[q][0], dhi[q][1]};
+            d1[q >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, xv), d1[q >> 3], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and loads retire out of order with each other: no counted wait here
+        __syncthreads();  // the A tile has landed for every wave
+        const uint32_t aoff = lds0 + (kh * 8 + (li >> 2)) * 256 + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x2 alo[8], ahi[8];
+#pragma unroll
+            for (int rs = 0; rs < 8; ++rs) {
+                const uint32_t a = aoff + (h * 128 + rs * 16) * 256;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[rs]) : "v"(a));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(ahi[rs]) : "v"(a));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]),
+                         "+v"(ahi[3]), "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]));
+#pragma unroll
+            for (int rs = 0; rs < 8; ++rs) {
+                const int q = h * 8 + rs;
+                const u32x4 dv = {dlo[q][0], dlo[q][1], dhi[q][0], dhi[q][1]};
+                const u32x4 av = {alo[rs][0], alo[rs][1], ahi[rs][0], ahi[rs][1]};
+                d2[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dv), __builtin_bit_cast(bf16x8, av), d2[h], 0, 0, 0);
+            }
+        }
+        const int cn = lane & 31, rsel = (cn & 3) + 4 * (cn >> 3);
+        const int rows2 = 2 * p.tilesL;  // partial rows per window (vm_conv_dgrad_bnred_rows)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float dq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dq = e == rsel ? d2[h][e] : dq;
+            const int64_t srow = n * rows2 + 2 * tl + h;
+            if (kh == 0) p.stat_sum[srow * p.N + n0 + 32 * w + cn] = d1[h][0];
+            if (kh == ((cn >> 2) & 1)) p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
         }
     }
 }
@@ -3031,6 +3121,58 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
+}
+
+// ---- dgrad with the BatchNorm-backward partial sums of the layer below fused into its epilogue (conv_nt2r_kernel only) ----
+static bool bnred_shape(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    if (dtype != VM_BF16 || !(g_nt_n2 & 2) || !g_nt_n2r || c_in % n2::TN != 0 || c_out % 32 != 0 || L <= 0 || n_windows <= 0) return false;
+    const double u256 = (double)L / (256.0 * ((L + 255) / 256)), u128 = (double)L / (128.0 * ((L + 127) / 128));
+    if (u256 + 0.10 < u128) return false;
+    const int64_t t254 = (L + n2r::TROWS - 1) / n2r::TROWS;
+    return n_windows * t254 * (c_in / n2::TN) < (1LL << 31);
+}
+
+extern "C" int64_t vm_conv_dgrad_bnred_rows(int64_t L) { return 2 * ((L + n2r::TROWS - 1) / n2r::TROWS); }
+
+extern "C" int vm_conv_dgrad_bnred_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    return bnred_shape(n_windows, L, c_in, c_out, dtype) ? 1 : 0;
+}
+
+extern "C" int vm_conv_dgrad_bnred(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                                   void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, void* stream) {
+    VM_REQUIRE(du && wd && dx && red_a && red_s0 && red_s1, "vm_conv_dgrad_bnred: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_dgrad_bnred: bad sizes");
+    VM_REQUIRE((L + 2) * (int64_t)c_out < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_dgrad_bnred: window too large");
+    if (!bnred_shape(n_windows, L, c_in, c_out, dtype)) {
+        set_error("vm_conv_dgrad_bnred: shape/dtype/tuning not served by the 256 x 128 input-resident kernel (ask vm_conv_dgrad_bnred_supported)");
+        return VM_ERR_UNSUPPORTED;
+    }
+    NtArgs<bf16> a;
+    a.a = (const bf16*)du;
+    a.bt = (const bf16*)wd;
+    a.bias = nullptr;
+    a.out = (bf16*)dx;
+    a.stat_sum = red_s0;
+    a.stat_sq = red_s1;
+    a.a_win_stride = (L + 2) * (int64_t)c_out;
+    a.a_c = c_out;
+    a.L = (int)L;
+    a.N = c_in;
+    a.Ktot = 3 * c_out;
+    a.tilesL = tiles(L, BM);
+    a.tilesN = tiles(c_in, BN);
+    a.ablate = 0;
+    a.order = g_nt_order;
+    a.skew = 0;
+    a.korder = 0;
+    a.red_a = (const bf16*)red_a;
+    a.red_a_win_stride = (L + (red_a_padded ? 2 : 0)) * (int64_t)c_in;
+    a.red_a_row0 = red_a_padded ? 1 : 0;
+    if (!launch_n2<EPI_DGRAD>(a, n_windows, (hipStream_t)stream)) {
+        set_error("vm_conv_dgrad_bnred: launch refused");
+        return VM_ERR_UNSUPPORTED;
+    }
+    return check_launch("vm_conv_dgrad_bnred");
 }
 
 int g_tn_tile = 256;  // wgrad output tile: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
