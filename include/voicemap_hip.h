@@ -150,6 +150,9 @@ int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, 
                   void* ws, float* grad_w, void* stream);
 /* fp32 Keras kernel (3, c_in, c_out) -> wf (c_out, 3*c_in) and wd (c_in, 3*c_out) in `dtype`. */
 int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream);
+/* the same for n_layers (<= 8) layers in ONE launch: host arrays of device pointers / channel counts, one entry per layer. */
+int vm_prep_conv_weights_batch(int n_layers, const float* const* w, const int* c_in, const int* c_out, int dtype,
+                               void* const* wf, void* const* wd, void* stream);
 
 /* ---- a1-BN: BatchNormalization()  (voicemap/models.py:17,23,28,33; Keras defaults eps 1e-3, momentum .99)
  * Reduces the conv partials per tower in a fixed order (fp64), producing per-tower

@@ -853,3 +853,25 @@ def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_d
     assert np.abs(b1 - b0)[:, ~vec].max() < 2e-5 * mag
     assert np.abs(b1 - b0)[:, 3].max() < 2e-5 * mag
     assert rel_err(b1[:, vec], b0[:, vec]) < 1.5e-2
+
+
+def test_prep_conv_weights_batch_equals_single():
+    import ctypes
+    vm, tdt = DTYPES["bf16"]
+    r = rng(12)
+    shapes = [(128, 256), (256, 384), (8, 24)]
+    ws = [dev(r.normal(0, 0.1, (3, ci, co))) for ci, co in shapes]
+    single = []
+    for w, (ci, co) in zip(ws, shapes):
+        wf, wd = torch.zeros(co * 3 * ci, dtype=tdt, device="cuda"), torch.zeros(ci * 3 * co, dtype=tdt, device="cuda")
+        L().call("vm_prep_conv_weights", p(w), ci, co, vm, p(wf), p(wd), stream())
+        single.append((wf, wd))
+    wfs = [torch.zeros_like(a) for a, _ in single]
+    wds = [torch.zeros_like(b) for _, b in single]
+    vp, ci_t = ctypes.c_void_p * 3, ctypes.c_int * 3
+    L().call("vm_prep_conv_weights_batch", 3, vp(*[p(w) for w in ws]), ci_t(*[s[0] for s in shapes]), ci_t(*[s[1] for s in shapes]), vm,
+             vp(*[p(t) for t in wfs]), vp(*[p(t) for t in wds]), stream())
+    for (a, b), a2, b2 in zip(single, wfs, wds):
+        assert torch.equal(a, a2) and torch.equal(b, b2)
+    with pytest.raises(RuntimeError):
+        L().call("vm_prep_conv_weights_batch", 9, vp(), ci_t(), ci_t(), vm, vp(), vp(), stream())

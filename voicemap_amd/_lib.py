@@ -48,6 +48,7 @@ SIGNATURES = {
     "vm_conv_dgrad_bnred_rows": (L, [L]),
     "vm_conv_dgrad_bnred_supported": (I, [L, L, I, I, I]),
     "vm_conv_dgrad_bnred": (I, [P, P, L, L, I, I, I, P, P, I, P, P, P]),
+    "vm_prep_conv_weights_batch": (I, [I, P, P, P, I, P, P, P]),
     "vm_conv_wgrad_splits": (I, [L, L, I, I]),
     "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),
     "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),

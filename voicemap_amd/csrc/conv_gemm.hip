@@ -3288,6 +3288,58 @@ extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dty
     return check_launch("vm_prep_conv_weights");
 }
 
+// All layers of an encoder in one launch (the optimizer step re-derives every copy; three 5 us launches back to back cost more
+// than the copies themselves).  blockIdx.y = layer.
+constexpr int PREP_MAX_LAYERS = 8;
+struct PrepBatch {
+    const float* w[PREP_MAX_LAYERS];
+    void* wf[PREP_MAX_LAYERS];
+    void* wd[PREP_MAX_LAYERS];
+    int c_in[PREP_MAX_LAYERS], c_out[PREP_MAX_LAYERS];
+};
+template <typename T>
+__global__ void prep_weights_batch_kernel(PrepBatch pb) {
+    const int l = blockIdx.y;
+    const int c_in = pb.c_in[l], c_out = pb.c_out[l];
+    const int64_t total = 3LL * c_in * c_out;
+    const float* w = pb.w[l];
+    T* wf = (T*)pb.wf[l];
+    T* wd = (T*)pb.wd[l];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % c_out);
+        const int64_t r = i / c_out;
+        const int ci = (int)(r % c_in);
+        const int k = (int)(r / c_in);
+        const T v = Elem<T>::from_f(w[i]);
+        wf[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = v;
+        wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
+    }
+}
+
+extern "C" int vm_prep_conv_weights_batch(int n_layers, const float* const* w, const int* c_in, const int* c_out, int dtype,
+                                          void* const* wf, void* const* wd, void* stream) {
+    VM_REQUIRE(w && c_in && c_out && wf && wd, "vm_prep_conv_weights_batch: null pointer");
+    VM_REQUIRE(n_layers > 0 && n_layers <= PREP_MAX_LAYERS, "vm_prep_conv_weights_batch: 1..%d layers per call (got %d)", PREP_MAX_LAYERS,
+               n_layers);
+    PrepBatch pb;
+    int64_t most = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        VM_REQUIRE(w[l] && wf[l] && wd[l] && c_in[l] > 0 && c_out[l] > 0, "vm_prep_conv_weights_batch: bad layer %d", l);
+        pb.w[l] = w[l];
+        pb.wf[l] = wf[l];
+        pb.wd[l] = wd[l];
+        pb.c_in[l] = c_in[l];
+        pb.c_out[l] = c_out[l];
+        const int64_t n = 3LL * c_in[l] * c_out[l];
+        most = n > most ? n : most;
+    }
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((prep_weights_batch_kernel<T>), dim3((unsigned)cdiv(most, 256), (unsigned)n_layers), dim3(256), 0,
+                           (hipStream_t)stream, pb);
+    });
+    return check_launch("vm_prep_conv_weights_batch");
+}
+
 // Tuning hook for A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     if (key != nullptr && strcmp(key, "gemm_kb") == 0 && (value == 64 || value == 128)) {

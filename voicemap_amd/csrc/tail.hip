@@ -88,53 +88,84 @@ __global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __
 // ---- Dense ------------------------------------------------------------------------------------------
 // Tiny fp32 GEMMs (256 x 512 x 64 at cfg-A).  blockIdx.y carries the index of the broadcast operand's row, so
 // that operand is read with wave-uniform (scalar) loads and the other one coalesced across the 64 lanes.
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                        const float* __restrict__ b, int n_in, int n_out,
-                                                        float* __restrict__ out) {
-    // 64 outputs x 4 slices of the reduction per workgroup: the dependent-load chain is 4x shorter than one thread per output
-    __shared__ float red[4][64];
+constexpr int DENSE_KS = 16;  // reduction slices per output in the dense kernels (one wave each)
+
+__global__ __launch_bounds__(64 * DENSE_KS) void dense_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, int n_in, int n_out,
+                                                                  float* __restrict__ out) {
+    // 64 outputs x DENSE_KS slices of the reduction per workgroup.  These layers are tiny (cfg-A: 256 x 512 -> 64) and bound by
+    // the dependent-load chain of one thread, not by bandwidth: many short slices, 8 loads in flight per slice, fixed-order tree.
+    __shared__ float red[DENSE_KS][64];
     const int ol = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + ol;
     const int64_t r = blockIdx.y;
-    const int per = (n_in + 3) / 4;
+    const int per = (n_in + DENSE_KS - 1) / DENSE_KS;
     const int i0 = kq * per, i1 = min(n_in, i0 + per);
     const float* ir = in + r * n_in;
-    float a0 = 0.f, a1 = 0.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (o < n_out) {
         int i = i0;
-        for (; i + 2 <= i1; i += 2) {
-            a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
-            a1 = fmaf(ir[i + 1], w[(int64_t)(i + 1) * n_out + o], a1);
+        for (; i + 8 <= i1; i += 8) {
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x[u] = ir[i + u];
+                y[u] = w[(int64_t)(i + u) * n_out + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u & 3] = fmaf(x[u], y[u], a[u & 3]);
         }
-        if (i < i1) a0 = fmaf(ir[i], w[(int64_t)i * n_out + o], a0);
+        for (; i < i1; ++i) a[0] = fmaf(ir[i], w[(int64_t)i * n_out + o], a[0]);
     }
-    red[kq][ol] = a0 + a1;
+    red[kq][ol] = (a[0] + a[1]) + (a[2] + a[3]);
     __syncthreads();
-    if (kq == 0 && o < n_out) out[r * n_out + o] = (b ? b[o] : 0.f) + ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]));
+    if (kq == 0 && o < n_out) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < DENSE_KS; q += 4) t += (red[q][ol] + red[q + 1][ol]) + (red[q + 2][ol] + red[q + 3][ol]);
+        out[r * n_out + o] = (b ? b[o] : 0.f) + t;
+    }
 }
 
 // grad_w[i][o] = sum_r in[r][i]*dout[r][o]; blockIdx.y = i.  The last y-row computes grad_b.
-__global__ __launch_bounds__(256) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                                          int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
-                                                          float* __restrict__ grad_b) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                                    int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
+                                                                    float* __restrict__ grad_b) {
+    __shared__ float red[DENSE_KS][64];
     const int ol = threadIdx.x & 63, rq = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + ol;
     const int i = blockIdx.y;
-    const int64_t per = (rows + 3) / 4;
+    const int64_t per = (rows + DENSE_KS - 1) / DENSE_KS;
     const int64_t r0 = rq * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-    float a0 = 0.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (o < n_out) {
+        int64_t r = r0;
         if (i < n_in) {
-            for (int64_t r = r0; r < r1; ++r) a0 = fmaf(in[r * n_in + i], dout[r * n_out + o], a0);
+            for (; r + 8 <= r1; r += 8) {
+                float x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    x[u] = in[(r + u) * n_in + i];
+                    y[u] = dout[(r + u) * n_out + o];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u & 3] = fmaf(x[u], y[u], a[u & 3]);
+            }
+            for (; r < r1; ++r) a[0] = fmaf(in[r * n_in + i], dout[r * n_out + o], a[0]);
         } else {
-            for (int64_t r = r0; r < r1; ++r) a0 += dout[r * n_out + o];
+            for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] += dout[(r + u) * n_out + o];
+            }
+            for (; r < r1; ++r) a[0] += dout[r * n_out + o];
         }
     }
-    red[rq][ol] = a0;
+    red[rq][ol] = (a[0] + a[1]) + (a[2] + a[3]);
     __syncthreads();
     if (rq == 0 && o < n_out) {
-        const float t = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < DENSE_KS; q += 4) t += (red[q][ol] + red[q + 1][ol]) + (red[q + 2][ol] + red[q + 3][ol]);
         if (i < n_in) {
             grad_w[(int64_t)i * n_out + o] = t;
         } else {
@@ -398,7 +429,7 @@ extern "C" int vm_dense_fwd(const float* in, const float* w, const float* b, int
     VM_REQUIRE(in && w && out && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_fwd: bad argument");
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // grid.y is limited to 65535
         const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        hipLaunchKernelGGL(dense_fwd_kernel, dim3((n_out + 63) / 64, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(dense_fwd_kernel, dim3((n_out + 63) / 64, (unsigned)nr), dim3(64 * DENSE_KS), 0, (hipStream_t)stream,
                            in + r0 * n_in, w, b, n_in, n_out, out + r0 * n_out);
     }
     return check_launch("vm_dense_fwd");
@@ -408,7 +439,7 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
                             float* grad_w, float* grad_b, float* din, void* stream) {
     VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
     VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(256), 0, (hipStream_t)stream, in, dout, rows,
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, dout, rows,
                        n_in, n_out, grad_w, grad_b);
     int rc = check_launch("vm_dense_bwd(w)");
     if (rc || din == nullptr) return rc;

@@ -8,6 +8,7 @@ experiments/siamese_contrastive_loss.py:67-70; experiments/train_classifier.py:1
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -278,10 +279,23 @@ class HipEncoderEngine:
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
-        for i in range(1, self.nb):
-            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
-            self._call("vm_prep_conv_weights", _p(self.view(f"conv{i+1}.kernel")), cin, cout, self.dtype,
-                          _p(self.wf[i]), _p(self.wd[i]), self.stream())
+        nl = self.nb - 1
+        if nl < 1:
+            return
+        if nl > 8:
+            for i in range(1, self.nb):
+                cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+                self._call("vm_prep_conv_weights", _p(self.view(f"conv{i+1}.kernel")), cin, cout, self.dtype,
+                           _p(self.wf[i]), _p(self.wd[i]), self.stream())
+            return
+        if getattr(self, "_prep_args", None) is None:  # the flat buffers never move: build the pointer tables once
+            vp, ci = ctypes.c_void_p * nl, ctypes.c_int * nl
+            self._prep_args = (vp(*[_p(self.view(f"conv{i+1}.kernel")) for i in range(1, self.nb)]),
+                               ci(*[self.blocks[i - 1][1] for i in range(1, self.nb)]),
+                               ci(*[self.blocks[i][1] for i in range(1, self.nb)]),
+                               vp(*[_p(self.wf[i]) for i in range(1, self.nb)]), vp(*[_p(self.wd[i]) for i in range(1, self.nb)]))
+        w, cin, cout, wf, wd = self._prep_args
+        self._call("vm_prep_conv_weights_batch", nl, w, cin, cout, self.dtype, wf, wd, self.stream())
 
     # ------------------------------------------------------------------------------------------------
     def lengths(self, l0: int) -> List[int]:
@@ -354,6 +368,7 @@ class HipEncoderEngine:
                                    device=dev)
         cmax = max(b[1] for b in self.blocks)
         pl["cr_ws"] = torch.empty(self.lib.query("vm_colreduce_workspace_bytes", 2, cmax) // 8, dtype=torch.float64, device=dev)
+        pl["cr_ws_side"] = torch.empty_like(pl["cr_ws"])  # reductions enqueued on the side stream (backward)
         self._plans[key] = pl
         return pl
 
@@ -553,8 +568,10 @@ class HipEncoderEngine:
                      _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
                        wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
-            self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]),
-                       st)
+            side = self.overlap_wgrad and i > 0
+            if not side:
+                self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)),
+                           _p(pl["cr_ws"]), st)
             gw = _p(self.view(f"conv{i+1}.kernel", G))
             if i == 0:
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
@@ -566,6 +583,10 @@ class HipEncoderEngine:
                         self.side_stream.wait_event(b["ev"])
                         self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw,
                                    self.stream())
+                        # the conv bias gradient (column sums of du, from the apply pass's partials) is nobody's input until
+                        # the optimizer: off the main stream, with its own reduction workspace
+                        self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)),
+                                   _p(pl["cr_ws_side"]), self.stream())
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, st)
                 if i == 1 and sync_tail:
