@@ -354,9 +354,27 @@ def main():
                 cos = lambda u, v: float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30))
                 out["extras"].update({"bf16_vs_f32_embedding_rel_err": rel(pl["emb"], p32["emb"]),
                                       "bf16_vs_f32_gradient_rel_err": rel(eng.G, e32.G), "bf16_vs_f32_gradient_cosine": cos(eng.G, e32.G)})
+                emb32, g32 = p32["emb"].clone(), e32.G.clone()  # before the timed steps move the parameters
                 t32 = timed(step32, reps=5)
                 out["extras"]["f32_storage_ms_per_step"] = t32 * 1e3
                 del e32, p32
+                # fp32 storage with split-bf16 products in the k=3 GEMMs (dtype "f32s"): step time and distance from the fp32 mode
+                es = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype="f32s", device=dev, seed=1234)
+                es.set_params({k: v for k, v in eng.get_params().items()})
+                ps = es.plan(2 * pairs, l0, True)
+
+                def step32s(update=True):
+                    es.preprocess(ps, xcat, 4, True, pairs)
+                    es.forward(ps, pairs, None)
+                    es.siamese_head(ps, y, a.loss)
+                    es.backward(ps)
+                    if update:
+                        es.optimizer_step()
+                step32s(False)
+                torch.cuda.synchronize()
+                out["extras"].update({"f32s_vs_f32_embedding_rel_err": rel(ps["emb"], emb32), "f32s_vs_f32_gradient_rel_err": rel(es.G, g32)})
+                out["extras"]["f32s_storage_ms_per_step"] = timed(step32s, reps=5) * 1e3
+                del es, ps
             except Exception as e:
                 out["extras"]["f32_storage_error"] = repr(e)
 

@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-enum { VM_F32 = 0, VM_BF16 = 1 };
+/* VM_F32S: fp32 storage like VM_F32; the k=3 convolution GEMMs (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) form every product
+ * from bf16 hi/lo halves of the fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation: ~2^-17 relative per product
+ * instead of exact) on the bf16 matrix pipe, which is 16x faster than the fp32 one.  Every other entry point treats it as VM_F32. */
+enum { VM_F32 = 0, VM_BF16 = 1, VM_F32S = 2 };
 enum { VM_OK = 0, VM_ERR_ARG = -1, VM_ERR_LAUNCH = -2, VM_ERR_UNSUPPORTED = -3 };
 enum { VM_LOSS_CONTRASTIVE = 0, VM_LOSS_BCE = 1 };
 enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };

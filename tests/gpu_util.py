@@ -3,9 +3,9 @@ import numpy as np
 import torch
 
 from voicemap_amd import _lib
-from voicemap_amd._lib import VM_BF16, VM_F32
+from voicemap_amd._lib import VM_BF16, VM_F32, VM_F32S
 
-DTYPES = {"f32": (VM_F32, torch.float32), "bf16": (VM_BF16, torch.bfloat16)}
+DTYPES = {"f32": (VM_F32, torch.float32), "bf16": (VM_BF16, torch.bfloat16), "f32s": (VM_F32S, torch.float32)}
 
 
 def L():

@@ -84,7 +84,7 @@ def _check_params_after_adam(newp, ref_params, ref_grads, atol, steps=1, lr=1e-3
             assert np.abs(got - want)[~live].max() < 1.01 * steps * lr, k
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "bf16"])
 @pytest.mark.parametrize("loss", ["contrastive", "bce"])
 def test_siamese_train_step_matches_oracle(dtype, loss):
     arch, p, x1, x2, y, m1, m2 = _tiny_case()
@@ -94,7 +94,7 @@ def test_siamese_train_step_matches_oracle(dtype, loss):
     ref = O.siamese_train_step(arch, p, O.AdamState(), *args, loss=loss, drop_masks1=m1, drop_masks2=m2)
     pairs = x1.shape[0]
     emb = pl["emb"].cpu().numpy()
-    tol_e = 1e-4 if dtype == "f32" else 3e-2
+    tol_e = 1e-4 if dtype in ("f32", "f32s") else 3e-2  # "f32s" (split-bf16 GEMM products) is held to the fp32 bounds
     tag = "train_step[%s-%s]" % (dtype, loss)
     e_ref = np.concatenate([ref["e1"].numpy(), ref["e2"].numpy()])
     report(tag, "emb_rel_err_vs_fp64", rel_err(emb, e_ref))
@@ -105,12 +105,13 @@ def test_siamese_train_step_matches_oracle(dtype, loss):
     assert abs(la[0] - ref["loss"].item()) < tol_e * max(1.0, abs(ref["loss"].item()))
     grads = eng.get_grads()
     newp = eng.get_params()
-    if dtype == "f32":
+    if dtype in ("f32", "f32s"):
         assert abs(la[1] - ref["acc"].item()) < 1e-6
         for k, g in ref["grads"].items():
             report(tag, "grad_rel_err[%s]" % k, rel_err(grads[k], g.numpy()))
             assert grad_close(grads[k], g.numpy(), 2e-3), k
-        _check_params_after_adam(newp, ref["params"], ref["grads"], 1e-5)
+        # Adam turns a relative gradient error e into a parameter error ~lr * e: 1e-5 for exact fp32 products, 3e-5 with the split ones
+        _check_params_after_adam(newp, ref["params"], ref["grads"], 1e-5 if dtype == "f32" else 3e-5)
     else:
         emu = O.siamese_train_step(arch, p, O.AdamState(), *args, loss=loss, drop_masks1=m1, drop_masks2=m2, storage="bf16")
         e_emu = np.concatenate([emu["e1"].numpy(), emu["e2"].numpy()])

@@ -10,7 +10,8 @@ from oracle import voicemap_oracle as O
 from tests.gpu_util import DTYPES, L, dev, max_err, p, padded, quant, rel_err, stream
 
 pytestmark = pytest.mark.gpu
-TOL = {"f32": 2e-5, "bf16": 1e-2}
+# "f32s": fp32 storage, split-bf16 products (3 bf16 MFMAs per product; ~2^-17 per product, measured <= 1e-5 on these shapes)
+TOL = {"f32": 2e-5, "bf16": 1e-2, "f32s": 5e-5}
 
 
 def rng(seed):
@@ -99,6 +100,16 @@ def test_conv_256x128_two_workgroups_per_cu_variant(n, l, cin, cout, gemm_kb):
     _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)
 
 
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (3, 131, 96, 32),
+                                          (8, 140, 64, 384), (3, 520, 256, 512), (4, 3000, 128, 256), (4, 1500, 256, 384),
+                                          (4, 750, 384, 512)])
+def test_conv_f32_storage_split_bf16_products(n, l, cin, cout):
+    """dtype VM_F32S: fp32 operands staged as bf16 hi + lo halves, a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe
+    (conv_nt_kernel / conv_tn_kernel / conv_tn256_kernel with SPLIT): forward + statistics, dgrad and wgrad against the float64
+    oracle; ragged tiles, K tails (c_in = 8, 16, 24, 96), both wgrad tilings and cfg-A's own geometries."""
+    _conv_fwd_dgrad_wgrad("f32s", n, l, cin, cout)
+
+
 def _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
     vm, tdt = DTYPES[dt]
     r = rng(2)
@@ -139,7 +150,7 @@ def _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
     gwd = torch.empty(3, cin, cout, device="cuda")
     L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gwd), stream())
     # fp32 accumulation of exact products of the (rounded) operands: tight in both modes
-    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < 2e-5
+    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < (5e-5 if dt == "f32s" else 2e-5)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -654,7 +665,7 @@ def _window_slices(n):
     return sorted({0, 1, n // 2 - 1, n // 2, n - 1})
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "f32s", "bf16"])
 @pytest.mark.parametrize("l,cin,cout", CFG_A_GEMMS)
 def test_conv_cfgA_full_batch_sampled_windows(dt, l, cin, cout):
     """The bench launch itself (256 windows = 128 pairs): forward + statistics and dgrad are per-window independent, so the
@@ -713,7 +724,7 @@ def test_conv_cfgA_full_batch_sampled_windows(dt, l, cin, cout):
     wr = w.clone().requires_grad_(True)
     y = torch.nn.functional.conv1d(torch.nn.functional.pad(xs.transpose(1, 2), (pl_, pr_)), wr.permute(2, 1, 0)).transpose(1, 2)
     gw, = torch.autograd.grad((y * duq[sel].double().cpu()).sum(), [wr])
-    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < 2e-5
+    assert rel_err(gwd.cpu().numpy(), gw.numpy()) < (5e-5 if dt == "f32s" else 2e-5)
     # wgrad (b): dense du, float64 restatement of the sum on the device (torch.matmul, not a kernel of this repo)
     L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gwd), stream())
     ref = torch.empty(3, cin, cout, dtype=torch.float64, device="cuda")

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "libvoicemap_hip.so")  # env: A/B experiments
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
-VM_F32, VM_BF16 = 0, 1
+VM_F32, VM_BF16, VM_F32S = 0, 1, 2
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2

@@ -105,7 +105,7 @@ int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n
 
 #define VM_DISPATCH_DTYPE(dtype, ...)                               \
     do {                                                            \
-        if ((dtype) == VM_F32) {                                    \
+        if ((dtype) == VM_F32 || (dtype) == VM_F32S) {              \
             using T = float;                                        \
             __VA_ARGS__;                                            \
         } else if ((dtype) == VM_BF16) {                            \

@@ -82,6 +82,61 @@ __device__ inline void mma_slice(const char* lds_a, const char* lds_b, int wm, i
     }
 }
 
+// ---- fp32 storage, split-bf16 arithmetic (dtype VM_F32S) ----------------------------------------------------------------
+// An fp32 operand x is staged as two bf16 values hi = bf16(x), lo = bf16(x - hi)  (x = hi + lo up to 2^-17 |x|) and a product
+// a * b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation: the dropped lo*lo term
+// and the representation error are both ~2^-17 relative, against 2^-9 for plain bf16 operands, at 3 MFMAs of the 16x faster
+// kind instead of one fp32 MFMA.  A 128-byte K slice (32 floats) becomes a 64-byte hi plane followed by a 64-byte lo plane in
+// the same LDS row, so tile sizes, pitches and the 16-byte fragment reads of the bf16 path carry over unchanged.
+// (the elements are copied to scalars first: __builtin_bit_cast applied directly to an ext-vector element, v[i] or v.y, reads
+// element 0 for every i with this compiler)
+__device__ inline uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t r = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ inline void split_f32x4(const u32x4& v, u32x2& hi, u32x2& lo) {
+    const uint32_t u0 = v[0], u1 = v[1], u2 = v[2], u3 = v[3];
+    const float x0 = __builtin_bit_cast(float, u0), x1 = __builtin_bit_cast(float, u1), x2 = __builtin_bit_cast(float, u2),
+                x3 = __builtin_bit_cast(float, u3);
+    const uint32_t h01 = pack_bf16x2(x0, x1), h23 = pack_bf16x2(x2, x3);
+    const uint32_t a0 = h01 << 16, a1 = h01 & 0xffff0000u, a2 = h23 << 16, a3 = h23 & 0xffff0000u;  // the hi halves as floats
+    hi = u32x2{h01, h23};
+    lo = u32x2{pack_bf16x2(x0 - __builtin_bit_cast(float, a0), x1 - __builtin_bit_cast(float, a1)),
+               pack_bf16x2(x2 - __builtin_bit_cast(float, a2), x3 - __builtin_bit_cast(float, a3))};
+}
+
+// mma_slice for a 128-byte slice staged as [hi 64 B | lo 64 B] rows: two bf16 k-steps, three MFMAs per accumulator tile each,
+// small terms first.
+template <int KB>
+__device__ inline void mma_slice_split(const char* lds_a, const char* lds_b, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+    static_assert(KB == 128, "split-bf16 staging is laid out for 128-byte slices");
+    using M = Mfma<bf16>;
+    constexpr int PITCH = Geo<KB>::PITCH;
+    const int r = lane & 31, kh = lane >> 5;
+    const char* pa0 = lds_a + (wm * 64 + r) * PITCH;
+    const char* pa1 = pa0 + 32 * PITCH;
+    const char* pb0 = lds_b + (wn * 64 + r) * PITCH;
+    const char* pb1 = pb0 + 32 * PITCH;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const M::Frag a0h = M::load(pa0, s, kh), a1h = M::load(pa1, s, kh), b0h = M::load(pb0, s, kh), b1h = M::load(pb1, s, kh);
+        const M::Frag a0l = M::load(pa0, s + 2, kh), a1l = M::load(pa1, s + 2, kh), b0l = M::load(pb0, s + 2, kh), b1l = M::load(pb1, s + 2, kh);
+        acc[0][0] = M::run(b0l, a0h, acc[0][0]);
+        acc[0][1] = M::run(b1l, a0h, acc[0][1]);
+        acc[1][0] = M::run(b0l, a1h, acc[1][0]);
+        acc[1][1] = M::run(b1l, a1h, acc[1][1]);
+        acc[0][0] = M::run(b0h, a0l, acc[0][0]);
+        acc[0][1] = M::run(b1h, a0l, acc[0][1]);
+        acc[1][0] = M::run(b0h, a1l, acc[1][0]);
+        acc[1][1] = M::run(b1h, a1l, acc[1][1]);
+        acc[0][0] = M::run(b0h, a0h, acc[0][0]);
+        acc[0][1] = M::run(b1h, a0h, acc[0][1]);
+        acc[1][0] = M::run(b0h, a1h, acc[1][0]);
+        acc[1][1] = M::run(b1h, a1h, acc[1][1]);
+    }
+}
+
 __device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -134,6 +189,7 @@ struct NtArgs {
     const T* red_a = nullptr;
     int64_t red_a_win_stride = 0;
     int red_a_row0 = 0;
+    int split = 0;  // fp32 storage only (dtype VM_F32S): split-bf16 products on the bf16 matrix pipe instead of fp32 MFMAs
 };
 
 template <int KB>
@@ -141,8 +197,9 @@ constexpr int nt_lds_bytes() {
     return (2 * 2 * Geo<KB>::TILE > BM * OUT_PITCH + 4096) ? 2 * 2 * Geo<KB>::TILE : BM * OUT_PITCH + 4096;
 }
 
-template <typename T, int EPI, int KB>
+template <typename T, int EPI, int KB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_groups) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 128-byte slices");
     using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BK = KB / (int)sizeof(T);
@@ -158,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
         const int id = tid + i * 256;
         srow[i] = id / G::CH;
         const int ch = id % G::CH;
-        lds_off[i] = srow[i] * G::PITCH + ch * 16;
+        lds_off[i] = srow[i] * G::PITCH + ch * (SPLIT ? 8 : 16);  // SPLIT: 8 bytes into the hi plane, 8 into the lo plane (+64)
         kch[i] = ch * VEC;
     }
 
@@ -210,12 +267,26 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
             char* tb = lds + ((kt & 1) * 2 + 1) * G::TILE;
 #pragma unroll
             for (int i = 0; i < G::NCHUNK; ++i) {
-                *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
-                *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
+                if constexpr (SPLIT) {
+                    u32x2 h, l;
+                    split_f32x4(ra[i], h, l);
+                    *reinterpret_cast<u32x2*>(ta + lds_off[i]) = h;
+                    *reinterpret_cast<u32x2*>(ta + lds_off[i] + 64) = l;
+                    split_f32x4(rb[i], h, l);
+                    *reinterpret_cast<u32x2*>(tb + lds_off[i]) = h;
+                    *reinterpret_cast<u32x2*>(tb + lds_off[i] + 64) = l;
+                } else {
+                    *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
+                    *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
+                }
             }
             __syncthreads();
             if (kt + 1 < nk && !(p.ablate & 8)) gload(kt + 1);
-            if (!(p.ablate & 4)) mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
+            if constexpr (SPLIT) {
+                mma_slice_split<KB>(ta, tb, wm, wn, lane, acc);
+            } else {
+                if (!(p.ablate & 4)) mma_slice<T, KB>(ta, tb, wm, wn, lane, acc);
+            }
         }
         // coordinates of the finished tile
         const int tl = (int)(group % p.tilesL);
@@ -2073,6 +2144,7 @@ struct TnArgs {
     int ablate;  // conv_tn8_kernel timing experiments (wrong results): 4 no MFMA, 8 no in-loop DMA, 16 no fragment reads,
                  // 32 no A DMA, 64 no B DMA
     int64_t n_windows, win_per_split;
+    int split = 0;  // fp32 storage only (dtype VM_F32S): split-bf16 products
 };
 
 template <typename T, int PITCH> struct Transpose4;
@@ -2100,8 +2172,24 @@ template <int PITCH> struct Transpose4<float, PITCH> {
     }
 };
 
-template <typename T, int KB>
+// fp32 rows -> per channel column the 4 positions as 4 bf16 hi (8 bytes, hi plane) + 4 bf16 lo (8 bytes, lo plane at +64)
+template <int PITCH>
+struct Transpose4Split {
+    __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 o = {v[0][j], v[1][j], v[2][j], v[3][j]};
+            u32x2 h, l;
+            split_f32x4(o, h, l);
+            *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + pg * 8) = h;
+            *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + 64 + pg * 8) = l;
+        }
+    }
+};
+
+template <typename T, int KB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 128-byte stages");
     using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
@@ -2184,10 +2272,20 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
         const int buf = (int)(st & 1);
         char* mine = lds + (buf * 2 + which) * G::TILE;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) Transpose4<T, G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
+        for (int it = 0; it < NIT; ++it) {
+            if constexpr (SPLIT) {
+                Transpose4Split<G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
+            } else {
+                Transpose4<T, G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
+            }
+        }
         __syncthreads();
         if (st + 1 < n_stages) gload();
-        mma_slice<T, KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
+        if constexpr (SPLIT) {
+            mma_slice_split<KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
+        } else {
+            mma_slice<T, KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
+        }
     }
 
     // slab tile: row = kk (m side), 4 consecutive co per register group -> 16-byte fp32 stores
@@ -2216,8 +2314,9 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
 // 128-byte stage it writes 32 KB (transposed 8-byte writes, ~85 B/clk) and reads 64 KB for 16 MFMAs per wave.  With a
 // 256 x 256 tile and 64 x 128 per wave (8 waves) a stage writes 64 KB and reads 192 KB for 32 MFMAs per wave: LDS
 // cycles per MFMA cycle drop from 1.25 to 0.75.  One workgroup per CU (144 KB of LDS, 128 accumulator registers).
-template <typename T, int KB>
+template <typename T, int KB, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 128-byte stages");
     using G = Geo<KB>;
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
@@ -2289,12 +2388,36 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
     auto step = [&](int64_t st, u32x4 (&rx)[4], u32x4 (&rd)[4]) {
         char* ta = lds + (int)(st & 1) * 2 * OPB;
         char* tb_ = ta + OPB;
-        Transpose4<T, G::PITCH>::store(ta, col0, pg, rx);
-        Transpose4<T, G::PITCH>::store(tb_, col0, pg, rd);
+        if constexpr (SPLIT) {
+            Transpose4Split<G::PITCH>::store(ta, col0, pg, rx);
+            Transpose4Split<G::PITCH>::store(tb_, col0, pg, rd);
+        } else {
+            Transpose4<T, G::PITCH>::store(ta, col0, pg, rx);
+            Transpose4<T, G::PITCH>::store(tb_, col0, pg, rd);
+        }
         __syncthreads();
         if (st + 2 < n_stages) gload(rx, rd);
         const char* pa = ta + (wm * 64 + r) * G::PITCH;
         const char* pb = tb_ + (wn * 128 + r) * G::PITCH;
+        if constexpr (SPLIT) {
+            using M = Mfma<bf16>;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const M::Frag a0h = M::load(pa, s, kh), a1h = M::load(pa + 32 * G::PITCH, s, kh);
+                const M::Frag a0l = M::load(pa, s + 2, kh), a1l = M::load(pa + 32 * G::PITCH, s + 2, kh);
+#pragma unroll
+                for (int in = 0; in < 4; ++in) {
+                    const M::Frag bh = M::load(pb + in * 32 * G::PITCH, s, kh), bl = M::load(pb + in * 32 * G::PITCH, s + 2, kh);
+                    acc[0][in] = M::run(bl, a0h, acc[0][in]);
+                    acc[1][in] = M::run(bl, a1h, acc[1][in]);
+                    acc[0][in] = M::run(bh, a0l, acc[0][in]);
+                    acc[1][in] = M::run(bh, a1l, acc[1][in]);
+                    acc[0][in] = M::run(bh, a0h, acc[0][in]);
+                    acc[1][in] = M::run(bh, a1h, acc[1][in]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             typename Mfma<T>::Frag a0 = Mfma<T>::load(pa, s, kh), a1 = Mfma<T>::load(pa + 32 * G::PITCH, s, kh);
@@ -3035,6 +3158,12 @@ template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_groups, hipStream_t stream) {
     const int64_t grid = n_groups < g_nt_blocks ? n_groups : g_nt_blocks;
     const int64_t kbytes = (int64_t)a.Ktot * (int64_t)sizeof(T);
+    if constexpr (sizeof(T) == 4) {
+        if (a.split) {
+            hipLaunchKernelGGL((conv_nt_kernel<T, EPI, 128, true>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_groups);
+            return;
+        }
+    }
     if (launch_nt8<T, EPI>(a, n_groups / a.tilesL, stream)) return;
     // measured at cfg-A: the 3-workgroup variant wins for the forward (epilogue-heavy, K = 384..1152: 0.94 -> 0.87 ms) and
     // loses for dgrad (K = 768..1536, light epilogue: 0.73 -> 0.81 ms), which keeps the 128-byte-slice kernel
@@ -3088,6 +3217,7 @@ extern "C" int vm_conv_fwd(const void* in, const void* wf, const float* bias, in
         a.order = g_nt_order;
         a.skew = 0;
         a.korder = g_nt_korder && (c_in * (int)sizeof(T)) % 128 == 0;
+        a.split = dtype == VM_F32S;
         launch_nt<T, EPI_FWD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd");
@@ -3118,6 +3248,7 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         a.order = g_nt_order;
         a.skew = 0;
         a.korder = g_nt_korder && (c_out * (int)sizeof(T)) % 128 == 0;
+        a.split = dtype == VM_F32S;
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
@@ -3261,7 +3392,19 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.n_windows = n_windows;
         a.win_per_split = (n_windows + splits - 1) / splits;
         const int64_t grid = (int64_t)splits * a.tilesI * a.tilesJ;
-        if (xres) {
+        a.split = dtype == VM_F32S;
+        bool split_done = false;
+        if constexpr (sizeof(T) == 4) {
+            if (a.split && big) {
+                hipLaunchKernelGGL((conv_tn256_kernel<T, 128, true>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, a);
+                split_done = true;
+            } else if (a.split) {
+                hipLaunchKernelGGL((conv_tn_kernel<T, 128, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+                split_done = true;
+            }
+        }
+        if (split_done) {
+        } else if (xres) {
             launch_tn8x<T>(a, grid, (hipStream_t)stream);
         } else if (big && launch_tn8<T>(a, grid, (hipStream_t)stream)) {
         } else if (big) {

@@ -17,10 +17,11 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import VM_BF16, VM_F32
+from ._lib import VM_BF16, VM_F32, VM_F32S
 
-_DT = {"f32": VM_F32, "fp32": VM_F32, "float32": VM_F32, "bf16": VM_BF16, "bfloat16": VM_BF16}
-_TORCH_DT = {VM_F32: torch.float32, VM_BF16: torch.bfloat16}
+# "f32s": fp32 storage, split-bf16 products in the k=3 convolution GEMMs (VM_F32S in include/voicemap_hip.h)
+_DT = {"f32": VM_F32, "fp32": VM_F32, "float32": VM_F32, "bf16": VM_BF16, "bfloat16": VM_BF16, "f32s": VM_F32S}
+_TORCH_DT = {VM_F32: torch.float32, VM_BF16: torch.bfloat16, VM_F32S: torch.float32}
 HEADS = {"uniform_euclidean": _lib.VM_HEAD_UNIFORM_EUCLIDEAN, "weighted_l1": _lib.VM_HEAD_WEIGHTED_L1}
 LOSSES = {"contrastive": _lib.VM_LOSS_CONTRASTIVE, "contrastive_loss": _lib.VM_LOSS_CONTRASTIVE,
           "bce": _lib.VM_LOSS_BCE, "binary_crossentropy": _lib.VM_LOSS_BCE}
