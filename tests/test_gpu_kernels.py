@@ -810,13 +810,15 @@ def test_conv_dgrad_bnred_refuses_unserved_shapes():
     vm, _ = DTYPES["bf16"]
     assert L().query("vm_conv_dgrad_bnred_supported", 2, 300, 136, 64, vm) == 0  # c_in not a multiple of 128
     assert L().query("vm_conv_dgrad_bnred_supported", 2, 300, 128, 64, DTYPES["f32"][0]) == 0
+    assert L().query("vm_conv_dgrad_bnred_supported", 2, 260, 128, 64, vm) == 0  # a 256-row tile would be half padding
+    assert L().query("vm_conv_dgrad_bnred_supported", 2, 500, 128, 64, vm) == 1
     d = torch.zeros(16, device="cuda")
     with pytest.raises(RuntimeError):
         L().call("vm_conv_dgrad_bnred", p(d), p(d), 2, 300, 136, 64, vm, p(d), p(d), 1, p(d), p(d), stream())
 
 
 @pytest.mark.parametrize("n,wpt,l,cin,cout,pool,use_drop", [(4, 2, 508, 128, 256, 2, True), (2, 1, 1016, 256, 128, 4, False),
-                                                            (6, 3, 260, 128, 64, 1, True)])
+                                                            (6, 3, 500, 128, 64, 1, True)])
 def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_drop):
     """dgrad + fused sums + vm_bn_bwd_from_sums against dgrad + vm_bn_pool_bwd_reduce_pooled: the same (sum dy, sum dy*zhat) per
     window up to fp32 summation order, including a channel with scale == 0 (re-derived from z) and dropped channels."""
