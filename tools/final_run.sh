@@ -13,6 +13,10 @@ export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$TAG -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > /dev/null 2>&1
 python $R/tools/trace_kernels.py $O/trace_$TAG conv_ 3 > $O/conv_kernels_by_layer_$TAG.txt
+# one step, kernel by kernel in launch order (rocprofv3 serialises the queues: durations add up)
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl_$TAG -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+python $R/tools/timeline.py $O/tl_$TAG > $O/step_timeline_$TAG.txt; rm -rf $O/tl_$TAG
+timeout 60 $R/tools/probe/launch_gap_probe > $O/launch_gap_probe_$TAG.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${C}_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > $O/pmc_${C}_$TAG.log 2>&1; echo "pmc $C rc=$?"
 done
