@@ -215,7 +215,7 @@ def main():
                       "global_pairs": pairs * n_gpus, "parallelism": "dp%d" % n_gpus, "final_loss": loss},
            "roofline": roof}
 
-    if a.breakdown and rank == 0:
+    if a.breakdown and rank == 0 and n_gpus == 1:  # its steps contain collectives: single-process runs only
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
                  "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
