@@ -86,6 +86,8 @@ def main():
             eng.split_towers = bool(int(v))
         elif k == "fused_bn_reduce":
             eng.fused_bn_reduce = bool(int(v))
+        elif k == "wgrad_after_dgrad":
+            eng.wgrad_after_dgrad = bool(int(v))
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
     if a.nt_blocks:

@@ -171,6 +171,10 @@ class HipEncoderEngine:
         # throughput mode: the two BatchNorm-backward sums of block i come out of the epilogue of block i+1's dgrad GEMM
         # (vm_conv_dgrad_bnred) instead of a separate pass over (act, dp); only where that kernel serves the shape
         self.fused_bn_reduce = (self.dtype == _lib.VM_BF16)
+        # side-stream wgrad of block i enqueued after (True) or before (False) that block's dgrad: after it the wgrad runs beside the
+        # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
+        # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
+        self.wgrad_after_dgrad = True
         self.side_stream = torch.cuda.Stream(device=self.device)
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
@@ -578,7 +582,8 @@ class HipEncoderEngine:
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
             else:
                 cin = self.blocks[i - 1][1]
-                if self.overlap_wgrad:
+
+                def side_wgrad():
                     b["ev"].record()
                     with torch.cuda.stream(self.side_stream):
                         self.side_stream.wait_event(b["ev"])
@@ -588,13 +593,22 @@ class HipEncoderEngine:
                         # the optimizer: off the main stream, with its own reduction workspace
                         self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)),
                                    _p(pl["cr_ws_side"]), self.stream())
-                else:
+                    if i == 1 and sync_tail:
+                        if "sync_ev" not in pl:
+                            pl["sync_ev"] = torch.cuda.Event()
+                        pl["sync_ev"].record()  # main stream: every gradient of G[conv2.kernel:] that is not on the side stream
+                        self.grad_sync.begin_tail(self, pl["sync_ev"])
+
+                late = self.overlap_wgrad and self.wgrad_after_dgrad and not (i == 1 and sync_tail)
+                if self.overlap_wgrad and not late:
+                    side_wgrad()
+                elif not self.overlap_wgrad:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, st)
-                if i == 1 and sync_tail:
-                    if "sync_ev" not in pl:
-                        pl["sync_ev"] = torch.cuda.Event()
-                    pl["sync_ev"].record()  # main stream: every gradient of G[conv2.kernel:] that is not on the side stream
-                    self.grad_sync.begin_tail(self, pl["sync_ev"])
+                    if i == 1 and sync_tail:
+                        if "sync_ev" not in pl:
+                            pl["sync_ev"] = torch.cuda.Event()
+                        pl["sync_ev"].record()
+                        self.grad_sync.begin_tail(self, pl["sync_ev"])
                 lo = pl[i - 1]
                 lo["bnred_now"] = self._bnred_plan(pl, i)
                 if lo["bnred_now"]:
@@ -603,6 +617,8 @@ class HipEncoderEngine:
                                _p(lo["e"] if below_fused else lo["act"]), 0 if below_fused else 1, _p(lo["rs0"]), _p(lo["rs1"]), st)
                 else:
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), st)
+                if late:
+                    side_wgrad()   # experiment: the weight-gradient GEMM beside the memory-bound passes of the block below
         if self.overlap_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
 
