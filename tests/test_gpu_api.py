@@ -271,3 +271,30 @@ def test_train_siamese_script_with_device_resident_data(tmp_path, monkeypatch):
                                "--validation-steps", "2", "--num-evaluation-tasks", "4", "--n-seconds", "3", "--dtype", "f32"])
     assert len(hist.history["loss"]) == 2 and all(np.isfinite(v) for v in hist.history["loss"])
     assert os.path.exists(os.path.join(str(tmp_path), "shards", "index.csv"))
+
+
+def test_f32s_model_tracks_f32_model_through_the_public_api(tmp_path):
+    """dtype='f32s' (fp32 storage, split-bf16 GEMM products) through the drop-in surface: the same batches train a model whose
+    losses, predictions and saved checkpoint stay within 1e-4 of the dtype='f32' model's, and the checkpoint reloads in its own mode."""
+    train = SyntheticSpeechDataset(num_speakers=12, files_per_speaker=3, seconds=0.5, pad=True, seed=1)
+    bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
+    np.random.seed(11)
+    batches = [bp(train.build_verification_batch(8)) for _ in range(3)]
+    nets = {}
+    for dt in ("f32", "f32s"):
+        enc = models.get_baseline_convolutional_encoder(16, 24, dropout=0.0, dtype=dt)
+        net = models.build_siamese_net(enc, (2000, 1), distance_metric="uniform_euclidean")
+        net.compile(loss=utils.contrastive_loss, optimizer=K.Adam(lr=1e-3, clipnorm=1.), metrics=["accuracy"])
+        nets[dt] = net
+    nets["f32s"].set_weights(nets["f32"].get_weights())
+    for x, y in batches[:2]:
+        la, lb = nets["f32"].train_on_batch(x, y), nets["f32s"].train_on_batch(x, y)
+        assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0]))
+    x, _ = batches[2]
+    pa, pb = nets["f32"].predict(x), nets["f32s"].predict(x)
+    assert np.abs(pa - pb).max() < 1e-4
+    path = str(tmp_path / "f32s.hdf5")
+    nets["f32s"].save(path)
+    loaded = models.load_model(path)
+    assert loaded._ensure_engine().dtype == nets["f32s"].engine.dtype
+    assert np.array_equal(loaded.predict(x), pb)

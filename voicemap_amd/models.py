@@ -5,7 +5,9 @@ get_weights / set_weights / add / pop``) whose arithmetic runs on the HIP path (
     get_baseline_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05)   models.py:6
     build_siamese_net(encoder, input_shape, distance_metric='uniform_euclidean')                        models.py:44
 
-Extra keyword ``dtype`` ('bf16' default | 'f32') selects the storage type of activations / GEMM operands.
+Extra keyword ``dtype`` selects storage and GEMM arithmetic: 'bf16' (default: bf16 tensors, bf16 MFMAs), 'f32' (fp32 tensors,
+fp32 MFMAs: the exact-parity mode) or 'f32s' (fp32 tensors, split-bf16 products in the k=3 conv GEMMs: ~1e-5 of 'f32' at
+~0.55x its step time).
 """
 from __future__ import annotations
 
