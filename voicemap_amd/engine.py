@@ -175,6 +175,7 @@ class HipEncoderEngine:
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
         self.wgrad_after_dgrad = True
+        self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
@@ -435,6 +436,8 @@ class HipEncoderEngine:
             cur = torch.cuda.current_stream(self.device)
             self.tower_stream.wait_stream(cur)   # the pre-processed windows are ready
             self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True)
+            if self.tower_stagger and "stagger_ev" in pl:
+                self.tower_stream.wait_event(pl["stagger_ev"])
             with torch.cuda.stream(self.tower_stream):
                 self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True)
             cur.wait_stream(self.tower_stream)
@@ -486,9 +489,17 @@ class HipEncoderEngine:
                 w1 = _p(self.view("conv1.kernel"))
                 if training:
                     self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 0, W(b["e"]), ssum, ssq, st)
+                    if first_of_two and self.tower_stagger == 1:
+                        if "stagger_ev" not in pl:
+                            pl["stagger_ev"] = torch.cuda.Event()
+                        pl["stagger_ev"].record()
                     finalize()
                     self._call("vm_bn_drop_pool_fwd", W(b["e"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, pl["L"][1], c, 1, dt,
                                W(b["act"]), st)
+                    if first_of_two and self.tower_stagger == 2:
+                        if "stagger_ev" not in pl:
+                            pl["stagger_ev"] = torch.cuda.Event()
+                        pl["stagger_ev"].record()
                 else:
                     self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
                     self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), nw, L, c, pool, 1,
