@@ -1505,18 +1505,30 @@ static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
 // accumulators start at the bias of their channel (forward) or 0 (dgrad): register 4g + e of block j <-> channel c0 + 32j + 8g + e
 template <int EPI>
-__device__ inline void n2_init_acc(const NtArgs<bf16>& p, f32x16 (&acc)[4][2], int c0) {
+__device__ inline void n2_load_bias(const NtArgs<bf16>& p, f32x4 (&b4)[2][4], int c0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_FWD) b4 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
+            b4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_FWD) b4[j][g] = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
+        }
+}
+__device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[e];
-        }
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[j][g][e];
+}
+template <int EPI>
+__device__ inline void n2_init_acc(const NtArgs<bf16>& p, f32x16 (&acc)[4][2], int c0) {
+    f32x4 b4[2][4];
+    n2_load_bias<EPI>(p, b4, c0);
+    n2_fill_acc(acc, b4);
 }
 
 // Shared epilogue of the 256 x 128 kernels below.  ``trows``: valid MFMA-tile rows (256, or 254 for the input-resident kernel).
@@ -1927,8 +1939,17 @@ __device__ inline void wait_vm_0246(int n) {
     }
 }
 
+#if defined(VM_EXPERIMENT_PROFILE)  // where a wave of conv_nt2r_kernel spends its clocks (s_memtime); experiment builds only
+constexpr int PROF_SLOTS = 8192 * 4;
+__device__ unsigned int g_prof[PROF_SLOTS * 8];  // per (workgroup, wave): total, first K tile, other K tiles, epilogue
+#define VM_PROF(...) __VA_ARGS__
+#else
+#define VM_PROF(...)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64_t n_groups) {
+    VM_PROF(const long long pt_start = __builtin_amdgcn_s_memtime(); long long pt_first = 0, pt_bar = 0;)
     using namespace n2;
     using namespace n2r;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -1937,22 +1958,28 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
     const int chunks = p.a_c / 32, nk = chunks * 3;
     const int row_bytes = p.a_c * 2;
 
-    int64_t group;
+    // tile coordinates in 32-bit unsigned arithmetic (the launch guarantees grid < 2^31): the 64-bit divisions this replaces were a
+    // visible part of the ~4 000 clocks a workgroup spent before its first DMA (profiles/r02_nt2r_wave_profile.txt)
+    unsigned group;
     int tn;
     {
-        const int64_t v = blockIdx.x;
+        const unsigned v = blockIdx.x, tiles_n = (unsigned)p.tilesN;
         if (p.order == 1 && (n_groups & 7) == 0) {
-            const int64_t j = v >> 3;
-            tn = (int)(j % p.tilesN);
-            group = (j / p.tilesN) * 8 + (v & 7);
+            const unsigned j = v >> 3, q = j / tiles_n;
+            tn = (int)(j - q * tiles_n);
+            group = q * 8 + (v & 7);
         } else {
-            group = v / p.tilesN;
-            tn = (int)(v % p.tilesN);
+            group = v / tiles_n;
+            tn = (int)(v - group * tiles_n);
         }
     }
-    const int tl = (int)(group % p.tilesL);
-    const int64_t n = group / p.tilesL;
+    const unsigned nw = group / (unsigned)p.tilesL;
+    const int tl = (int)(group - nw * (unsigned)p.tilesL);
+    const int64_t n = nw;
     const int t0 = tl * TROWS, n0 = tn * TN;
+    // forward: the bias loads go out first and are consumed (accumulator init) only after the prologue DMA has been issued
+    f32x4 bias4[2][4];
+    n2_load_bias<EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
 
     // ---- DMA sources: one instruction = 16 rows x 64 B; A block row R <-> padded input row t0 + R (clamped to the L + 2 rows) ----
     const int lrow = lane >> 2, lchunk = lane & 3;
@@ -1998,14 +2025,13 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
         for (int ks = 0; ks < 2; ++ks) b_addr[ks] = B0 + row * KB + (((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
     }
 
-    f32x16 acc[4][2];
-    n2_init_acc<EPI>(p, acc, n0 + wn * 64 + 4 * (lane >> 5));
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
 #else
     const uint32_t lds0 = 0;
 #endif
 
+    VM_PROF(const long long pt_s2 = __builtin_amdgcn_s_memtime();)
     // ---- prologue: A(0), B(0), A(1), B(1) in that order ----
     issue_a(0, 0, 0);
     issue_a(0, 0, 2);
@@ -2015,6 +2041,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
         issue_a(1, 1, 2);
     }
     issue_b(1, row_bytes);  // K tile 1 = (chunk 0, tap 1)
+    VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
+    f32x16 acc[4][2];
+    n2_fill_acc(acc, bias4);
     int n_wait = (chunks > 1 ? 4 : 0) + 2;  // pieces issued after B(0)
     int ia_prev = 0;                        // A pieces issued in the previous iteration (after its B pieces)
     // of the next B slice to issue (K tile kt + 2)
@@ -2040,6 +2069,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
             const int kt = 3 * c + tap;
             wait_vm_0246(n_wait);
             __builtin_amdgcn_s_barrier();
+            VM_PROF(if (kt == 0) pt_bar = __builtin_amdgcn_s_memtime();)
             int ib = 0, ia = 0;
             if (!(p.ablate & 8)) {
                 if (kt + 2 < nk) {
@@ -2114,6 +2144,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
             __builtin_amdgcn_sched_barrier(0);
 #undef VM_MM
             __builtin_amdgcn_sched_barrier(0);
+            VM_PROF(if (kt == 0) pt_first = __builtin_amdgcn_s_memtime();)
         }
         a_blk = a_blk == 2 ? 0 : a_blk + 1;
     }
@@ -2122,8 +2153,34 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
         if (acc[0][0][0] == 123.456f) p.out[0] = (bf16)acc[3][1][15];
         return;
     }
+    VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
     n2_epilogue<EPI>(p, lds, acc, n, tl, t0, n0, TROWS, tid, lane, w, wm, wn);
+#if defined(VM_EXPERIMENT_PROFILE)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long pt_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
+            q[0] = (unsigned int)(pt_end - pt_start);    // the whole wave-tile (incl. the drain of its stores)
+            q[1] = (unsigned int)(pt_first - pt_start);  // start -> end of the first K tile
+            q[2] = (unsigned int)(pt_loop - pt_first);   // the other nk - 1 K tiles
+            q[3] = (unsigned int)(pt_end - pt_loop);     // epilogue + store drain
+            q[4] = (unsigned int)(pt_s2 - pt_start);     // tile coordinates, bias loads, DMA / fragment addresses
+            q[5] = (unsigned int)(pt_s3 - pt_s2);        // issue of the 10-14 prologue DMA instructions
+            q[6] = (unsigned int)(pt_bar - pt_s3);       // accumulator init, first data wait, first barrier
+            q[7] = (unsigned int)(pt_first - pt_bar);    // fragment reads + 16 MFMAs of the first K tile
+        }
+    }
+#endif
 }
+
+#if defined(VM_EXPERIMENT_PROFILE)
+extern "C" int vm_debug_prof_read(unsigned int* out, int n_slots) {  // out: n_slots x 4 host values
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned int) * 8 * (size_t)n_slots);
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
