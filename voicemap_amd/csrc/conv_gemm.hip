@@ -27,6 +27,20 @@
 
 namespace vm {
 
+// cache-policy bits of the LDS-DMA streams (see glds16); -D overrides are for A/B builds
+#if !defined(VM_NT2R_AUX_A)
+#define VM_NT2R_AUX_A 0
+#endif
+#if !defined(VM_NT2R_AUX_B)
+#define VM_NT2R_AUX_B 0
+#endif
+#if !defined(VM_TNX_AUX_A)
+#define VM_TNX_AUX_A 0
+#endif
+#if !defined(VM_TNX_AUX_B)
+#define VM_TNX_AUX_B 0
+#endif
+
 constexpr int BM = 128, BN = 128;
 
 template <int KB>
@@ -395,9 +409,14 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
 // 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_base + lane*16.  The body only exists in
 // the device pass: the host pass of hipcc cannot type-check the LDS address-space cast and would silently drop the
 // kernel's launch stub.
+// AUX: cache-policy bits of the instruction (1 = sc0, 2 = nt); all streams use 0.  Measured (same-box A/B of builds, -DVM_*_AUX_*):
+// nt on the forward / dgrad kernels' streams +34 % (their half-line pieces and tap re-reads live on cache hits); nt on the wgrad
+// kernel's streams -1 % for wgrad and +2 % for the step (the kernels that follow lose their hits); sc0 anywhere: no change.  (A build
+// with nt everywhere showed wgrad at -5 %: the slower neighbours let the chip clock higher -- not a property of the kernel.)
+template <int AUX = 0>
 __device__ inline void glds16(const char* gsrc, char* lds_base) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_base, 16, 0, AUX);
 #endif
 }
 
@@ -2000,12 +2019,12 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<bf16> p, int64
     auto issue_a = [&](int blk, int chunk, int i0) {  // pieces i0, i0 + 1 of this wave's four
         char* base = lds + blk * A_BLK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(a_src[i0 + i] + chunk * KB, base + __builtin_amdgcn_readfirstlane((w + 4 * (i0 + i)) * 1024));
+        for (int i = 0; i < 2; ++i) glds16<VM_NT2R_AUX_A>(a_src[i0 + i] + chunk * KB, base + __builtin_amdgcn_readfirstlane((w + 4 * (i0 + i)) * 1024));
     };
     auto issue_b = [&](int stg, int ko) {
         char* base = lds + B0 + stg * B_STG;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(b_src[i] + ko, base + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
+        for (int i = 0; i < 2; ++i) glds16<VM_NT2R_AUX_B>(b_src[i] + ko, base + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
     };
 
     // ---- fragment geometry: A row of tap k = block row m + k.  The four 32-row blocks of a wave are 2048 bytes apart and share the
@@ -2854,7 +2873,7 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
                 for (int j = 0; j < 2; ++j) {
                     int c0 = ci0 + j * 64;
                     c0 = c0 < p.c_in ? c0 : 0;
-                    glds16(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + j * ABLK);
+                    glds16<VM_TNX_AUX_A>(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + j * ABLK);
                 }
             }
             if (!(abl & 64)) {
@@ -2865,7 +2884,7 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<bf16> p) {
                 for (int j = 0; j < 2; ++j) {
                     int co0 = j0 + j * 64;
                     co0 = co0 < p.c_out ? co0 : 0;
-                    glds16(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + j * BBLK);
+                    glds16<VM_TNX_AUX_B>(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + j * BBLK);
                 }
             }
         };
