@@ -16,6 +16,7 @@ python $R/tools/trace_kernels.py $O/trace_$TAG conv_ 3 > $O/conv_kernels_by_laye
 # one step, kernel by kernel in launch order (rocprofv3 serialises the queues: durations add up)
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl_$TAG -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python $R/tools/timeline.py $O/tl_$TAG > $O/step_timeline_$TAG.txt; rm -rf $O/tl_$TAG
+[ -x $R/tools/probe/launch_gap_probe ] || hipcc --offload-arch=gfx950 -O3 -o $R/tools/probe/launch_gap_probe $R/tools/probe/launch_gap_probe.hip >/dev/null 2>&1
 timeout 60 $R/tools/probe/launch_gap_probe > $O/launch_gap_probe_$TAG.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${C}_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-overlap-wgrad --tune split_towers=0 > $O/pmc_${C}_$TAG.log 2>&1; echo "pmc $C rc=$?"
