@@ -128,6 +128,14 @@ int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const 
 int64_t vm_conv_stat_rows(int64_t L);
 int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in,
                 int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
+/* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
+ * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
+ * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by
+ * vm_bn_drop_pool_fwd(pool = 2, drop = NULL).  Served by the 256 x 128 input-resident kernel only (bf16, even L):
+ * vm_conv_fwd_pool_supported() says whether a shape is, VM_ERR_UNSUPPORTED otherwise. */
+int vm_conv_fwd_pool_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
+int vm_conv_fwd_pool(const void* in, const void* wf, const float* bias, const float* scale, const float* shift,
+                     int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, void* stream);
 /* dgrad: dx[n][t][ci] = sum_{k,co} du[n][t+1-k][co] * W[k][ci][co].  du padded (n_windows, L+2, c_out);
  * wd: (c_in, 3*c_out) `dtype` tap-flipped copy from vm_prep_conv_weights; dx: (n_windows, L, c_in). */
 int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,

@@ -278,3 +278,24 @@ def test_full_size_properties_cfgA_bf16():
     assert abs(res["bf16"][1][0] - res["f32"][1][0]) < 3e-2
     # bf16 storage re-routes some max-pool gradients (module docstring): direction must agree, magnitude loosely
     assert cosine(res["bf16"][2], res["f32"][2]) > 0.9
+
+
+def test_inference_fused_conv_pool_is_bit_identical_at_full_size():
+    """embed() with the conv + BatchNorm + max-pool epilogue fusion (default in bf16) against the kernel-per-stage inference path:
+    the same embeddings, bit for bit, at cfg-A's size (256 windows of 12000 samples); the fused path must actually have run."""
+    from voicemap_amd.engine import HipEncoderEngine
+    blocks = O.EncoderArch.baseline(128, 64, dropout=0.0).blocks
+    eng = HipEncoderEngine(blocks, 64, dropout=0.0, head="uniform_euclidean", dtype="bf16", seed=7)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(256, 12000, device="cuda", generator=g) * 0.5
+    assert eng.fused_infer_pool
+    calls = []
+    orig = eng._call
+    eng._call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    e1 = eng.embed(x).clone()
+    assert calls.count("vm_conv_fwd_pool") == 3 and "vm_conv_fwd" not in calls
+    eng.fused_infer_pool = False
+    calls.clear()
+    e0 = eng.embed(x).clone()
+    assert calls.count("vm_conv_fwd") == 3 and "vm_conv_fwd_pool" not in calls
+    assert torch.equal(e0, e1) and torch.isfinite(e1).all()

@@ -888,3 +888,45 @@ def test_prep_conv_weights_batch_equals_single():
         assert torch.equal(a, a2) and torch.equal(b, b2)
     with pytest.raises(RuntimeError):
         L().call("vm_prep_conv_weights_batch", 9, vp(), ci_t(), ci_t(), vm, vp(), vp(), stream())
+
+
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 254, 128, 256), (2, 256, 32, 128), (2, 1000, 256, 384), (5, 750, 384, 512), (4, 3000, 128, 256),
+                                          (1, 508, 64, 128)])
+def test_conv_fwd_pool_equals_two_kernel_inference_path(n, l, cin, cout):
+    """vm_conv_fwd_pool (conv + ReLU + BatchNorm affine + MaxPool1D(2) in the GEMM epilogue, inference mode) is bit-identical to
+    vm_conv_fwd followed by vm_bn_drop_pool_fwd, leaves the halo rows of the pooled tensor alone, and both agree with the oracle."""
+    vm, tdt = DTYPES["bf16"]
+    assert L().query("vm_conv_fwd_pool_supported", n, l, cin, cout, vm) == 1
+    r = rng(21)
+    x = quant(r.normal(0, 1.0, (n, l, cin)), "bf16")
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    b = torch.tensor(r.normal(0, 0.3, (cout,)).astype(np.float32), dtype=torch.float64)
+    scale = dev(r.normal(1.0, 0.3, (1, cout)) * np.where(r.random((1, cout)) < 0.3, -1, 1))
+    shift = dev(r.normal(0, 0.3, (1, cout)))
+    wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
+    wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
+    xp = padded(x, tdt)
+    z = torch.empty(n, l, cout, dtype=tdt, device="cuda")
+    L().call("vm_conv_fwd", p(xp), p(wf), p(dev(b)), n, l, cin, cout, vm, p(z), None, None, stream())
+    lq = l // 2
+    a0 = torch.zeros(n, lq + 2, cout, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), None, n, n, l, cout, 2, vm, p(a0), stream())
+    a1 = torch.full((n, lq + 2, cout), 7.0, dtype=tdt, device="cuda")
+    L().call("vm_conv_fwd_pool", p(xp), p(wf), p(dev(b)), p(scale), p(shift), n, l, cin, cout, vm, p(a1), stream())
+    assert torch.equal(a1[:, 1:lq + 1], a0[:, 1:lq + 1])
+    assert (a1[:, 0] == 7.0).all() and (a1[:, lq + 1] == 7.0).all()
+    ref = _conv_ref(x, w, b)
+    y = ref * scale.double().cpu()[0] + shift.double().cpu()[0]
+    pooled = torch.maximum(y[:, 0:2 * lq:2], y[:, 1:2 * lq:2]).numpy()
+    assert rel_err(a1[:, 1:lq + 1].float().cpu().numpy(), pooled) < 2e-2
+
+
+def test_conv_fwd_pool_refuses_unserved_shapes():
+    vm, _ = DTYPES["bf16"]
+    assert L().query("vm_conv_fwd_pool_supported", 2, 301, 128, 128, vm) == 0   # odd length
+    assert L().query("vm_conv_fwd_pool_supported", 2, 300, 128, 136, vm) == 0   # c_out not a multiple of 128
+    assert L().query("vm_conv_fwd_pool_supported", 2, 300, 128, 128, DTYPES["f32"][0]) == 0
+    d = torch.zeros(16, device="cuda")
+    with pytest.raises(RuntimeError):
+        L().call("vm_conv_fwd_pool", p(d), p(d), p(d), p(d), p(d), 2, 301, 128, 128, vm, p(d), stream())

@@ -178,7 +178,8 @@ __device__ inline void acc_to_lds(char* out_tile, int wm, int wn, int lane, cons
     }
 }
 
-enum { EPI_FWD = 0, EPI_DGRAD = 1 };
+// EPI_FWD_POOL (conv_nt2r_kernel only): forward in inference mode with the BatchNorm affine and MaxPool1D(2) applied in the epilogue
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_FWD_POOL = 2 };
 
 template <typename T>
 struct NtArgs {
@@ -204,6 +205,9 @@ struct NtArgs {
     int64_t red_a_win_stride = 0;
     int red_a_row0 = 0;
     int split = 0;  // fp32 storage only (dtype VM_F32S): split-bf16 products on the bf16 matrix pipe instead of fp32 MFMAs
+    // EPI_FWD_POOL: per-channel scale / shift of the inference-mode BatchNorm; out is then the padded pooled tensor (L / 2 + 2 rows)
+    const float* aff_scale = nullptr;
+    const float* aff_shift = nullptr;
 };
 
 template <int KB>
@@ -1530,7 +1534,7 @@ __device__ inline void n2_load_bias(const NtArgs<bf16>& p, f32x4 (&b4)[2][4], in
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             b4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_FWD) b4[j][g] = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
+            if (EPI != EPI_DGRAD) b4[j][g] = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
         }
 }
 __device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4]) {
@@ -1589,7 +1593,7 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][4 * g + e];
                 u32x2 pk = *reinterpret_cast<const u32x2*>(o);
-                if (EPI == EPI_FWD) {
+                if (EPI != EPI_DGRAD) {
                     uint32_t lo = pk[0], hi = pk[1];
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
@@ -1602,9 +1606,47 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
         }
     }
     __syncthreads();
+    const int c8 = tid & 15, rg = tid >> 4;
+    if (EPI == EPI_FWD_POOL) {
+        // ---- inference: y = z * scale + shift per channel, max over the position pairs (2q, 2q + 1) -- the arithmetic of
+        // bn_drop_pool_fwd_kernel on the same storage-rounded z, so the pooled tensor is bit-identical to the two-kernel path; z itself
+        // is never written.  Tiles start at even positions and L is even (checked by the launch): a pair never straddles tiles ----
+        float sc[8], sh[8];
+        {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.aff_scale + n0 + c8 * 8), s1 = *reinterpret_cast<const f32x4*>(p.aff_scale + n0 + c8 * 8 + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.aff_shift + n0 + c8 * 8), h1 = *reinterpret_cast<const f32x4*>(p.aff_shift + n0 + c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[e] = s0[e];
+                sc[4 + e] = s1[e];
+                sh[e] = h0[e];
+                sh[4 + e] = h1[e];
+            }
+        }
+        const int vq = valid >> 1;
+        bf16* pbase = p.out + (n * (int64_t)(p.L / 2 + 2) + 1 + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
+        bf16x8 r0[8], r1[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int q = rg + 16 * jj;
+            r0[jj] = *reinterpret_cast<const bf16x8*>(lds + (2 * q) * TP + c8 * 16);
+            r1[jj] = *reinterpret_cast<const bf16x8*>(lds + (2 * q + 1) * TP + c8 * 16);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int q = rg + 16 * jj;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y0 = fmaf((float)r0[jj][e], sc[e], sh[e]), y1 = fmaf((float)r1[jj][e], sc[e], sh[e]);
+                o[e] = (bf16)(y1 > y0 ? y1 : y0);
+            }
+            if (q < vq) *reinterpret_cast<bf16x8*>(pbase + (int64_t)q * p.N) = o;
+        }
+        return;
+    }
     // ---- read-back: 8 rows per thread and half, ALL tile reads first, then the 8 whole-row stores back to back; interior tiles
     // take a predicate-free path ----
-    const int c8 = tid & 15, rg = tid >> 4;
     bf16* obase = p.out + (n * p.L + t0) * (int64_t)p.N + n0 + c8 * 8;
     const bool interior = t0 + trows <= p.L;  // every valid MFMA row of the tile is a position of the window
     const bool no_store = (p.ablate & 1) != 0;
@@ -3157,7 +3199,7 @@ int g_nt_n2_prio = 0;  // experiment: s_setprio(2) around the K loop of conv_nt2
 int g_nt_n2r = 1;  // prefer the input-resident form (conv_nt2r_kernel) where its tiling fits; vm_set_tuning("nt_n2r", 0 | 1)
 template <int EPI>
 static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stream) {
-    if (!(g_nt_n2 & (EPI == EPI_FWD ? 1 : 2)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c) return false;
+    if (!(g_nt_n2 & (EPI == EPI_DGRAD ? 2 : 1)) || a.N % n2::TN != 0 || a.a_c % 32 != 0 || a.Ktot != 3 * a.a_c) return false;
     // short windows (the 2-D variant runs L = 298 .. 37): a 256-row tile that is mostly padding loses to the 128-row kernels
     {
         const double u256 = (double)a.L / (256.0 * ((a.L + 255) / 256)), u128 = (double)a.L / (128.0 * ((a.L + 127) / 128));
@@ -3178,11 +3220,12 @@ static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stre
         hipLaunchKernelGGL((conv_nt2r_kernel<EPI>), dim3((unsigned)grid), dim3(256), (g_nt_n2_prio & 64) ? 8192 : 0, stream, b, n_groups);
         return true;
     }
+    if (EPI == EPI_FWD_POOL) return false;  // the pooled epilogue exists in the input-resident kernel only
     b.tilesL = (a.L + n2::TM - 1) / n2::TM;
     const int64_t n_groups = n_windows * b.tilesL;
     const int64_t grid = n_groups * b.tilesN;
     if (grid >= (1LL << 31)) return false;
-    hipLaunchKernelGGL((conv_nt2_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b, n_groups);
+    if constexpr (EPI != EPI_FWD_POOL) hipLaunchKernelGGL((conv_nt2_kernel<EPI>), dim3((unsigned)grid), dim3(256), 0, stream, b, n_groups);
     return true;
 }
 
@@ -3328,6 +3371,55 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
+}
+
+// ---- inference forward with BatchNorm affine + MaxPool1D(2) in the epilogue (conv_nt2r_kernel only) ----
+static bool fwd_pool_shape(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    if (dtype != VM_BF16 || !(g_nt_n2 & 1) || !g_nt_n2r || c_out % n2::TN != 0 || c_in % 32 != 0 || L < 2 || (L & 1) || n_windows <= 0) return false;
+    const double u256 = (double)L / (256.0 * ((L + 255) / 256)), u128 = (double)L / (128.0 * ((L + 127) / 128));
+    if (u256 + 0.10 < u128) return false;
+    const int64_t t254 = (L + n2r::TROWS - 1) / n2r::TROWS;
+    return n_windows * t254 * (c_out / n2::TN) < (1LL << 31);
+}
+
+extern "C" int vm_conv_fwd_pool_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    return fwd_pool_shape(n_windows, L, c_in, c_out, dtype) ? 1 : 0;
+}
+
+extern "C" int vm_conv_fwd_pool(const void* in, const void* wf, const float* bias, const float* scale, const float* shift,
+                                int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, void* stream) {
+    VM_REQUIRE(in && wf && bias && scale && shift && act, "vm_conv_fwd_pool: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_fwd_pool: bad sizes");
+    VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd_pool: window too large");
+    if (!fwd_pool_shape(n_windows, L, c_in, c_out, dtype)) {
+        set_error("vm_conv_fwd_pool: shape/dtype/tuning not served by the 256 x 128 input-resident kernel (ask vm_conv_fwd_pool_supported)");
+        return VM_ERR_UNSUPPORTED;
+    }
+    NtArgs<bf16> a;
+    a.a = (const bf16*)in;
+    a.bt = (const bf16*)wf;
+    a.bias = bias;
+    a.out = (bf16*)act;
+    a.stat_sum = nullptr;
+    a.stat_sq = nullptr;
+    a.a_win_stride = (L + 2) * (int64_t)c_in;
+    a.a_c = c_in;
+    a.L = (int)L;
+    a.N = c_out;
+    a.Ktot = 3 * c_in;
+    a.tilesL = tiles(L, BM);
+    a.tilesN = tiles(c_out, BN);
+    a.ablate = 0;
+    a.order = g_nt_order;
+    a.skew = 0;
+    a.korder = 0;
+    a.aff_scale = scale;
+    a.aff_shift = shift;
+    if (!launch_n2<EPI_FWD_POOL>(a, n_windows, (hipStream_t)stream)) {
+        set_error("vm_conv_fwd_pool: launch refused");
+        return VM_ERR_UNSUPPORTED;
+    }
+    return check_launch("vm_conv_fwd_pool");
 }
 
 // ---- dgrad with the BatchNorm-backward partial sums of the layer below fused into its epilogue (conv_nt2r_kernel only) ----

@@ -175,6 +175,7 @@ class HipEncoderEngine:
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
         self.wgrad_after_dgrad = True
+        self.fused_infer_pool = (self.dtype == _lib.VM_BF16)  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
         # training forward: the second tower on its own stream (see forward())
@@ -509,6 +510,14 @@ class HipEncoderEngine:
                 self._call("vm_conv1_fwd", W(pl["x0"]), _p(self.view("conv1.kernel")), bias, nw, L, c, dt, W(b["z"]), ssum, ssq, st)
             else:
                 cin = self.blocks[i - 1][1]
+                if (not training and self.fused_infer_pool and pool == 2
+                        and self.lib.query("vm_conv_fwd_pool_supported", nw, L, cin, c, dt)):
+                    # inference: conv + ReLU + BatchNorm affine + max-pool in one launch, z is never written (bit-identical to the
+                    # two-kernel path below); the last block's GlobalMaxPool1D then runs on its pooled tensor
+                    self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
+                    self._call("vm_conv_fwd_pool", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, _p(b["scale"]), _p(b["shift"]), nw, L, cin,
+                               c, dt, W(b["act"]), st)
+                    continue
                 self._call("vm_conv_fwd", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, nw, L, cin, c, dt, W(b["z"]), ssum, ssq, st)
             if training:
                 finalize()
