@@ -88,6 +88,8 @@ def main():
             eng.fused_bn_reduce = bool(int(v))
         elif k == "wgrad_after_dgrad":
             eng.wgrad_after_dgrad = bool(int(v))
+        elif k == "fused_pool_extreme":
+            eng.fused_pool_extreme = bool(int(v))
         elif k == "tower_stagger":
             eng.tower_stagger = int(v)
         else:

@@ -128,6 +128,14 @@ int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const 
 int64_t vm_conv_stat_rows(int64_t L);
 int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in,
                 int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
+/* vm_conv_fwd (training form: statistics required) that also writes the pool-window extreme of z for MaxPool1D(2):
+ * e[n][q][c] = max(z[n][2q][c], z[n][2q+1][c]) where gamma[c] >= 0, the min where gamma[c] < 0 -- the element the max-pool of the
+ * BatchNorm output will select, known before the statistics are (sign(scale) = sign(gamma)).  e: unpadded (n_windows, L/2, c_out).
+ * vm_bn_drop_pool_fwd(e, ..., L/2, pool = 1) then gives the bit-identical pooled output from a pooled-size tensor, and
+ * vm_conv_dgrad_bnred can take its sums against e directly (red_a_padded = 0).  Same kernel restriction as vm_conv_fwd_pool. */
+int vm_conv_fwd_e_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
+int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float* gamma, int64_t n_windows, int64_t L,
+                  int c_in, int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* e, void* stream);
 /* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
  * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
  * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by

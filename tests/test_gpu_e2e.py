@@ -255,6 +255,14 @@ def test_full_size_properties_cfgA_bf16():
         assert d_emb < (1e-5 if dtype == "f32" else 3e-3) and d_nt < 1e-5 and d_g < (1e-4 if dtype == "f32" else 5e-2), (d_emb, d_g, d_nt)
         assert torch.isfinite(eng.G).all() and torch.isfinite(loss1).all()
         if dtype == "bf16":
+            eng.split_towers = not eng.split_towers   # back to the default (the block above left it toggled)
+            eng.init_params(1234)
+            pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,
+                                        apply_update=False)
+            torch.cuda.synchronize()
+            emb_fused_ref = pl["emb"].clone()
+            assert pl[1].get("e_now") and pl[2].get("e_now"), "vm_conv_fwd_e must serve blocks 2 and 3 at cfg-A"
+            eng.split_towers = not eng.split_towers
             # the BatchNorm-backward sums out of the dgrad epilogue (default) or from the separate pass over (act, dp): the same
             # sums of the same bf16 values, in a different fp32 order
             assert eng.fused_bn_reduce
@@ -267,6 +275,14 @@ def test_full_size_properties_cfgA_bf16():
             d_g = rel_err(eng.G.cpu().numpy(), g1.cpu().numpy())
             report("full_size_cfgA", "fused_bn_reduce_vs_separate_pass_grad", d_g)
             assert d_g < 2e-3, d_g
+            # ... and with the pool pass reading z instead of the pooled extreme the conv epilogue leaves: the same forward bits
+            eng.fused_pool_extreme = False
+            eng.init_params(1234)
+            pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,
+                                        apply_update=False)
+            torch.cuda.synchronize()
+            assert torch.equal(pl["emb"], emb_fused_ref), "the pooled-extreme path must not change the forward"
+            eng.fused_pool_extreme = True
             assert any("rs0" in pl[i] for i in range(3)), "the fused form must have run in the default configuration"
         res[dtype] = (emb.cpu().numpy(), loss1.cpu().numpy(), g1.cpu().numpy())
         del eng, pl

@@ -930,3 +930,43 @@ def test_conv_fwd_pool_refuses_unserved_shapes():
     d = torch.zeros(16, device="cuda")
     with pytest.raises(RuntimeError):
         L().call("vm_conv_fwd_pool", p(d), p(d), p(d), p(d), p(d), 2, 301, 128, 128, vm, p(d), stream())
+
+
+@pytest.mark.parametrize("n,l,cin,cout", [(3, 508, 128, 256), (2, 254, 32, 128), (2, 1016, 256, 384), (4, 3000, 128, 256), (4, 1500, 256, 384)])
+def test_conv_fwd_e_pool_extreme(n, l, cin, cout):
+    """vm_conv_fwd_e: z and the statistics bit-identical to vm_conv_fwd, e = the pair maximum where gamma >= 0 and the pair minimum where
+    gamma < 0 of the stored z, and vm_bn_drop_pool_fwd(e, pool 1) == vm_bn_drop_pool_fwd(z, pool 2) bit for bit (negative scales and
+    dropped channels included)."""
+    vm, tdt = DTYPES["bf16"]
+    assert L().query("vm_conv_fwd_e_supported", n, l, cin, cout, vm) == 1
+    r = rng(23)
+    x = quant(r.normal(0, 1.0, (n, l, cin)), "bf16")
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    b = dev(r.normal(0, 0.3, (cout,)))
+    gamma = r.normal(1.0, 0.3, (cout,)) * np.where(r.random(cout) < 0.4, -1, 1)
+    gamma[5] = 0.0
+    wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
+    wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
+    xp = padded(x, tdt)
+    rows = L().query("vm_conv_stat_rows", l)
+    z0, z1 = (torch.empty(n, l, cout, dtype=tdt, device="cuda") for _ in range(2))
+    s0, q0, s1, q1 = (torch.zeros(n * rows, cout, device="cuda") for _ in range(4))
+    lq = l // 2
+    e = torch.full((n, lq, cout), -5.0, dtype=tdt, device="cuda")
+    L().call("vm_conv_fwd", p(xp), p(wf), p(b), n, l, cin, cout, vm, p(z0), p(s0), p(q0), stream())
+    L().call("vm_conv_fwd_e", p(xp), p(wf), p(b), p(dev(gamma)), n, l, cin, cout, vm, p(z1), p(s1), p(q1), p(e), stream())
+    assert torch.equal(z0, z1) and torch.equal(s0, s1) and torch.equal(q0, q1)
+    zz = z0.float()
+    hi, lo = torch.maximum(zz[:, 0::2], zz[:, 1::2]), torch.minimum(zz[:, 0::2], zz[:, 1::2])
+    want = torch.where(torch.tensor(gamma < 0, device="cuda")[None, None, :], lo, hi)
+    assert torch.equal(e.float(), want)
+    # the pass over e gives the pooled output of the pass over z (per-tower scale with the sign of gamma, dropout mask)
+    invstd = r.uniform(0.5, 2.0, (1, cout))
+    scale, shift = dev(gamma[None, :] * invstd), dev(r.normal(0, 0.3, (1, cout)))
+    drop = dev((r.random((n, cout)) > 0.25) / 0.75)
+    a0 = torch.zeros(n, lq + 2, cout, dtype=tdt, device="cuda")
+    a1 = torch.zeros_like(a0)
+    L().call("vm_bn_drop_pool_fwd", p(z0), p(scale), p(shift), p(drop), n, n, l, cout, 2, vm, p(a0), stream())
+    L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(drop), n, n, lq, cout, 1, vm, p(a1), stream())
+    assert torch.equal(a0, a1)

@@ -45,6 +45,8 @@ SIGNATURES = {
     "vm_conv_stat_rows": (L, [L]),
     "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
+    "vm_conv_fwd_e_supported": (I, [L, L, I, I, I]),
+    "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
     "vm_conv_fwd_pool_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P]),
     "vm_conv_dgrad_bnred_rows": (L, [L]),

@@ -208,6 +208,9 @@ struct NtArgs {
     // EPI_FWD_POOL: per-channel scale / shift of the inference-mode BatchNorm; out is then the padded pooled tensor (L / 2 + 2 rows)
     const float* aff_scale = nullptr;
     const float* aff_shift = nullptr;
+    // EPI_FWD (training, vm_conv_fwd_e): also write the pool-window extreme of the (2q, 2q + 1) position pairs -- the maximum where
+    // aff_scale (= the BatchNorm gamma) is >= 0, the minimum where it is negative -- as an unpadded (n_windows, L / 2, N) tensor
+    T* pool_e = nullptr;
 };
 
 template <int KB>
@@ -1671,6 +1674,44 @@ __device__ inline void n2_epilogue(const NtArgs<bf16>& p, char* lds, const f32x1
     } else {
         half(0, std::false_type{});
         half(1, std::false_type{});
+    }
+    if (EPI == EPI_FWD && p.pool_e != nullptr) {
+        // ---- pool-window extreme of z for the BatchNorm / pool pass that follows the statistics (it then reads a pooled-size tensor
+        // instead of z: max_j fma(z_j, s, h) == fma(ext_j z, s, h), the extreme being the maximum for s >= 0 and the minimum for
+        // s < 0; sign(s) = sign(gamma) is known before the statistics are).  z >= 0 after ReLU, so the packed 16-bit integer max / min
+        // order the bf16 values. ----
+        u32x4 neg;  // 0xFFFF in the 16-bit lanes of channels with gamma < 0
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.aff_scale + n0 + c8 * 8), g1 = *reinterpret_cast<const f32x4*>(p.aff_scale + n0 + c8 * 8 + 4);
+            neg[0] = (g0[0] < 0.f ? 0xFFFFu : 0u) | (g0[1] < 0.f ? 0xFFFF0000u : 0u);
+            neg[1] = (g0[2] < 0.f ? 0xFFFFu : 0u) | (g0[3] < 0.f ? 0xFFFF0000u : 0u);
+            neg[2] = (g1[0] < 0.f ? 0xFFFFu : 0u) | (g1[1] < 0.f ? 0xFFFF0000u : 0u);
+            neg[3] = (g1[2] < 0.f ? 0xFFFFu : 0u) | (g1[3] < 0.f ? 0xFFFF0000u : 0u);
+        }
+        const int vq = valid >> 1;
+        bf16* ebase = p.pool_e + (n * (int64_t)(p.L / 2) + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
+        u32x4 r0[8], r1[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int q = rg + 16 * jj;
+            r0[jj] = *reinterpret_cast<const u32x4*>(lds + (2 * q) * TP + c8 * 16);
+            r1[jj] = *reinterpret_cast<const u32x4*>(lds + (2 * q + 1) * TP + c8 * 16);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int q = rg + 16 * jj;
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t a = r0[jj][d], b = r1[jj][d];
+                uint32_t mx, mn;
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+                asm("v_pk_min_i16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+                const uint32_t m = neg[d];
+                o[d] = (mx & ~m) | (mn & m);
+            }
+            if (q < vq) *reinterpret_cast<u32x4*>(ebase + (int64_t)q * p.N) = o;
+        }
     }
     if (stats) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3220,7 +3261,7 @@ static bool launch_n2(const NtArgs<bf16>& a, int64_t n_windows, hipStream_t stre
         hipLaunchKernelGGL((conv_nt2r_kernel<EPI>), dim3((unsigned)grid), dim3(256), (g_nt_n2_prio & 64) ? 8192 : 0, stream, b, n_groups);
         return true;
     }
-    if (EPI == EPI_FWD_POOL) return false;  // the pooled epilogue exists in the input-resident kernel only
+    if (EPI == EPI_FWD_POOL || a.pool_e != nullptr) return false;  // the pooled epilogues are served by the input-resident kernel only
     b.tilesL = (a.L + n2::TM - 1) / n2::TM;
     const int64_t n_groups = n_windows * b.tilesL;
     const int64_t grid = n_groups * b.tilesN;
@@ -3371,6 +3412,56 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         launch_nt<T, EPI_DGRAD>(a, n_windows * a.tilesL, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
+}
+
+// ---- training forward that also emits the pool-window extreme (conv_nt2r_kernel only) ----
+static bool fwd_e_shape(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    if (dtype != VM_BF16 || !(g_nt_n2 & 1) || !g_nt_n2r || c_out % n2::TN != 0 || c_in % 32 != 0 || L < 2 || (L & 1) || n_windows <= 0) return false;
+    const double u256 = (double)L / (256.0 * ((L + 255) / 256)), u128 = (double)L / (128.0 * ((L + 127) / 128));
+    if (u256 + 0.10 < u128) return false;
+    const int64_t t254 = (L + n2r::TROWS - 1) / n2r::TROWS;
+    if (2 * t254 != (L + 127) / 128) return false;  // the statistics rows of vm_conv_stat_rows must be the kernel's two per tile
+    return n_windows * t254 * (c_out / n2::TN) < (1LL << 31);
+}
+
+extern "C" int vm_conv_fwd_e_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype) {
+    return fwd_e_shape(n_windows, L, c_in, c_out, dtype) ? 1 : 0;
+}
+
+extern "C" int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float* gamma, int64_t n_windows, int64_t L,
+                             int c_in, int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* e, void* stream) {
+    VM_REQUIRE(in && wf && bias && gamma && z && stat_sum && stat_sq && e, "vm_conv_fwd_e: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_fwd_e: bad sizes");
+    VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd_e: window too large");
+    if (!fwd_e_shape(n_windows, L, c_in, c_out, dtype)) {
+        set_error("vm_conv_fwd_e: shape/dtype/tuning not served by the 256 x 128 input-resident kernel (ask vm_conv_fwd_e_supported)");
+        return VM_ERR_UNSUPPORTED;
+    }
+    NtArgs<bf16> a;
+    a.a = (const bf16*)in;
+    a.bt = (const bf16*)wf;
+    a.bias = bias;
+    a.out = (bf16*)z;
+    a.stat_sum = stat_sum;
+    a.stat_sq = stat_sq;
+    a.a_win_stride = (L + 2) * (int64_t)c_in;
+    a.a_c = c_in;
+    a.L = (int)L;
+    a.N = c_out;
+    a.Ktot = 3 * c_in;
+    a.tilesL = tiles(L, BM);
+    a.tilesN = tiles(c_out, BN);
+    a.ablate = 0;
+    a.order = g_nt_order;
+    a.skew = 0;
+    a.korder = 0;
+    a.aff_scale = gamma;
+    a.pool_e = (bf16*)e;
+    if (!launch_n2<EPI_FWD>(a, n_windows, (hipStream_t)stream)) {
+        set_error("vm_conv_fwd_e: launch refused");
+        return VM_ERR_UNSUPPORTED;
+    }
+    return check_launch("vm_conv_fwd_e");
 }
 
 // ---- inference forward with BatchNorm affine + MaxPool1D(2) in the epilogue (conv_nt2r_kernel only) ----

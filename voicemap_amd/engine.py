@@ -98,8 +98,9 @@ class FlatState:
         pass
 
 
-# entry points whose launches bench.py books under another name (same leading arguments)
-_TIMED_AS = {"vm_conv_dgrad_bnred": "vm_conv_dgrad"}
+# entry points whose launches bench.py books under another name: (name, index of an extra argument to drop so that the leading
+# arguments line up with that entry point's)
+_TIMED_AS = {"vm_conv_dgrad_bnred": ("vm_conv_dgrad", None), "vm_conv_fwd_e": ("vm_conv_fwd", 3)}
 
 
 class HipEncoderEngine:
@@ -175,6 +176,7 @@ class HipEncoderEngine:
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
         self.wgrad_after_dgrad = True
+        self.fused_pool_extreme = (self.dtype == _lib.VM_BF16)  # training: vm_conv_fwd_e, the pool pass reads the pooled extreme
         self.fused_infer_pool = (self.dtype == _lib.VM_BF16)  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
@@ -216,7 +218,8 @@ class HipEncoderEngine:
     def _call(self, name, *args):
         """Enqueue one C-ABI entry point; entry points listed in ``self.timed`` are bracketed by HIP events on the
         launch stream (bench.py uses this for the per-kernel roofline figure)."""
-        rec = self.timed.get(_TIMED_AS.get(name, name)) if self.timed else None
+        as_name, drop = _TIMED_AS.get(name, (name, None))
+        rec = self.timed.get(as_name) if self.timed else None
         if rec is None:
             self.lib.call(name, *args)
             return
@@ -224,7 +227,7 @@ class HipEncoderEngine:
         e0.record()
         self.lib.call(name, *args)
         e1.record()
-        rec.append((e0, e1, args))
+        rec.append((e0, e1, args if drop is None else args[:drop] + args[drop + 1:]))
 
     def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
         if name in self.nt_off:
@@ -518,6 +521,20 @@ class HipEncoderEngine:
                     self._call("vm_conv_fwd_pool", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, _p(b["scale"]), _p(b["shift"]), nw, L, cin,
                                c, dt, W(b["act"]), st)
                     continue
+                b["e_now"] = False
+                if (training and self.fused_pool_extreme and pool == 2 and i < self.nb - 1
+                        and self.lib.query("vm_conv_fwd_e_supported", nw, L, cin, c, dt)):
+                    # the conv epilogue also leaves the pool-window extreme of z (chosen by sign(gamma)): the BatchNorm / pool pass
+                    # then reads that pooled-size tensor instead of z -- same bits -- and the backward sums are taken against it
+                    if "e" not in b:
+                        b["e"] = torch.empty(pl["n"], L // 2, c, dtype=self.tdt, device=self.device)
+                    self._call("vm_conv_fwd_e", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, gam, nw, L, cin, c, dt, W(b["z"]), ssum, ssq,
+                               W(b["e"]), st)
+                    finalize()
+                    self._call("vm_bn_drop_pool_fwd", W(b["e"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, L // 2, c, 1, dt,
+                               W(b["act"]), st)
+                    b["e_now"] = True
+                    continue
                 self._call("vm_conv_fwd", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, nw, L, cin, c, dt, W(b["z"]), ssum, ssq, st)
             if training:
                 finalize()
@@ -580,8 +597,8 @@ class HipEncoderEngine:
                 self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             elif b.get("bnred_now"):
                 self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
-                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 1, _p(b["pa"]), _p(b["pb"]),
-                           st)
+                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
+                           _p(b["pa"]), _p(b["pb"]), st)
             elif self.pooled_reduce and L % pool == 0:
                 # throughput mode: the pool-window extreme comes from this block's pooled output (= the next block's input),
                 # so the pass reads two pooled-size tensors instead of z + dp
@@ -632,9 +649,9 @@ class HipEncoderEngine:
                 lo = pl[i - 1]
                 lo["bnred_now"] = self._bnred_plan(pl, i)
                 if lo["bnred_now"]:
-                    below_fused = (i == 1 and self.fuse_block1)
+                    use_e = (i == 1 and self.fuse_block1) or bool(lo.get("e_now"))   # the extreme itself, else the pooled output
                     self._call("vm_conv_dgrad_bnred", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]),
-                               _p(lo["e"] if below_fused else lo["act"]), 0 if below_fused else 1, _p(lo["rs0"]), _p(lo["rs1"]), st)
+                               _p(lo["e"] if use_e else lo["act"]), 0 if use_e else 1, _p(lo["rs0"]), _p(lo["rs1"]), st)
                 else:
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), st)
                 if late:
@@ -649,7 +666,7 @@ class HipEncoderEngine:
             return False
         lo, n, L = pl[i - 1], pl["n"], pl["L"][i]
         cin, c = self.blocks[i - 1][1], self.blocks[i][1]
-        if not (i == 1 and self.fuse_block1):
+        if not (i == 1 and self.fuse_block1) and not lo.get("e_now"):
             if not (self.pooled_reduce and pl["L"][i - 1] % self.blocks[i - 1][2] == 0):
                 return False
         if not self.lib.query("vm_conv_dgrad_bnred_supported", n, L, cin, c, self.dtype):
