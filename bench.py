@@ -35,11 +35,15 @@ TRAIN_FLOPS_PER_WINDOW = 7.373e9
 
 def conv_launch_work(name, args, esize):
     """Algorithmic bytes and FLOPs of one conv entry-point launch (layer-granular compulsory traffic of SURVEY 8d:
-    each operand tensor is read once and each result written once; weights excluded)."""
+    each operand tensor is read once and each result written once; weights excluded).  ``args`` may end with the name of the fused
+    form that actually ran (engine._call books vm_conv_fwd_e / vm_conv_dgrad_bnred under the plain entry points): its extra tensor
+    -- the pooled extreme written by the forward epilogue, the tensor the dgrad epilogue takes its BatchNorm sums against -- counts."""
     base = {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[name]
     n, L, cin, cout = args[base:base + 4]
-    shape = {"n_windows": n, "L": L, "c_in": cin, "c_out": cout}
-    return (n * L * (cin + cout)) * esize, 2.0 * n * L * 3 * cin * cout, shape
+    fused = args[-1] if args and isinstance(args[-1], str) else ""
+    shape = {"n_windows": n, "L": L, "c_in": cin, "c_out": cout, "fused": fused}
+    extra = {"vm_conv_fwd_e": n * (L // 2) * cout, "vm_conv_dgrad_bnred": n * L * cin}.get(fused, 0)
+    return (n * L * (cin + cout) + extra) * esize, 2.0 * n * L * 3 * cin * cout, shape
 
 
 def main():
@@ -169,7 +173,7 @@ def main():
         launches = []
         for key, ts in by_shape.items():
             t_med = float(np.median(ts))
-            nb_, nf_, shp = conv_launch_work(nm, (None,) * {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[nm] + key, esize)
+            nb_, nf_, shp = conv_launch_work(nm, (None,) * {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[nm] + key[:4] + (key[4],), esize)
             launches.append({"shape": shp, "ms": t_med * 1e3, "tflops": nf_ / t_med / 1e12, "gbs": nb_ / t_med / 1e9,
                              "algorithmic_bytes": nb_, "flops": nf_})
         fam[nm] = {"ms_per_step": sum(l["ms"] for l in launches), "launches": launches}
@@ -205,7 +209,7 @@ def main():
     roof["families_serial"] = {nm: {"ms_per_step": round(f["ms_per_step"], 4),
                                     "frac_of_mfma_peak": round(sum(l["flops"] for l in f["launches"]) / (f["ms_per_step"] * 1e-3) / 1e12
                                                                / MFMA_BF16_PEAK_TF, 4),
-                                    "launches": [{"L": l["shape"]["L"], "c_in": l["shape"]["c_in"], "c_out": l["shape"]["c_out"],
+                                    "launches": [{"L": l["shape"]["L"], "c_in": l["shape"]["c_in"], "c_out": l["shape"]["c_out"], "fused": l["shape"]["fused"],
                                                   "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                                   "algorithmic_gbs": round(l["gbs"], 1)} for l in f["launches"]]}
                                for nm, f in fam.items()}

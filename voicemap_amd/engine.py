@@ -176,7 +176,10 @@ class HipEncoderEngine:
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
         self.wgrad_after_dgrad = True
-        self.fused_pool_extreme = (self.dtype == _lib.VM_BF16)  # training: vm_conv_fwd_e, the pool pass reads the pooled extreme
+        # training option (bf16): vm_conv_fwd_e -- the conv epilogue also writes the pool-window extreme, the pool pass reads that
+        # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
+        # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
+        self.fused_pool_extreme = False
         self.fused_infer_pool = (self.dtype == _lib.VM_BF16)  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
@@ -227,7 +230,7 @@ class HipEncoderEngine:
         e0.record()
         self.lib.call(name, *args)
         e1.record()
-        rec.append((e0, e1, args if drop is None else args[:drop] + args[drop + 1:]))
+        rec.append((e0, e1, (args if drop is None else args[:drop] + args[drop + 1:]) + ((name,) if as_name != name else ())))
 
     def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
         if name in self.nt_off:
