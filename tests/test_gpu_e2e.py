@@ -315,3 +315,32 @@ def test_inference_fused_conv_pool_is_bit_identical_at_full_size():
     e0 = eng.embed(x).clone()
     assert calls.count("vm_conv_fwd") == 3 and "vm_conv_fwd_pool" not in calls
     assert torch.equal(e0, e1) and torch.isfinite(e1).all()
+
+
+def test_fused_backward_sums_with_dropout_masks_at_cfgA_channels():
+    """The dgrad-epilogue BatchNorm sums (and the pooled-extreme option) with SpatialDropout masks at cfg-A's channel counts: the masks
+    enter the sums per (window, channel), so the fused forms must agree with the separate reduce pass when channels are dropped."""
+    from voicemap_amd.engine import HipEncoderEngine
+    blocks = O.EncoderArch.baseline(128, 64, dropout=0.25).blocks
+    eng = HipEncoderEngine(blocks, 64, dropout=0.25, head="uniform_euclidean", dtype="bf16", seed=11)
+    pairs, l0 = 8, 8192
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x1 = (torch.randn(pairs, l0, device="cuda", generator=g) * 0.5).cpu().numpy()
+    x2 = (torch.randn(pairs, l0, device="cuda", generator=g) * 0.5).cpu().numpy()
+    y = np.array([[0.0], [1.0]] * (pairs // 2))
+    masks = eng.make_drop_masks(2 * pairs, torch.Generator(device="cuda").manual_seed(9))
+    assert any((m == 0).any() for m in masks)
+    grads = {}
+    for name, bnred, ext in (("fused", True, False), ("fused+extreme", True, True), ("separate", False, False)):
+        eng.fused_bn_reduce, eng.fused_pool_extreme = bnred, ext
+        eng.init_params(11)
+        pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=True, drop_masks=masks, apply_update=False)
+        torch.cuda.synchronize()
+        grads[name] = (eng.G.clone(), pl["emb"].clone())
+        if bnred:
+            assert all(pl[i].get("bnred_now") for i in range(3))
+    assert torch.equal(grads["fused"][1], grads["separate"][1]) and torch.equal(grads["fused"][1], grads["fused+extreme"][1])
+    ref = grads["separate"][0].cpu().numpy()
+    assert rel_err(grads["fused"][0].cpu().numpy(), ref) < 1e-3
+    assert rel_err(grads["fused+extreme"][0].cpu().numpy(), ref) < 3e-2   # exact extreme vs the one recovered from the rounded pooled output
+    assert torch.isfinite(grads["fused"][0]).all()
