@@ -71,6 +71,8 @@ def main():
     rank, world, local = parallel.init_distributed()
     assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
     n_gpus = world
+    if os.environ.get("VOICEMAP_DIST_BACKEND") == "gloo":   # rehearsal: more ranks than GPUs, the replicas share devices
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -225,12 +225,25 @@ def test_two_rank_hip_engine_replicas_bit_identical(tmp_path):
         assert res["same_P"] and res["same_M"] and res["same_V"] and res["sum_ok"] and res["finite"]
 
 
-def _gpu_worker(rank, world, port, outdir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.gpu
+def test_two_rank_hip_engine_on_one_gpu_over_gloo(tmp_path):
+    """The same check on ONE GPU: two processes share cuda:0 and exchange the flat gradient buffer through gloo (RCCL refuses two ranks
+    on one device).  Everything but the transport is the production path: HipEncoderEngine, broadcast_state, the early tail
+    all-reduce enqueued from the side stream, the head all-reduce in the optimizer hook, the 1/world prescale in the Adam kernel."""
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path), "gloo"), nprocs=2, join=True)
+    for r in (0, 1):
+        res = torch.load(str(tmp_path / ("gres%d.pt" % r)))
+        assert res["same_P"] and res["same_M"] and res["same_V"] and res["sum_ok"] and res["finite"]
+        assert res["collectives_per_step"] == 2
+
+
+def _gpu_worker(rank, world, port, outdir, backend="nccl"):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from voicemap_amd.engine import HipEncoderEngine
-    parallel.init_distributed("nccl")
-    torch.cuda.set_device(rank)
+    parallel.init_distributed(backend)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
     blocks = [(32, 16, 4), (3, 32, 2), (3, 48, 2), (3, 64, 2)]
     eng = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype="bf16", seed=5 + rank)
     g = np.random.default_rng(50 + rank)
@@ -244,11 +257,13 @@ def _gpu_worker(rank, world, port, outdir):
     eng.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=False)
     local = eng.G.clone()
     eng.grad_sync = sync
+    c0 = sync.collectives
     pl = eng.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=True)
+    c1 = sync.collectives
     torch.cuda.synchronize()
     locals_ = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(locals_, local)
-    res = {"sum_ok": bool(torch.allclose(eng.G, sum(locals_), rtol=1e-5, atol=1e-7))}
+    res = {"sum_ok": bool(torch.allclose(eng.G, sum(locals_), rtol=1e-5, atol=1e-7)), "collectives_per_step": c1 - c0}
     for _ in range(3):
         pl = eng.siamese_train_step(x1, x2, y, drop_masks=None)
     torch.cuda.synchronize()
