@@ -94,6 +94,8 @@ def setup(seed=0):
     from voicemap_amd import parallel
     rank, world, local = parallel.init_distributed()
     if torch.cuda.is_available():
+        if os.environ.get("VOICEMAP_DIST_BACKEND") == "gloo":   # rehearsal with more ranks than GPUs (voicemap_amd/parallel.py)
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     seed_everything(seed, rank)
     return rank, world

@@ -293,4 +293,6 @@ class NShotEvaluationCallback(Callback):
                                            self.k_way, network_type=self.mode)
         n_shot_acc = n_correct * 1. / self.num_tasks
         logs["val_{}-shot_acc".format(self.n_shot)] = n_shot_acc
-        print("val_{}-shot_acc: {:.4f}".format(self.n_shot, n_shot_acc))
+        from . import parallel
+        if parallel.rank_world()[0] == 0:   # every rank holds the same (summed) figure; one line like the reference's
+            print("val_{}-shot_acc: {:.4f}".format(self.n_shot, n_shot_acc))
