@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
     int lds_off[G::NCHUNK], kch[G::NCHUNK], srow[G::NCHUNK];
 #pragma unroll
     for (int i = 0; i < G::NCHUNK; ++i) {
-        const int id = tid + i * 256;
+        // SPLIT: chunks 2j, 2j + 1 of a thread are neighbours in a row (8 floats), so that their bf16 halves leave as one 16-byte
+        // LDS write per plane (the 8-byte writes of one chunk at a time ran at half the LDS write rate)
+        const int id = SPLIT ? (tid + (i >> 1) * 256) * 2 + (i & 1) : tid + i * 256;
         srow[i] = id / G::CH;
         const int ch = id % G::CH;
         lds_off[i] = srow[i] * G::PITCH + ch * (SPLIT ? 8 : 16);  // SPLIT: 8 bytes into the hi plane, 8 into the lo plane (+64)
@@ -289,13 +291,17 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
 #pragma unroll
             for (int i = 0; i < G::NCHUNK; ++i) {
                 if constexpr (SPLIT) {
-                    u32x2 h, l;
-                    split_f32x4(ra[i], h, l);
-                    *reinterpret_cast<u32x2*>(ta + lds_off[i]) = h;
-                    *reinterpret_cast<u32x2*>(ta + lds_off[i] + 64) = l;
-                    split_f32x4(rb[i], h, l);
-                    *reinterpret_cast<u32x2*>(tb + lds_off[i]) = h;
-                    *reinterpret_cast<u32x2*>(tb + lds_off[i] + 64) = l;
+                    if (i & 1) {
+                        u32x2 h0, l0, h1, l1;
+                        split_f32x4(ra[i - 1], h0, l0);
+                        split_f32x4(ra[i], h1, l1);
+                        *reinterpret_cast<u32x4*>(ta + lds_off[i - 1]) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                        *reinterpret_cast<u32x4*>(ta + lds_off[i - 1] + 64) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                        split_f32x4(rb[i - 1], h0, l0);
+                        split_f32x4(rb[i], h1, l1);
+                        *reinterpret_cast<u32x4*>(tb + lds_off[i - 1]) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                        *reinterpret_cast<u32x4*>(tb + lds_off[i - 1] + 64) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                    }
                 } else {
                     *reinterpret_cast<u32x4*>(ta + lds_off[i]) = ra[i];
                     *reinterpret_cast<u32x4*>(tb + lds_off[i]) = rb[i];
