@@ -341,6 +341,34 @@ def main():
                          "pcie_inclusive_ms_per_step_int16_host_windows": t_h2d * 1e3,
                          "device_resident_corpus_ms_per_step_int16_offsets": t_off * 1e3}
         out["extras"].update(spectro_extras)
+        # BASELINE config 5: the n-shot k-way evaluation loop of experiments/k_way_accuracy.py (5-way 1-shot, siamese distances) over a
+        # device-resident synthetic corpus -- tasks are start offsets, embedded in batches by the cfg-A encoder of this run's shape
+        try:
+            import tempfile
+            from voicemap_amd import models as VM, shards as VS, utils as VU
+            from voicemap_amd.librispeech import SyntheticSpeechDataset
+            with tempfile.TemporaryDirectory() as td:
+                VS.write_shards(SyntheticSpeechDataset(num_speakers=40, files_per_speaker=4, seconds=3, seed=3), td)
+                sd = VS.ShardedSpeechDataset(td, 3, stochastic=True)
+                enc = VM.get_baseline_convolutional_encoder(F, E, dropout=0.0, dtype=a.dtype)
+                net = VM.build_siamese_net(enc, (sd.fragment_length // 4, 1))
+                net.compile(loss="binary_crossentropy", optimizer="adam")
+                bp = VU.BatchPreProcessor("siamese", VU.preprocess_instances(4))
+                sd.to_device("cuda")
+                np.random.seed(5)
+                VU.n_shot_task_evaluation(net, sd, bp, 50, 1, 5, network_type="siamese", distance="euclidean")
+                torch.cuda.synchronize()
+                tasks = 400
+                t1 = time.perf_counter()
+                VU.n_shot_task_evaluation(net, sd, bp, tasks, 1, 5, network_type="siamese", distance="euclidean")
+                torch.cuda.synchronize()
+                t_k = time.perf_counter() - t1
+                out["extras"].update({"kway_eval_5way_1shot_tasks_per_s": tasks / t_k,
+                                      "kway_eval_audio_s_per_s": tasks * 6 * 3.0 / t_k,
+                                      "kway_eval_config": "%d tasks of 6 x 3 s windows from a device-resident int16 corpus, host draws the tasks" % tasks})
+                del net, enc, sd
+        except Exception as e:
+            out["extras"]["kway_eval_error"] = repr(e)
         if a.dtype == "bf16":
             # the exact-parity storage mode (fp32 activations, split-precision MFMAs) on the same windows: its step time and how far the
             # bf16 embeddings / gradients of THIS run are from it (north star: embeddings within 1e-3 of the reference arithmetic)
