@@ -299,3 +299,28 @@ def test_numpy_sampling_reproduces_the_pandas_draws():
         a = [np.random.randint(0, int(s)) for s in spans]
         np.random.seed(trial)
         assert a == list(np.random.randint(0, spans))
+
+
+def test_single_weighted_draw_fast_path_is_np_random_choice():
+    """LibriSpeechDataset._weighted(1, w) (cached cdf for the all-files draw, validation-free cdf for a speaker's files) returns what
+    np.random.choice(len(w), 1, replace=False, p=w / w.sum()) returns and leaves the random stream where choice leaves it: the n-shot
+    tasks and verification pairs of a seed do not change (reference draws: voicemap/librispeech.py:139-240)."""
+    import types
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+
+    def by_choice(self, n, weights):
+        return np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum())
+
+    res = {}
+    for name in ("fast", "choice"):
+        d = SyntheticSpeechDataset(num_speakers=90, files_per_speaker=7, seconds=1, seed=3)
+        if name == "choice":
+            d._weighted = types.MethodType(by_choice, d)
+        np.random.seed(11)
+        out = []
+        for i in range(120):
+            q = int(d._weighted(1, d._len)[0])
+            out.append((q, tuple(d._n_shot_support(q, 5, 1 + (i % 3)))))
+        out.append(tuple(map(tuple, d.get_alike_pairs(8))) + tuple(map(tuple, d.get_differing_pairs(8))))
+        res[name] = (out, np.random.random())
+    assert res["fast"] == res["choice"]

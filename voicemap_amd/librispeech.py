@@ -146,10 +146,27 @@ class LibriSpeechDataset(Sequence):
         np.minimum.at(first, self._code, np.arange(len(spk)))
         self._appear = np.argsort(first, kind='stable')                       # speaker codes in order of first appearance
 
-    @staticmethod
-    def _weighted(n, weights):
-        """``DataFrame.sample(n, weights=...)`` on row positions."""
-        return np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum())
+    _cdf_cache = None   # (id of the weights array, its length, cdf): the all-files draw repeats with the same weights every task
+
+    def _weighted(self, n, weights):
+        """``DataFrame.sample(n, weights=...)`` on row positions = ``np.random.choice(len, n, replace=False, p=w / w.sum())``.
+
+        A single draw (every n-shot task starts with one over ALL files: an O(files) normalisation, validation and cumsum per task
+        inside ``choice`` -- most of the evaluation loop's time on train-clean-360) is taken from a cached cdf instead, with exactly
+        ``choice``'s arithmetic and random-stream use: one ``random_sample(1)``, ``cdf = cumsum(p); cdf /= cdf[-1]``,
+        ``searchsorted(side='right')`` -- the same index for the same seed (tests/test_host_api.py)."""
+        if n != 1:
+            return np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum())
+        if weights is not self._len:   # a speaker's own files: a fresh array per call, nothing to cache -- but choice()'s argument
+            cdf = np.cumsum(weights / weights.sum())   # validation (several passes and ~25 us per call) is skipped here too
+            cdf /= cdf[-1]
+            return cdf.searchsorted(np.random.random_sample(1), side='right')
+        c = self._cdf_cache
+        if c is None or c[0] is not weights or c[1] != len(weights):
+            cdf = np.cumsum(weights / weights.sum())
+            cdf /= cdf[-1]
+            c = self._cdf_cache = (weights, len(weights), cdf)
+        return c[2].searchsorted(np.random.random_sample(1), side='right')
 
     # ---- Sequence ------------------------------------------------------------------------------------------
     def _load(self, index):
