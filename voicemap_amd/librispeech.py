@@ -146,27 +146,48 @@ class LibriSpeechDataset(Sequence):
         np.minimum.at(first, self._code, np.arange(len(spk)))
         self._appear = np.argsort(first, kind='stable')                       # speaker codes in order of first appearance
 
-    _cdf_cache = None   # (id of the weights array, its length, cdf): the all-files draw repeats with the same weights every task
+    _cdf_cache = None   # (the weights array, its length, p, cdf): the all-files draws repeat with the same weights every batch / task
 
     def _weighted(self, n, weights):
         """``DataFrame.sample(n, weights=...)`` on row positions = ``np.random.choice(len, n, replace=False, p=w / w.sum())``.
 
-        A single draw (every n-shot task starts with one over ALL files: an O(files) normalisation, validation and cumsum per task
-        inside ``choice`` -- most of the evaluation loop's time on train-clean-360) is taken from a cached cdf instead, with exactly
-        ``choice``'s arithmetic and random-stream use: one ``random_sample(1)``, ``cdf = cumsum(p); cdf /= cdf[-1]``,
-        ``searchsorted(side='right')`` -- the same index for the same seed (tests/test_host_api.py)."""
-        if n != 1:
-            return np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum())
-        if weights is not self._len:   # a speaker's own files: a fresh array per call, nothing to cache -- but choice()'s argument
-            cdf = np.cumsum(weights / weights.sum())   # validation (several passes and ~25 us per call) is skipped here too
+        This is ``choice``'s own algorithm for weighted sampling without replacement, restated so that (a) its argument validation
+        (half a dozen passes over p per call) is skipped and (b) the first-round cdf of the all-files draws -- an O(files)
+        normalisation and cumsum per batch and per n-shot task inside ``choice``, most of the host time on an index of
+        train-clean-360's size -- is cached: rounds of ``random_sample(n - found)`` -> ``cdf.searchsorted(side='right')`` -> first
+        occurrences kept, with the weights of the found rows zeroed and the cdf rebuilt before another round.  Same arithmetic, same
+        use of the random stream: the same rows for the same seed (tests/test_host_api.py checks it against ``choice``)."""
+        if weights is self._len:
+            c = self._cdf_cache
+            if c is None or c[0] is not weights or c[1] != len(weights):
+                p = weights / weights.sum()
+                cdf = np.cumsum(p)
+                cdf /= cdf[-1]
+                c = self._cdf_cache = (weights, len(weights), p, cdf)
+            p, cdf = c[2], c[3]
+        else:
+            p = weights / weights.sum()
+            cdf = np.cumsum(p)
             cdf /= cdf[-1]
+        if n == 1:
             return cdf.searchsorted(np.random.random_sample(1), side='right')
-        c = self._cdf_cache
-        if c is None or c[0] is not weights or c[1] != len(weights):
-            cdf = np.cumsum(weights / weights.sum())
-            cdf /= cdf[-1]
-            c = self._cdf_cache = (weights, len(weights), cdf)
-        return c[2].searchsorted(np.random.random_sample(1), side='right')
+        found = np.zeros(n, dtype=np.int64)
+        n_uniq, pw = 0, None
+        while n_uniq < n:
+            x = np.random.random_sample(n - n_uniq)
+            if n_uniq > 0:
+                if pw is None:
+                    pw = p.copy()
+                pw[found[:n_uniq]] = 0
+                cdf = np.cumsum(pw)
+                cdf /= cdf[-1]
+            new = cdf.searchsorted(x, side='right')
+            _, first = np.unique(new, return_index=True)
+            first.sort()
+            new = new.take(first)
+            found[n_uniq:n_uniq + new.size] = new
+            n_uniq += new.size
+        return found
 
     # ---- Sequence ------------------------------------------------------------------------------------------
     def _load(self, index):
