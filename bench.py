@@ -60,9 +60,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side figures (other loss, embed-only pass)")
     ap.add_argument("--no-overlap-wgrad", action="store_true",
                     help="keep the weight-gradient GEMMs on the main stream (default: side stream, concurrent with dgrad)")
-    ap.add_argument("--gemm-kb", type=int, default=0, help="tuning: bytes of K per GEMM slice (64 | 128), 0 = library default")
     ap.add_argument("--tune", default="", help="extra tuning knobs key=value,key=value (vm_set_tuning)")
-    ap.add_argument("--nt-blocks", type=int, default=0, help="tuning: persistent grid of the NT conv GEMMs, 0 = library default")
     ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
     a = ap.parse_args()
 
@@ -80,8 +78,6 @@ def main():
     blocks = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
     eng = HipEncoderEngine(blocks, E, dropout=0.0, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
     eng.overlap_wgrad = not a.no_overlap_wgrad
-    if a.gemm_kb:
-        eng.lib.call("vm_set_tuning", b"gemm_kb", a.gemm_kb)
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
         if k == "overlap_wgrad":
@@ -100,8 +96,6 @@ def main():
             eng.tower_stagger = int(v)
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
-    if a.nt_blocks:
-        eng.lib.call("vm_set_tuning", b"nt_blocks", a.nt_blocks)
     parallel.attach(eng, n_gpus)
     parallel.broadcast_state(eng)
 
@@ -156,11 +150,11 @@ def main():
 
     # ---- serial attribution pass (untimed, after the timed region): the same step with the weight-gradient GEMMs on the main
     # stream, every GEMM launch bracketed by HIP events on its launch stream; median over the repetitions per launch shape ----
-    esize = 2 if a.dtype == "bf16" else 4
+    esize = 2 if a.dtype in ("bf16", "f16") else 4
     gemm = ["vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"]
     was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False
     was_split, eng.split_towers = eng.split_towers, False   # one launch per GEMM of the step, nothing else in flight
-    snap0 = (eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.NT.clone(), eng.iterations)
+    snap0 = (eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.NT.clone(), eng.iterations, eng.ZD.clone(), eng.bn_steps)
     eng.timed = {nm: [] for nm in gemm}
     att_reps = max(5, min(a.steps, 20))
     for _ in range(att_reps):
@@ -183,6 +177,7 @@ def main():
     eng.overlap_wgrad = was_overlap
     eng.split_towers = was_split
     eng.P.copy_(snap0[0]); eng.M.copy_(snap0[1]); eng.V.copy_(snap0[2]); eng.NT.copy_(snap0[3]); eng.iterations = snap0[4]
+    eng.ZD.copy_(snap0[5]); eng.bn_steps = snap0[6]
     eng.refresh_weights()
     if a.dominant == "auto":
         a.dominant = max(fam, key=lambda k: fam[k]["ms_per_step"])
@@ -369,7 +364,7 @@ def main():
                 del net, enc, sd
         except Exception as e:
             out["extras"]["kway_eval_error"] = repr(e)
-        if a.dtype == "bf16":
+        if a.dtype in ("bf16", "f16"):
             # the exact-parity storage mode (fp32 activations, split-precision MFMAs) on the same windows: its step time and how far the
             # bf16 embeddings / gradients of THIS run are from it (north star: embeddings within 1e-3 of the reference arithmetic)
             try:
@@ -392,8 +387,9 @@ def main():
                 torch.cuda.synchronize()
                 rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-30))
                 cos = lambda u, v: float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30))
-                out["extras"].update({"bf16_vs_f32_embedding_rel_err": rel(pl["emb"], p32["emb"]),
-                                      "bf16_vs_f32_gradient_rel_err": rel(eng.G, e32.G), "bf16_vs_f32_gradient_cosine": cos(eng.G, e32.G)})
+                gs = eng.G / float(eng.loss_scale)   # f16 storage keeps loss_scale x the gradients in G
+                out["extras"].update({"%s_vs_f32_embedding_rel_err" % a.dtype: rel(pl["emb"], p32["emb"]),
+                                      "%s_vs_f32_gradient_rel_err" % a.dtype: rel(gs, e32.G), "%s_vs_f32_gradient_cosine" % a.dtype: cos(gs, e32.G)})
                 emb32, g32 = p32["emb"].clone(), e32.G.clone()  # before the timed steps move the parameters
                 t32 = timed(step32, reps=5)
                 out["extras"]["f32_storage_ms_per_step"] = t32 * 1e3

@@ -1,7 +1,6 @@
 """Speaker-identification classifier on the same encoder (+ Dense(num_classes, softmax), categorical cross-entropy) --
 counterpart of the reference's experiments/train_classifier.py; its bottleneck layer is evaluated with the same
 n-shot tasks (mode='classifier').     python -m experiments.train_classifier [--synthetic] ..."""
-import sys
 
 import numpy as np
 
@@ -32,7 +31,7 @@ class ShuffledBatches(Sequence):
 
 
 def main(argv=None):
-    a = C.base_parser(__doc__, pad=False).parse_args(argv)
+    a = C.base_parser(__doc__, pad=False, dropout=None).parse_args(argv)
     C.setup()
     train, valid = C.datasets(a, pad=False)
     ids = sorted(train.df["speaker_id"].unique())
@@ -42,7 +41,8 @@ def main(argv=None):
     # the reference defines dropout = 0.0 (train_classifier.py:28) but never passes it to the build function (:110), so its
     # classifier trains at the function's default SpatialDropout1D rate 0.05 while the run is NAMED drop_0.0 (:40).  Same here
     # unless --dropout is given explicitly.
-    rate = a.dropout if "--dropout" in (argv if argv is not None else sys.argv[1:]) else 0.05
+    rate = 0.05 if a.dropout is None else a.dropout   # default None: "--dropout=0.1" and argparse abbreviations count as explicit
+    a.dropout = 0.0 if a.dropout is None else a.dropout   # the name the reference gives the run (:28,:40)
     classifier = get_baseline_convolutional_encoder(a.filters, a.embedding_dimension, (C.input_length(a), 1), dropout=rate,
                                                     dtype=a.dtype)
     classifier.add(Dense(train.num_classes(), activation="softmax"))

@@ -36,35 +36,34 @@ extern "C" {
 /* VM_F32S: fp32 storage like VM_F32; the k=3 convolution GEMMs (vm_conv_fwd / vm_conv_dgrad / vm_conv_wgrad) form every product
  * from bf16 hi/lo halves of the fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation: ~2^-17 relative per product
  * instead of exact) on the bf16 matrix pipe, which is 16x faster than the fp32 one.  Every other entry point treats it as VM_F32. */
-enum { VM_F32 = 0, VM_BF16 = 1, VM_F32S = 2 };
+/* VM_F16: IEEE half storage (11 significand bits against bf16's 8: ~8x less rounding per stored value at the same bytes and the same
+ * matrix-pipe rate, v_mfma_f32_32x32x16_f16).  Every entry point that takes VM_BF16 takes it.  Its exponent range is narrow (6e-8 ..
+ * 65504), so the caller scales the loss gradient (vm_siamese_head_loss / vm_softmax_cce `grad_scale`) and un-scales in
+ * vm_adam_clip_step (`grad_prescale`); everything between them is linear in the gradient. */
+enum { VM_F32 = 0, VM_BF16 = 1, VM_F32S = 2, VM_F16 = 3 };
 enum { VM_OK = 0, VM_ERR_ARG = -1, VM_ERR_LAUNCH = -2, VM_ERR_UNSUPPORTED = -3 };
 enum { VM_LOSS_CONTRASTIVE = 0, VM_LOSS_BCE = 1 };
 enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
+/* 3.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
+ * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
 
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
-/* Kernel-selection table for A/B measurements and for the tests that pin a kernel variant (process-global, see the conventions
+/* Kernel-selection table for the tests that pin a fallback kernel and for A/B measurements (process-global, see the conventions
  * above; not part of the drop-in surface: voicemap_amd never calls it outside bench.py --tune).  Unknown keys / values out of
- * range return VM_ERR_ARG.
- *   "nt_n2" 0..3    forward / dgrad: the 256 x 128, two-workgroups-per-CU kernels (bit 0 forward, bit 1 dgrad; default 3);
- *   "nt_n2r" 0|1    ... prefer their input-resident form conv_nt2r_kernel where its tiling fits (default 1)
- *   "nt_p8" 0|1|2   forward/dgrad: 256x256 phase-interleaved kernel off / every eligible shape / K >= 1152 only (default 2; only
- *                   reached when nt_n2 does not take the launch)
- *   "nt_w4" 0|1|2   forward/dgrad: one-wave-per-SIMD 254x256 kernel with an input-resident A (conv_w4_kernel) off (default) /
- *                   every eligible shape / K >= 1152 only
- *   "tn_x"  0|1|2   wgrad: input-resident (3 taps x 128 ci) x 128 co kernel off / phase form (default) / free-running form
- *   "tn_p8" 0|1     wgrad: LDS-DMA + transposing-read 256x256 kernel when tn_x does not apply (default 1)
- *   "tn_tile" 128|256, "gemm_kb" 64|128, "nt_glds", "nt_tepi", "nt_ring", "nt_order", "tn_xcd": the older variants
- *   "nt_blocks", "nt_blocks3", "nt_p8_blocks", "nt_p8_phases" 2|4, "nt_p8_skew", "nt_n2_prio", "f1_blocks", "f1_fwd_blocks":
- *                   launch geometry / scheduling experiments (results unchanged)
- *   "nt_ablate"     timing experiments that switch parts of a kernel OFF and therefore produce WRONG results: compiled in only
- *                   when the library is built with -DVM_ENABLE_ABLATION (VM_EXTRA_HIPCC_FLAGS, tools/); the shipped build answers
- *                   VM_ERR_UNSUPPORTED to any non-zero value. */
+ * range return VM_ERR_ARG.  Six keys:
+ *   "nt_n2" 0..3      forward / dgrad, 16-bit storage: conv_nt2r_kernel (254 x 128 tiles, two workgroups per CU, input-resident A
+ *                     by LDS-DMA; bit 0 forward, bit 1 dgrad; default 3); where it is off or does not serve the shape:
+ *   "nt_glds" 0|1     the 128 x 128 LDS-DMA kernel where K * sizeof(T) % 64 == 0 (default 1), else the register-staged 128 x 128 one
+ *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA kernel (default 1), else
+ *   "tn_tile" 128|256 the tile of the register-transposing wgrad kernels (default 256 where the layer is wide enough)
+ *   "f1_blocks", "f1_fwd_blocks"   target workgroup counts of the fused block-1 kernels (launch geometry; the fp32 partial sums of a
+ *                     window are grouped differently, i.e. results change in the last bits). */
 int vm_set_tuning(const char* key, int value);
 
 /* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------
@@ -98,7 +97,7 @@ int64_t vm_conv1_wgrad_workspace_bytes(int64_t n_windows, int F);
 int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L, int F, int dtype,
                    float* ws, float* grad_w, void* stream);
 
-/* Fused block 1 for bf16 storage (voicemap/models.py:13-19: Conv1D(F,32) -> BatchNormalization -> SpatialDropout1D ->
+/* Fused block 1 for 16-bit storage (dtype VM_BF16 or VM_F16; voicemap/models.py:13-19: Conv1D(F,32) -> BatchNormalization -> SpatialDropout1D ->
  * MaxPool1D(pool)): the full-resolution relu(conv) tensor is never written.
  *   training (inference = 0): out = e (n_windows, L/pool, F) bf16 = per-pool-window max (gamma >= 0) or min (gamma < 0) of
  *     relu(conv+b), rounded to bf16 -- BN is a monotone per-channel affine, so pooling commutes with it; the affine +
@@ -110,16 +109,16 @@ int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L,
  *     gamma_or_scale = scale, shift from vm_bn_infer_affine.
  * pool: 2 or 4. */
 int vm_conv1_fused_fwd(const float* x, const float* w, const float* bias, const float* gamma_or_scale, const float* shift,
-                       int64_t n_windows, int64_t L, int F, int pool, int inference, void* out, float* stat_sum,
+                       int64_t n_windows, int64_t L, int F, int pool, int inference, int dtype, void* out, float* stat_sum,
                        float* stat_sq, void* stream);
-/* Backward of the same block from dp (n_windows, L/pool, F) bf16: recomputes the conv tile on the matrix cores,
+/* Backward of the same block from dp (n_windows, L/pool, F) `dtype`: recomputes the conv tile on the matrix cores,
  * evaluates the pool/dropout/BN/ReLU backward in registers (c1, c2 from vm_bn_pool_bwd_reduce(z = e, pool = 1) +
  * vm_bn_bwd_finalize(count = wpt*L)) and accumulates grad_w (32,1,F) and grad_b (F) (overwritten; fixed order). */
 int64_t vm_conv1_fused_bwd_workspace_bytes(int64_t n_windows, int64_t L, int F);
 int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const void* dp, const float* scale,
                        const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
-                       int64_t n_windows, int64_t windows_per_tower, int64_t L, int F, int pool, void* ws, float* grad_w,
-                       float* grad_b, void* stream);
+                       int64_t n_windows, int64_t windows_per_tower, int64_t L, int F, int pool, int dtype, void* ws,
+                       float* grad_w, float* grad_b, void* stream);
 
 /* ---- a1 blocks 2-4: Conv1D(c_out, 3, padding='same', activation='relu')  (voicemap/models.py:22,27,32)
  * implicit GEMM on MFMA.  in: padded (n_windows, L+2, c_in) `dtype`; wf: (c_out, 3*c_in) `dtype` from
@@ -277,15 +276,17 @@ int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t row
  * y: (pairs) fp32 labels, 0 = same speaker (voicemap/librispeech.py:194).  y may be NULL for predict-only
  * (then loss/backward outputs are not touched).
  * pred (pairs); loss_acc[0] = loss, [1] = binary accuracy; demb (2*pairs, E); grad_hw (1 or E); grad_hb (1).
- * ws: 4*pairs floats of scratch (per-pair terms, summed in fixed order by a second small launch); unused when y is NULL. */
+ * ws: 4*pairs floats of scratch (per-pair terms, summed in fixed order by a second small launch); unused when y is NULL.
+ * grad_scale: every gradient output (demb, grad_hw, grad_hb) is multiplied by it -- 1 for fp32 / bf16 storage; the loss scale of
+ * VM_F16 storage, whose activation gradients would otherwise fall under half's 6e-8; loss_acc and pred are not scaled. */
 int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
-                         int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
+                         int E, int head_kind, int loss_kind, float grad_scale, float* pred, float* loss_acc, float* demb,
                          float* grad_hw, float* grad_hb, float* ws, void* stream);
 
 /* ---- a9: classifier head Dense(num_classes, softmax) + categorical CE  (experiments/train_classifier.py:112,115)
  * logits (rows, n_classes) fp32 -> prob; labels int32 (rows); loss_acc[0] = mean CE (Keras clip 1e-7), [1] = accuracy;
- * dlogits = d loss / d logits (may be NULL).  labels may be NULL for predict-only.  ws: 2*rows floats. */
-int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float* prob,
+ * dlogits = grad_scale * d loss / d logits (may be NULL).  labels may be NULL for predict-only.  ws: 2*rows floats. */
+int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float grad_scale, float* prob,
                    float* loss_acc, float* dlogits, float* ws, void* stream);
 
 /* ---- a5: Adam(clipnorm=1.)  (experiments/train_siamese.py:56; Keras 2.2.2 optimizers.py) -------------------
@@ -294,9 +295,13 @@ int64_t vm_sqnorm_workspace_bytes(int64_t n);
 int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm, void* stream);
 /* g *= grad_prescale (e.g. 1/world after an all-reduce sum); norm = grad_prescale*sqrt(*sqnorm);
  * if clipnorm > 0 and norm >= clipnorm: g *= clipnorm/norm;  m,v,p updated with lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
- * (computed on the host, passed in), p -= lr_t*m/(sqrt(v)+eps). */
+ * (computed on the host, passed in), p -= lr_t*m/(sqrt(v)+eps).
+ * skip_nonfinite != 0 (needs sqnorm): a step whose gradient norm is inf / NaN leaves p, m, v untouched (loss-scaled VM_F16
+ * training: an overflowed activation gradient costs one step instead of the model) and sets *skipped (1 int32, may be NULL) to 1,
+ * else to 0; with 0 the update is Keras' own arithmetic, NaNs included. */
 int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
-                      float eps, float clipnorm, float grad_prescale, const float* sqnorm, void* stream);
+                      float eps, float clipnorm, float grad_prescale, const float* sqnorm, int skip_nonfinite, int32_t* skipped,
+                      void* stream);
 
 /* ---- a8: n-shot evaluation distances  (voicemap/utils.py:159-206) ------------------------------------------
  * For each task: query embedding (E) vs k class prototypes built from n support embeddings each

@@ -279,38 +279,57 @@ def maxpool1d(y: torch.Tensor, pool: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 
 
-class _StoreBf16(torch.autograd.Function):
-    """Emulates a tensor that the HIP path keeps in bf16 in HBM: the value is rounded on the way forward and the
-    gradient that is stored at the same point (du / dp) is rounded on the way back.  Used only to *calibrate* the
-    tolerances of the bf16 parity tests (what error does bf16 storage alone introduce?)."""
+# Storage emulation: what error does 16-bit storage ALONE introduce?  Used only to calibrate the tolerances of the bf16 / f16
+# parity tests.  ``storage`` is None (exact), "bf16" or "f16"; with "f16" the HIP path multiplies the loss gradient by a loss scale
+# (engine.loss_scale) so that the stored activation gradients stay inside half's range: _GSCALE is that factor for the backward
+# roundings (set by siamese_train_step for the duration of a step).
+_STORE_DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+_GSCALE = [1.0]
+
+
+def _rnd(x, storage):
+    return x.to(_STORE_DT[storage]).to(x.dtype)
+
+
+def _rnd_grad(g, storage):
+    s = _GSCALE[0] if storage == "f16" else 1.0
+    return _rnd(g * s, storage) / s
+
+
+class _Store16(torch.autograd.Function):
+    """Emulates a tensor that the HIP path keeps in a 16-bit type in HBM: the value is rounded on the way forward and the
+    gradient that is stored at the same point (du / dp) is rounded on the way back."""
 
     @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+    def forward(ctx, x, storage):
+        ctx.storage = storage
+        return _rnd(x, storage)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return _rnd_grad(g, ctx.storage), None
 
 
 def _store(x, storage):
-    return _StoreBf16.apply(x) if storage == "bf16" else x
+    return _Store16.apply(x, storage) if storage in _STORE_DT else x
 
 
-class _StoreAsBf16(torch.autograd.Function):
-    """Forward: the given (already rounded) value; backward: like _StoreBf16 (the gradient stored there is bf16)."""
+class _StoreAs16(torch.autograd.Function):
+    """Forward: the given (already rounded) value; backward: like _Store16 (the gradient stored there is 16-bit)."""
 
     @staticmethod
-    def forward(ctx, x, value):
+    def forward(ctx, x, value, storage):
+        ctx.storage = storage
         return value
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype), None
+        return _rnd_grad(g, ctx.storage), None, None
 
 
 class _Bf16GradOnly(torch.autograd.Function):
-    """A tensor that never reaches HBM (forward exact) but whose gradient is consumed as a bf16 matrix operand."""
+    """A tensor that never reaches HBM (forward exact) but whose gradient is consumed as a bf16 matrix operand (block 1's du in
+    the fused kernels: bf16 whatever the storage type -- bf16 has fp32's exponent range, no scale needed)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -319,10 +338,6 @@ class _Bf16GradOnly(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.to(torch.bfloat16).to(g.dtype)
-
-
-def _bf16(x):
-    return x.to(torch.bfloat16).to(x.dtype)
 
 
 def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
@@ -335,12 +350,12 @@ def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
     h = x
     for i, (k, c, pool) in enumerate(arch.blocks):
         kern = p[f"conv{i+1}.kernel"]
-        if storage == "bf16" and i > 0:  # GEMM operand copies of the k=3 kernels are bf16; block 1 stays fp32
-            kern = kern + (kern.detach().to(torch.bfloat16).to(kern.dtype) - kern.detach())
+        if storage in _STORE_DT and i > 0:  # GEMM operand copies of the k=3 kernels are 16-bit; block 1 stays fp32
+            kern = kern + (_rnd(kern.detach(), storage) - kern.detach())
         # bf16 emulation of block 1: the fused kernels never store z1 (statistics, arg-max and the backward recompute see
         # the fp32 accumulator; only du1 becomes a bf16 MFMA operand); what IS stored is bf16(pooled extreme of z1), and the
         # BN affine + dropout run over that -- so the pooled activation is rounded twice.
-        fused1 = storage == "bf16" and i == 0 and pool in (2, 4)
+        fused1 = storage in _STORE_DT and i == 0 and pool in (2, 4)
         z = conv1d_same_relu(h, kern, p[f"conv{i+1}.bias"])
         z = _Bf16GradOnly.apply(z) if fused1 else _store(z, storage)
         if training:
@@ -366,8 +381,8 @@ def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
                     sh = bet - p[f"bn{i+1}.moving_mean"] * inv
                     mult = 1.0
                 ext = torch.where(inv >= 0, maxpool1d(z, pool), -maxpool1d(-z, pool))
-                act = _bf16((_bf16(ext) * inv + sh) * mult)
-            h = _StoreAsBf16.apply(maxpool1d(y, pool), act)
+                act = _rnd((_rnd(ext, storage) * inv + sh) * mult, storage)
+            h = _StoreAs16.apply(maxpool1d(y, pool), act, storage)
         else:
             h = _store(maxpool1d(y, pool), storage)
         if collect is not None:
@@ -509,7 +524,8 @@ def adam_step(state: AdamState, params, grads: Dict[str, torch.Tensor]):
 
 def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str = "contrastive",
                        distance_metric: str = "uniform_euclidean", drop_masks1=None, drop_masks2=None,
-                       unbiased_moving_variance: bool = True, storage: Optional[str] = None, bn_state="fresh"):
+                       unbiased_moving_variance: bool = True, storage: Optional[str] = None, bn_state="fresh",
+                       loss_scale: float = 4096.0):
     """train_on_batch of experiments/siamese_contrastive_loss.py:70 (loss='contrastive') or
     experiments/train_siamese.py:57 (loss='bce'): forward both towers in training mode, loss, grads
     wrt the 20 trainable tensors, global-norm clip + Adam, two sequential BN moving-stat updates
@@ -526,7 +542,11 @@ def siamese_train_step(arch, p, state: Optional[AdamState], x1, x2, y, loss: str
     else:
         raise ValueError(loss)
     acc = binary_accuracy(y, pred)
-    gl = torch.autograd.grad(l, [leaf[k] for k in names])
+    _GSCALE[0] = float(loss_scale) if storage == "f16" else 1.0   # storage emulation only: the backward roundings see scaled gradients
+    try:
+        gl = torch.autograd.grad(l, [leaf[k] for k in names])
+    finally:
+        _GSCALE[0] = 1.0
     grads = OrderedDict((k, g.detach()) for k, g in zip(names, gl))
     new_p = OrderedDict((k, v.detach().clone()) for k, v in p.items())
     bn_state = apply_moving_updates(new_p, (c1, c2), len(arch.blocks), arch.bn_eps, arch.bn_momentum, unbiased_moving_variance, bn_state)

@@ -3,9 +3,9 @@ import numpy as np
 import torch
 
 from voicemap_amd import _lib
-from voicemap_amd._lib import VM_BF16, VM_F32, VM_F32S
+from voicemap_amd._lib import VM_BF16, VM_F16, VM_F32, VM_F32S
 
-DTYPES = {"f32": (VM_F32, torch.float32), "bf16": (VM_BF16, torch.bfloat16), "f32s": (VM_F32S, torch.float32)}
+DTYPES = {"f32": (VM_F32, torch.float32), "bf16": (VM_BF16, torch.bfloat16), "f32s": (VM_F32S, torch.float32), "f16": (VM_F16, torch.float16)}
 
 
 def L():
@@ -64,6 +64,8 @@ def quant(x, name):
     t = torch.as_tensor(np.asarray(x), dtype=torch.float64)
     if name == "bf16":
         return t.to(torch.bfloat16).to(torch.float64)
+    if name == "f16":
+        return t.to(torch.float16).to(torch.float64)
     return t.to(torch.float32).to(torch.float64)
 
 

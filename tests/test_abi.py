@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in _lib.header_functions():
         assert hasattr(cdll, name), name
     lib = _lib.lib()
-    assert lib.abi == 1
+    assert lib.abi == 3
     assert lib.query("vm_bn_part_rows") > 0
     assert lib.query("vm_conv_stat_rows", 3000) == 24
     assert lib.query("vm_conv_wgrad_splits", 256, 3000, 128, 256) >= 1
@@ -46,11 +46,15 @@ def test_engine_refuses_to_run_without_gpu():
         HipEncoderEngine([(32, 16, 4), (3, 32, 2)], 8)
 
 
-def test_shipped_build_refuses_result_changing_tuning():
-    """vm_set_tuning only selects among kernels that compute the same result; the ablation switches (wrong results, timing
-    experiments) exist only in -DVM_ENABLE_ABLATION builds (include/voicemap_hip.h).  Host-only call: no GPU needed."""
+def test_tuning_table_is_small_and_rejects_unknown_keys():
+    """vm_set_tuning only selects among kernels that compute the same result (six keys, include/voicemap_hip.h); the experiment
+    switches of rounds 1-2 (ablations, ring / phase / skew variants) are gone from the shipped library.  Host-only call: no GPU."""
     from voicemap_amd import _lib
     lib = _lib.lib()
-    assert lib.cdll.vm_set_tuning(b"nt_ablate", 0) == 0
-    assert lib.cdll.vm_set_tuning(b"nt_ablate", 2) == -3 and b"VM_ENABLE_ABLATION" in lib.cdll.vm_last_error()
-    assert lib.cdll.vm_set_tuning(b"no_such_knob", 1) != 0
+    for key, good, bad in ((b"nt_n2", 3, 4), (b"nt_glds", 1, 2), (b"tn_x", 1, 2), (b"tn_tile", 256, 64), (b"f1_blocks", 1024, 0),
+                           (b"f1_fwd_blocks", 4096, -1)):
+        assert lib.cdll.vm_set_tuning(key, bad) != 0, key
+        assert lib.cdll.vm_set_tuning(key, good) == 0, key
+    for gone in (b"nt_ablate", b"nt_ring", b"nt_p8", b"nt_w4", b"nt_n2r", b"gemm_kb", b"no_such_knob"):
+        assert lib.cdll.vm_set_tuning(gone, 1) != 0, gone
+    assert lib.cdll.vm_set_tuning(None, 1) != 0

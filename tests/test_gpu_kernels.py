@@ -11,7 +11,8 @@ from tests.gpu_util import DTYPES, L, dev, max_err, p, padded, quant, rel_err, s
 
 pytestmark = pytest.mark.gpu
 # "f32s": fp32 storage, split-bf16 products (3 bf16 MFMAs per product; ~2^-17 per product, measured <= 1e-5 on these shapes)
-TOL = {"f32": 2e-5, "bf16": 1e-2, "f32s": 5e-5}
+# f16: 11 significand bits, 2^-12 = 2.4e-4 per rounding (inputs are pre-rounded, the output is rounded once)
+TOL = {"f32": 2e-5, "bf16": 1e-2, "f32s": 5e-5, "f16": 1.5e-3}
 
 
 def rng(seed):
@@ -19,7 +20,7 @@ def rng(seed):
 
 
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,l,f", [(3, 700, 16), (2, 256, 128), (1, 37, 8)])
 def test_conv1_fwd(dt, n, l, f):
     vm, tdt = DTYPES[dt]
@@ -47,15 +48,13 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-NT_N2_DEFAULT = 3  # library default of vm_set_tuning("nt_n2", ..) -- keep in step with conv_gemm.hip g_nt_n2
-GEMM_DEFAULTS = {"gemm_kb": 128, "nt_ring": 0, "nt_glds": 1, "tn_tile": 256, "nt_order": 1, "nt_tepi": 1, "nt_p8": 2, "nt_p8_phases": 2, "nt_p8_korder": 1, "nt_korder": 0, "tn_p8": 1, "tn_x": 1,
-                 "nt_p8_blocks": 256, "nt_w4": 0, "nt_n2": NT_N2_DEFAULT, "nt_n2r": 1}
+GEMM_DEFAULTS = {"nt_n2": 3, "nt_glds": 1, "tn_x": 1, "tn_tile": 256}   # the library's defaults (conv_gemm.hip / conv_wgrad.hip)
 
 
 @pytest.fixture
-def gemm_kb(request):
-    """Selects one of the GEMM kernel variants (all must agree with the oracle): ring-pipelined LDS-DMA (default),
-    two-buffer LDS-DMA, register-staged with 128- or 64-byte K slices, 256- or 128-wide wgrad tiles."""
+def gemm_kernels(request):
+    """Pins a kernel selection (vm_set_tuning) for one test and restores the defaults: every selectable kernel must agree with
+    the oracle on every shape."""
     for k, v in request.param.items():
         L().call("vm_set_tuning", k.encode(), v)
     yield request.param
@@ -63,41 +62,28 @@ def gemm_kb(request):
         L().call("vm_set_tuning", k.encode(), v)
 
 
-@pytest.mark.parametrize("gemm_kb", [{"nt_p8": 1, "tn_x": 2}, {"nt_p8": 1, "nt_p8_blocks": 3}, {"nt_p8": 1, "nt_p8_blocks": 8, "nt_order": 0},
-                                     {"nt_p8": 1, "nt_p8_phases": 4, "nt_p8_blocks": 8, "nt_p8_korder": 0}, {"nt_p8": 0, "nt_korder": 1},
-                                     {"nt_p8": 0, "nt_tepi": 0, "tn_p8": 0, "tn_x": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_ring": 1, "tn_x": 0},
-                                     {"nt_p8": 0, "nt_order": 0}, {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "tn_tile": 128},
-                                     {"nt_p8": 0, "nt_tepi": 0, "nt_glds": 0, "gemm_kb": 64, "tn_tile": 128}], indirect=True,
-                         ids=["p8", "p8-3wg", "p8-8wg-seq", "p8-4ph", "tepi3", "glds2", "ring", "seq-order", "reg128", "reg64"])
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
-                                          (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),
-                                          (16, 1030, 256, 256)])
-def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kb):
+GEMM_SHAPES = [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64), (3, 131, 96, 32),
+               (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256), (16, 1030, 256, 256)]
+
+
+@pytest.mark.parametrize("gemm_kernels", [{}, {"nt_n2": 0, "tn_x": 0}, {"nt_n2": 0, "nt_glds": 0, "tn_x": 0, "tn_tile": 128}],
+                         indirect=True, ids=["default", "lds-dma-128+tn256", "register-staged-128"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,l,cin,cout", GEMM_SHAPES)
+def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kernels):
+    """The three forward / dgrad kernels and the three wgrad kernels (see the headers of conv_gemm.hip / conv_wgrad.hip) against
+    the float64 oracle: K tails (c_in = 8, 16, 24, 96), ragged t-tiles, N tails (136), windows shorter than a tile (5)."""
     _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
 
 
-@pytest.mark.parametrize("gemm_kb", [{"nt_w4": 1}], indirect=True, ids=["w4"])
-@pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (2, 260, 32, 64),
-                                          (3, 131, 96, 32), (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256),
-                                          (16, 1030, 256, 256), (2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512)])
-def test_conv_one_wave_per_simd_variant(n, l, cin, cout, gemm_kb):
-    """conv_w4_kernel (opt-in, vm_set_tuning("nt_w4", 1); bf16): forward with fused statistics where L fills the statistics rows
-    (700, 760, 650 here), dgrad wherever C_in % 256 == 0 and C_out % 64 == 0 (520 and 1030: ragged last tiles of 254 positions);
-    every other launch of the test falls back to the default kernels."""
-    _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)
-
-
-@pytest.mark.parametrize("gemm_kb", [{"nt_n2": 3}, {"nt_n2": 3, "nt_n2r": 0}, {"nt_n2": 0}], indirect=True, ids=["n2r", "n2", "n2-off"])
-@pytest.mark.parametrize("n,l,cin,cout", [(2, 300, 128, 256), (3, 520, 256, 512), (8, 300, 64, 256), (16, 1030, 256, 256), (8, 140, 64, 384),
-                                          (2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512), (1, 129, 32, 128), (2, 5, 128, 128),
-                                          (4, 3000, 128, 256), (4, 1500, 256, 384), (4, 750, 384, 512), (3, 131, 96, 32)])
-def test_conv_256x128_two_workgroups_per_cu_variant(n, l, cin, cout, gemm_kb):
-    """conv_nt2r_kernel (input-resident A, 254-position tiles; where its statistics tiling fits) / conv_nt2_kernel (bf16;
-    vm_set_tuning("nt_n2", 1 forward | 2 dgrad | 3 both), "nt_n2r" 0 forces the plain form): every shape with a channel count that is a
-    multiple of 32 on the K side and of 128 on the N side -- ragged last t-tiles (300, 520, 1030 ..., 5 < one tile), windows whose
-    second statistics row of the last tile does not exist (129, 140, 650), cfg-A's own geometries; (131, 96, 32) falls back."""
-    _conv_fwd_dgrad_wgrad("bf16", n, l, cin, cout)
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("n,l,cin,cout", [(2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512), (1, 129, 32, 128), (2, 5, 128, 128),
+                                          (4, 3000, 128, 256), (4, 1500, 256, 384), (4, 750, 384, 512)])
+def test_conv_input_resident_kernel_shapes(dt, n, l, cin, cout):
+    """conv_nt2r_kernel / conv_tn8x_kernel under the default dispatch on the shapes that exercise their tiling: 254-position tiles
+    with ragged last tiles (700, 760, 650), windows whose second statistics row of the last tile does not exist (129, 650: the
+    forward falls back to the 128 x 128 kernel there, dgrad does not), a window shorter than one tile (5), cfg-A's own geometries."""
+    _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (3, 131, 96, 32),
@@ -153,7 +139,7 @@ def _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
     assert rel_err(gwd.cpu().numpy(), gw.numpy()) < (5e-5 if dt == "f32s" else 2e-5)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_conv1_wgrad(dt):
     vm, tdt = DTYPES[dt]
     r = rng(3)
@@ -185,7 +171,7 @@ def _bn_block_oracle(z, gamma, beta, drop, pool, wpt, eps=1e-3):
     return torch.cat(outs, 0), stats
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 50, 16, 2, True), (2, 1, 64, 136, 4, False), (4, 4, 31, 8, 2, True),
                                                      (2, 2, 9, 24, 4, False)])
 def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
@@ -286,7 +272,7 @@ def test_bn_infer_affine():
 
 
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,l,c", [(3, 375, 64), (2, 7, 136), (1, 1, 8)])
 def test_global_maxpool(dt, n, l, c):
     vm, tdt = DTYPES[dt]
@@ -306,7 +292,7 @@ def test_global_maxpool(dt, n, l, c):
     assert np.array_equal(dp.float().cpu().numpy().astype(np.float64), ref)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 750, 64, 2, True), (2, 1, 37, 136, 4, False), (3, 3, 9, 8, 2, True),
                                                      (2, 2, 64, 512, 1, False)])
 def test_bn_drop_pool_gmax_fused_equals_two_pass(dt, n, wpt, l, c, pool, use_drop):
@@ -331,7 +317,7 @@ def test_bn_drop_pool_gmax_fused_equals_two_pass(dt, n, wpt, l, c, pool, use_dro
     assert torch.equal(i0, i1)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,wpt,l,c,pool,use_drop", [(4, 2, 300, 64, 2, True), (2, 1, 64, 136, 4, False), (3, 3, 19, 8, 2, True)])
 def test_bn_pool_bwd_reduce_pooled_form(dt, n, wpt, l, c, pool, use_drop):
     """vm_bn_pool_bwd_reduce_pooled (extreme of z recovered from the pooled forward output) against the z form: equal up to the
@@ -383,8 +369,8 @@ def test_dense_fwd_bwd():
 
 @pytest.mark.parametrize("head", ["uniform_euclidean", "weighted_l1"])
 @pytest.mark.parametrize("loss", ["contrastive", "bce"])
-@pytest.mark.parametrize("pairs,e", [(6, 32), (300, 8)])
-def test_siamese_head_loss(head, loss, pairs, e):
+@pytest.mark.parametrize("pairs,e,gscale", [(6, 32, 1.0), (300, 8, 1.0), (6, 32, 4096.0)])
+def test_siamese_head_loss(head, loss, pairs, e, gscale):
     from voicemap_amd.engine import HEADS, LOSSES
     r = rng(8)
     emb = r.normal(0, 0.4, (2 * pairs, e)).astype(np.float32)
@@ -394,7 +380,7 @@ def test_siamese_head_loss(head, loss, pairs, e):
     pred, la = torch.empty(pairs, device="cuda"), torch.empty(2, device="cuda")
     demb = torch.empty(2 * pairs, e, device="cuda")
     ghw, ghb = torch.empty(hw.size, device="cuda"), torch.empty(1, device="cuda")
-    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), p(dev(y)), pairs, e, HEADS[head], LOSSES[loss],
+    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), p(dev(y)), pairs, e, HEADS[head], LOSSES[loss], gscale,
              p(pred), p(la), p(demb), p(ghw), p(ghb), p(torch.empty(4 * pairs, device="cuda")), stream())
     et = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
     prm = {"head.kernel": torch.tensor(hw, dtype=torch.float64, requires_grad=True),
@@ -406,12 +392,13 @@ def test_siamese_head_loss(head, loss, pairs, e):
     assert rel_err(pred.cpu().numpy(), pr.detach().numpy()[:, 0]) < 1e-5
     assert abs(la[0].item() - lo.item()) < 2e-5 * max(1.0, abs(lo.item()))
     assert abs(la[1].item() - O.binary_accuracy(yt, pr).item()) < 1e-6
-    assert rel_err(demb.cpu().numpy(), ge.numpy()) < 1e-4
-    assert rel_err(ghw.cpu().numpy(), gw.numpy().ravel()) < 1e-4
-    assert rel_err(ghb.cpu().numpy(), gb.numpy()) < 1e-4
+    # grad_scale (the loss scale of f16 storage) multiplies every gradient output and nothing else
+    assert rel_err(demb.cpu().numpy() / gscale, ge.numpy()) < 1e-4
+    assert rel_err(ghw.cpu().numpy() / gscale, gw.numpy().ravel()) < 1e-4
+    assert rel_err(ghb.cpu().numpy() / gscale, gb.numpy()) < 1e-4
     # predict-only launch leaves the training outputs alone and gives the same pred
     pred2 = torch.empty(pairs, device="cuda")
-    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), None, pairs, e, HEADS[head], LOSSES[loss],
+    L().call("vm_siamese_head_loss", p(dev(emb)), p(dev(hw)), p(dev(hb)), None, pairs, e, HEADS[head], LOSSES[loss], 1.0,
              p(pred2), None, None, None, None, None, stream())
     assert torch.equal(pred, pred2)
 
@@ -420,17 +407,17 @@ def test_siamese_head_rejects_unimplemented_metric():
     from voicemap_amd._lib import VoicemapHipError
     d = torch.zeros(8, device="cuda")
     with pytest.raises(VoicemapHipError):
-        L().call("vm_siamese_head_loss", p(d), p(d), p(d), None, 2, 2, 5, 0, p(d), None, None, None, None, None, stream())
+        L().call("vm_siamese_head_loss", p(d), p(d), p(d), None, 2, 2, 5, 0, 1.0, p(d), None, None, None, None, None, stream())
 
 
-@pytest.mark.parametrize("rows,nc", [(5, 40), (3, 1172)])
-def test_softmax_cce(rows, nc):
+@pytest.mark.parametrize("rows,nc,gscale", [(5, 40, 1.0), (3, 1172, 1.0), (5, 40, 4096.0)])
+def test_softmax_cce(rows, nc, gscale):
     r = rng(9)
     logits = r.normal(0, 2, (rows, nc)).astype(np.float32)
     labels = r.integers(0, nc, rows).astype(np.int32)
     prob, dl = torch.empty(rows, nc, device="cuda"), torch.empty(rows, nc, device="cuda")
     la, ws = torch.empty(2, device="cuda"), torch.empty(2 * rows, device="cuda")
-    L().call("vm_softmax_cce", p(dev(logits)), p(dev(labels, torch.int32)), rows, nc, p(prob), p(la), p(dl), p(ws), stream())
+    L().call("vm_softmax_cce", p(dev(logits)), p(dev(labels, torch.int32)), rows, nc, gscale, p(prob), p(la), p(dl), p(ws), stream())
     lt = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
     pr = torch.softmax(lt, -1)
     oh = torch.nn.functional.one_hot(torch.tensor(labels, dtype=torch.int64), nc).double()
@@ -439,7 +426,7 @@ def test_softmax_cce(rows, nc):
     assert rel_err(prob.cpu().numpy(), pr.detach().numpy()) < 1e-5
     assert abs(la[0].item() - lo.item()) < 1e-5 * max(1, abs(lo.item()))
     assert abs(la[1].item() - O.categorical_accuracy(oh, pr).item()) < 1e-6
-    assert rel_err(dl.cpu().numpy(), g.numpy()) < 1e-4
+    assert rel_err(dl.cpu().numpy() / gscale, g.numpy()) < 1e-4
 
 
 def test_adam_clip_step():
@@ -458,10 +445,26 @@ def test_adam_clip_step():
         ref = O.adam_step(st, {"w": torch.tensor(pv, dtype=torch.float64)}, {"w": torch.tensor(g, dtype=torch.float64)})["w"]
         t = 7
         lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
-        L().call("vm_adam_clip_step", p(P_), p(G_), p(M_), p(V_), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq), stream())
+        L().call("vm_adam_clip_step", p(P_), p(G_), p(M_), p(V_), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq), 0, None, stream())
         assert max_err(P_.cpu().numpy(), ref.numpy()) < 2e-6
         assert rel_err(M_.cpu().numpy(), st.m["w"].numpy()) < 1e-5
         assert rel_err(V_.cpu().numpy(), st.v["w"].numpy()) < 1e-5
+        # loss-scaled form (f16 storage): G holds 4096 x the gradients, grad_prescale divides it out before the clip -- the same
+        # update to rounding; skip_nonfinite with a finite norm changes nothing and reports 0
+        P2, G2, M2, V2 = dev(pv), dev(g * np.float32(4096.0)), dev(m0), dev(v0)
+        flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
+        assert max_err(P2.cpu().numpy(), ref.numpy()) < 2e-6 and flag.item() == 0
+        # a non-finite gradient norm: the step is skipped on the device (p, m, v untouched) and flagged; without the switch the
+        # NaN goes through like in Keras
+        G2[17] = float("inf")
+        before = (P2.clone(), M2.clone(), V2.clone())
+        L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
+        assert flag.item() == 1 and torch.equal(P2, before[0]) and torch.equal(M2, before[1]) and torch.equal(V2, before[2])
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 0, None, stream())
+        assert not torch.isfinite(P2).all()
 
 
 @pytest.mark.parametrize("i16", [False, True])
@@ -525,9 +528,23 @@ def f1_splits(request):
 @pytest.mark.parametrize("n,wpt,l,f,pool,use_drop", [(4, 2, 700, 16, 4, True), (2, 1, 1200, 128, 4, False), (2, 2, 530, 40, 2, True),
                                                      (2, 1, 300, 160, 4, False), (3, 3, 2100, 64, 4, False)])
 def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
-    """Fused bf16 block 1 (conv k=32 -> relu -> BN -> dropout -> maxpool) forward, inference forward and backward vs
+    """Fused block 1 (conv k=32 -> relu -> BN -> dropout -> maxpool) forward, inference forward and backward vs
     the float64 oracle.  z1 never reaches HBM, so it has no storage rounding: statistics, arg-max routing and the
-    backward see the fp32 accumulator; the stored tensors are bf16(pooled extreme of z) and the bf16 activation."""
+    backward see the fp32 accumulator; the stored tensors are the rounded pooled extreme of z and the rounded activation."""
+    _conv1_fused_block("bf16", n, wpt, l, f, pool, use_drop, neg)
+
+
+@pytest.mark.parametrize("neg", [0.25, 0.0])
+@pytest.mark.parametrize("n,wpt,l,f,pool,use_drop", [(4, 2, 700, 16, 4, True), (2, 1, 1200, 128, 4, False), (2, 2, 530, 40, 2, True),
+                                                     (2, 1, 300, 160, 4, False), (3, 3, 2100, 64, 4, False)])
+def test_conv1_fused_block_f16(n, wpt, l, f, pool, use_drop, neg):
+    """The same kernels with half storage (dtype VM_F16): the stored tensors carry 11 significand bits instead of 8."""
+    _conv1_fused_block("f16", n, wpt, l, f, pool, use_drop, neg)
+
+
+def _conv1_fused_block(dt, n, wpt, l, f, pool, use_drop, neg):
+    vm, tdt = DTYPES[dt]
+    tol_e, tol_act = (2e-3, 8e-3) if dt == "bf16" else (3e-4, 1e-3)
     r = rng(20)
     x = r.normal(0, 0.05, (n, l)).astype(np.float32)
     w = r.normal(0, 0.2, (32, 1, f)).astype(np.float32)
@@ -543,9 +560,9 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     rows = L().query("vm_conv1_stat_rows", l)
     xd, wd_, bd, gd, btd = dev(xp), dev(w), dev(b), dev(gamma), dev(beta)
     dropd = dev(drop) if drop is not None else None
-    e = torch.empty(n, lq, f, dtype=torch.bfloat16, device="cuda")
+    e = torch.empty(n, lq, f, dtype=tdt, device="cuda")
     ss, sq = torch.zeros(n * rows, f, **f32), torch.zeros(n * rows, f, **f32)
-    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(gd), None, n, l, f, pool, 0, p(e), p(ss), p(sq), stream())
+    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(gd), None, n, l, f, pool, 0, vm, p(e), p(ss), p(sq), stream())
 
     # ---- oracle: z (unrounded), BN per tower, dropout, pool
     T = lambda a: torch.tensor(a, dtype=torch.float64)
@@ -555,8 +572,8 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     zz = z.detach()
     pooled_max = O.maxpool1d(zz, pool)
     pooled_min = -O.maxpool1d(-zz, pool)
-    e_ref = quant(torch.where(T(gamma) >= 0, pooled_max, pooled_min), "bf16")
-    assert rel_err(e.float().cpu().numpy(), e_ref.numpy()) < 2e-3
+    e_ref = quant(torch.where(T(gamma) >= 0, pooled_max, pooled_min), dt)
+    assert rel_err(e.float().cpu().numpy(), e_ref.numpy()) < tol_e
     assert rel_err(ss.cpu().numpy().reshape(n, rows, f).sum(1), zz.sum(1).numpy()) < 1e-4
     assert rel_err(sq.cpu().numpy().reshape(n, rows, f).sum(1), (zz * zz).sum(1).numpy()) < 1e-4
 
@@ -565,26 +582,26 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, f) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, f, float(wpt * l), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
              p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, stream())
-    act = torch.zeros(n, lq + 2, f, dtype=torch.bfloat16, device="cuda")
-    L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(dropd), n, wpt, lq, f, 1, 1, p(act), stream())
+    act = torch.zeros(n, lq + 2, f, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(dropd), n, wpt, lq, f, 1, vm, p(act), stream())
     out_ref, _ = _bn_block_oracle(z, gr, btr, T(drop) if drop is not None else None, pool, wpt)
-    assert rel_err(act.float().cpu().numpy()[:, 1:-1], out_ref.detach().numpy()) < 8e-3
+    assert rel_err(act.float().cpu().numpy()[:, 1:-1], out_ref.detach().numpy()) < tol_act
 
     # ---- backward
-    dpq = quant(r.normal(0, 1, (n, lq, f)), "bf16")
+    dpq = quant(r.normal(0, 1, (n, lq, f)), dt)
     gw_ref, gb_ref, gg_ref, gbt_ref = torch.autograd.grad((out_ref * dpq).sum(), [wr, br, gr, btr])
     prow = L().query("vm_bn_part_rows")
     pa, pb = torch.zeros(n * prow, f, **f32), torch.zeros(n * prow, f, **f32)
     c1, c2 = torch.empty(towers, f, **f32), torch.empty(towers, f, **f32)
     ggam, gbet = torch.empty(f, **f32), torch.empty(f, **f32)
-    dpd = dpq.to("cuda", torch.bfloat16).contiguous()
-    L().call("vm_bn_pool_bwd_reduce", p(e), p(dpd), p(scale), p(shift), p(mean), p(invstd), p(dropd), n, wpt, lq, f, 1, 1,
+    dpd = dpq.to("cuda", tdt).contiguous()
+    L().call("vm_bn_pool_bwd_reduce", p(e), p(dpd), p(scale), p(shift), p(mean), p(invstd), p(dropd), n, wpt, lq, f, 1, vm,
              p(pa), p(pb), stream())
     L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, f, float(wpt * l), p(c1), p(c2), p(ggam), p(gbet), p(crws), stream())
     ws = torch.empty(L().query("vm_conv1_fused_bwd_workspace_bytes", n, l, f) // 4 + 16, **f32)
     gw, gb = torch.empty(32, 1, f, **f32), torch.empty(f, **f32)
     L().call("vm_conv1_fused_bwd", p(xd), p(wd_), p(bd), p(dpd), p(scale), p(mean), p(invstd), p(dropd), p(c1), p(c2), n, wpt,
-             l, f, pool, p(ws), p(gw), p(gb), stream())
+             l, f, pool, vm, p(ws), p(gw), p(gb), stream())
     assert rel_err(ggam.cpu().numpy(), gg_ref.numpy()) < 2e-2
     assert rel_err(gbet.cpu().numpy(), gbt_ref.numpy()) < 2e-2
     assert rel_err(gw.cpu().numpy(), gw_ref.numpy()) < 2e-2
@@ -594,16 +611,16 @@ def test_conv1_fused_block(n, wpt, l, f, pool, use_drop, neg, f1_splits):
     mm, mv = r.normal(0.1, 0.05, f).astype(np.float32), (r.random(f) * 0.01 + 1e-4).astype(np.float32)
     sc_i, sh_i = torch.empty(f, **f32), torch.empty(f, **f32)
     L().call("vm_bn_infer_affine", p(gd), p(btd), p(dev(mm)), p(dev(mv)), 1e-3, f, p(sc_i), p(sh_i), stream())
-    act_i = torch.zeros(n, lq + 2, f, dtype=torch.bfloat16, device="cuda")
-    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(sc_i), p(sh_i), n, l, f, pool, 1, p(act_i), None, None, stream())
+    act_i = torch.zeros(n, lq + 2, f, dtype=tdt, device="cuda")
+    L().call("vm_conv1_fused_fwd", p(xd), p(wd_), p(bd), p(sc_i), p(sh_i), n, l, f, pool, 1, vm, p(act_i), None, None, stream())
     y_i = O.batchnorm_infer(zz, T(gamma), T(beta), T(mm), T(mv), 1e-3)
     ref_i = O.maxpool1d(y_i, pool).numpy()
     a = act_i.float().cpu().numpy()
     assert np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
-    assert rel_err(a[:, 1:-1], ref_i) < 8e-3
+    assert rel_err(a[:, 1:-1], ref_i) < tol_act
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_bn_pool_bwd_sparse_gmax_form_equals_dense(dt):
     """The last block's BN-backward passes fed with (dg, gidx) must equal the passes fed with the dense tensor that
     vm_global_maxpool_bwd would have written: the apply pass bit for bit, the reduce pass (a gather in the sparse form, with
@@ -650,12 +667,12 @@ def test_bn_pool_bwd_sparse_gmax_form_equals_dense(dt):
 # ----------------------------------------------------------------------------------------------------------
 # cfg-A's own GEMM geometries (experiments/train_siamese.py:20-25: filters 128 -> blocks 2..4 are 128->256 @ L=3000,
 # 256->384 @ L=1500, 384->512 @ L=750) under the DEFAULT dispatch -- no vm_set_tuning call in these tests, so they
-# exercise exactly the kernels the bench line runs (conv_nt8 / conv_w4 for the K >= 1152 launches, the three-chunk
-# c_in = 384 walk of conv_tn8x, ...).  Reference arithmetic: voicemap/models.py:22-35.
+# exercise exactly the kernels the bench line runs (conv_nt2r_kernel, the three-chunk c_in = 384 walk of conv_tn8x_kernel, ...).
+# Reference arithmetic: voicemap/models.py:22-35.
 CFG_A_GEMMS = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("l,cin,cout", CFG_A_GEMMS)
 def test_conv_cfgA_geometry_default_dispatch(dt, l, cin, cout):
     _conv_fwd_dgrad_wgrad(dt, 4, l, cin, cout)
@@ -665,7 +682,7 @@ def _window_slices(n):
     return sorted({0, 1, n // 2 - 1, n // 2, n - 1})
 
 
-@pytest.mark.parametrize("dt", ["f32", "f32s", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "f32s", "bf16", "f16"])
 @pytest.mark.parametrize("l,cin,cout", CFG_A_GEMMS)
 def test_conv_cfgA_full_batch_sampled_windows(dt, l, cin, cout):
     """The bench launch itself (256 windows = 128 pairs): forward + statistics and dgrad are per-window independent, so the
@@ -767,16 +784,17 @@ def test_crop_decimate_whiten_vs_oracle(i16):
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,l,cin,cout,padded_a", [(3, 254, 128, 256, True), (2, 255, 128, 64, False), (2, 1000, 256, 384, True),
                                                    (5, 509, 384, 512, True), (2, 2000, 128, 256, False), (1, 130, 128, 32, True)])
-def test_conv_dgrad_bnred(n, l, cin, cout, padded_a):
+@pytest.mark.parametrize("dt16", ["bf16", "f16"])
+def test_conv_dgrad_bnred(n, l, cin, cout, padded_a, dt16):
     """vm_conv_dgrad_bnred: dx bit-identical to vm_conv_dgrad, and the partial rows sum to sum_t dx and sum_t dx * A taken over
     the stored (bf16) dx in float64.  Lengths either side of the 254-row tile edge, several channel tiles, both layouts of A
     with garbage in the halo rows (they must not be read into the sums)."""
-    vm, tdt = DTYPES["bf16"]
+    vm, tdt = DTYPES[dt16]
     if not L().query("vm_conv_dgrad_bnred_supported", n, l, cin, cout, vm):
         pytest.skip("shape not served by the 256 x 128 kernel under the current tuning")
     g = torch.Generator(device="cuda").manual_seed(l + cin)
     r = rng(9)
-    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt16)
     wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
     wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
     L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
@@ -819,17 +837,18 @@ def test_conv_dgrad_bnred_refuses_unserved_shapes():
 
 @pytest.mark.parametrize("n,wpt,l,cin,cout,pool,use_drop", [(4, 2, 508, 128, 256, 2, True), (2, 1, 1016, 256, 128, 4, False),
                                                             (6, 3, 500, 128, 64, 1, True)])
-def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_drop):
+@pytest.mark.parametrize("dt16", ["bf16", "f16"])
+def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_drop, dt16):
     """dgrad + fused sums + vm_bn_bwd_from_sums against dgrad + vm_bn_pool_bwd_reduce_pooled: the same (sum dy, sum dy*zhat) per
     window up to fp32 summation order, including a channel with scale == 0 (re-derived from z) and dropped channels."""
-    vm, tdt = DTYPES["bf16"]
+    vm, tdt = DTYPES[dt16]
     lq = l // pool
     if not L().query("vm_conv_dgrad_bnred_supported", n, lq, cin, cout, vm):
         pytest.skip("shape not served under the current tuning")
     r = rng(43)
     g = torch.Generator(device="cuda").manual_seed(3)
     towers = n // wpt
-    z = quant(np.maximum(r.normal(0.3, 1.0, (n, l, cin)), 0.0), "bf16").to("cuda", tdt).contiguous()
+    z = quant(np.maximum(r.normal(0.3, 1.0, (n, l, cin)), 0.0), dt16).to("cuda", tdt).contiguous()
     sc = r.normal(1.0, 0.3, (towers, cin)) * np.where(r.random((towers, cin)) < 0.3, -1, 1)
     sc[:, 3] = 0.0
     scale, shift = dev(sc), dev(r.normal(0, 0.3, (towers, cin)))
@@ -837,7 +856,7 @@ def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_d
     drop = dev((r.random((n, cin)) > 0.25) / 0.75) if use_drop else None
     act = torch.zeros(n, lq + 2, cin, dtype=tdt, device="cuda")
     L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), p(drop), n, wpt, l, cin, pool, vm, p(act), stream())
-    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt16)
     wf = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda")
     wd = torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
     L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
@@ -892,14 +911,15 @@ def test_prep_conv_weights_batch_equals_single():
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 254, 128, 256), (2, 256, 32, 128), (2, 1000, 256, 384), (5, 750, 384, 512), (4, 3000, 128, 256),
                                           (1, 508, 64, 128)])
-def test_conv_fwd_pool_equals_two_kernel_inference_path(n, l, cin, cout):
+@pytest.mark.parametrize("dt16", ["bf16", "f16"])
+def test_conv_fwd_pool_equals_two_kernel_inference_path(n, l, cin, cout, dt16):
     """vm_conv_fwd_pool (conv + ReLU + BatchNorm affine + MaxPool1D(2) in the GEMM epilogue, inference mode) is bit-identical to
     vm_conv_fwd followed by vm_bn_drop_pool_fwd, leaves the halo rows of the pooled tensor alone, and both agree with the oracle."""
-    vm, tdt = DTYPES["bf16"]
+    vm, tdt = DTYPES[dt16]
     assert L().query("vm_conv_fwd_pool_supported", n, l, cin, cout, vm) == 1
     r = rng(21)
-    x = quant(r.normal(0, 1.0, (n, l, cin)), "bf16")
-    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    x = quant(r.normal(0, 1.0, (n, l, cin)), dt16)
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt16)
     b = torch.tensor(r.normal(0, 0.3, (cout,)).astype(np.float32), dtype=torch.float64)
     scale = dev(r.normal(1.0, 0.3, (1, cout)) * np.where(r.random((1, cout)) < 0.3, -1, 1))
     shift = dev(r.normal(0, 0.3, (1, cout)))
@@ -933,15 +953,16 @@ def test_conv_fwd_pool_refuses_unserved_shapes():
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 508, 128, 256), (2, 254, 32, 128), (2, 1016, 256, 384), (4, 3000, 128, 256), (4, 1500, 256, 384)])
-def test_conv_fwd_e_pool_extreme(n, l, cin, cout):
+@pytest.mark.parametrize("dt16", ["bf16", "f16"])
+def test_conv_fwd_e_pool_extreme(n, l, cin, cout, dt16):
     """vm_conv_fwd_e: z and the statistics bit-identical to vm_conv_fwd, e = the pair maximum where gamma >= 0 and the pair minimum where
     gamma < 0 of the stored z, and vm_bn_drop_pool_fwd(e, pool 1) == vm_bn_drop_pool_fwd(z, pool 2) bit for bit (negative scales and
     dropped channels included)."""
-    vm, tdt = DTYPES["bf16"]
+    vm, tdt = DTYPES[dt16]
     assert L().query("vm_conv_fwd_e_supported", n, l, cin, cout, vm) == 1
     r = rng(23)
-    x = quant(r.normal(0, 1.0, (n, l, cin)), "bf16")
-    w = quant(r.normal(0, 0.1, (3, cin, cout)), "bf16")
+    x = quant(r.normal(0, 1.0, (n, l, cin)), dt16)
+    w = quant(r.normal(0, 0.1, (3, cin, cout)), dt16)
     b = dev(r.normal(0, 0.3, (cout,)))
     gamma = r.normal(1.0, 0.3, (cout,)) * np.where(r.random(cout) < 0.4, -1, 1)
     gamma[5] = 0.0

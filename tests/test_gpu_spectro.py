@@ -124,16 +124,23 @@ def _clips(n, raw_len, seed):
     return x.astype(np.float32)
 
 
-@pytest.mark.parametrize("dt,drop", [("f32", 0.0), ("f32", 0.25), ("bf16", 0.0)])
-def test_spectrogram_siamese_step_vs_oracle(dt, drop):
+SMALL = (4, 400 + 160 * 63, 8, 8)     # 64 frames x 64 mels -> 4 x 4 before the global max
+CONFIG4 = (2, 48000, 32, 64)          # BASELINE.json config 4 at its own size: 3 s clips -> 298 x 64 log-mel, filters 32, embedding 64
+
+
+@pytest.mark.parametrize("dt,drop,size", [("f32", 0.0, SMALL), ("f32", 0.25, SMALL), ("bf16", 0.0, SMALL), ("f16", 0.0, SMALL),
+                                          ("f32", 0.0, CONFIG4), ("f16", 0.0, CONFIG4), ("bf16", 0.0, CONFIG4)],
+                         ids=["f32-small", "f32-drop-small", "bf16-small", "f16-small", "f32-config4", "f16-config4", "bf16-config4"])
+def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
     """One train_on_batch of the 2-D variant: embeddings, loss, every gradient (in Keras' Conv2D shapes), the parameters after the
-    Adam step and the moving statistics, against the float64 oracle on the same clips."""
+    Adam step and the moving statistics, against the float64 oracle on the same clips -- on a small geometry and at config 4's own
+    (298 x 64 frames, filters 32: the size bench.py's extras time)."""
     from voicemap_amd.spectro_engine import HipSpectrogramEncoderEngine
-    pairs, raw_len, F_, E = 4, 400 + 160 * 63, 8, 8     # 64 frames x 64 mels -> 4 x 4 before the global max
+    pairs, raw_len, F_, E = size
     arch = O.Encoder2dArch(F_, E, dropout=drop)
     pr = O.init_params2d(arch, head="uniform_euclidean", seed=5)
     x1, x2 = _clips(pairs, raw_len, 6), _clips(pairs, raw_len, 7)
-    y = np.array([[0.0], [0.0], [1.0], [1.0]])
+    y = np.concatenate([np.zeros(pairs // 2), np.ones(pairs - pairs // 2)])[:, None]
     eng = HipSpectrogramEncoderEngine(F_, E, dropout=drop, head="uniform_euclidean", dtype=dt)
     eng.set_params({k: v.numpy() for k, v in pr.items()})
     masks = None
@@ -149,8 +156,9 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop):
     torch.cuda.synchronize()
     emb = pl["emb"].cpu().numpy()
     e_ref = np.concatenate([ref["e1"].numpy(), ref["e2"].numpy()])
-    tol = 2e-4 if dt == "f32" else 6e-2
-    report("spectro_step_%s_drop%g" % (dt, drop), "emb_rel_err", rel_err(emb, e_ref))
+    tol = {"f32": 2e-4, "bf16": 6e-2, "f16": 8e-3}[dt]
+    tag = "spectro_step_%s_drop%g_%dx%d_F%d" % (dt, drop, f1.shape[1], f1.shape[2], F_)
+    report(tag, "emb_rel_err", rel_err(emb, e_ref))
     assert rel_err(emb, e_ref) < tol
     assert abs(pl["loss_acc"][0].item() - ref["loss"].item()) < tol * max(1.0, abs(ref["loss"].item()))
     grads = eng.get_grads()
@@ -161,7 +169,7 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop):
         else:
             assert cosine(grads[k], gref.numpy()) > 0.9 or max_err(grads[k], gref.numpy()) < 1e-5, k
         worst = max(worst, rel_err(grads[k], gref.numpy()))
-    report("spectro_step_%s_drop%g" % (dt, drop), "worst_grad_rel_err", worst)
+    report(tag, "worst_grad_rel_err", worst)
     if dt == "f32":
         eng.optimizer_step()
         torch.cuda.synchronize()

@@ -324,3 +324,29 @@ def test_single_weighted_draw_fast_path_is_np_random_choice():
         out.append(tuple(map(tuple, d.get_alike_pairs(8))) + tuple(map(tuple, d.get_differing_pairs(8))))
         res[name] = (out, np.random.random())
     assert res["fast"] == res["choice"]
+
+
+def test_sampling_refuses_under_populated_indexes_like_np_random_choice():
+    """The restated weighted sampling keeps np.random.choice's refusals (pandas' DataFrame.sample raises them in the reference,
+    voicemap/librispeech.py:145-240): a speaker with fewer than n other files cannot fill an n-shot class, one speaker owning the
+    whole index has no differing pairs, more pairs than files cannot be drawn without replacement -- ValueError, never a silently
+    padded or duplicated sample."""
+    import pytest
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    d = SyntheticSpeechDataset(num_speakers=4, files_per_speaker=3, seconds=1, seed=1)
+    with pytest.raises(ValueError):
+        d._weighted(5, np.array([1.0, 2.0, 3.0]))            # larger than the population
+    with pytest.raises(ValueError):
+        d._weighted(2, np.array([0.0, 2.0, 0.0]))            # fewer rows with positive weight than requested
+    with pytest.raises(ValueError):
+        d._weighted(1, np.array([]))                          # empty population
+    np.random.seed(0)
+    with pytest.raises(ValueError):
+        d.build_n_shot_task(3, 4)                             # 3 files per speaker: no 4-shot support set for the query's class
+    assert len(d._weighted(3, np.array([1.0, 2.0, 3.0]))) == 3
+    one = SyntheticSpeechDataset(num_speakers=1, files_per_speaker=5, seconds=1, seed=2)
+    np.random.seed(0)
+    with pytest.raises(ValueError):
+        one.get_differing_pairs(2)                            # the remainder after removing the anchor's speaker is empty
+    with pytest.raises(ValueError):
+        one.get_alike_pairs(4)                                # 8 anchors from 5 files without replacement

@@ -18,7 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "libvoicemap_hip.so")  # env: A/B experiments
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
-VM_F32, VM_BF16, VM_F32S = 0, 1, 2
+VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
+ABI_VERSION = 3  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -39,9 +40,9 @@ SIGNATURES = {
     "vm_conv1_fwd": (I, [P, P, P, L, L, I, I, P, P, P, P]),
     "vm_conv1_wgrad_workspace_bytes": (L, [L, I]),
     "vm_conv1_wgrad": (I, [P, P, L, L, I, I, P, P, P]),
-    "vm_conv1_fused_fwd": (I, [P, P, P, P, P, L, L, I, I, I, P, P, P, P]),
+    "vm_conv1_fused_fwd": (I, [P, P, P, P, P, L, L, I, I, I, I, P, P, P, P]),
     "vm_conv1_fused_bwd_workspace_bytes": (L, [L, L, I]),
-    "vm_conv1_fused_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P, P]),
+    "vm_conv1_fused_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P, P]),
     "vm_conv_stat_rows": (L, [L]),
     "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
@@ -76,11 +77,11 @@ SIGNATURES = {
     "vm_global_maxpool_bwd": (I, [P, P, L, L, I, I, P, P]),
     "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),
     "vm_dense_bwd": (I, [P, P, P, L, I, I, P, P, P, P]),
-    "vm_siamese_head_loss": (I, [P, P, P, P, L, I, I, I, P, P, P, P, P, P, P]),
-    "vm_softmax_cce": (I, [P, P, L, I, P, P, P, P, P]),
+    "vm_siamese_head_loss": (I, [P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P]),
+    "vm_softmax_cce": (I, [P, P, L, I, F, P, P, P, P, P]),
     "vm_sqnorm_workspace_bytes": (L, [L]),
     "vm_grad_sqnorm": (I, [P, L, P, P, P]),
-    "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P]),
+    "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, I, P, P]),
     "vm_nshot_distances": (I, [P, P, L, I, I, I, I, P, P, P]),
     "vm_stft_frames": (L, [L, I, I]),
     "vm_stft_logmel": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
@@ -115,6 +116,9 @@ class _Lib:
             fn.restype = res
             fn.argtypes = args
         self.abi = self.cdll.vm_abi_version()
+        if self.abi != ABI_VERSION:  # a stale prebuilt library: its entry points take different arguments
+            raise VoicemapHipError("%s reports ABI %d, this package binds ABI %d -- rebuild it (python -m voicemap_amd.build --force)"
+                                   % (LIB_PATH, self.abi, ABI_VERSION))
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise with vm_last_error() on failure."""

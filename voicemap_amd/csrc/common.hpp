@@ -22,7 +22,9 @@ int check_launch(const char* what);
 
 // ---- storage types ------------------------------------------------------------------------------
 typedef __bf16 bf16;
+typedef _Float16 f16;  // IEEE half: the second 16-bit storage type (dtype VM_F16) -- 11 significand bits against bf16's 8
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -55,6 +57,12 @@ template <> struct Elem<bf16> {
     __device__ static inline bf16 from_f(float v) { return (bf16)v; }
 };
 
+template <> struct Elem<f16> {
+    static constexpr int kVec = 8;
+    __device__ static inline float to_f(f16 v) { return (float)v; }
+    __device__ static inline f16 from_f(float v) { return (f16)v; }  // v_cvt_f16_f32, round-to-nearest-even
+};
+
 // 16-byte vector of T <-> floats
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -66,6 +74,12 @@ template <> struct Vec16<bf16> {
     bf16x8 v;
     __device__ inline float get(int i) const { return (float)v[i]; }
     __device__ inline void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <> struct Vec16<f16> {
+    f16x8 v;
+    __device__ inline float get(int i) const { return (float)v[i]; }
+    __device__ inline void set(int i, float x) { v[i] = (f16)x; }
 };
 
 template <typename T>
@@ -95,6 +109,18 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int f1_set_blocks(int v);  // conv1_fused.hip tuning
 int f1_set_fwd_blocks(int v);
 
+// 16-bit storage types only (bf16 / f16): the LDS-DMA kernels and the fused block-1 kernels
+#define VM_DISPATCH_16(dtype, ...)                                  \
+    do {                                                            \
+        if ((dtype) == VM_BF16) {                                   \
+            using T = vm::bf16;                                     \
+            __VA_ARGS__;                                            \
+        } else {                                                    \
+            using T = vm::f16;                                      \
+            __VA_ARGS__;                                            \
+        }                                                           \
+    } while (0)
+
 // reduce.hip: out0[i] (i < n0) / out1[i - n0] = sum over `slabs` slabs of ws[k][i], two fixed-order stages.
 // `part` needs slab_sum_part_bytes(nel) bytes of scratch.
 constexpr int SLAB_RCH = 16;
@@ -110,6 +136,9 @@ int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n
             __VA_ARGS__;                                            \
         } else if ((dtype) == VM_BF16) {                            \
             using T = vm::bf16;                                     \
+            __VA_ARGS__;                                            \
+        } else if ((dtype) == VM_F16) {                             \
+            using T = vm::f16;                                      \
             __VA_ARGS__;                                            \
         } else {                                                    \
             vm::set_error("unknown dtype %d", (int)(dtype));        \

@@ -1,4 +1,4 @@
-// Block 1 of the encoder, fused for bf16 storage (voicemap/models.py:13-19: Conv1D(F,32,'same',relu) ->
+// Block 1 of the encoder, fused for 16-bit storage (bf16 / f16; voicemap/models.py:13-19: Conv1D(F,32,'same',relu) ->
 // BatchNormalization -> SpatialDropout1D -> MaxPool1D).
 //
 // C_in = 1 makes this block 4 % of the FLOPs but the largest activation (B x 12000 x F): writing relu(conv) at
@@ -153,15 +153,15 @@ __device__ inline void f1_relu4(const f32x16& acc, int g, f32x2 bv2, f32x2& a, f
 // ------------------------------------------------------------------------------------------------------
 // forward.  grid = (n_windows * splits, ceil(F/128)); a block walks `cps` chunks of one window (weights and the per-channel
 // constants are loaded once, the waveform copies are double-buffered: one barrier per chunk).
-//   TRAIN: e[n][q][c] = bf16 pooled extreme of relu(conv+b) (max if gamma >= 0 else min) + stat partials of the fp32 z
-//   INFER: act[n][1+q][c] = bf16(pooled extreme * scale + shift), sign from scale (moving-statistics affine)
+//   TRAIN: e[n][q][c] = stored (TS) pooled extreme of relu(conv+b) (max if gamma >= 0 else min) + stat partials of the fp32 z
+//   INFER: act[n][1+q][c] = TS(pooled extreme * scale + shift), sign from scale (moving-statistics affine)
 // z itself is never stored, so it has no storage rounding: statistics, pooling and the backward recompute all see the
 // fp32 accumulator.
-template <int POOL, bool INFER>
+template <typename TS, int POOL, bool INFER>
 __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                               const float* __restrict__ bias, const float* __restrict__ sgn,
                                                               const float* __restrict__ shift, int64_t L, int F, int chunks,
-                                                              int splits, int cps, bf16* __restrict__ out,
+                                                              int splits, int cps, TS* __restrict__ out,
                                                               float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
     __shared__ __attribute__((aligned(16))) F1Copies cp[2];
     __shared__ float red[4][32][2];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
 
     // all 32 positions of a tile pooled and in range (every tile at cfg-A): no per-element predicates, one scalar base
     // pointer per tile.  ALLMAX (wave-uniform): plain maxima, no min/max selects.
-    auto fast_tile = [&](const f32x16& acc, bf16* ob, auto allmax) {
+    auto fast_tile = [&](const f32x16& acc, TS* ob, auto allmax) {
         constexpr bool ALLMAX = decltype(allmax)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 const f32x2 a = f32x2{acc[4 * g], acc[4 * g + 1]} + bv2, b = f32x2{acc[4 * g + 2], acc[4 * g + 3]} + bv2;
                 if (POOL == 4) {
                     const float ext = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), b[0]), __builtin_fmaxf(b[1], 0.f));
-                    ob[(2 * g) * F] = (bf16)fmaf(ext, sg, sh);
+                    ob[(2 * g) * F] = (TS)fmaf(ext, sg, sh);
                 } else {
-                    ob[(4 * g) * F] = (bf16)fmaf(__builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), 0.f), sg, sh);
-                    ob[(4 * g + 1) * F] = (bf16)fmaf(__builtin_fmaxf(__builtin_fmaxf(b[0], b[1]), 0.f), sg, sh);
+                    ob[(4 * g) * F] = (TS)fmaf(__builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), 0.f), sg, sh);
+                    ob[(4 * g + 1) * F] = (TS)fmaf(__builtin_fmaxf(__builtin_fmaxf(b[0], b[1]), 0.f), sg, sh);
                 }
                 continue;
             }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                     const float v = z[pw * POOL + j];
                     ext = ALLMAX ? __builtin_fmaxf(ext, v) : (use_min ? __builtin_fminf(ext, v) : __builtin_fmaxf(ext, v));
                 }
-                ob[((8 * g) / POOL + pw) * F] = INFER ? (bf16)fmaf(ext, sg, sh) : (bf16)ext;
+                ob[((8 * g) / POOL + pw) * F] = INFER ? (TS)fmaf(ext, sg, sh) : (TS)ext;
             }
         }
     };
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
             if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
-                bf16* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F : out + (n * Lq + (t0 + 32 * rt) / POOL) * F) + lane_off;
+                TS* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F : out + (n * Lq + (t0 + 32 * rt) / POOL) * F) + lane_off;
                 if (all_max) {
                     fast_tile(acc, ob, std::true_type{});
                 } else {
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                     const int64_t q = tg / POOL + pw;
                     if (cok && q < Lq) {
                         if (INFER) {
-                            out[(n * (Lq + 2) + 1 + q) * F + c] = (bf16)fmaf(ext, sg, sh);  // ... and here it is the scale
+                            out[(n * (Lq + 2) + 1 + q) * F + c] = (TS)fmaf(ext, sg, sh);  // ... and here it is the scale
                         } else {
-                            out[(n * Lq + q) * F + c] = (bf16)ext;
+                            out[(n * Lq + q) * F + c] = (TS)ext;
                         }
                     }
                 }
@@ -322,9 +322,9 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------
 // backward.  grid = (n_windows * splits, ceil(F/128)); a block walks `cps` chunks of one window and keeps its
 // dW (32 taps x 32 channels per wave) and bias-gradient partials in registers; slab layout (33, F) fp32.
-template <int POOL>
+template <typename TS, int POOL>
 __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
-                                                              const float* __restrict__ bias, const bf16* __restrict__ dp,
+                                                              const float* __restrict__ bias, const TS* __restrict__ dp,
                                                               const float* __restrict__ scale, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ drop,
                                                               const float* __restrict__ c1, const float* __restrict__ c2,
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     constexpr int PW = 4 / POOL;    // pool windows per group of 4 consecutive positions
     constexpr int NDP = 4 * PW;     // pooled gradients one lane needs per tile
     // du of a tile whose 32 positions are all pooled and in range (every tile at cfg-A), dpv = its pooled gradients
-    auto fast_tile = [&](const f32x16& acc, const bf16 (&dpv)[NDP], bf16x2 (&dub)[8], auto allmax) {
+    auto fast_tile = [&](const f32x16& acc, const TS (&dpv)[NDP], bf16x2 (&dub)[8], auto allmax) {
         constexpr bool ALLMAX = decltype(allmax)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -432,10 +432,10 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     // fast-path one (or a lane without a channel) reads a valid dummy element instead, so the compiler keeps the loads in
     // flight until their first use instead of waiting at a branch join.
     const int csafe = cok ? c : 0;
-    auto load_dp = [&](bf16 (&dpv)[NDP], int64_t t0, int rt) {
+    auto load_dp = [&](TS (&dpv)[NDP], int64_t t0, int rt) {
         const bool fast = rt < 8 && t0 + 32 * rt + 32 <= Lq * POOL;  // wave-uniform
         const int64_t Fs = fast ? F : 0;
-        const bf16* dpb = dp + (fast ? (n * Lq + (t0 + 32 * rt) / POOL) * F : 0) + csafe + PW * hi * Fs;
+        const TS* dpb = dp + (fast ? (n * Lq + (t0 + 32 * rt) / POOL) * F : 0) + csafe + PW * hi * Fs;
 #pragma unroll
         for (int k = 0; k < NDP; ++k) dpv[k] = dpb[((8 * (k / PW)) / POOL + k % PW) * Fs];
     };
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int buf = (chunk - ch_lo) & 1;
         const int64_t t0 = (int64_t)chunk * F1_CHUNK;
-        bf16 dpn[NDP];  // the next tile's pooled gradients, loaded one tile ahead (their latency hides behind a tile of VALU work)
+        TS dpn[NDP];  // the next tile's pooled gradients, loaded one tile ahead (their latency hides behind a tile of VALU work)
         load_dp(dpn, t0, role.rs);
         __syncthreads();  // this chunk's copies are visible; the other buffer's readers (previous chunk) are done
         const bool more = chunk + 1 < ch_hi;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
         for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
-            bf16 dpv[NDP];
+            TS dpv[NDP];
 #pragma unroll
             for (int k = 0; k < NDP; ++k) dpv[k] = dpn[k];
             load_dp(dpn, t0, rt + role.RS);
@@ -585,11 +585,12 @@ int f1_set_fwd_blocks(int v) {
 using namespace vm;
 
 extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* bias, const float* gamma_or_scale,
-                                  const float* shift, int64_t n_windows, int64_t L, int F, int pool, int inference, void* out,
-                                  float* stat_sum, float* stat_sq, void* stream) {
+                                  const float* shift, int64_t n_windows, int64_t L, int F, int pool, int inference, int dtype,
+                                  void* out, float* stat_sum, float* stat_sq, void* stream) {
     VM_REQUIRE(x && w && bias && gamma_or_scale && out, "vm_conv1_fused_fwd: null pointer");
     VM_REQUIRE(n_windows > 0 && L > 0 && F > 0 && F % 8 == 0, "vm_conv1_fused_fwd: bad sizes");
     VM_REQUIRE(pool == 2 || pool == 4, "vm_conv1_fused_fwd: pool must be 2 or 4 (got %d)", pool);
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_conv1_fused_fwd: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     VM_REQUIRE(inference ? shift != nullptr : (stat_sum && stat_sq), "vm_conv1_fused_fwd: missing shift / stat buffers");
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
     const int splits = f1_splits(n_windows, chunks, g_f1_fwd_blocks);
@@ -598,13 +599,15 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_fwd: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
 #define VM_F1_FWD(POOL, INF)                                                                                              \
-    hipLaunchKernelGGL((conv1_fused_fwd_kernel<POOL, INF>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,           \
-                       gamma_or_scale, shift, L, F, chunks, splits, cps, (bf16*)out, stat_sum, stat_sq)
-    if (pool == 2) {
-        if (inference) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
-    } else {
-        if (inference) VM_F1_FWD(4, true); else VM_F1_FWD(4, false);
-    }
+    hipLaunchKernelGGL((conv1_fused_fwd_kernel<T, POOL, INF>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,        \
+                       gamma_or_scale, shift, L, F, chunks, splits, cps, (T*)out, stat_sum, stat_sq)
+    VM_DISPATCH_16(dtype, {
+        if (pool == 2) {
+            if (inference) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
+        } else {
+            if (inference) VM_F1_FWD(4, true); else VM_F1_FWD(4, false);
+        }
+    });
 #undef VM_F1_FWD
     return check_launch("vm_conv1_fused_fwd");
 }
@@ -617,25 +620,28 @@ extern "C" int64_t vm_conv1_fused_bwd_workspace_bytes(int64_t n_windows, int64_t
 
 extern "C" int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const void* dp, const float* scale,
                                   const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
-                                  int64_t n_windows, int64_t windows_per_tower, int64_t L, int F, int pool, void* ws,
+                                  int64_t n_windows, int64_t windows_per_tower, int64_t L, int F, int pool, int dtype, void* ws,
                                   float* grad_w, float* grad_b, void* stream) {
     VM_REQUIRE(x && w && bias && dp && scale && mean && invstd && c1 && c2 && ws && grad_w && grad_b,
                "vm_conv1_fused_bwd: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && F > 0 && F % 8 == 0, "vm_conv1_fused_bwd: bad sizes");
     VM_REQUIRE(pool == 2 || pool == 4, "vm_conv1_fused_bwd: pool must be 2 or 4 (got %d)", pool);
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_conv1_fused_bwd: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
     const int splits = f1_splits(n_windows, chunks, g_f1_blocks);
     const int cps = (chunks + splits - 1) / splits;
     const int64_t gx = n_windows * splits;
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_bwd: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
-    if (pool == 2) {
-        hipLaunchKernelGGL((conv1_fused_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const bf16*)dp,
-                           scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
-    } else {
-        hipLaunchKernelGGL((conv1_fused_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const bf16*)dp,
-                           scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
-    }
+    VM_DISPATCH_16(dtype, {
+        if (pool == 2) {
+            hipLaunchKernelGGL((conv1_fused_bwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const T*)dp,
+                               scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
+        } else {
+            hipLaunchKernelGGL((conv1_fused_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const T*)dp,
+                               scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
+        }
+    });
     int rc = check_launch("vm_conv1_fused_bwd");
     if (rc) return rc;
     const int64_t nel = 33LL * F;

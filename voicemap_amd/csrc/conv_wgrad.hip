@@ -1,0 +1,772 @@
+// Weight gradient of the k=3 convolutions (blocks 2-4 of voicemap/models.py:22-35) as a TN GEMM on the CDNA4 matrix cores:
+//   dW[kk][co] = sum_(n,t) A[(n,t)][kk] * dU[(n,t+1)][co],   kk = tap * C_in + ci, reduction over every position of every window.
+// Both operands are position-major in memory while an MFMA lane wants 8 consecutive POSITIONS of one channel.  Three kernels:
+//   conv_tn8x_kernel   16-bit storage (bf16 / f16), channel counts % 64 == 0: operands staged UNtransposed by LDS-DMA and
+//                      transposed on the read by ds_read_b64_tr_b16; a workgroup owns 128 input channels for all three taps
+//                      (one staged ring of input rows serves them) -- what every cfg-A launch runs
+//   conv_tn256_kernel  256 x 256 tile, register transposes (v_perm_b32): fp32 storage (and the split-bf16 arithmetic of VM_F32S)
+//   conv_tn_kernel     128 x 128 tile, register transposes: any shape
+// The reduction is split over windows into fp32 slabs that are summed in a fixed order (reduce.hip): no float atomics, run-to-run
+// bit-identical gradients.  (conv_tn8_kernel, the 256 x 256 LDS-DMA form that re-fetched the input for every tap, and the
+// free-running form of conv_tn8x_kernel were removed in round 3: history up to commit 7ccb023, measurements in DESIGN.md 4.2.)
+#include "conv_common.hpp"
+
+namespace vm {
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: TN GEMM with a transposing stager.  Output tile 128 (kk) x 128 (co); reduction over the positions
+// of windows [w_begin, w_end).  Each stage brings BKP positions x 128 columns of both operands; a thread loads
+// 4 consecutive positions x 16 bytes per item and writes them position-contiguous, so the fragment reads are the
+// same 16-byte K-contiguous reads as in the NT kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct TnArgs {
+    const T* x;   // padded input activations  (n_windows, L+2, c_in)
+    const T* du;  // padded output gradients   (n_windows, L+2, c_out)
+    float* ws;    // (splits, 3*c_in, c_out)
+    int64_t x_win_stride, du_win_stride;
+    int c_in, c_out, L;
+    int Kk;  // 3*c_in
+    int tilesI, tilesJ, splits;
+    int xcd_remap;
+    int64_t n_windows, win_per_split;
+    int split = 0;  // fp32 storage only (dtype VM_F32S): split-bf16 products
+};
+
+template <typename T, int PITCH, int SZ = (int)sizeof(T)> struct Transpose4;
+template <typename T, int PITCH> struct Transpose4<T, PITCH, 2> {
+    // 4 position rows of 8 16-bit values -> 8 columns of 4 (8 bytes each)
+    // v_perm_b32: result bytes selected from {first operand = bytes 7..4, second = bytes 3..0}
+    __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;  // high / low halves of the two dwords
+            u32x2 o;
+            o[0] = __builtin_amdgcn_perm(v[1][j >> 1], v[0][j >> 1], sel);
+            o[1] = __builtin_amdgcn_perm(v[3][j >> 1], v[2][j >> 1], sel);
+            *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + pg * 8) = o;
+        }
+    }
+};
+template <typename T, int PITCH> struct Transpose4<T, PITCH, 4> {
+    __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 o = {v[0][j], v[1][j], v[2][j], v[3][j]};
+            *reinterpret_cast<u32x4*>(lds_tile + (col0 + j) * PITCH + pg * 16) = o;
+        }
+    }
+};
+
+// fp32 rows -> per channel column the 4 positions as 4 bf16 hi (8 bytes, hi plane) + 4 bf16 lo (8 bytes, lo plane at +64)
+template <int PITCH>
+struct Transpose4Split {
+    __device__ static inline void store(char* lds_tile, int col0, int pg, const u32x4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 o = {v[0][j], v[1][j], v[2][j], v[3][j]};
+            u32x2 h, l;
+            split_f32x4(o, h, l);
+            *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + pg * 8) = h;
+            *reinterpret_cast<u32x2*>(lds_tile + (col0 + j) * PITCH + 64 + pg * 8) = l;
+        }
+    }
+};
+
+template <typename T, int KB, bool SPLIT = false>
+__global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 128-byte stages");
+    using G = Geo<KB>;
+    constexpr int VEC = Elem<T>::kVec;
+    constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
+    constexpr int PG = BKP / 4;               // groups of 4 positions
+    constexpr int ITEMS = (128 / VEC) * PG;   // (column group, position group) items per operand
+    constexpr int NIT = ITEMS / 128;          // items per thread (threads 0..127 stage X, 128..255 stage dU)
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * G::TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    // All output tiles of one split stream the SAME positions of X and dU, so they should share an L2: workgroup b
+    // runs on XCD b % 8 (observed dispatch order; only speed depends on it), hence split s is given the workgroups
+    // {b : b % 8 == s % 8}.  Splits beyond the last multiple of 8 fall back to the plain order.
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = (int)(b % p.tilesJ);
+    b /= p.tilesJ;
+    const int ti = (int)(b % p.tilesI);
+    const int split = (int)(b / p.tilesI);
+    const int i0 = ti * BM, j0 = tj * BN;
+
+    const bool is_x = tid < 128;
+    const T* base0 = is_x ? p.x : p.du + p.c_out;  // +1 halo row: dU row t lives at padded row t+1
+    const int64_t win_stride = is_x ? p.x_win_stride : p.du_win_stride;
+    const int row_c = is_x ? p.c_in : p.c_out;
+    const int which = is_x ? 0 : 1;
+    int pg[NIT], col0[NIT], toff[NIT];
+    bool col_ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = (tid & 127) + it * 128;
+        pg[it] = item % PG;
+        col0[it] = (item / PG) * VEC;
+        const int gcol = (is_x ? i0 : j0) + col0[it];
+        col_ok[it] = gcol < (is_x ? p.Kk : p.c_out);
+        toff[it] = pg[it] * 4 * row_c + (col_ok[it] ? gcol : 0);  // element offset of this item's first row in a stage
+    }
+
+    const int64_t w_begin = (int64_t)split * p.win_per_split;
+    int64_t w_end = w_begin + p.win_per_split;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const int stages_per_win = (p.L + BKP - 1) / BKP;
+    const int64_t n_stages = (w_end - w_begin) * stages_per_win;
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    // (window, stage-in-window) cursor of the NEXT stage to load -- incremented, never divided
+    int64_t ld_n = w_begin;
+    int ld_s = 0;
+    u32x4 rv[NIT][4];
+    auto gload = [&]() {
+        const int tb = ld_s * BKP;
+        const T* wbase = base0 + ld_n * win_stride + (int64_t)tb * row_c;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = tb + pg[it] * 4 + r;
+                if (col_ok[it] && t < p.L) {
+                    rv[it][r] = *reinterpret_cast<const u32x4*>(wbase + toff[it] + r * row_c);
+                } else {
+                    rv[it][r] = u32x4{0, 0, 0, 0};
+                }
+            }
+        }
+        if (++ld_s == stages_per_win) {
+            ld_s = 0;
+            ++ld_n;
+        }
+    };
+    if (n_stages > 0) gload();
+    for (int64_t st = 0; st < n_stages; ++st) {
+        const int buf = (int)(st & 1);
+        char* mine = lds + (buf * 2 + which) * G::TILE;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if constexpr (SPLIT) {
+                Transpose4Split<G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
+            } else {
+                Transpose4<T, G::PITCH>::store(mine, col0[it], pg[it], rv[it]);
+            }
+        }
+        __syncthreads();
+        if (st + 1 < n_stages) gload();
+        if constexpr (SPLIT) {
+            mma_slice_split<KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
+        } else {
+            mma_slice<T, KB>(lds + (buf * 2 + 0) * G::TILE, lds + (buf * 2 + 1) * G::TILE, wm, wn, lane, acc);
+        }
+    }
+
+    // slab tile: row = kk (m side), 4 consecutive co per register group -> 16-byte fp32 stores
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        const int row = i0 + wm * 64 + im * 32 + (lane & 31);
+        if (row >= p.Kk) continue;
+#pragma unroll
+        for (int in = 0; in < 2; ++in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = j0 + wn * 64 + in * 32 + 8 * g + 4 * hi;
+                if (col < p.c_out) {  // c_out is a multiple of 8 -> the 4 columns are all valid
+                    f32x4 v = {acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, 256 x 256 output tile.  The 128 x 128 kernel above is bound by LDS traffic, not by the matrix cores: per
+// 128-byte stage it writes 32 KB (transposed 8-byte writes, ~85 B/clk) and reads 64 KB for 16 MFMAs per wave.  With a
+// 256 x 256 tile and 64 x 128 per wave (8 waves) a stage writes 64 KB and reads 192 KB for 32 MFMAs per wave: LDS
+// cycles per MFMA cycle drop from 1.25 to 0.75.  One workgroup per CU (144 KB of LDS, 128 accumulator registers).
+template <typename T, int KB, bool SPLIT = false>
+__global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 128-byte stages");
+    using G = Geo<KB>;
+    constexpr int VEC = Elem<T>::kVec;
+    constexpr int BKP = KB / (int)sizeof(T);  // positions per stage
+    constexpr int PG = BKP / 4;
+    constexpr int TM = 256, TN_ = 256;
+    constexpr int OPB = TM * G::PITCH;        // bytes of one operand tile (256 rows)
+    constexpr int KSTEPS = KB / Mfma<T>::KSTEP_BYTES;
+    static_assert((TM / VEC) * PG == 512, "one item per thread and operand");
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * OPB];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = (int)(b % p.tilesJ);
+    b /= p.tilesJ;
+    const int ti = (int)(b % p.tilesI);
+    const int split = (int)(b / p.tilesI);
+    const int i0 = ti * TM, j0 = tj * TN_;
+
+    // every thread stages one item of X and one of dU per stage
+    const int pg = tid % PG, col0 = (tid / PG) * VEC;
+    const bool x_ok = i0 + col0 < p.Kk, d_ok = j0 + col0 < p.c_out;
+    const int x_toff = pg * 4 * p.c_in + (x_ok ? i0 + col0 : 0);
+    const int d_toff = pg * 4 * p.c_out + (d_ok ? j0 + col0 : 0);
+    const T* d_base0 = p.du + p.c_out;  // dU row t lives at padded row t+1
+
+    const int64_t w_begin = (int64_t)split * p.win_per_split;
+    int64_t w_end = w_begin + p.win_per_split;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const int stages_per_win = (p.L + BKP - 1) / BKP;
+    const int64_t n_stages = (w_end - w_begin) * stages_per_win;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Two register sets: the loads of stage st+2 are issued while stage st is multiplied, so a load has two full stages
+    // (~2 us of MFMA at one workgroup per CU) to come back -- with one set the K loop was bound by that latency.
+    int64_t ld_n = w_begin;
+    int ld_s = 0;
+    u32x4 rx0[4], rd0[4], rx1[4], rd1[4];
+    auto gload = [&](u32x4 (&rx)[4], u32x4 (&rd)[4]) {
+        const int tb = ld_s * BKP;
+        const T* xb = p.x + ld_n * p.x_win_stride + (int64_t)tb * p.c_in;
+        const T* db = d_base0 + ld_n * p.du_win_stride + (int64_t)tb * p.c_out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool tok = tb + pg * 4 + r < p.L;
+            rx[r] = (x_ok && tok) ? *reinterpret_cast<const u32x4*>(xb + x_toff + r * p.c_in) : u32x4{0, 0, 0, 0};
+            rd[r] = (d_ok && tok) ? *reinterpret_cast<const u32x4*>(db + d_toff + r * p.c_out) : u32x4{0, 0, 0, 0};
+        }
+        if (++ld_s == stages_per_win) {
+            ld_s = 0;
+            ++ld_n;
+        }
+    };
+    const int r = lane & 31, kh = lane >> 5;
+    auto step = [&](int64_t st, u32x4 (&rx)[4], u32x4 (&rd)[4]) {
+        char* ta = lds + (int)(st & 1) * 2 * OPB;
+        char* tb_ = ta + OPB;
+        if constexpr (SPLIT) {
+            Transpose4Split<G::PITCH>::store(ta, col0, pg, rx);
+            Transpose4Split<G::PITCH>::store(tb_, col0, pg, rd);
+        } else {
+            Transpose4<T, G::PITCH>::store(ta, col0, pg, rx);
+            Transpose4<T, G::PITCH>::store(tb_, col0, pg, rd);
+        }
+        __syncthreads();
+        if (st + 2 < n_stages) gload(rx, rd);
+        const char* pa = ta + (wm * 64 + r) * G::PITCH;
+        const char* pb = tb_ + (wn * 128 + r) * G::PITCH;
+        if constexpr (SPLIT) {
+            using M = Mfma<bf16>;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const M::Frag a0h = M::load(pa, s, kh), a1h = M::load(pa + 32 * G::PITCH, s, kh);
+                const M::Frag a0l = M::load(pa, s + 2, kh), a1l = M::load(pa + 32 * G::PITCH, s + 2, kh);
+#pragma unroll
+                for (int in = 0; in < 4; ++in) {
+                    const M::Frag bh = M::load(pb + in * 32 * G::PITCH, s, kh), bl = M::load(pb + in * 32 * G::PITCH, s + 2, kh);
+                    acc[0][in] = M::run(bl, a0h, acc[0][in]);
+                    acc[1][in] = M::run(bl, a1h, acc[1][in]);
+                    acc[0][in] = M::run(bh, a0l, acc[0][in]);
+                    acc[1][in] = M::run(bh, a1l, acc[1][in]);
+                    acc[0][in] = M::run(bh, a0h, acc[0][in]);
+                    acc[1][in] = M::run(bh, a1h, acc[1][in]);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            typename Mfma<T>::Frag a0 = Mfma<T>::load(pa, s, kh), a1 = Mfma<T>::load(pa + 32 * G::PITCH, s, kh);
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                typename Mfma<T>::Frag bf = Mfma<T>::load(pb + in * 32 * G::PITCH, s, kh);
+                acc[0][in] = Mfma<T>::run(bf, a0, acc[0][in]);
+                acc[1][in] = Mfma<T>::run(bf, a1, acc[1][in]);
+            }
+        }
+    };
+    if (n_stages > 0) gload(rx0, rd0);
+    if (n_stages > 1) gload(rx1, rd1);
+    for (int64_t st = 0; st < n_stages; st += 2) {
+        step(st, rx0, rd0);
+        if (st + 1 < n_stages) step(st + 1, rx1, rd1);
+    }
+
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        const int row = i0 + wm * 64 + im * 32 + (lane & 31);
+        if (row >= p.Kk) continue;
+#pragma unroll
+        for (int in = 0; in < 4; ++in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = j0 + wn * 128 + in * 32 + 8 * g + 4 * hi;
+                if (col < p.c_out) {
+                    f32x4 v = {acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)row * p.c_out + col) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, input-resident form: output tile = (3 taps x 128 input channels) x 128 output channels.
+//
+// Ablating conv_tn8_kernel shows that it is bound by its LDS-DMA traffic, not by the matrix cores (block 3, us: full 316,
+// no MFMA 300, no DMA 202): with kk = tap * C_in + ci tiled 256-wide, a tile's A operand is re-fetched for every tap and
+// every output-channel tile, and 256-wide tiles waste 10-25 % on C_out = 384 / Kk = 384.  Here a workgroup owns 128 input
+// channels for ALL THREE taps: the A operand of tap t at position p is X[p + t], so one staged block of X rows serves the
+// three taps (the fragment reads just start 0, 1 or 2 rows later) and the DMA bytes per MFMA drop by ~45 %; the tiles
+// (384 x 128) divide every layer of the model exactly.
+//   * A lives in a ring of 256 position rows per 32-channel block (4 blocks, 64 KB): stage g occupies rows (g & 3) * 64..+63,
+//     tap reads run up to 2 rows into the next stage's rows (ring indices wrap with an AND).  B (dU) has 4 stage buffers of
+//     4 blocks [64 positions][32 channels] (64 KB).  A stage is 64 positions; a window takes ceil((L + 2) / 64) stages so that
+//     its last stage holds the zero halo row L + 1; positions >= L are neutralised on the dU side (source row L + 1 = zero
+//     halo), so what the A rows of such positions hold does not matter as long as it is finite (the ring is zeroed once).
+//   * 8 waves = 4 (input-channel blocks of 32) x 2 (64 output channels): a wave owns 3 taps x 32 ci x 64 co = 6 accumulator
+//     tiles; 24 MFMAs per stage in clusters of 8 and 16; waves 4-7 (channel blocks 2, 3) run one slot behind waves 0-3.
+//   * DMA runs three stages ahead: stage g + 3 is issued in the second READ slot of stage g (into the ring slot of stage
+//     g - 1, whose last reads completed a phase earlier) and the counted vmcnt(4) there retires stage g + 2 -- stage g + 1
+//     needs it for its tap overflow rows.
+//   phase 0: read A(t0), A(t1), B_c0, B_c1 | MFMA t0 x c0, t0 x c1, t1 x c0
+//   phase 1: read A(t2) | DMA stage g+3 | vmcnt(4) | MFMA t1 x c1, t2 x c0, t2 x c1
+// ------------------------------------------------------------------------------------------------
+namespace t8x {
+constexpr int ROWS = 256;                  // ring rows per A block
+constexpr int ABLK = ROWS * 128;           // 32 KB: one block = 64 channels, 128-byte rows (whole cache lines per DMA row)
+constexpr int A_BYTES = 2 * ABLK;          // 64 KB
+constexpr int BBLK = 64 * 128;             // 8 KB
+constexpr int BSTAGE = 2 * BBLK;           // 16 KB
+constexpr int LDS_BYTES = A_BYTES + 4 * BSTAGE;  // 128 KB
+struct Frag4 {  // 4 k-steps; the two 8-byte halves are only joined at the MFMA, i.e. after the lgkmcnt wait
+    u32x2 lo[4], hi[4];
+};
+}  // namespace t8x
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<T> p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types (bf16 / f16)");
+    using V8 = typename Mfma<T>::Frag;
+    using namespace t8x;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;  // channel block (0..3), output-column half (0..1); waves 4-7 = blocks 2, 3
+
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = __builtin_amdgcn_readfirstlane((int)(b % p.tilesJ));
+    b /= p.tilesJ;
+    const int ti = __builtin_amdgcn_readfirstlane((int)(b % p.tilesI));
+    const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
+    const int ci0 = ti * 128, j0 = tj * 128;
+
+    const int w_begin = (int)((int64_t)split * p.win_per_split);
+    int w_end = w_begin + (int)p.win_per_split;
+    if (w_end > (int)p.n_windows) w_end = (int)p.n_windows;
+    const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
+    const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
+
+    if (G > 0) {
+        // zero the A ring once: tap-overflow reads of never-staged rows must be finite
+        for (int i = tid * 16; i < A_BYTES; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+
+        // ---- DMA geometry: per stage 16 wave-instructions for A and 16 for B; one instruction = 8 position rows x 128 bytes
+        // (64 channels: whole 128-byte lines -- with 64-byte rows two instructions fetched the halves of every line and the
+        // vector L1 spent half its time on hits-on-miss).  Inside a row the two 64-byte halves (32 channels each) are swapped
+        // when bit 1 of the row index is set, so that the 4 rows x 64 bytes a transposing read touches fall in 4 different
+        // 64-byte bank segments; the swap is applied to the per-lane SOURCE chunk here and again in the read addresses.
+        const int drow = w * 8 + (lane >> 3);
+        const int dchunk = ((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8;  // elements; (row >> 1) & 1 == (lane >> 4) & 1
+        const char* const x_base = reinterpret_cast<const char*>(p.x);
+        const char* const d_base = reinterpret_cast<const char*>(p.du);
+        auto stage = [&](int slot, int n, int st) {
+            const int t = st * 64 + drow;
+            {
+                int r = t < p.L + 1 ? t : p.L + 1;  // padded row of tap 0 at position t; rows past the halo are never used
+                const char* src = x_base + n * p.x_win_stride * 2;
+                char* dst = lds + slot * 8192 + w * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int c0 = ci0 + j * 64;
+                    c0 = c0 < p.c_in ? c0 : 0;
+                    glds16(src + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, dst + j * ABLK);
+                }
+            }
+            {
+                const int r = (t < p.L ? t : p.L) + 1;  // row L + 1 of the padded dU tensor is the zero halo
+                const char* src = d_base + n * p.du_win_stride * 2;
+                char* dst = lds + A_BYTES + slot * BSTAGE + w * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int co0 = j0 + j * 64;
+                    co0 = co0 < p.c_out ? co0 : 0;
+                    glds16(src + (unsigned)(r * p.c_out + co0 + dchunk) * 2u, dst + j * BBLK);
+                }
+            }
+        };
+
+        // ---- fragment reads (transposing, see conv_tn8_kernel) ----
+        // lane -> row (kh * 8 + (li >> 2)) of the 16 rows of a k-step, channel lg * 16 + li of the wave's 32-channel half
+        const int li = lane & 15, lg = (lane >> 4) & 1, kh = lane >> 5;
+        const int rowl = kh * 8 + (li >> 2);
+        const int sub = lg * 32 + (li & 3) * 8;
+        // A: half (wm & 1) of 64-channel block (wm >> 1); the swap bit of ring row U + rowl + tap (U % 4 == 0) depends on tap
+        int a_off[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a_off[t] = (rowl + t) * 128 + (((wm & 1) ^ (((rowl + t) >> 1) & 1)) * 64) + sub;
+        const int b_off = rowl * 128 + ((((rowl >> 1) & 1)) * 64) + sub;  // xor with the column half jn below
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+        auto tr_pair = [&](u32x2& lo, u32x2& hi, uint32_t a_lo, uint32_t a_hi) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
+        };
+        auto read_a = [&](Frag4& fa, int slot, int tap) {
+            const uint32_t blk = lds0 + (wm >> 1) * ABLK;
+            const uint32_t u = slot * 8192 + a_off[tap];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                tr_pair(fa.lo[s], fa.hi[s], blk + ((u + s * 2048) & (ABLK - 1)), blk + ((u + s * 2048 + 512) & (ABLK - 1)));
+        };
+        auto read_b = [&](Frag4& fb, int slot, int jn) {
+            const uint32_t a = lds0 + A_BYTES + slot * BSTAGE + wn * BBLK + (b_off ^ (jn * 64));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tr_pair(fb.lo[s], fb.hi[s], a + s * 2048, a + s * 2048 + 512);
+        };
+        // clusters of 8 (one tap) and 16 (two taps) MFMAs, k-steps interleaved over the accumulator tiles
+        auto opf = [](const Frag4& f, int s) {
+            const u32x4 v = {f.lo[s][0], f.lo[s][1], f.hi[s][0], f.hi[s][1]};
+            return __builtin_bit_cast(V8, v);
+        };
+        auto mma_a = [&](const Frag4& a0, const Frag4& b0, const Frag4& b1, f32x16& c0, f32x16& c1) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c0 = Mfma<T>::run(opf(b0, s), opf(a0, s), c0);
+                c1 = Mfma<T>::run(opf(b1, s), opf(a0, s), c1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto mma_b = [&](const Frag4& a0, const Frag4& a1, const Frag4& b0, const Frag4& b1, f32x16& c00, f32x16& c01, f32x16& c10,
+                         f32x16& c11) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c00 = Mfma<T>::run(opf(b0, s), opf(a0, s), c00);
+                c01 = Mfma<T>::run(opf(b1, s), opf(a0, s), c01);
+                c10 = Mfma<T>::run(opf(b0, s), opf(a1, s), c10);
+                c11 = Mfma<T>::run(opf(b1, s), opf(a1, s), c11);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto slot_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+        // stream cursor of the stage to be staged next
+        int nn = w_begin, ss = 0, staged = 0;
+        auto stage_next = [&]() {
+            stage(staged & 3, nn, ss);
+            ++staged;
+            if (++ss == spw) {
+                ss = 0;
+                ++nn;
+            }
+        };
+        // ---- prologue: stages 0, 1, 2 ----
+        stage_next();
+        if (G > 1) stage_next();
+        if (G > 2) stage_next();
+
+        Frag4 fa0, fa1, fb0, fb1;
+        {
+            if (G > 2) {
+                wait_vmcnt<4>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            slot_end();
+            if (w >= 4) slot_end();  // channel blocks 2, 3 run one slot behind
+            // A wave keeps at most 15 LDS reads in flight (lgkmcnt is 4 bits), so a READ slot costs about one LDS round trip
+            // per 15 reads: the slots are paired big-with-big -- READ0 (24 reads) runs beside the other group's MFMA1 (16
+            // MFMAs), READ1 (16 reads + the DMA) beside its MFMA0 (8).
+            for (int g = 0; g < G; ++g) {
+                const int slot = g & 3;
+                read_a(fa0, slot, 0);
+                read_b(fb0, slot, 0);
+                read_b(fb1, slot, 1);
+                read_done();
+                slot_end();
+                mma_a(fa0, fb0, fb1, acc[0][0], acc[0][1]);
+                slot_end();
+                read_a(fa1, slot, 1);
+                read_a(fa0, slot, 2);
+                if (staged < G) {
+                    stage_next();
+                    wait_vmcnt<4>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                read_done();
+                slot_end();
+                mma_b(fa1, fa0, fb0, fb1, acc[1][0], acc[1][1], acc[2][0], acc[2][1]);
+                slot_end();
+            }
+            if (w < 4) slot_end();  // balance the barrier count of the two groups
+        }
+    }
+
+    // ---- the split's slab tile: rows kk = tap * C_in + ci ----
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+    const int ci = ci0 + wm * 32 + (lane & 31);
+    if (ci0 + wm * 32 < p.c_in) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t row = (int64_t)t * p.c_in + ci;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = j0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+                    if (col < p.c_out) {
+                        const f32x4 v = {acc[t][jn][4 * g4], acc[t][jn][4 * g4 + 1], acc[t][jn][4 * g4 + 2], acc[t][jn][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(out + row * p.c_out + col) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fp32 Keras kernel (3, c_in, c_out) -> wf[co][k*c_in + ci] = W[k][ci][co];  wd[ci][j*c_out + co] = W[2-j][ci][co]
+template <typename T>
+__global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, T* wd) {
+    const int64_t total = 3LL * c_in * c_out;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // i indexes the source: ((k*c_in)+ci)*c_out + co
+    const int co = (int)(i % c_out);
+    const int64_t r = i / c_out;
+    const int ci = (int)(r % c_in);
+    const int k = (int)(r / c_in);
+    const T v = Elem<T>::from_f(w[i]);
+    wf[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = v;
+    wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
+}
+
+}  // namespace vm
+
+using namespace vm;
+
+static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
+
+namespace vm {
+int g_tn_x = 1;       // conv_tn8x_kernel for 16-bit storage with channel counts % 64 == 0; vm_set_tuning("tn_x", 0 | 1)
+int g_tn_tile = 256;  // tile of the register-transposing kernels: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
+}  // namespace vm
+
+static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 64 == 0 && c_out % 64 == 0; }
+static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_in >= 192 && c_out >= 192; }
+
+// Split of the position reduction over windows.  All workgroups of a launch do the same amount of work
+// (windows_per_split windows) and a fixed number of them is resident at a time (2 per CU for the 128-tile kernel, 1 per
+// CU for the others), so the launch takes rounds = ceil(tiles * splits / slots) rounds of windows_per_split
+// windows each -- a launch of 3 rounds + 12 workgroups pays a whole 4th round -- plus the write + re-read of one fp32
+// slab per split.  Pick the split that minimises   rounds * wps * t_window  +  splits * t_slab.
+extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
+    const bool big = tn_use_256(c_in, c_out);
+    const bool xres = tn_x_shape(c_in, c_out);  // (the fp32 kernels then run with a split count tuned for the 16-bit tiling)
+    const int tile = big ? 256 : 128;
+    const int64_t t = xres ? (int64_t)tiles(c_in, 128) * tiles(c_out, 128) : (int64_t)tiles(3 * c_in, tile) * tiles(c_out, tile);
+    const int64_t slots = (big || xres) ? 256 : 512;
+    const double t_window = xres ? 2.0 * 384 * 128 * (double)L / 5.0e12 : 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
+    const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
+    int64_t best_wps = 1;
+    double best_cost = -1.0;
+    for (int64_t wps = 1; wps <= n_windows; ++wps) {
+        const int64_t splits = (n_windows + wps - 1) / wps;
+        const int64_t rounds = (t * splits + slots - 1) / slots;
+        const double cost = (double)(rounds * wps) * t_window + (double)splits * t_slab;
+        if (best_cost < 0.0 || cost < best_cost) {
+            best_cost = cost;
+            best_wps = wps;
+        }
+    }
+    return (int)((n_windows + best_wps - 1) / best_wps);
+}
+
+extern "C" int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out) {
+    return (int64_t)vm_conv_wgrad_splits(n_windows, L, c_in, c_out) * 3 * c_in * c_out * (int64_t)sizeof(float) +
+           slab_sum_part_bytes(3LL * c_in * c_out);
+}
+
+extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                             void* ws, float* grad_w, void* stream) {
+    VM_REQUIRE(in && du && ws && grad_w, "vm_conv_wgrad: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_wgrad: bad sizes");
+    VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_wgrad: channels must be multiples of 8");
+    const int splits = vm_conv_wgrad_splits(n_windows, L, c_in, c_out);
+    VM_DISPATCH_DTYPE(dtype, {
+        TnArgs<T> a;
+        a.x = (const T*)in;
+        a.du = (const T*)du;
+        a.ws = (float*)ws;
+        a.x_win_stride = (L + 2) * (int64_t)c_in;
+        a.du_win_stride = (L + 2) * (int64_t)c_out;
+        a.c_in = c_in;
+        a.c_out = c_out;
+        a.L = (int)L;
+        a.Kk = 3 * c_in;
+        const bool big = tn_use_256(c_in, c_out);
+        const bool xres = sizeof(T) == 2 && tn_x_shape(c_in, c_out) && n_windows < (1LL << 30);
+        a.tilesI = xres ? tiles(c_in, 128) : tiles(3 * c_in, big ? 256 : BM);
+        a.tilesJ = xres ? tiles(c_out, 128) : tiles(c_out, big ? 256 : BN);
+        a.splits = splits;
+        a.xcd_remap = 1;
+        a.n_windows = n_windows;
+        a.win_per_split = (n_windows + splits - 1) / splits;
+        a.split = dtype == VM_F32S;
+        const dim3 grid((unsigned)((int64_t)splits * a.tilesI * a.tilesJ));
+        hipStream_t st = (hipStream_t)stream;
+        if constexpr (sizeof(T) == 4) {
+            if (a.split && big) {
+                hipLaunchKernelGGL((conv_tn256_kernel<T, 128, true>), grid, dim3(512), 0, st, a);
+            } else if (a.split) {
+                hipLaunchKernelGGL((conv_tn_kernel<T, 128, true>), grid, dim3(256), 0, st, a);
+            } else if (big) {
+                hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), grid, dim3(512), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((conv_tn_kernel<T, 128>), grid, dim3(256), 0, st, a);
+            }
+        } else {
+            if (xres) {
+                hipLaunchKernelGGL((conv_tn8x_kernel<T>), grid, dim3(512), 0, st, a);
+            } else if (big) {
+                hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), grid, dim3(512), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((conv_tn_kernel<T, 128>), grid, dim3(256), 0, st, a);
+            }
+        }
+    });
+    int rc = check_launch("vm_conv_wgrad");
+    if (rc) return rc;
+    const int64_t n = 3LL * c_in * c_out;
+    return slab_sum((const float*)ws, splits, n, grad_w, n, nullptr, (float*)ws + (int64_t)splits * n, (hipStream_t)stream);
+}
+
+extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream) {
+    VM_REQUIRE(w && wf && wd, "vm_prep_conv_weights: null pointer");
+    const int64_t n = 3LL * c_in * c_out;
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((prep_weights_kernel<T>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           c_in, c_out, (T*)wf, (T*)wd);
+    });
+    return check_launch("vm_prep_conv_weights");
+}
+
+// All layers of an encoder in one launch (the optimizer step re-derives every copy; three 5 us launches back to back cost more
+// than the copies themselves).  blockIdx.y = layer.
+constexpr int PREP_MAX_LAYERS = 8;
+struct PrepBatch {
+    const float* w[PREP_MAX_LAYERS];
+    void* wf[PREP_MAX_LAYERS];
+    void* wd[PREP_MAX_LAYERS];
+    int c_in[PREP_MAX_LAYERS], c_out[PREP_MAX_LAYERS];
+};
+template <typename T>
+__global__ void prep_weights_batch_kernel(PrepBatch pb) {
+    const int l = blockIdx.y;
+    const int c_in = pb.c_in[l], c_out = pb.c_out[l];
+    const int64_t total = 3LL * c_in * c_out;
+    const float* w = pb.w[l];
+    T* wf = (T*)pb.wf[l];
+    T* wd = (T*)pb.wd[l];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % c_out);
+        const int64_t r = i / c_out;
+        const int ci = (int)(r % c_in);
+        const int k = (int)(r / c_in);
+        const T v = Elem<T>::from_f(w[i]);
+        wf[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = v;
+        wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
+    }
+}
+
+extern "C" int vm_prep_conv_weights_batch(int n_layers, const float* const* w, const int* c_in, const int* c_out, int dtype,
+                                          void* const* wf, void* const* wd, void* stream) {
+    VM_REQUIRE(w && c_in && c_out && wf && wd, "vm_prep_conv_weights_batch: null pointer");
+    VM_REQUIRE(n_layers > 0 && n_layers <= PREP_MAX_LAYERS, "vm_prep_conv_weights_batch: 1..%d layers per call (got %d)", PREP_MAX_LAYERS,
+               n_layers);
+    PrepBatch pb;
+    int64_t most = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        VM_REQUIRE(w[l] && wf[l] && wd[l] && c_in[l] > 0 && c_out[l] > 0, "vm_prep_conv_weights_batch: bad layer %d", l);
+        pb.w[l] = w[l];
+        pb.wf[l] = wf[l];
+        pb.wd[l] = wd[l];
+        pb.c_in[l] = c_in[l];
+        pb.c_out[l] = c_out[l];
+        const int64_t n = 3LL * c_in[l] * c_out[l];
+        most = n > most ? n : most;
+    }
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((prep_weights_batch_kernel<T>), dim3((unsigned)cdiv(most, 256), (unsigned)n_layers), dim3(256), 0,
+                           (hipStream_t)stream, pb);
+    });
+    return check_launch("vm_prep_conv_weights_batch");
+}

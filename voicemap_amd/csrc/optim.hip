@@ -33,8 +33,14 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const double* __restr
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
                                                         float eps, float clipnorm, float prescale,
-                                                        const float* __restrict__ sqnorm) {
+                                                        const float* __restrict__ sqnorm, int skip_nonfinite,
+                                                        int32_t* __restrict__ skipped) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (skip_nonfinite) {  // loss-scaled f16 training: an overflowed gradient costs this step, not the model
+        const bool bad = !isfinite(sqnorm[0]);
+        if (i == 0 && skipped != nullptr) skipped[0] = bad ? 1 : 0;
+        if (bad) return;
+    }
     if (i >= n) return;
     float scale = prescale;
     if (clipnorm > 0.f) {
@@ -63,10 +69,11 @@ extern "C" int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm
 }
 
 extern "C" int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
-                                 float eps, float clipnorm, float grad_prescale, const float* sqnorm, void* stream) {
+                                 float eps, float clipnorm, float grad_prescale, const float* sqnorm, int skip_nonfinite,
+                                 int32_t* skipped, void* stream) {
     VM_REQUIRE(p && g && m && v && n > 0, "vm_adam_clip_step: bad argument");
-    VM_REQUIRE(clipnorm <= 0.f || sqnorm != nullptr, "vm_adam_clip_step: clipnorm needs sqnorm");
+    VM_REQUIRE((clipnorm <= 0.f && !skip_nonfinite) || sqnorm != nullptr, "vm_adam_clip_step: clipnorm / skip_nonfinite need sqnorm");
     hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
-                       beta1, beta2, eps, clipnorm, grad_prescale, sqnorm);
+                       beta1, beta2, eps, clipnorm, grad_prescale, sqnorm, skip_nonfinite, skipped);
     return check_launch("vm_adam_clip_step");
 }

@@ -227,7 +227,7 @@ __device__ inline float block_sum_256(float v, float* red) {
 // pair_ws[b] = {loss term, accuracy hit, dL/da, dL/da * distance}.
 __global__ __launch_bounds__(256) void siamese_head_pair_kernel(const float* __restrict__ emb, const float* __restrict__ hw,
                                                                 const float* __restrict__ hb, const float* __restrict__ y,
-                                                                int64_t pairs, int E, int head_kind, int loss_kind,
+                                                                int64_t pairs, int E, int head_kind, int loss_kind, float grad_scale,
                                                                 float* __restrict__ pred, float* __restrict__ demb,
                                                                 float* __restrict__ pair_ws) {
     const int lane = threadIdx.x & 63;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void siamese_head_pair_kernel(const float* __r
     if (lane == 0) pred[b] = p;
     if (y == nullptr) return;
     const float yy = y[b];
-    const float dlda = dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs;
+    const float dlda = grad_scale * (dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs);  // x 1.0f is exact
     if (lane == 0) {
         pair_ws[b * 4 + 0] = loss_value(p, yy, loss_kind);
         pair_ws[b * 4 + 1] = (rintf(p) == yy) ? 1.f : 0.f;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void siamese_head_reduce_kernel(const float* _
 __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                           int64_t rows, int n_classes, float* __restrict__ prob,
                                                           float* __restrict__ row_loss, float* __restrict__ row_hit,
-                                                          float* __restrict__ dlogits) {
+                                                          float* __restrict__ dlogits, float grad_scale) {
     __shared__ float red[4];
     __shared__ float redm[4];
     __shared__ int redi[4];
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restric
         for (int c = tid; c < n_classes; c += 256) {
             const float q = (expf(x[c] - m) / S) / PS;
             float g = in_range ? (q - (c == lab ? 1.f : 0.f)) : 0.f;
-            dlogits[r * n_classes + c] = g / (float)rows;
+            dlogits[r * n_classes + c] = grad_scale * (g / (float)rows);
         }
     }
 }
@@ -452,8 +452,8 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
 }
 
 extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
-                                    int E, int head_kind, int loss_kind, float* pred, float* loss_acc, float* demb,
-                                    float* grad_hw, float* grad_hb, float* ws, void* stream) {
+                                    int E, int head_kind, int loss_kind, float grad_scale, float* pred, float* loss_acc,
+                                    float* demb, float* grad_hw, float* grad_hb, float* ws, void* stream) {
     VM_REQUIRE(emb && head_w && head_b && pred, "vm_siamese_head_loss: null pointer");
     VM_REQUIRE(pairs > 0 && E > 0, "vm_siamese_head_loss: bad sizes");
     VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1,
@@ -461,7 +461,7 @@ extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const
     VM_REQUIRE(loss_kind == VM_LOSS_CONTRASTIVE || loss_kind == VM_LOSS_BCE, "vm_siamese_head_loss: unknown loss %d", loss_kind);
     VM_REQUIRE(y == nullptr || (loss_acc && demb && grad_hw && grad_hb && ws), "vm_siamese_head_loss: training outputs missing");
     hipLaunchKernelGGL(siamese_head_pair_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, head_w,
-                       head_b, y, pairs, E, head_kind, loss_kind, pred, demb, ws);
+                       head_b, y, pairs, E, head_kind, loss_kind, grad_scale, pred, demb, ws);
     int rc = check_launch("vm_siamese_head_loss");
     if (rc || y == nullptr) return rc;
     hipLaunchKernelGGL(siamese_head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, (const float*)ws, pairs, E,
@@ -469,12 +469,12 @@ extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const
     return check_launch("vm_siamese_head_loss(reduce)");
 }
 
-extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float* prob,
+extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float grad_scale, float* prob,
                               float* loss_acc, float* dlogits, float* ws, void* stream) {
     VM_REQUIRE(logits && prob && rows > 0 && n_classes > 0, "vm_softmax_cce: bad argument");
     VM_REQUIRE(labels == nullptr || (loss_acc && ws), "vm_softmax_cce: loss_acc and ws (2*rows floats) required with labels");
     hipLaunchKernelGGL(softmax_cce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, labels, rows,
-                       n_classes, prob, ws, ws ? ws + rows : nullptr, dlogits);
+                       n_classes, prob, ws, ws ? ws + rows : nullptr, dlogits, grad_scale);
     int rc = check_launch("vm_softmax_cce");
     if (rc || labels == nullptr) return rc;
     hipLaunchKernelGGL(mean2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (const float*)(ws + rows),

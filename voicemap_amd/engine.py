@@ -17,11 +17,14 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import VM_BF16, VM_F32, VM_F32S
+from ._lib import VM_BF16, VM_F16, VM_F32, VM_F32S
 
 # "f32s": fp32 storage, split-bf16 products in the k=3 convolution GEMMs (VM_F32S in include/voicemap_hip.h)
-_DT = {"f32": VM_F32, "fp32": VM_F32, "float32": VM_F32, "bf16": VM_BF16, "bfloat16": VM_BF16, "f32s": VM_F32S}
-_TORCH_DT = {VM_F32: torch.float32, VM_BF16: torch.bfloat16, VM_F32S: torch.float32}
+# "f16": IEEE half storage -- the bf16 kernels with 11 instead of 8 significand bits per stored value, loss-scaled gradients
+_DT = {"f32": VM_F32, "fp32": VM_F32, "float32": VM_F32, "bf16": VM_BF16, "bfloat16": VM_BF16, "f32s": VM_F32S,
+       "f16": VM_F16, "fp16": VM_F16, "float16": VM_F16}
+_TORCH_DT = {VM_F32: torch.float32, VM_BF16: torch.bfloat16, VM_F32S: torch.float32, VM_F16: torch.float16}
+DEFAULT_F16_LOSS_SCALE = 4096.0
 HEADS = {"uniform_euclidean": _lib.VM_HEAD_UNIFORM_EUCLIDEAN, "weighted_l1": _lib.VM_HEAD_WEIGHTED_L1}
 LOSSES = {"contrastive": _lib.VM_LOSS_CONTRASTIVE, "contrastive_loss": _lib.VM_LOSS_CONTRASTIVE,
           "bce": _lib.VM_LOSS_BCE, "binary_crossentropy": _lib.VM_LOSS_BCE}
@@ -108,7 +111,8 @@ class HipEncoderEngine:
 
     blocks: [(kernel_size, channels, pool)] -- first block must be (32, F, p) on a 1-channel waveform, the others
     k=3 (the only geometries the reference builds).  head: None | 'uniform_euclidean' | 'weighted_l1' |
-    'classifier'.  dtype: storage type of activations / GEMM operands ('bf16' or 'f32').
+    'classifier'.  dtype: storage type of activations / GEMM operands: 'bf16', 'f16' (half, loss-scaled), 'f32' (fp32 MFMAs) or
+    'f32s' (fp32 storage, split-bf16 products).
     """
 
     def __init__(self, blocks: Sequence[Tuple[int, int, int]], embedding_dimension: int, dropout: float = 0.05,
@@ -136,7 +140,9 @@ class HipEncoderEngine:
         self.nb = len(self.blocks)
         # bf16 storage: block 1 runs the fused MFMA kernels (no full-resolution z1 / du1 in HBM); fp32 storage keeps
         # the exact fp32 vector-ALU path
-        self.fuse_block1 = self.dtype == VM_BF16 and self.blocks[0][2] in (2, 4)
+        self.is16 = self.dtype in (VM_BF16, VM_F16)
+        self.fuse_block1 = self.is16 and self.blocks[0][2] in (2, 4)
+        self._init_loss_scale()
 
         # ---- flat parameter store, Keras trainable_weights order -------------------------------------
         if head not in (None, "uniform_euclidean", "weighted_l1", "classifier"):
@@ -168,10 +174,10 @@ class HipEncoderEngine:
         # BN-backward reduce of blocks 2..n-1 from the pooled forward output instead of z (vm_bn_pool_bwd_reduce_pooled): -0.34 GB
         # of reads per step at cfg-A.  Changes the two sums by the storage rounding of the pooled tensor (1e-3 relative in
         # bf16), so it is on for bf16 storage (the throughput mode) and off for fp32 (the exact-parity mode).
-        self.pooled_reduce = (self.dtype == _lib.VM_BF16)
+        self.pooled_reduce = self.is16
         # throughput mode: the two BatchNorm-backward sums of block i come out of the epilogue of block i+1's dgrad GEMM
         # (vm_conv_dgrad_bnred) instead of a separate pass over (act, dp); only where that kernel serves the shape
-        self.fused_bn_reduce = (self.dtype == _lib.VM_BF16)
+        self.fused_bn_reduce = self.is16
         # side-stream wgrad of block i enqueued after (True) or before (False) that block's dgrad: after it the wgrad runs beside the
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
@@ -180,7 +186,7 @@ class HipEncoderEngine:
         # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
         # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
         self.fused_pool_extreme = False
-        self.fused_infer_pool = (self.dtype == _lib.VM_BF16)  # inference: vm_conv_fwd_pool where the kernel serves the shape
+        self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
         # training forward: the second tower on its own stream (see forward())
@@ -190,6 +196,16 @@ class HipEncoderEngine:
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
         self.init_params(seed)
+
+    def _init_loss_scale(self):
+        """f16 storage: activation gradients of this net are 1e-5 .. 1e-8 per element -- under half's normal range (6e-5) -- so the
+        loss gradient is multiplied by loss_scale in the head kernel (every kernel between the head and the optimizer is linear in
+        it), the flat gradient buffer G then holds loss_scale x the gradients and the optimizer kernel divides it out again
+        (grad_prescale) before the clip; a step whose scaled gradients overflowed (non-finite norm) is skipped on the device and
+        counted in ``skipped_steps()``.  1.0 for the other storage types: their arithmetic is untouched."""
+        self.loss_scale = DEFAULT_F16_LOSS_SCALE if self.dtype == VM_F16 else 1.0
+        self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._skip_total = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     def _init_zero_debias(self):
         """Keras 2.2.2 BatchNormalization updates its moving statistics with TF 1.10's assign_moving_average(zero_debias=True)
@@ -288,7 +304,13 @@ class HipEncoderEngine:
         return out
 
     def get_grads(self) -> "OrderedDict[str, np.ndarray]":
-        return OrderedDict((name, self.view(name, self.G).detach().cpu().numpy().copy()) for name in self.offsets)
+        """The gradients of the last backward pass (G holds loss_scale x them with f16 storage: divided out here)."""
+        inv = 1.0 / float(self.loss_scale)
+        return OrderedDict((name, self.view(name, self.G).detach().cpu().numpy().copy() * np.float32(inv)) for name in self.offsets)
+
+    def skipped_steps(self) -> int:
+        """Optimizer steps skipped because the loss-scaled gradients were not finite (f16 storage only; synchronises)."""
+        return int(self._skip_total.item())
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
@@ -495,7 +517,7 @@ class HipEncoderEngine:
             if i == 0 and self.fuse_block1:
                 w1 = _p(self.view("conv1.kernel"))
                 if training:
-                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 0, W(b["e"]), ssum, ssq, st)
+                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 0, dt, W(b["e"]), ssum, ssq, st)
                     if first_of_two and self.tower_stagger == 1:
                         if "stagger_ev" not in pl:
                             pl["stagger_ev"] = torch.cuda.Event()
@@ -509,7 +531,7 @@ class HipEncoderEngine:
                         pl["stagger_ev"].record()
                 else:
                     self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
-                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), nw, L, c, pool, 1,
+                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, _p(b["scale"]), _p(b["shift"]), nw, L, c, pool, 1, dt,
                                W(b["act"]), None, None, st)
                 continue
             if i == 0:
@@ -588,7 +610,7 @@ class HipEncoderEngine:
                            _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
                 self._call("vm_conv1_fused_bwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
                            _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
-                           c, pool, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
+                           c, pool, dt, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
                 continue
             sparse = (i == last and last > 0)
             if sparse:
@@ -688,7 +710,7 @@ class HipEncoderEngine:
         G = self.G
         train = y is not None
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")),
-                      _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]),
+                      _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], float(self.loss_scale), _p(pl["pred"]),
                       _p(pl["loss_acc"]) if train else None, _p(pl["demb"]) if train else None,
                       _p(self.view("head.kernel", G)) if train else None, _p(self.view("head.bias", G)) if train else None,
                       _p(pl["head_ws"]), self.stream())
@@ -701,7 +723,7 @@ class HipEncoderEngine:
         self._call("vm_dense_fwd", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), n, self.E,
                  self.num_classes, _p(pl["logits"]), st)
         train = labels is not None
-        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, _p(pl["prob"]),
+        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, float(self.loss_scale), _p(pl["prob"]),
                  _p(pl["loss_acc"]) if train else None, _p(pl["dlogits"]) if train else None, _p(pl["cce_ws"]), st)
         if train:
             G = self.G
@@ -714,7 +736,8 @@ class HipEncoderEngine:
         if self.grad_sync is not None:
             self.grad_sync(self.G)
         lib, st = self.lib, self.stream()
-        if self.clipnorm and self.clipnorm > 0:
+        skip = self.loss_scale != 1.0   # loss-scaled storage: a non-finite gradient norm skips the update on the device
+        if (self.clipnorm and self.clipnorm > 0) or skip:
             self._call("vm_grad_sqnorm", _p(self.G), self.n_flat, _p(self._sq_ws), _p(self._sqnorm), st)
         lr = self.lr
         if self.decay > 0:
@@ -722,7 +745,10 @@ class HipEncoderEngine:
         t = self.iterations + 1
         lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         self._call("vm_adam_clip_step", _p(self.P), _p(self.G), _p(self.M), _p(self.V), self.n_flat, lr_t, self.beta_1,
-                 self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale), _p(self._sqnorm), st)
+                 self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale) / float(self.loss_scale),
+                 _p(self._sqnorm), int(skip), _p(self._skipped) if skip else None, st)
+        if skip:
+            self._skip_total += self._skipped   # device-side count: no host sync in the step
         self.iterations = t
         self.refresh_weights()
 
@@ -847,7 +873,7 @@ class HipEncoderEngine:
         sc = pl["scratch"]
         off = 2 * pairs * self.E
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), _p(yd),
-                   pairs, self.E, HEADS[self.head], LOSSES[loss], _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc),
+                   pairs, self.E, HEADS[self.head], LOSSES[loss], 1.0, _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc),
                    sc.data_ptr() + 4 * off, sc.data_ptr() + 4 * (off + self.E), _p(pl["head_ws"]), self.stream())
         return pl
 
@@ -856,7 +882,7 @@ class HipEncoderEngine:
         n = pl["n"]
         self._call("vm_dense_fwd", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), n, self.E,
                    self.num_classes, _p(pl["logits"]), self.stream())
-        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, _p(pl["prob"]), _p(pl["loss_acc"]),
+        self._call("vm_softmax_cce", _p(pl["logits"]), _p(labels), n, self.num_classes, 1.0, _p(pl["prob"]), _p(pl["loss_acc"]),
                    None, _p(pl["cce_ws"]), self.stream())
         return pl["prob"]
 

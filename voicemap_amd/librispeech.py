@@ -157,18 +157,29 @@ class LibriSpeechDataset(Sequence):
         train-clean-360's size -- is cached: rounds of ``random_sample(n - found)`` -> ``cdf.searchsorted(side='right')`` -> first
         occurrences kept, with the weights of the found rows zeroed and the cdf rebuilt before another round.  Same arithmetic, same
         use of the random stream: the same rows for the same seed (tests/test_host_api.py checks it against ``choice``)."""
+        # np.random.choice's own refusals (pandas' sample raises the same ValueErrors through it): an empty population, a sample
+        # larger than the population, fewer rows with positive weight than requested -- e.g. an n-shot task on a speaker with
+        # fewer than n other files, or differing pairs when one speaker owns the whole index
+        if len(weights) == 0:
+            raise ValueError("a must be non-empty")
+        if n > len(weights):
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
         if weights is self._len:
             c = self._cdf_cache
             if c is None or c[0] is not weights or c[1] != len(weights):
                 p = weights / weights.sum()
                 cdf = np.cumsum(p)
                 cdf /= cdf[-1]
-                c = self._cdf_cache = (weights, len(weights), p, cdf)
-            p, cdf = c[2], c[3]
+                c = self._cdf_cache = (weights, len(weights), p, cdf, int(np.count_nonzero(weights > 0)))
+            p, cdf, npos = c[2], c[3], c[4]
         else:
-            p = weights / weights.sum()
-            cdf = np.cumsum(p)
-            cdf /= cdf[-1]
+            npos = int(np.count_nonzero(weights > 0))
+            if npos >= n:
+                p = weights / weights.sum()
+                cdf = np.cumsum(p)
+                cdf /= cdf[-1]
+        if npos < n:
+            raise ValueError("Fewer non-zero entries in p than size")
         if n == 1:
             return cdf.searchsorted(np.random.random_sample(1), side='right')
         found = np.zeros(n, dtype=np.int64)

@@ -285,6 +285,11 @@ class _TrainableModel:
                 if validation_data is not None:
                     if isinstance(validation_data, tuple):
                         vl, va = self.test_on_batch(validation_data[0], validation_data[1])
+                        # data parallel: every rank holds its own tuple -- the sample-weighted mean over ranks, so that callbacks
+                        # acting on val_loss / val_acc (ReduceLROnPlateau, early stopping) decide identically everywhere
+                        nv = self._batch_size(validation_data[0])
+                        r_ = parallel.weighted_mean_logs({"val_loss": vl * nv, "val_acc": va * nv}, nv)
+                        vl, va = r_["val_loss"], r_["val_acc"]
                     else:
                         vl, va = self.evaluate_generator(valid, validation_steps)
                     logs["val_loss"], logs["val_acc"] = vl, va

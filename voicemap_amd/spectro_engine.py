@@ -100,6 +100,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.grad_sync = None
         self.grad_prescale = 1.0
         self._plans: Dict[tuple, dict] = {}
+        self.is16 = self.dtype in (_lib.VM_BF16, _lib.VM_F16)
+        self._init_loss_scale()
         self._init_zero_debias()
         self.basis = torch.from_numpy(spectro.dft_basis(self.win_length)).to(dev)
         self.melw = torch.from_numpy(spectro.mel_filterbank(self.n_mels)).to(dev)
@@ -168,7 +170,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         return OrderedDict((name, self._public(name, self.view(name))) for name in list(self.offsets) + list(self.nt_off))
 
     def get_grads(self):
-        return OrderedDict((name, self._public(name, self.view(name, self.G))) for name in self.offsets)
+        inv = np.float32(1.0 / float(self.loss_scale))   # G holds loss_scale x the gradients with f16 storage
+        return OrderedDict((name, self._public(name, self.view(name, self.G)) * inv) for name in self.offsets)
 
     def refresh_weights(self):
         for i in range(4):
@@ -392,7 +395,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         sc = pl["scratch"]
         off = 2 * pairs * self.E
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")), _p(yd), pairs, self.E,
-                   HEADS[self.head], LOSSES[loss], _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc), sc.data_ptr() + 4 * off,
+                   HEADS[self.head], LOSSES[loss], 1.0, _p(pl["pred"]), _p(pl["loss_acc"]), _p(sc), sc.data_ptr() + 4 * off,
                    sc.data_ptr() + 4 * (off + self.E), _p(pl["head_ws"]), self.stream())
         return pl
 
