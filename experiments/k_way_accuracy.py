@@ -23,6 +23,11 @@ def main(argv=None):
     p.add_argument("--num-tasks", type=int, default=1000)
     p.add_argument("--distance", default="dot_product", choices=["euclidean", "cosine", "dot_product"])
     p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--cached", action="store_true",
+                   help="embed the evaluation set ONCE per model and run every (k, n) cell on the cached (N, E) matrix "
+                        "(voicemap_amd/retrieval.py: tasks are row indices, one launch per cell; each window whitened alone)")
+    p.add_argument("--device-sampler", action="store_true", help="with --cached: draw the tasks on the GPU (same distribution, not "
+                                                                 "the reference's np.random sequence)")
     a = p.parse_args(argv)
     # under torchrun the tasks of every (k, n) cell are sharded over the ranks (BASELINE.json config 5); rank 0 writes the CSV
     from experiments._common import setup
@@ -37,13 +42,24 @@ def main(argv=None):
         nets.append(("classifier", "classifier", load_model(a.classifier)))
     out = PATH + "/logs/k-way_n-shot_accuracy_{}_{}.csv".format(a.validation_set, a.distance)
     rows = []
+    caches, sampler = {}, None
+    if a.cached:
+        from voicemap_amd import retrieval
+        for method, kind, net in nets:
+            caches[method] = retrieval.embed_corpus(net, valid, pre, kind)      # sharded over ranks + all-gathered under torchrun
+        if a.device_sampler:
+            sampler = retrieval.DeviceTaskSampler(valid, caches["siamese"].emb.device, seed=rank)
     if rank == 0:
         with open(out, "w") as f:
             f.write("method,n_correct,n_tasks,n_shot,k_way\n")
     for k in a.k_way:
         for n in a.n_shot:
             for method, kind, net in nets:
-                correct = n_shot_task_evaluation(net, valid, pre, a.num_tasks, n, k, network_type=kind, distance=a.distance)
+                if a.cached:
+                    correct = retrieval.n_shot_task_evaluation_cached(net, valid, pre, a.num_tasks, n, k, kind, a.distance,
+                                                                      cache=caches[method], sampler=sampler or "reference")
+                else:
+                    correct = n_shot_task_evaluation(net, valid, pre, a.num_tasks, n, k, network_type=kind, distance=a.distance)
                 rows.append({"method": method, "n_correct": correct, "n_tasks": a.num_tasks, "n": n, "k": k})
                 if rank == 0:
                     with open(out, "a") as f:

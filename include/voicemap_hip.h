@@ -310,6 +310,26 @@ int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, f
 int vm_nshot_distances(const float* query, const float* support, int64_t tasks, int k, int n, int E, int dist_kind,
                        float* pred, int32_t* argmin, void* stream);
 
+/* ---- f2 / BASELINE.json config 5: evaluation over a CACHED embedding matrix -----------------------------------------
+ * The reference embeds the k*n + 1 windows of every task anew (voicemap/utils.py:121-212; the sweep of
+ * experiments/k_way_accuracy.py:52-69 does so 38 000 times).  Its evaluation datasets are built with stochastic=False
+ * (experiments/train_siamese.py:44), i.e. every file has ONE window; embed the corpus once into emb (n_rows, E) fp32 and a task
+ * is k*n + 1 row indices.
+ * vm_nshot_indexed: vm_nshot_distances with the rows gathered by index: query_idx (tasks), support_idx (tasks, k*n) laid out
+ * [class_1]*n + ... + [class_k]*n like voicemap/librispeech.py:224-237; float64 arithmetic of voicemap/utils.py:159-206;
+ * pred (tasks, k) may be NULL; argmin (tasks) int32, first minimum, a NaN distance first like numpy.argmin.  E <= 256. */
+int vm_nshot_indexed(const float* emb, int64_t n_rows, const int32_t* query_idx, const int32_t* support_idx, int64_t tasks, int k,
+                     int n, int E, int dist_kind, float* pred, int32_t* argmin, void* stream);
+/* vm_pairdist_argmin: the pairwise-distance matrix between q (M, E) and ref (N, E), fp32, and per query row the nearest reference
+ * row (first minimum).  dist_kind: EUCLIDEAN sqrt(sum (a-b)^2) (direct form, no norm-expansion cancellation), COSINE
+ * 1 - a.b / (|a| |b|), DOT -a.b.  q_row0 >= 0: query row m IS reference row q_row0 + m (q is a row shard of ref -- the
+ * data-parallel form: all-gather the embeddings, every rank takes its rows) and is excluded from its own argmin; -1: no exclusion.
+ * dist (M, N) may be NULL (argmin only: nothing but best_val / best_idx (M) leaves the chip; best_idx = -1 if every distance of the
+ * row is NaN).  ws >= vm_pairdist_workspace_bytes(M, N).  E <= 256, N < 2^31. */
+int64_t vm_pairdist_workspace_bytes(int64_t M, int64_t N);
+int vm_pairdist_argmin(const float* q, const float* ref, int64_t M, int64_t N, int E, int dist_kind, int64_t q_row0, float* dist,
+                       float* best_val, int32_t* best_idx, void* ws, void* stream);
+
 /* ---- a10 / f4: log-mel front-end and the 2-D CNN encoder variant (BASELINE.json config 4) -------------------
  * NOT in the reference (nothing to cite under /root/reference); the specification is DESIGN.md section 9 and the
  * CPU oracle is oracle/voicemap_oracle.py (logmel_features, encoder2d_forward): parity unpinned by construction.

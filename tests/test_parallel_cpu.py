@@ -190,6 +190,11 @@ def _worker(rank, world, port, outdir):
     res["nshot_local"] = seen[0]
     res["max"] = parallel.max_over_ranks(1.0 + rank)
     res["sum"] = parallel.sum_over_ranks(1.0 + rank)
+    # ---- 4. the row all-gather of the cached-embedding evaluation (retrieval.embed_corpus): unequal shards, rank order ----------
+    from voicemap_amd import retrieval
+    full = torch.arange(5 * 3, dtype=torch.float32).reshape(5, 3)
+    lo, hi = parallel.shard_range(5, rank, world)
+    res["gather_rows"] = bool(torch.equal(retrieval.all_gather_rows(full[lo:hi].clone(), 5), full))
     torch.save(res, os.path.join(outdir, "res%d.pt" % rank))
     parallel.barrier()
     dist.destroy_process_group()
@@ -204,7 +209,7 @@ def test_two_rank_data_parallel_gloo(tmp_path):
         assert r["collectives"] == 2 and r["prescale"] == 0.5
         assert r["logs_same"] and r["replicas_same_after_fit"] and r["seen_by_all"]
         assert r["lr_final"] == pytest.approx(1e-3 * 0.5 * 0.5)   # patience 1: reductions after epochs 2 and 3 -- on BOTH ranks
-        assert r["nshot_total"] == 9 and r["max"] == 2.0 and r["sum"] == 3.0
+        assert r["nshot_total"] == 9 and r["max"] == 2.0 and r["sum"] == 3.0 and r["gather_rows"]
     assert (r0["nshot_local"], r1["nshot_local"]) == (6, 5)
     files = sorted(os.listdir(str(tmp_path)))
     assert [f for f in files if f.startswith("marker_")] == ["marker_rank0_epoch%d" % e for e in range(3)]   # rank-0-only callback
@@ -236,6 +241,8 @@ def test_two_rank_hip_engine_on_one_gpu_over_gloo(tmp_path):
         res = torch.load(str(tmp_path / ("gres%d.pt" % r)))
         assert res["same_P"] and res["same_M"] and res["same_V"] and res["sum_ok"] and res["finite"]
         assert res["collectives_per_step"] == 2
+        assert res["cache_rows"] == 45 and res["cache_same"]
+        assert res["nshot_sharded"] == res["nshot_single"] and res["retrieval_sharded"] == res["retrieval_single"]
 
 
 def _gpu_worker(rank, world, port, outdir, backend="nccl"):
@@ -273,6 +280,28 @@ def _gpu_worker(rank, world, port, outdir, backend="nccl"):
         dist.all_gather(parts, t)
         res["same_" + name] = bool(all(torch.equal(parts[0], q) for q in parts))
     res["finite"] = bool(torch.isfinite(pl["loss_acc"]).all().item())
+    # BASELINE.json config 5 sharded: every rank embeds its rows of the corpus, the (N, E) matrix is all-gathered, tasks / query rows
+    # are split over ranks and one integer is summed -- every rank must hold the single-process answers
+    from voicemap_amd import models as VM, retrieval as R, utils as VU
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    torch.manual_seed(4)
+    ds = SyntheticSpeechDataset(num_speakers=9, files_per_speaker=5, seconds=1, stochastic=False, seed=5)
+    enc = VM.get_baseline_convolutional_encoder(16, 32, dropout=0.0, dtype="f32")
+    net = VM.build_siamese_net(enc, (ds.fragment_length // 4, 1))
+    net.compile(loss="binary_crossentropy", optimizer="adam")
+    pre = VU.BatchPreProcessor("siamese", VU.preprocess_instances(4))
+    cache = R.embed_corpus(net, ds, pre)                      # sharded rows + all-gather
+    np.random.seed(21)                                        # the same stream on both ranks: each evaluates its own share of ...
+    q, s_ = R.draw_tasks_reference(ds, 40, 4, 2)              # ... these 40 tasks below (drawn here once to have the single-rank answer)
+    res["cache_rows"] = int(cache.emb.shape[0])
+    res["nshot_single"] = R.evaluate_tasks(cache, q, s_, 4, 2, "cosine")
+    lo, hi = parallel.shard_range(40, rank, world)
+    res["nshot_sharded"] = int(round(parallel.sum_over_ranks(float(R.evaluate_tasks(cache, q[lo:hi], s_[lo:hi], 4, 2, "cosine")))))
+    res["retrieval_sharded"] = R.pairwise_retrieval(cache, "euclidean")["n_correct"]
+    res["retrieval_single"] = R.pairwise_retrieval(cache, "euclidean", rows=(0, cache.n))["n_correct"]
+    sums = [torch.zeros(1, device="cuda") for _ in range(world)]
+    dist.all_gather(sums, cache.emb.double().sum().float().reshape(1))
+    res["cache_same"] = bool(all(torch.equal(sums[0], t) for t in sums))
     torch.save(res, os.path.join(outdir, "gres%d.pt" % rank))
     parallel.barrier()
     dist.destroy_process_group()

@@ -8,14 +8,15 @@ import sys
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("conv_nt_glds", "conv_nt_ring", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_fwd",
-                "conv1_fused_bwd", "conv1_fused_fwd", "global_maxpool", "slab_stage", "colreduce", "whiten", "dense", "adam", "siamese"):
+    for key in ("conv_nt2r", "conv_tn8x", "conv_nt_glds", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_gmax",
+                "bn_drop_pool_fwd", "conv1_fused_bwd", "conv1_fused_fwd", "global_maxpool", "slab_stage", "colreduce", "whiten", "dense", "adam",
+                "siamese"):
         if key in name:
             extra = ""
-            if "conv_nt" in name:
-                extra = "<fwd>" if ("Li0E" in name or ", 0," in name or "E, 128>" in name and "int, E" in name) else "<dgrad?>"
+            if "conv_nt" in name:   # mangled: ...ILi0E / Li1E ...; demangled: <T, 0> / <T, 1>
+                extra = "<fwd>" if ("Li0E" in name or ", 0>" in name or "(int)0>" in name) else "<dgrad>"
             if "bn_pool_bwd" in name:
-                extra = "<apply>" if ("Lb1E" in name or "bool, E>" in name) else "<reduce>"
+                extra = "<apply>" if ("Lb1E" in name or "bool, E>" in name or "apply" in name) else "<reduce>"
             return key + extra
     return name[-40:]
 

@@ -57,9 +57,9 @@ def main(fetch_dir, write_dir, out):
     # forward / dgrad launches share one grid size: told apart by dispatch order (forward: blocks 2,3,4; dgrad: 4,3,2)
     shapes = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
     # (rocprofv3 prints some instantiations demangled, with the epilogue enum elided: "<bool _Accum, int, E, 128, false>")
-    for entry, has, order in (("vm_conv_fwd", [("conv_nt", "Li0E"), ("conv_nt2r_kernel<0>",), ("conv_nt2r_kernel<(int)0>",)], shapes),
-                              ("vm_conv_dgrad", [("conv_nt", "Li1E"), ("conv_nt2r_kernel<1>",), ("conv_nt2r_kernel<(int)1>",),
-                                                 ("conv_nt_glds_kernel<", "128, false>")], shapes[::-1])):
+    for entry, has, order in (("vm_conv_fwd", [("conv_nt2r", "Li0E"), ("conv_nt2r_kernel<", ", 0>"), ("conv_nt2r_kernel<", "(int)0>")], shapes),
+                              ("vm_conv_dgrad", [("conv_nt2r", "Li1E"), ("conv_nt2r_kernel<", ", 1>"), ("conv_nt2r_kernel<", "(int)1>")],
+                               shapes[::-1])):
         fv, wv = per_order(fetch_dir, "FETCH_SIZE", has, 3), per_order(write_dir, "WRITE_SIZE", has, 3)
         for (L, cin, cout), f_, w_ in zip(order, fv, wv):
             if f_ is not None and w_ is not None:

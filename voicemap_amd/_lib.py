@@ -83,6 +83,9 @@ SIGNATURES = {
     "vm_grad_sqnorm": (I, [P, L, P, P, P]),
     "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, I, P, P]),
     "vm_nshot_distances": (I, [P, P, L, I, I, I, I, P, P, P]),
+    "vm_nshot_indexed": (I, [P, L, P, P, L, I, I, I, I, P, P, P]),
+    "vm_pairdist_workspace_bytes": (L, [L, L]),
+    "vm_pairdist_argmin": (I, [P, P, L, L, I, I, L, P, P, P, P, P]),
     "vm_stft_frames": (L, [L, I, I]),
     "vm_stft_logmel": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),

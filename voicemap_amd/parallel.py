@@ -81,6 +81,10 @@ class GradAllReduce:
         self._work = None
         self._split = 0
         self.collectives = 0  # issued so far (tests / diagnostics)
+        # bench.py: with ``time_wait`` on, every optimizer-step hook is bracketed by two events on the current stream -- the time
+        # the step's stream spends in (and waiting for) the collectives, i.e. what the gradient exchange costs that is NOT hidden
+        self.time_wait = False
+        self.wait_events = []
 
     # -- called from HipEncoderEngine.backward ------------------------------------------------------------
     def begin_tail(self, engine, main_event=None):
@@ -112,6 +116,16 @@ class GradAllReduce:
     def __call__(self, flat_grad: torch.Tensor):
         if self.world <= 1:
             return
+        if self.time_wait and flat_grad.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._reduce(flat_grad)
+            e1.record()
+            self.wait_events.append((e0, e1))
+            return
+        self._reduce(flat_grad)
+
+    def _reduce(self, flat_grad: torch.Tensor):
         if self._work is None:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
             self.collectives += 1
