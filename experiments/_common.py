@@ -57,7 +57,10 @@ def device_resident(a, train):
     from voicemap_amd import shards
     if not os.path.exists(os.path.join(a.device_data, "index.csv")):
         shards.write_shards(train, a.device_data)
-    ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False)
+    from voicemap_amd import parallel
+    rank, world = parallel.rank_world()
+    # under torchrun every rank keeps 1 / world of the speakers resident (shards.ShardedSpeechDataset speaker_shard)
+    ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False, speaker_shard=(rank, world) if world > 1 else None)
     ds.to_device("cuda")
     return ds
 

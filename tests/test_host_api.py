@@ -377,3 +377,29 @@ def test_cached_evaluation_draws_the_reference_tasks():
             np.random.seed(9)
             (qa, _), (sa, _) = ds.build_n_shot_task(4, 2)
             assert np.array_equal(qa, R._first_fragment(ds, int(q[0]))) and np.array_equal(sa[3], R._first_fragment(ds, int(s[0][3])))
+
+
+def test_sharded_dataset_speaker_shard_partitions_the_corpus(tmp_path):
+    """ShardedSpeechDataset(speaker_shard=(rank, world)): the ranks' speaker sets partition the corpus, every rank's dataset is a
+    complete LibriSpeechDataset over its speakers (pairs / tasks drawn inside it), and the compact device buffer of a rank holds
+    exactly its recordings at the re-based offsets (checked on the CPU: 'device' = cpu)."""
+    from voicemap_amd import shards
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    src = SyntheticSpeechDataset(num_speakers=9, files_per_speaker=3, seconds=3, seed=4)
+    shards.write_shards(src, str(tmp_path), shard_samples=400000)
+    whole = shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=False)
+    parts = [shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=False, speaker_shard=(r, 4)) for r in range(4)]
+    seen = [set(p.df['speaker_id'].unique()) for p in parts]
+    assert sum(len(s) for s in seen) == 9 and set().union(*seen) == set(whole.df['speaker_id'].unique())
+    assert sum(len(p) for p in parts) == len(whole)
+    for p in parts:
+        audio = p.to_device("cpu").numpy()
+        assert len(audio) == int(p.file_length.sum())
+        for i in (0, len(p) - 1):
+            o = int(p.global_offset[i])
+            assert np.array_equal(audio[o:o + int(p.file_length[i])], np.asarray(p._pcm(i)))
+        np.random.seed(1)
+        for a, b in p.get_alike_pairs(2):
+            assert p.datasetid_to_speaker_id[a] == p.datasetid_to_speaker_id[b]
+        o1, o2, y = p.build_verification_batch_offsets(4)
+        assert o1.max() + p.fragment_length <= len(audio) and o2.max() + p.fragment_length <= len(audio)
