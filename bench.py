@@ -100,6 +100,7 @@ def main():
                     help="keep the weight-gradient GEMMs on the main stream (default: side stream, concurrent with dgrad)")
     ap.add_argument("--tune", default="", help="extra tuning knobs key=value,key=value (engine switches / vm_set_tuning)")
     ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
+    ap.add_argument("--allow-nonfinite", action="store_true", help="timing experiments with ablated builds (tools/build_variant.sh): results are wrong by design")
     a = ap.parse_args()
 
     from voicemap_amd import parallel
@@ -177,8 +178,8 @@ def main():
     dt = float(np.median(block_s))
     loss = float(pl["loss_acc"][0].item())
     # a tuning set may switch kernels, never results: a non-finite loss is an error
-    assert np.isfinite(loss), "training diverged"
-    assert eng.skipped_steps() == 0, "loss-scaled steps were skipped (non-finite gradients)"
+    assert np.isfinite(loss) or a.allow_nonfinite, "training diverged"
+    assert eng.skipped_steps() == 0 or a.allow_nonfinite, "loss-scaled steps were skipped (non-finite gradients)"
 
     value = 2 * pairs * n_gpus * a.steps * 3.0 / dt
     ms = dt / a.steps * 1e3

@@ -19,6 +19,12 @@
 // epilogue -- were removed in round 3; they are in the history up to commit 7ccb023 and their measurements in DESIGN.md 4.2-4.4.)
 #include "conv_common.hpp"
 
+// Timing experiments of conv_nt2r_kernel (WRONG results: parts of the kernel are switched off); compiled in only by
+// tools/build_variant.sh -DVM_ABL=<bits>: 1 no in-loop weight DMA, 2 no in-loop input DMA, 4 no output stores, 8 no statistics.
+#ifndef VM_ABL
+#define VM_ABL 0
+#endif
+
 namespace vm {
 
 template <int KB>
@@ -482,7 +488,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
     using namespace n2;
     using V8 = typename Mfma<T>::Frag;  // eight 16-bit values
     const int r = lane & 31, kh = lane >> 5;
-    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr;
+    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr && !(VM_ABL & 8);
     const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
@@ -569,7 +575,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
             const int row = h * 128 + rg + 16 * jj;
             // rows >= trows exist only in the last 16 rows of the tile (trows >= 240)
             const bool ok = INTERIOR ? (h == 0 || jj < 7 || row < trows) : row < valid;
-            if (ok) *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.N) = v[jj];
+            if (ok && !((VM_ABL & 4) && row > 0)) *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.N) = v[jj];
         }
     };
     if (interior) {
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
             VM_PROF(if (kt == 0) pt_bar = __builtin_amdgcn_s_memtime();)
             int ib = 0, ia = 0;
             {
-                if (kt + 2 < nk) {
+                if (kt + 2 < nk && !(VM_ABL & 1)) {
                     issue_b(b_stage, b_tap * row_bytes + b_chunk_off);
                     b_stage = b_stage == 2 ? 0 : b_stage + 1;
                     if (++b_tap == 3) {
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
                     }
                     ib = 2;
                 }
-                if (tap < 2 && more_a) {
+                if (tap < 2 && more_a && !(VM_ABL & 2)) {
                     issue_a(a_next_blk, c + 2, 2 * tap);
                     ia = 2;
                 }
