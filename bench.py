@@ -119,7 +119,7 @@ def main():
         return e
     eng = make_engine(a.dtype)
     ENGINE_SWITCHES = {"overlap_wgrad": bool, "pooled_reduce": bool, "split_towers": bool, "fused_bn_reduce": bool, "wgrad_after_dgrad": bool,
-                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float}
+                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool}
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
         if k in ENGINE_SWITCHES:
@@ -276,7 +276,7 @@ def main():
     if a.breakdown and rank == 0 and n_gpus == 1:  # its steps contain collectives: single-process runs only
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
-                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
+                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_from_sums_finalize", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
                  "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights", "vm_prep_conv_weights_batch"]
         eng.timed = {nm: [] for nm in names}

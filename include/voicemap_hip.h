@@ -207,6 +207,14 @@ int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, con
                           int64_t L, int C, int pool, int dtype, float* part_dy, float* part_dyz, void* stream);
 /* reduce those partials per tower: c1 = sum(dy)/count, c2 = sum(dy*zhat)/count (each (n_towers, C)); and add the
  * parameter gradients over all towers: grad_gamma = sum(dy*zhat), grad_beta = sum(dy)  (overwritten). */
+/* vm_bn_bwd_from_sums followed by vm_bn_bwd_finalize in two launches instead of three and without the (n_windows * part_rows, C) partial
+ * tensors in between: the per-window map is applied to the dgrad epilogue's partial rows on their way into the column sums (fp64).
+ * Same arguments as the two calls; ws >= vm_colreduce_workspace_bytes(n_towers, C). */
+int vm_bn_bwd_from_sums_finalize(const float* s0, const float* sa, int64_t rows_per_window, const void* z, const void* dp,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd, const float* drop,
+                                 int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, int a_is_act,
+                                 double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta, void* ws,
+                                 void* stream);
 int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int64_t n_windows, int64_t windows_per_tower,
                        int C, double count_per_tower, float* c1, float* c2, float* grad_gamma, float* grad_beta,
                        void* ws, void* stream);
@@ -297,8 +305,8 @@ int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm, void* str
  * if clipnorm > 0 and norm >= clipnorm: g *= clipnorm/norm;  m,v,p updated with lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
  * (computed on the host, passed in), p -= lr_t*m/(sqrt(v)+eps).
  * skip_nonfinite != 0 (needs sqnorm): a step whose gradient norm is inf / NaN leaves p, m, v untouched (loss-scaled VM_F16
- * training: an overflowed activation gradient costs one step instead of the model) and sets *skipped (1 int32, may be NULL) to 1,
- * else to 0; with 0 the update is Keras' own arithmetic, NaNs included. */
+ * training: an overflowed activation gradient costs one step instead of the model) and increments the caller's running count *skipped
+ * (1 int32 on the device, zeroed by the caller, may be NULL); with 0 the update is Keras' own arithmetic, NaNs included. */
 int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                       float eps, float clipnorm, float grad_prescale, const float* sqnorm, int skip_nonfinite, int32_t* skipped,
                       void* stream);

@@ -180,9 +180,13 @@ def test_f16_overflowing_step_is_skipped_not_applied():
     eng.loss_scale = 2.0 ** 40
     eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None)
     assert eng.skipped_steps() == 1 and torch.equal(eng.P, before) and not eng.M.any()
+    assert eng.adjust_loss_scale() == 2.0 ** 39          # one skipped step since the last look: halved once
     eng.loss_scale = 4096.0
     eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None)
     assert eng.skipped_steps() == 1 and not torch.equal(eng.P, before) and torch.isfinite(eng.P).all()
+    for _ in range(3):
+        assert eng.adjust_loss_scale() == 4096.0         # clean checks accumulate ...
+    assert eng.adjust_loss_scale() == 8192.0             # ... and the fourth doubles the scale
 
 
 def test_two_steps_fp32_keep_tracking_oracle():

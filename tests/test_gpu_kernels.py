@@ -455,14 +455,14 @@ def test_adam_clip_step():
         flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
         L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
         L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
-        assert max_err(P2.cpu().numpy(), ref.numpy()) < 2e-6 and flag.item() == 0
+        assert max_err(P2.cpu().numpy(), ref.numpy()) < 2e-6 and flag.item() == 7     # a running count: untouched by a good step
         # a non-finite gradient norm: the step is skipped on the device (p, m, v untouched) and flagged; without the switch the
         # NaN goes through like in Keras
         G2[17] = float("inf")
         before = (P2.clone(), M2.clone(), V2.clone())
         L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
         L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
-        assert flag.item() == 1 and torch.equal(P2, before[0]) and torch.equal(M2, before[1]) and torch.equal(V2, before[2])
+        assert flag.item() == 8 and torch.equal(P2, before[0]) and torch.equal(M2, before[1]) and torch.equal(V2, before[2])
         L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 0, None, stream())
         assert not torch.isfinite(P2).all()
 
@@ -885,6 +885,21 @@ def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_d
     assert np.abs(b1 - b0)[:, ~vec].max() < 2e-5 * mag
     assert np.abs(b1 - b0)[:, 3].max() < 2e-5 * mag
     assert rel_err(b1[:, vec], b0[:, vec]) < 1.5e-2
+    # the fused form (sums -> per-window map -> fp64 column reduction in one launch, then the finalize): the same c1 / c2 and BatchNorm
+    # parameter gradients as vm_bn_bwd_from_sums + vm_bn_bwd_finalize, up to the summation order (fp64 here, fp32 per window there)
+    f32 = dict(dtype=torch.float32, device="cuda")
+    crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, cin) // 8, dtype=torch.float64, device="cuda")
+    outs = []
+    for fused in (False, True):
+        c1, c2, gg, gb = torch.empty(towers, cin, **f32), torch.empty(towers, cin, **f32), torch.empty(cin, **f32), torch.empty(cin, **f32)
+        if fused:
+            L().call("vm_bn_bwd_from_sums_finalize", p(s0), p(s1), rows2, p(z), p(dp), p(scale), p(shift), p(mean), p(invstd), p(drop), n,
+                     wpt, l, cin, pool, vm, 1, float(wpt * l), p(c1), p(c2), p(gg), p(gb), p(crws), stream())
+        else:
+            L().call("vm_bn_bwd_finalize", p(pa1), p(pb1), n, wpt, cin, float(wpt * l), p(c1), p(c2), p(gg), p(gb), p(crws), stream())
+        outs.append([t.double().cpu().numpy() for t in (c1, c2, gg, gb)])
+    for u, v, scale_ in zip(outs[0], outs[1], (mag / (wpt * l), mag / (wpt * l), mag, mag)):
+        assert np.abs(u - v).max() < 1e-4 * scale_
 
 
 def test_prep_conv_weights_batch_equals_single():

@@ -66,6 +66,7 @@ SIGNATURES = {
     "vm_bn_pool_bwd_reduce": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_pooled": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_bwd_from_sums": (I, [P, P, L, P, P, P, P, P, P, P, L, L, L, I, I, I, I, P, P, P]),
+    "vm_bn_bwd_from_sums_finalize": (I, [P, P, L, P, P, P, P, P, P, P, L, L, L, I, I, I, I, D, P, P, P, P, P, P]),
     "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P, P]),
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),

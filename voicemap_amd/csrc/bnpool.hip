@@ -688,6 +688,77 @@ __global__ __launch_bounds__(256) void bn_bwd_from_sums_kernel(const float* __re
     }
 }
 
+// vm_bn_bwd_from_sums + the first stage of vm_bn_bwd_finalize in ONE launch (the backward chain of a block is a string of small
+// dependent kernels, each worth its ~4.5 us of launch latency with the chip idle): the per-(window, channel) map of
+// bn_bwd_from_sums_kernel is linear in (S0, SA), so it is applied to every partial row of the dgrad epilogue and the results go
+// straight into the fp64 column sums of colreduce_stage1_kernel's layout (grid (C / 64, towers * CR_CHUNKS), 64 channels x 16 row
+// lanes; a chunk = a range of windows of one tower, its (window, partial row) items dealt round-robin to the row lanes).  The
+// scale == 0 channel (no invertible map: S1 re-derived from z) is handled once per window by the lane that owns its row 0.
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_bwd_sums_stage1_kernel(const float* __restrict__ s0p, const float* __restrict__ sap, int rows,
+                                                                  const T* __restrict__ z, const T* __restrict__ dp,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ drop, int64_t wpt, int64_t L, int C, int pool,
+                                                                  int a_is_act, double* __restrict__ ws) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int tw = blockIdx.y / CR_CHUNKS, chunk = blockIdx.y % CR_CHUNKS;
+    const int64_t per = (wpt + CR_CHUNKS - 1) / CR_CHUNKS;
+    const int64_t w_lo = chunk * per;
+    int64_t w_hi = w_lo + per;
+    if (w_hi > wpt) w_hi = wpt;
+    double sa_ = 0.0, sb_ = 0.0;
+    if (c < C && w_hi > w_lo) {
+        const float sc = scale[tw * C + c], sh = shift[tw * C + c], mu = mean[tw * C + c], is = invstd[tw * C + c];
+        const int64_t items = (w_hi - w_lo) * rows;
+        for (int64_t it = rg; it < items; it += 16) {
+            const int64_t wl = it / rows;
+            const int r = (int)(it - wl * rows);
+            const int64_t n = (int64_t)tw * wpt + w_lo + wl;
+            const float dr = drop ? drop[n * C + c] : 1.f;
+            const float S0 = s0p[(n * rows + r) * C + c], SA = sap[(n * rows + r) * C + c];
+            float S1 = SA;
+            if (a_is_act) {
+                if (sc != 0.f && dr != 0.f) {
+                    S1 = fmaf(SA, 1.0f / (sc * dr), (-sh / sc) * S0);
+                } else if (dr != 0.f) {  // scale == 0: the forward kept the maximum of z; the whole window once, with its row 0
+                    S1 = 0.f;
+                    if (r == 0) {
+                        const int64_t Lq = L / pool;
+                        for (int64_t q = 0; q < Lq; ++q) {
+                            float m = Elem<T>::to_f(z[(n * L + q * pool) * C + c]);
+                            for (int j = 1; j < pool; ++j) {
+                                const float y = Elem<T>::to_f(z[(n * L + q * pool + j) * C + c]);
+                                m = y > m ? y : m;
+                            }
+                            S1 = fmaf(Elem<T>::to_f(dp[(n * Lq + q) * C + c]), m, S1);
+                        }
+                    }
+                } else {
+                    S1 = 0.f;
+                }
+            }
+            sa_ += (double)(dr * S0);
+            sb_ += (double)(dr * is * (S1 - mu * S0));
+        }
+    }
+    red[0][rg][cl] = sa_;
+    red[1][rg][cl] = sb_;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ss += red[0][i][cl];
+            qq += red[1][i][cl];
+        }
+        ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
+        ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+    }
+}
+
 // Reduce pass when dp is the sparse GlobalMaxPool1D-backward form: dy is non-zero at ONE pool group per (window, channel),
 // so the two sums need z at that group only -- a gather of n*C*POOL elements instead of a pass over z.
 // Writes all BN_SEG partial rows of a window (row 0 = the value, the others 0).
@@ -922,6 +993,28 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
     return check_launch("vm_bn_bwd_finalize");
+}
+
+extern "C" int vm_bn_bwd_from_sums_finalize(const float* s0, const float* sa, int64_t rows_per_window, const void* z, const void* dp,
+                                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                                            const float* drop, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool,
+                                            int dtype, int a_is_act, double count_per_tower, float* c1, float* c2, float* grad_gamma,
+                                            float* grad_beta, void* ws, void* stream) {
+    VM_REQUIRE(s0 && sa && dp && scale && shift && mean && invstd && c1 && c2 && grad_gamma && grad_beta && ws,
+               "vm_bn_bwd_from_sums_finalize: null pointer");
+    VM_REQUIRE(!a_is_act || z, "vm_bn_bwd_from_sums_finalize: z is needed next to the pooled output (channels with scale == 0)");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && rows_per_window > 0 && pool >= 1 && L >= pool &&
+                   C > 0,
+               "vm_bn_bwd_from_sums_finalize: bad sizes");
+    const int n_towers = (int)(n_windows / windows_per_tower);
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((bn_bwd_sums_stage1_kernel<T>), dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, s0,
+                           sa, (int)rows_per_window, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop, windows_per_tower, L, C, pool,
+                           a_is_act, (double*)ws);
+    });
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, n_towers, C,
+                       count_per_tower, c1, c2, grad_gamma, grad_beta);
+    return check_launch("vm_bn_bwd_from_sums_finalize");
 }
 
 static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp_dg, const int32_t* sp_idx, const float* scale,

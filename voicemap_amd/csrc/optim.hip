@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (skip_nonfinite) {  // loss-scaled f16 training: an overflowed gradient costs this step, not the model
         const bool bad = !isfinite(sqnorm[0]);
-        if (i == 0 && skipped != nullptr) skipped[0] = bad ? 1 : 0;
+        if (i == 0 && skipped != nullptr && bad) skipped[0] += 1;   // a running count: one thread of the launch, no atomics needed
         if (bad) return;
     }
     if (i >= n) return;

@@ -69,6 +69,9 @@ int slab_sum(const float* ws, int64_t slabs, int64_t nel, float* out0, int64_t n
     int64_t rch = cdiv(2048, blocks);
     if (rch > slabs / 4) rch = slabs / 4;
     if (rch > SLAB_RCH) rch = SLAB_RCH;
+    // up to 64 slabs of >= 256 workgroups' worth of elements (the split-K slabs of the k=3 weight gradients at cfg-A: 16..36 slabs of
+    // 98 K..590 K elements) go through ONE launch: the second stage's launch latency (~4.5 us) is more than the parallelism it buys
+    if (slabs <= 64 && blocks >= 256) rch = 1;
     if (rch <= 1) {
         hipLaunchKernelGGL(slab_single_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, slabs, nel, n0, out0, out1);
         return check_launch("slab_sum");

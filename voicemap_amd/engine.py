@@ -178,6 +178,9 @@ class HipEncoderEngine:
         # throughput mode: the two BatchNorm-backward sums of block i come out of the epilogue of block i+1's dgrad GEMM
         # (vm_conv_dgrad_bnred) instead of a separate pass over (act, dp); only where that kernel serves the shape
         self.fused_bn_reduce = self.is16
+        # ... and those sums go straight into the column reduction (vm_bn_bwd_from_sums_finalize: two small launches per block instead
+        # of three, no per-window partial tensors in between); False = the separate vm_bn_bwd_from_sums + vm_bn_bwd_finalize calls
+        self.fused_sums_finalize = True
         # side-stream wgrad of block i enqueued after (True) or before (False) that block's dgrad: after it the wgrad runs beside the
         # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
         # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
@@ -204,8 +207,8 @@ class HipEncoderEngine:
         (grad_prescale) before the clip; a step whose scaled gradients overflowed (non-finite norm) is skipped on the device and
         counted in ``skipped_steps()``.  1.0 for the other storage types: their arithmetic is untouched."""
         self.loss_scale = DEFAULT_F16_LOSS_SCALE if self.dtype == VM_F16 else 1.0
-        self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._skip_total = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)   # running count, incremented by the optimizer kernel
+        self._skip_seen, self._clean_checks = 0, 0
 
     def _init_zero_debias(self):
         """Keras 2.2.2 BatchNormalization updates its moving statistics with TF 1.10's assign_moving_average(zero_debias=True)
@@ -310,7 +313,26 @@ class HipEncoderEngine:
 
     def skipped_steps(self) -> int:
         """Optimizer steps skipped because the loss-scaled gradients were not finite (f16 storage only; synchronises)."""
-        return int(self._skip_total.item())
+        return int(self._skipped.item())
+
+    def adjust_loss_scale(self, grow_after: int = 4, max_scale: float = 32768.0) -> float:
+        """Dynamic loss scaling at the caller's cadence (``fit_generator`` calls it once per epoch: one device read, no per-step
+        synchronisation): steps were skipped since the last call -> halve the scale once per skipped step (at most 2^-4); none for
+        ``grow_after`` calls in a row -> double it (an overflow it may cause costs one skipped step and is halved away at the next
+        call).  No-op for the storage types that do not scale."""
+        if self.loss_scale == 1.0:
+            return 1.0
+        total = self.skipped_steps()
+        new, self._skip_seen = total - self._skip_seen, total
+        if new > 0:
+            self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), 1.0)
+            self._clean_checks = 0
+        else:
+            self._clean_checks += 1
+            if self._clean_checks >= grow_after:
+                self.loss_scale = min(self.loss_scale * 2.0, max_scale)
+                self._clean_checks = 0
+        return self.loss_scale
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
@@ -599,15 +621,21 @@ class HipEncoderEngine:
             dm = _p(drop[i]) if drop is not None and drop[i] is not None else None
             if i == 0 and self.fuse_block1:
                 Lq = pl["L"][1]
-                if b.get("bnred_now"):
-                    self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
-                               _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, _p(b["pa"]),
-                               _p(b["pb"]), st)
+                if b.get("bnred_now") and self.fused_sums_finalize:
+                    # the sums of the dgrad epilogue straight into the column reduction: two small launches instead of three
+                    self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
+                               _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, float(wpt * L), _p(b["c1"]),
+                               _p(b["c2"]), _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
                 else:
-                    self._call("vm_bn_pool_bwd_reduce", _p(b["e"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
-                               _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, _p(b["pa"]), _p(b["pb"]), st)
-                self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                           _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
+                    if b.get("bnred_now"):
+                        self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
+                                   _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, _p(b["pa"]),
+                                   _p(b["pb"]), st)
+                    else:
+                        self._call("vm_bn_pool_bwd_reduce", _p(b["e"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
+                                   _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, _p(b["pa"]), _p(b["pb"]), st)
+                    self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                               _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
                 self._call("vm_conv1_fused_bwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
                            _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
                            c, pool, dt, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
@@ -618,8 +646,15 @@ class HipEncoderEngine:
                           _p(b["invstd"]), dm)
             else:
                 common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
+            fused_fin = False
             if sparse:
                 self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
+            elif b.get("bnred_now") and self.fused_sums_finalize:
+                self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
+                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
+                           float(wpt * L), _p(b["c1"]), _p(b["c2"]), _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)),
+                           _p(pl["cr_ws"]), st)
+                fused_fin = True
             elif b.get("bnred_now"):
                 self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
                            _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
@@ -631,8 +666,9 @@ class HipEncoderEngine:
                            _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             else:
                 self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
-            self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                     _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
+            if not fused_fin:
+                self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                           _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
                        wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
             side = self.overlap_wgrad and i > 0
@@ -747,8 +783,6 @@ class HipEncoderEngine:
         self._call("vm_adam_clip_step", _p(self.P), _p(self.G), _p(self.M), _p(self.V), self.n_flat, lr_t, self.beta_1,
                  self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale) / float(self.loss_scale),
                  _p(self._sqnorm), int(skip), _p(self._skipped) if skip else None, st)
-        if skip:
-            self._skip_total += self._skipped   # device-side count: no host sync in the step
         self.iterations = t
         self.refresh_weights()
 
