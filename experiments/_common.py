@@ -30,7 +30,7 @@ def base_parser(description, **defaults):
     p.add_argument("--n-shot", type=int, default=d["n_shot"])
     p.add_argument("--k-way", type=int, default=d["k_way"])
     p.add_argument("--no-pad", dest="pad", action="store_false", default=d["pad"])
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32s"])
+    p.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32", "f32s"])
     p.add_argument("--workers", type=int, default=min(8, os.cpu_count() or 1))
     p.add_argument("--synthetic", action="store_true", help="generated speakers instead of LibriSpeech on disk")
     p.add_argument("--device-data", metavar="DIR", default="",

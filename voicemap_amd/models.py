@@ -5,9 +5,10 @@ get_weights / set_weights / add / pop``) whose arithmetic runs on the HIP path (
     get_baseline_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05)   models.py:6
     build_siamese_net(encoder, input_shape, distance_metric='uniform_euclidean')                        models.py:44
 
-Extra keyword ``dtype`` selects storage and GEMM arithmetic: 'bf16' (default: bf16 tensors, bf16 MFMAs), 'f32' (fp32 tensors,
-fp32 MFMAs: the exact-parity mode) or 'f32s' (fp32 tensors, split-bf16 products in the k=3 conv GEMMs: ~1e-5 of 'f32' at
-~0.55x its step time).
+Extra keyword ``dtype`` selects storage and GEMM arithmetic: 'f16' (default: IEEE half tensors, f16 MFMAs, loss-scaled gradients --
+embeddings within 1e-3 of the fp32 arithmetic), 'bf16' (the same kernels with bf16 tensors: 2 % faster, 6e-3),
+'f32' (fp32 tensors, fp32 MFMAs: the exact-parity mode) or 'f32s' (fp32 tensors, split-bf16 products in the k=3 conv GEMMs: ~1e-5 of
+'f32' at ~0.55x its step time; section 4.6a).
 """
 from __future__ import annotations
 
@@ -315,7 +316,7 @@ class _TrainableModel:
 class ConvolutionalEncoder(_TrainableModel):
     """The Sequential returned by ``get_baseline_convolutional_encoder`` (voicemap/models.py:6-41)."""
 
-    def __init__(self, filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16", first_pool=4):
+    def __init__(self, filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="f16", first_pool=4):
         super().__init__()
         self.filters, self.embedding_dimension = int(filters), int(embedding_dimension)
         self.input_shape = tuple(input_shape) if input_shape is not None else None
@@ -481,7 +482,7 @@ class SpectrogramEncoder(ConvolutionalEncoder):
     image that ``vm_stft_logmel`` computes from the RAW 16 kHz window (so the batch pre-processor must not decimate or whiten:
     ``preprocess_instances(1, whitening=False)``)."""
 
-    def __init__(self, filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16", n_mels=64):
+    def __init__(self, filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="f16", n_mels=64):
         super().__init__(filters, embedding_dimension, input_shape, dropout, dtype)
         from . import spectro
         self.n_mels = int(n_mels)
@@ -521,7 +522,7 @@ class SpectrogramEncoder(ConvolutionalEncoder):
         raise NotImplementedError("Keras HDF5 checkpoints describe the reference's 1-D encoder; save the spectrogram variant as .npz")
 
 
-def get_spectrogram_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16", n_mels=64):
+def get_spectrogram_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="f16", n_mels=64):
     """The build function of the log-mel / 2-D CNN variant, same signature as ``get_baseline_convolutional_encoder``
     (voicemap/models.py:6); ``input_shape`` = (samples, 1) of the RAW window."""
     return SpectrogramEncoder(filters, embedding_dimension, input_shape, dropout, dtype=dtype, n_mels=n_mels)
@@ -653,7 +654,7 @@ class SiameseNet(_TrainableModel):
 # =========================================================================================================
 # the reference's two build functions
 # =========================================================================================================
-def get_baseline_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="bf16",
+def get_baseline_convolutional_encoder(filters, embedding_dimension, input_shape=None, dropout=0.05, dtype="f16",
                                        first_pool=4):
     """voicemap/models.py:6-41.  ``input_shape`` only matters for ``summary()``: the siamese wrapper supplies it
     (models.py:10-16).  ``first_pool=2`` reproduces the geometry of the checkpoint the reference ships."""
@@ -709,11 +710,11 @@ def load_model(filepath: str, custom_objects=None, dtype=None):
 
 def _load_keras_hdf5(filepath: str, dtype=None):
     """``dtype``: activation storage mode of the loaded model; default = what the file records (files written here) or
-    "bf16" (files written by Keras carry no such thing)."""
+    "f16" (files written by Keras carry no such thing)."""
     from . import keras_hdf5 as KH
     ck = KH.read_checkpoint(filepath)
     g = ck["config"]
-    dtype = dtype or g.get("dtype") or "bf16"
+    dtype = dtype or g.get("dtype") or "f16"
     enc = get_baseline_convolutional_encoder(g["filters"], g["embedding_dimension"], input_shape=g["input_shape"],
                                              dropout=g["dropout"], dtype=dtype, first_pool=g["first_pool"])
     if ck["kind"] == "classifier":
@@ -738,7 +739,7 @@ def contrastive_loss_by_name(loss):
     return "contrastive_loss" if loss == "contrastive_loss" else loss
 
 
-def load_keras_checkpoint_npz(weights_npz: str, dtype="bf16"):
+def load_keras_checkpoint_npz(weights_npz: str, dtype="f16"):
     """Build the siamese model of the reference's shipped Keras checkpoint from its exported arrays
     (tests/golden/ckpt_cfgCK_weights.npz, produced by tests/golden/extract_reference_fixtures.py with h5py): filters and
     embedding size are read from the arrays; first pool 2 and the weighted-L1 head are that checkpoint's geometry

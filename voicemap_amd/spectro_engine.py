@@ -29,7 +29,7 @@ from .engine import HEADS, LOSSES, FlatState, HipEncoderEngine, _DT, _TORCH_DT, 
 class HipSpectrogramEncoderEngine(HipEncoderEngine):
     """filters F -> channels F, 2F, 3F, 4F; head: None | 'uniform_euclidean' | 'weighted_l1'."""
 
-    def __init__(self, filters: int, embedding_dimension: int, dropout: float = 0.05, head: Optional[str] = None, dtype: str = "bf16",
+    def __init__(self, filters: int, embedding_dimension: int, dropout: float = 0.05, head: Optional[str] = None, dtype: str = "f16",
                  device="cuda", bn_eps: float = 1e-3, bn_momentum: float = 0.99, unbiased_moving_variance: bool = True,
                  seed: Optional[int] = None, n_mels: int = spectro.N_MELS, win_length: int = spectro.WIN_LENGTH,
                  hop: int = spectro.HOP, log_floor: float = spectro.LOG_FLOOR):
