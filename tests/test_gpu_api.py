@@ -298,3 +298,40 @@ def test_f32s_model_tracks_f32_model_through_the_public_api(tmp_path):
     loaded = models.load_model(path)
     assert loaded._ensure_engine().dtype == nets["f32s"].engine.dtype
     assert np.array_equal(loaded.predict(x), pb)
+
+
+def test_k_way_accuracy_script_cached_sweep(tmp_path, monkeypatch):
+    """experiments/k_way_accuracy.py (the reference's sweep, experiments/k_way_accuracy.py:52-69) in its --cached form: the model is
+    saved as a Keras HDF5 file, loaded back, the evaluation set is embedded ONCE and every (k, n) cell runs on the cached matrix --
+    with the reference-order task draws and with the device sampler; the CSV has the reference's columns, and under the script's seed
+    the cached cells equal retrieval.n_shot_task_evaluation_cached called by hand."""
+    import config
+    from experiments import k_way_accuracy
+    from voicemap_amd import models as VM, retrieval as R, utils as VU
+    from voicemap_amd.librispeech import SyntheticSpeechDataset
+    monkeypatch.setattr(config, "PATH", str(tmp_path))
+    monkeypatch.setattr(k_way_accuracy, "PATH", str(tmp_path))
+    os.makedirs(os.path.join(str(tmp_path), "logs"), exist_ok=True)
+    torch.manual_seed(2)
+    enc = VM.get_baseline_convolutional_encoder(16, 16, dropout=0.0, dtype="f32")
+    net = VM.build_siamese_net(enc, (12000, 1))
+    net.compile(loss="binary_crossentropy", optimizer="adam")
+    path = os.path.join(str(tmp_path), "siamese.hdf5")
+    net.save(path)
+    args = ["--siamese", path, "--synthetic", "--k-way", "2", "5", "--n-shot", "1", "3", "--num-tasks", "40", "--distance", "cosine", "--cached"]
+    df = k_way_accuracy.main(args)       # (the script seeds np.random itself: experiments/_common.setup)
+    assert list(df.columns) == ["method", "n_correct", "n_tasks", "n", "k"] and len(df) == 4
+    assert ((df["n_correct"] >= 0) & (df["n_correct"] <= 40)).all()
+    rows = open(os.path.join(str(tmp_path), "logs", "k-way_n-shot_accuracy_dev-clean_cosine.csv")).read().strip().splitlines()
+    assert rows[0] == "method,n_correct,n_tasks,n_shot,k_way" and len(rows) == 5
+    # the same cells by hand, same seed
+    valid = SyntheticSpeechDataset(num_speakers=40, files_per_speaker=12, seconds=3, stochastic=False, seed=1)
+    pre = VU.BatchPreProcessor("siamese", VU.preprocess_instances(4))
+    loaded = VM.load_model(path)
+    cache = R.embed_corpus(loaded, valid, pre)
+    from experiments import _common as C
+    C.seed_everything(0, 0)              # what setup() did before the script's first draw
+    want = [R.n_shot_task_evaluation_cached(loaded, valid, pre, 40, n, k, "siamese", "cosine", cache=cache) for k in (2, 5) for n in (1, 3)]
+    assert list(df["n_correct"]) == want
+    df2 = k_way_accuracy.main(args + ["--device-sampler"])
+    assert len(df2) == 4 and ((df2["n_correct"] >= 0) & (df2["n_correct"] <= 40)).all()

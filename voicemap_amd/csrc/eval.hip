@@ -111,7 +111,7 @@ constexpr int NSI_MAX_EL = 4;  // elements of an embedding per lane: E <= 256
 // vm_nshot_indexed: one wave per task, lane <-> embedding component(s); the arithmetic of voicemap/utils.py:159-206 in float64
 // (per-class mean of the support embeddings -> L2; mean of the unit vectors -> cosine; mean magnitude x mean unit vector -> negative
 // dot product), the rows gathered from the cached matrix by index.
-__global__ __launch_bounds__(256) void nshot_indexed_kernel(const float* __restrict__ emb, const int32_t* __restrict__ query_idx,
+__global__ __launch_bounds__(256) void nshot_indexed_kernel(const float* __restrict__ emb, int64_t n_rows, const int32_t* __restrict__ query_idx,
                                                             const int32_t* __restrict__ support_idx, int64_t tasks, int k, int n, int E,
                                                             int dist_kind, float* __restrict__ pred, int32_t* __restrict__ argmin_out) {
     const int lane = threadIdx.x & 63;
@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void nshot_indexed_kernel(const float* __restr
     if (task >= tasks) return;
     const int EL = (E + 63) / 64;
     double q[NSI_MAX_EL];
-    const float* qrow = emb + (int64_t)query_idx[task] * E;
+    // an index outside [0, n_rows) never leaves the matrix: it is clamped (and the task is then simply wrong -- the host checks ranges)
+    auto row_of = [&](int32_t i) { return emb + (int64_t)(i < 0 ? 0 : (i >= n_rows ? n_rows - 1 : i)) * E; };
+    const float* qrow = row_of(query_idx[task]);
     double q2 = 0.0;
 #pragma unroll
     for (int u = 0; u < NSI_MAX_EL; ++u) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void nshot_indexed_kernel(const float* __restr
         for (int u = 0; u < NSI_MAX_EL; ++u) acc[u] = 0.0;
         double magsum = 0.0;
         for (int i = 0; i < n; ++i) {
-            const float* srow = emb + (int64_t)sidx[cls * n + i] * E;
+            const float* srow = row_of(sidx[cls * n + i]);
             double v[NSI_MAX_EL], m2 = 0.0;
 #pragma unroll
             for (int u = 0; u < NSI_MAX_EL; ++u) {
@@ -365,7 +367,7 @@ extern "C" int vm_nshot_indexed(const float* emb, int64_t n_rows, const int32_t*
     VM_REQUIRE(dist_kind >= VM_DIST_EUCLIDEAN && dist_kind <= VM_DIST_DOT,
                "vm_nshot_indexed: Distance must be in (euclidean, cosine, dot_product)");
     VM_REQUIRE((tasks + 3) / 4 < (1LL << 31), "vm_nshot_indexed: too many tasks for one launch");
-    hipLaunchKernelGGL(vm::nshot_indexed_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, query_idx,
+    hipLaunchKernelGGL(vm::nshot_indexed_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, n_rows, query_idx,
                        support_idx, tasks, k, n, E, dist_kind, pred, argmin);
     return vm::check_launch("vm_nshot_indexed");
 }

@@ -223,6 +223,8 @@ def evaluate_tasks(cache: EmbeddingCache, query_idx, support_idx, k: int, n: int
     if tasks == 0:
         return (0, None) if return_pred else 0
     assert s.numel() == tasks * k * n
+    if int(torch.minimum(q.min(), s.min())) < 0 or int(torch.maximum(q.max(), s.max())) >= cache.n:
+        raise IndexError("task indices outside the cached matrix (0 .. %d)" % (cache.n - 1))
     am = torch.empty(tasks, dtype=torch.int32, device=dev)
     pred = torch.empty(tasks, k, dtype=torch.float32, device=dev) if return_pred else None
     _lib.lib().call("vm_nshot_indexed", cache.emb.data_ptr(), cache.n, q.data_ptr(), s.data_ptr(), tasks, k, n, cache.E, _DIST[distance],
