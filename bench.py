@@ -59,6 +59,9 @@ def conv_launch_work(name, args, esize):
     fused = args[-1] if args and isinstance(args[-1], str) else ""
     shape = {"n_windows": n, "L": L, "c_in": cin, "c_out": cout, "fused": fused}
     extra = {"vm_conv_fwd_e": n * (L // 2) * cout, "vm_conv_dgrad_bnred": n * L * cin}.get(fused, 0)
+    if fused == "vm_conv_fwd_fold" and args[base + 8] is not None:   # (in_e, wf, bias, n, L, c_in, c_out, dtype, z, sum, sq, e, ...)
+        extra = n * (L // 2) * cout
+        shape["fused"] = "vm_conv_fwd_fold+e"
     return (n * L * (cin + cout) + extra) * esize, 2.0 * n * L * 3 * cin * cout, shape
 
 
@@ -119,7 +122,7 @@ def main():
         return e
     eng = make_engine(a.dtype)
     ENGINE_SWITCHES = {"overlap_wgrad": bool, "pooled_reduce": bool, "split_towers": bool, "fused_bn_reduce": bool, "wgrad_after_dgrad": bool,
-                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool}
+                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool, "fold_affine": bool}
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
         if k in ENGINE_SWITCHES:
@@ -215,22 +218,23 @@ def main():
     was_split, eng.split_towers = eng.split_towers, False   # one launch per GEMM of the step, nothing else in flight
     snap0 = snapshot(eng)
     eng.timed = {nm: [] for nm in gemm}
-    for _ in range(max(5, min(a.steps, 20))):
+    attr_steps = max(5, min(a.steps, 20))
+    for _ in range(attr_steps):
         step()
     torch.cuda.synchronize()
     fam = {}
     for nm in gemm:
         by_shape = {}
         for e0, e1, args in eng.timed[nm]:
-            nb_, nf_, shp = conv_launch_work(nm, args, esize)
-            by_shape.setdefault(tuple(shp.values()), []).append(e0.elapsed_time(e1) * 1e-3)
+            work = conv_launch_work(nm, args, esize)
+            by_shape.setdefault(tuple(work[2].values()), (work, []))[1].append(e0.elapsed_time(e1) * 1e-3)
         launches = []
-        for key, ts in by_shape.items():
+        for key, ((nb_, nf_, shp), ts) in by_shape.items():
             t_med = float(np.median(ts))
-            nb_, nf_, shp = conv_launch_work(nm, (None,) * {"vm_conv_fwd": 3, "vm_conv_dgrad": 2, "vm_conv_wgrad": 2}[nm] + key[:4] + (key[4],), esize)
+            # (the folded forward launches every layer once per tower: ``per_step`` launches of this shape in a step)
             launches.append({"shape": shp, "ms": t_med * 1e3, "tflops": nf_ / t_med / 1e12, "gbs": nb_ / t_med / 1e9,
-                             "algorithmic_bytes": nb_, "flops": nf_})
-        fam[nm] = {"ms_per_step": sum(l["ms"] for l in launches), "launches": launches}
+                             "algorithmic_bytes": nb_, "flops": nf_, "per_step": len(ts) // attr_steps})
+        fam[nm] = {"ms_per_step": sum(l["ms"] * l["per_step"] for l in launches), "launches": launches}
     eng.timed = {}
     eng.overlap_wgrad = was_overlap
     eng.split_towers = was_split
@@ -263,9 +267,10 @@ def main():
     roof["launch_shape"] = shape
     # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense 16-bit peak) and algorithmic GB/s
     roof["families_serial"] = {nm: {"ms_per_step": round(f["ms_per_step"], 4), "kernel_symbol": KERNEL_SYMBOL[nm].format(T=CTYPE.get(a.dtype, a.dtype)),
-                                    "frac_of_mfma_peak": round(sum(l["flops"] for l in f["launches"]) / (f["ms_per_step"] * 1e-3) / 1e12
+                                    "frac_of_mfma_peak": round(sum(l["flops"] * l["per_step"] for l in f["launches"]) / (f["ms_per_step"] * 1e-3) / 1e12
                                                                / MFMA_16BIT_PEAK_TF, 4),
                                     "launches": [{"L": l["shape"]["L"], "c_in": l["shape"]["c_in"], "c_out": l["shape"]["c_out"], "fused": l["shape"]["fused"],
+                                                  "n_windows": l["shape"]["n_windows"], "per_step": l["per_step"],
                                                   "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                                   "algorithmic_gbs": round(l["gbs"], 1)} for l in f["launches"]]}
                                for nm, f in fam.items()}
@@ -277,7 +282,7 @@ def main():
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
                  "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_from_sums_finalize", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
-                 "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_conv_wgrad",
+                 "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_du_tower_sums", "vm_fold_bn_weights", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights", "vm_prep_conv_weights_batch"]
         eng.timed = {nm: [] for nm in names}
         was_overlap, eng.overlap_wgrad = eng.overlap_wgrad, False  # serial, so that every entry point is attributable

@@ -47,8 +47,10 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 3.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
- * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3). */
+/* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
+ * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
+ * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums; vm_conv1_fused_fwd mode 2; `wt` in
+ * vm_prep_conv_weights_batch) (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -107,6 +109,8 @@ int vm_conv1_wgrad(const float* x, const void* du, int64_t n_windows, int64_t L,
  *     backward recompute all see the same fp32 values.
  *   inference (inference = 1): out = padded act (n_windows, L/pool + 2, F) bf16 = bf16(extreme * scale + shift);
  *     gamma_or_scale = scale, shift from vm_bn_infer_affine.
+ *   training, padded extreme (inference = 2): as 0, but e is written as a padded activation tensor (n_windows, L/pool + 2, F), rows
+ *     1 .. L/pool (halo rows untouched: the caller zeroes them once) -- the input layout of vm_conv_fwd_fold.
  * pool: 2 or 4. */
 int vm_conv1_fused_fwd(const float* x, const float* w, const float* bias, const float* gamma_or_scale, const float* shift,
                        int64_t n_windows, int64_t L, int F, int pool, int inference, int dtype, void* out, float* stat_sum,
@@ -135,6 +139,25 @@ int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_win
 int vm_conv_fwd_e_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
 int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float* gamma, int64_t n_windows, int64_t L,
                   int c_in, int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* e, void* stream);
+/* Training forward WITHOUT the BatchNorm / pool pass between two blocks (dropout rate 0).  The max-pool of a BatchNorm output picks
+ * the pool-window extreme e of the conv output (vm_conv_fwd_e, vm_conv1_fused_fwd), and BatchNorm is a per-channel affine
+ * y = scale[c] * e + shift[c] -- so the next Conv1D can read e itself with the affine folded into its weights:
+ *     conv(y)[t][co] = sum_k sum_ci (W[k][ci][co] * scale[ci]) * e[t + k - 1][ci]  +  bias[co] + sum_{k inside} hb[k][co],
+ *     hb[k][co] = sum_ci W[k][ci][co] * shift[ci];   tap 0 is outside the window at t = 0, tap 2 at t = L - 1 (SAME pads y with 0).
+ * BatchNorm statistics are per encoder call ("tower": windows [t * windows_per_tower, (t + 1) * windows_per_tower)), so there is one
+ * set of folded weights per tower.  vm_fold_bn_weights: wt = the fp32 kernel in wf's layout (c_out, 3 * c_in) (the `wt` output of
+ * vm_prep_conv_weights_batch) + scale / shift (towers, c_in) -> wf_folded (towers, c_out, 3 * c_in) `dtype` and hb (towers, 3, c_out)
+ * fp32.  vm_conv_fwd_fold: in_e = padded extreme (n_windows, L + 2, c_in) of the layer below (zero halo
+ * rows), z / stat_* as vm_conv_fwd; e (optional) = this layer's own extreme for MaxPool1D(2), PADDED (n_windows, L/2 + 2, c_out), the
+ * maximum where gamma >= 0 else the minimum.  16-bit storage, conv_nt2r_kernel shapes only (vm_conv_fwd_fold_supported).  The
+ * pooled BatchNorm output is never materialised: -1 read and -1 write of it per block and no pass over z in the forward.
+ * vm_conv_wgrad_fold is the matching weight gradient, vm_conv_dgrad[_bnred] is unchanged (it takes the un-folded wd). */
+int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, int towers, int c_in, int c_out, int dtype,
+                       void* wf_folded, float* hb, void* stream);
+int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e);
+int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
+                     int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z, float* stat_sum,
+                     float* stat_sq, void* e, void* stream);
 /* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
  * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
  * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by
@@ -166,11 +189,20 @@ int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out);
 int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out);
 int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
                   void* ws, float* grad_w, void* stream);
+/* wgrad of a layer that ran vm_conv_fwd_fold: the layer's true input is y = scale_t[ci] * e + shift_t[ci] inside the window (t = the
+ * tower of the window: n_windows / windows_per_tower towers, scale / shift (towers, c_in)), 0 in the padding, hence
+ *     dW[k][ci][co] = sum_t scale_t[ci] * (sum_{n in t, pos} e[n][pos+k][ci] * du[n][pos+1][co]) + shift_t[ci] * dsum[t][k][co]
+ * -- the same split GEMM on e with every slab inside one tower, then one fixed-order pass that sums the slabs per tower and applies
+ * the two factors.  dsum (towers, 3, c_out) from vm_du_tower_sums. */
+int64_t vm_conv_wgrad_fold_workspace_bytes(int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out);
+int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out,
+                       int dtype, const float* scale, const float* shift, const float* dsum, void* ws, float* grad_w, void* stream);
 /* fp32 Keras kernel (3, c_in, c_out) -> wf (c_out, 3*c_in) and wd (c_in, 3*c_out) in `dtype`. */
 int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream);
-/* the same for n_layers (<= 8) layers in ONE launch: host arrays of device pointers / channel counts, one entry per layer. */
+/* the same for n_layers (<= 8) layers in ONE launch: host arrays of device pointers / channel counts, one entry per layer.  wt
+ * (optional array, entries may be NULL): also the fp32 kernel itself in wf's layout (c_out, 3*c_in) -- what vm_fold_bn_weights reads. */
 int vm_prep_conv_weights_batch(int n_layers, const float* const* w, const int* c_in, const int* c_out, int dtype,
-                               void* const* wf, void* const* wd, void* stream);
+                               void* const* wf, void* const* wd, float* const* wt, void* stream);
 
 /* ---- a1-BN: BatchNormalization()  (voicemap/models.py:17,23,28,33; Keras defaults eps 1e-3, momentum .99)
  * Reduces the conv partials per tower in a fixed order (fp64), producing per-tower
@@ -253,6 +285,12 @@ int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gid
                               float* part_du, void* stream);
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
+/* vm_colsum of the apply pass's part_du (n_windows * vm_bn_part_rows(), C) per tower, plus what vm_conv_wgrad_fold needs:
+ * dsum[t][k][c] = sum over the windows of tower t and the positions whose tap k lies inside the window of du[n][pos][c] (k = 1: all
+ * positions; k = 0: all but position 0; k = 2: all but position L - 1; du: padded (n_windows, L + 2, C) `dtype`).  grad_b (optional,
+ * C) = the sum over all towers (the conv bias gradient).  ws: vm_colreduce_workspace_bytes(towers, C). */
+int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int dtype,
+                     float* grad_b, float* dsum, void* ws, void* stream);
 
 /* LAST block only: vm_bn_drop_pool_fwd fused with GlobalMaxPool1D (voicemap/models.py:31-37).  The pooled tensor of the
  * last block is never materialised: gmax / gidx are exactly what vm_global_maxpool_fwd would return for it (values rounded

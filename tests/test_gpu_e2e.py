@@ -313,9 +313,23 @@ def test_full_size_properties_cfgA_bf16():
         d_nt = rel_err(eng.NT.cpu().numpy(), nt1.cpu().numpy())
         report("full_size_cfgA", "tower_split_vs_one_launch_%s_emb" % dtype, d_emb)
         report("full_size_cfgA", "tower_split_vs_one_launch_%s_grad" % dtype, d_g)
-        assert d_emb < (1e-5 if dtype == "f32" else 3e-3) and d_nt < 1e-5 and d_g < (1e-4 if dtype == "f32" else 5e-2), (d_emb, d_g, d_nt)
+        assert d_emb < (1e-5 if dtype == "f32" else 3e-3) and d_nt < (1e-5 if dtype == "f32" else 3e-5), (d_emb, d_nt)
+        assert d_g < (1e-4 if dtype == "f32" else 5e-2), d_g
         assert torch.isfinite(eng.G).all() and torch.isfinite(loss1).all()
         if dtype == "bf16":
+            assert pl["fold_now"], "the folded-BatchNorm forward must serve cfg-A"
+            # the options below belong to the un-folded path (BatchNorm / pool pass between the blocks): compare them there
+            eng.fold_affine = False
+            eng.init_params(1234)
+            pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,
+                                        apply_update=False)
+            torch.cuda.synchronize()
+            assert not pl["fold_now"]
+            d_emb = rel_err(pl["emb"].cpu().numpy(), emb.cpu().numpy())
+            report("full_size_cfgA", "folded_vs_unfolded_bf16_emb", d_emb)
+            report("full_size_cfgA", "folded_vs_unfolded_bf16_grad_cosine", cosine(eng.G.cpu().numpy(), g1.cpu().numpy()))
+            assert d_emb < 1e-2 and cosine(eng.G.cpu().numpy(), g1.cpu().numpy()) > 0.9
+            g1 = eng.G.clone()
             eng.split_towers = not eng.split_towers   # back to the default (the block above left it toggled)
             eng.fused_pool_extreme = True             # option: the conv epilogue leaves the pool-window extreme (vm_conv_fwd_e)
             eng.init_params(1234)

@@ -1,0 +1,248 @@
+"""-m gpu parity of the folded-BatchNorm training path (vm_fold_bn_weights, vm_conv_fwd_fold, vm_du_tower_sums, vm_conv_wgrad_fold and the
+engine mode that strings them together: ``HipEncoderEngine.fold_affine``).
+
+What is folded: models.py:20-35 of the reference puts BatchNormalization -> SpatialDropout1D -> MaxPool1D between two Conv1D layers.
+With dropout rate 0 the pooled BatchNorm output is y = scale[c] * e + shift[c], e = the pool-window extreme of the conv output, so the
+next conv can run on e with W * scale as weights and the shift as per-tap constants -- except in the SAME padding, where y (not e) is
+0.  The tests compare every kernel with that definition evaluated in float64 on the same (storage-rounded) operands, and the whole
+training step with the float64 oracle and with the un-folded engine path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voicemap_oracle as O
+from tests.gpu_util import DTYPES, L, dev, grad_close, p, padded, quant, rel_err, report, stream
+
+pytestmark = pytest.mark.gpu
+
+DT16 = ["f16", "bf16"]
+
+
+def _fold_weights(w, s, h, dtype):
+    """w (3, c_in, c_out) Keras kernel, s / h (towers, c_in) or (c_in,) -> wf (towers, c_out, 3 * c_in), hb (towers, 3, c_out)."""
+    vm, tdt = DTYPES[dtype]
+    cin, cout = w.shape[1], w.shape[2]
+    s, h = np.atleast_2d(s), np.atleast_2d(h)
+    towers = s.shape[0]
+    wt = np.ascontiguousarray(w.transpose(2, 0, 1).reshape(cout, 3 * cin))   # the `wt` output of vm_prep_conv_weights_batch
+    wf = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda")
+    hb = torch.empty(towers, 3, cout, dtype=torch.float32, device="cuda")
+    L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), towers, cin, cout, vm, p(wf), p(hb), stream())
+    torch.cuda.synchronize()
+    return wf, hb
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("cin,cout", [(128, 256), (40, 24)])
+def test_fold_bn_weights(dtype, cin, cout):
+    r = np.random.default_rng(cin + cout)
+    w = r.normal(0, 0.1, (3, cin, cout)).astype(np.float32)
+    s = r.normal(0, 2.0, (2, cin)).astype(np.float32)
+    h = r.normal(0, 1.0, (2, cin)).astype(np.float32)
+    wf, hb = _fold_weights(w, s, h, dtype)
+    for t in range(2):
+        # the fp32 product rounded to the storage type, or -- where the compiler picks a mixed-precision fma (v_fma_mixlo_f16) -- the
+        # exact product rounded once; the two differ only on double-rounding ties
+        want = quant((w * s[t][None, :, None]).astype(np.float32), dtype).numpy()
+        want1 = quant(w.astype(np.float64) * s[t][None, :, None].astype(np.float64), dtype).numpy()
+        got = wf[t].to(torch.float64).cpu().numpy().reshape(cout, 3, cin).transpose(1, 2, 0)  # (c_out, 3 * c_in) -> (3, c_in, c_out)
+        assert ((got == want) | (got == want1)).all()
+        hb_ref = np.einsum("kio,i->ko", w.astype(np.float64), h[t].astype(np.float64))
+        assert np.abs(hb[t].cpu().numpy() - hb_ref).max() < 1e-5 * max(1.0, np.abs(hb_ref).max())
+
+
+def _fold_case(r, n, Lw, cin, cout, dtype):
+    e = np.abs(r.normal(0, 1.0, (n, Lw, cin)))                 # a pool extreme of relu(conv) is >= 0
+    e = quant(e, dtype).numpy()
+    w = r.normal(0, 0.6 / np.sqrt(3 * cin), (3, cin, cout)).astype(np.float32)
+    bias = r.normal(0, 0.1, cout).astype(np.float32)
+    s = (r.normal(1.0, 0.3, cin) * np.where(r.random(cin) < 0.2, -1, 1)).astype(np.float32)
+    h = r.normal(0.0, 0.7, cin).astype(np.float32)             # large on purpose: a missing edge correction would be a gross error
+    gamma = (r.normal(1.0, 0.2, cout) * np.where(r.random(cout) < 0.25, -1, 1)).astype(np.float32)
+    return e, w, bias, s, h, gamma
+
+
+def _conv_same(y, w):
+    """y (n, L, c_in) float64, w (3, c_in, c_out) -> (n, L, c_out): Conv1D(3, padding='same') of the reference (cross-correlation)."""
+    n, Lw, _ = y.shape
+    yp = np.zeros((n, Lw + 2, y.shape[2]))
+    yp[:, 1:Lw + 1] = y
+    return sum(np.einsum("nli,io->nlo", yp[:, k:k + Lw], w[k]) for k in range(3))
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("n,Lw,cin,cout,with_e", [(3, 508, 128, 256, True), (2, 254, 256, 128, False), (2, 1016, 64, 128, True),
+                                                  (1, 300, 32, 128, True)])
+def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
+    vm, tdt = DTYPES[dtype]
+    if not L().query("vm_conv_fwd_fold_supported", n, Lw, cin, cout, vm, int(with_e)):
+        pytest.skip("shape not served by conv_nt2r_kernel")
+    r = np.random.default_rng(Lw + cin)
+    e, w, bias, s, h, gamma = _fold_case(r, n, Lw, cin, cout, dtype)
+    towers = 2 if n % 2 == 0 else 1                            # an even window count runs as two towers with their own affines
+    wpt = n // towers
+    s = np.stack([s, (s * r.normal(1.0, 0.2, cin)).astype(np.float32)][:towers])
+    h = np.stack([h, (h + r.normal(0.0, 0.3, cin)).astype(np.float32)][:towers])
+    wf, hb = _fold_weights(w, s, h, dtype)
+    rows = L().query("vm_conv_stat_rows", Lw)
+    z = torch.empty(n, Lw, cout, dtype=tdt, device="cuda")
+    ssum = torch.empty(n * rows, cout, dtype=torch.float32, device="cuda")
+    ssq = torch.empty_like(ssum)
+    eo = torch.full((n, Lw // 2 + 2, cout), 7.0, dtype=tdt, device="cuda") if with_e else None
+    L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
+             vm, p(z), p(ssum), p(ssq), p(eo), stream())
+    torch.cuda.synchronize()
+    # the definition, with the weights the kernel multiplies by (W * scale rounded to the storage type) and exact shift terms
+    zr = np.empty((n, Lw, cout))
+    for t in range(towers):
+        wq = quant((w * s[t][None, :, None]).astype(np.float32), dtype).numpy()
+        ones = np.ones((wpt, Lw, cin))
+        zr[t * wpt:(t + 1) * wpt] = np.maximum(_conv_same(e[t * wpt:(t + 1) * wpt], wq)
+                                               + _conv_same(ones * h[t][None, None, :].astype(np.float64), w.astype(np.float64)) + bias, 0.0)
+    zg = z.to(torch.float64).cpu().numpy()
+    tol = 2e-3 if dtype == "f16" else 1.2e-2
+    report("conv_fwd_fold[%s]" % dtype, "rel_err[n%d L%d %d->%d]" % (n, Lw, cin, cout), rel_err(zg, zr))
+    assert rel_err(zg, zr) < tol
+    for pos in (0, Lw - 1):   # the positions whose padding tap must NOT see the shift
+        assert rel_err(zg[:, pos], zr[:, pos]) < 2 * tol, pos
+    # statistics = sums of the STORED values; the extreme = pair max / min of the stored values by sign(gamma), padded layout
+    assert np.allclose(ssum.cpu().numpy().reshape(n, rows, cout).sum(1), zg.sum(1), rtol=1e-4, atol=1e-3)
+    assert np.allclose(ssq.cpu().numpy().reshape(n, rows, cout).sum(1), (zg * zg).sum(1), rtol=1e-4, atol=1e-3)
+    if with_e:
+        pairs = zg.reshape(n, Lw // 2, 2, cout)
+        want = np.where(gamma[None, None, :] >= 0, pairs.max(2), pairs.min(2))
+        eg = eo.to(torch.float64).cpu().numpy()
+        assert np.array_equal(eg[:, 1:-1], want)
+        assert (eg[:, 0] == 7.0).all() and (eg[:, -1] == 7.0).all()   # halo rows are the caller's
+
+
+@pytest.mark.parametrize("dtype", DT16)
+def test_du_tower_sums(dtype):
+    vm, tdt = DTYPES[dtype]
+    r = np.random.default_rng(5)
+    n, wpt, Lw, c = 6, 3, 40, 72
+    prow = L().query("vm_bn_part_rows")
+    pdu = r.normal(0, 1, (n * prow, c)).astype(np.float32)
+    du = quant(r.normal(0, 1, (n, Lw, c)), dtype).numpy()
+    gb = torch.empty(c, dtype=torch.float32, device="cuda")
+    ds = torch.empty(2, 3, c, dtype=torch.float32, device="cuda")
+    ws = torch.empty(L().query("vm_colreduce_workspace_bytes", 2, c) // 8, dtype=torch.float64, device="cuda")
+    L().call("vm_du_tower_sums", p(dev(pdu)), p(padded(du, tdt)), n, wpt, Lw, c, vm, p(gb), p(ds), p(ws), stream())
+    torch.cuda.synchronize()
+    cs = pdu.astype(np.float64).reshape(2, wpt * prow, c).sum(1)
+    want = np.stack([cs - du.reshape(2, wpt, Lw, c)[:, :, 0].sum(1), cs, cs - du.reshape(2, wpt, Lw, c)[:, :, -1].sum(1)], 1)
+    assert np.abs(ds.cpu().numpy() - want).max() < 1e-4
+    assert np.abs(gb.cpu().numpy() - cs.sum(0)).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("n,wpt,Lw,cin,cout", [(6, 3, 254, 128, 128), (4, 4, 100, 64, 192), (10, 5, 61, 40, 24)])
+def test_conv_wgrad_fold_matches_definition(dtype, n, wpt, Lw, cin, cout):
+    vm, tdt = DTYPES[dtype]
+    r = np.random.default_rng(n * Lw)
+    towers = n // wpt
+    e = quant(np.abs(r.normal(0, 1, (n, Lw, cin))), dtype).numpy()
+    du = quant(r.normal(0, 1, (n, Lw, cout)), dtype).numpy()
+    s = r.normal(1.0, 0.5, (towers, cin)).astype(np.float32)
+    h = r.normal(0.0, 0.7, (towers, cin)).astype(np.float32)
+    # D_t[k] from the definition (vm_du_tower_sums is tested above)
+    dut = du.reshape(towers, wpt, Lw, cout)
+    cs = dut.sum((1, 2))
+    dsum = np.stack([cs - dut[:, :, 0].sum(1), cs, cs - dut[:, :, -1].sum(1)], 1).astype(np.float32)
+    ws = torch.empty(L().query("vm_conv_wgrad_fold_workspace_bytes", n, wpt, Lw, cin, cout) // 4 + 16, dtype=torch.float32, device="cuda")
+    gw = torch.empty(3, cin, cout, dtype=torch.float32, device="cuda")
+    L().call("vm_conv_wgrad_fold", p(padded(e, tdt)), p(padded(du, tdt)), n, wpt, Lw, cin, cout, vm, p(dev(s)), p(dev(h)), p(dev(dsum)),
+             p(ws), p(gw), stream())
+    torch.cuda.synchronize()
+    # definition: the layer's input is y = s_t * e + h_t inside the window, 0 in the padding
+    y = e.reshape(towers, wpt, Lw, cin) * s[:, None, None, :].astype(np.float64) + h[:, None, None, :].astype(np.float64)
+    yp = np.zeros((n, Lw + 2, cin))
+    yp[:, 1:Lw + 1] = y.reshape(n, Lw, cin)
+    want = np.stack([np.einsum("nli,nlo->io", yp[:, k:k + Lw], du) for k in range(3)])
+    err = rel_err(gw.cpu().numpy(), want)
+    report("conv_wgrad_fold[%s]" % dtype, "rel_err[n%d L%d %d->%d]" % (n, Lw, cin, cout), err)
+    assert err < 2e-5
+
+
+def _fold_arch_case(seed, pairs, l0, f=128, e=64):
+    """An encoder whose k = 3 layers ARE served by conv_nt2r_kernel at a small window (channels 128..512, lengths 1016 / 508 / 254)."""
+    arch = O.EncoderArch.baseline(f, e, dropout=0.0)
+    p_ = O.init_params(arch, head="uniform_euclidean", seed=seed)
+    r = np.random.default_rng(seed)
+    for i in range(1, 5):
+        c = p_[f"bn{i}.gamma"].shape[0]
+        p_[f"bn{i}.gamma"] = torch.tensor(r.normal(1.0, 0.2, c) * np.where(r.random(c) < 0.15, -1, 1))
+        p_[f"bn{i}.beta"] = torch.tensor(r.normal(0.0, 0.2, c))
+        p_[f"conv{i}.bias"] = torch.tensor(r.normal(0.0, 0.05, c))
+    mk = lambda: O.whiten(r.normal(0, 0.05, (pairs, l0, 1)) + r.uniform(-0.01, 0.01, (pairs, 1, 1))).astype(np.float32).astype(np.float64)
+    x1, x2 = mk(), mk()
+    y = np.concatenate([np.zeros(pairs // 2), np.ones(pairs - pairs // 2)])[:, None]
+    return arch, p_, x1, x2, y
+
+
+def _run(arch, p_, x1, x2, y, dtype, fold, split=True, loss="contrastive"):
+    from voicemap_amd.engine import HipEncoderEngine
+    eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=0.0, head="uniform_euclidean", dtype=dtype)
+    eng.set_params({k: v.numpy() for k, v in p_.items()})
+    eng.fold_affine = fold
+    eng.split_towers = split
+    pl = eng.siamese_train_step(x1, x2, y, loss=loss, drop_masks=None)
+    torch.cuda.synchronize()
+    return eng, pl
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("split", [True, False])
+def test_folded_train_step_matches_oracle_and_unfolded_path(dtype, split):
+    """One train_on_batch with and without the fold against the float64 oracle (train_siamese.py:52-71 on models.py:6-60): the folded
+    embeddings must stay as close as the pass they replace (measured over six seeds at this size: 5-10 % further -- the weight
+    rounding now scales with |scale * e| instead of |y| -- against one storage rounding of y less; at cfg-A's size 6.9e-4 against
+    7.4e-4 in half, 5.5e-3 against 5.9e-3 in bf16, tests/test_gpu_fullsize_oracle.py).  Gradients of 16-bit storage are dominated
+    by max-pool re-routing (tests/test_gpu_e2e.py docstring), a discrete effect of which any change of the rounding pattern draws a
+    new sample: bounded loosely against the oracle here (tools/probe/fold_seeds.py prints both paths over seeds: equal on average)."""
+    arch, p_, x1, x2, y = _fold_arch_case(3, 4, 4064)
+    ref = O.siamese_train_step(arch, p_, O.AdamState(), torch.tensor(x1), torch.tensor(x2), torch.tensor(y))
+    e_ref = np.concatenate([ref["e1"].numpy(), ref["e2"].numpy()])
+    eng_f, pl_f = _run(arch, p_, x1, x2, y, dtype, True, split)
+    assert pl_f["fold_now"], "the folded path did not run on a shape it is built for"
+    eng_u, pl_u = _run(arch, p_, x1, x2, y, dtype, False, split)
+    assert not pl_u["fold_now"]
+    tag = "fold_step[%s-%s]" % (dtype, "split" if split else "serial")
+    err_f, err_u = rel_err(pl_f["emb"].cpu().numpy(), e_ref), rel_err(pl_u["emb"].cpu().numpy(), e_ref)
+    report(tag, "emb_rel_err_vs_fp64_folded", err_f)
+    report(tag, "emb_rel_err_vs_fp64_unfolded", err_u)
+    tol = 4e-3 if dtype == "f16" else 3e-2
+    assert err_f < tol and err_f < 1.25 * err_u
+    lf = pl_f["loss_acc"][0].item()
+    assert abs(lf - ref["loss"].item()) < tol * max(1.0, abs(ref["loss"].item()))
+    gf, gu = eng_f.get_grads(), eng_u.get_grads()
+    gtol = 0.3 if dtype == "f16" else 0.9
+    for k, g in ref["grads"].items():
+        report(tag, "grad_rel_err_vs_fp64_folded[%s]" % k, rel_err(gf[k], g.numpy()))
+        report(tag, "grad_rel_err_vs_fp64_unfolded[%s]" % k, rel_err(gu[k], g.numpy()))
+        assert grad_close(gf[k], g.numpy(), gtol, atol=1e-5), k
+    pf = eng_f.get_params()
+    for k, v in ref["params"].items():
+        if "moving" in k:
+            assert rel_err(pf[k], v.numpy()) < (3e-3 if dtype == "f16" else 2e-2), k
+    assert eng_f.skipped_steps() == 0
+
+
+def test_folded_path_falls_back_with_dropout_masks_and_is_deterministic():
+    """Dropout masks (SpatialDropout1D scales per window and channel) switch the fold off for that call; two folded steps from the same
+    state give bit-identical gradients (fixed summation orders throughout)."""
+    from voicemap_amd.engine import HipEncoderEngine
+    arch, p_, x1, x2, y = _fold_arch_case(4, 2, 4064)
+    eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=0.0, head="uniform_euclidean", dtype="f16")
+    eng.set_params({k: v.numpy() for k, v in p_.items()})
+    masks = [torch.ones(4, c, device="cuda") for (_, c, _) in arch.blocks]
+    pl = eng.siamese_train_step(x1, x2, y, drop_masks=masks, apply_update=False)
+    assert not pl["fold_now"]
+    g_masked = eng.G.clone()
+    pl = eng.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=False)
+    assert pl["fold_now"]
+    g1 = eng.G.clone()
+    eng.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=False)
+    assert torch.equal(g1, eng.G)
+    # all-ones masks are the identity: the two paths compute the same step up to the storage roundings they do not share
+    assert rel_err(g1.cpu().numpy(), g_masked.cpu().numpy()) < 0.2

@@ -915,13 +915,21 @@ def test_prep_conv_weights_batch_equals_single():
         single.append((wf, wd))
     wfs = [torch.zeros_like(a) for a, _ in single]
     wds = [torch.zeros_like(b) for _, b in single]
+    wts = [torch.zeros(a.numel(), dtype=torch.float32, device="cuda") for a, _ in single]
     vp, ci_t = ctypes.c_void_p * 3, ctypes.c_int * 3
     L().call("vm_prep_conv_weights_batch", 3, vp(*[p(w) for w in ws]), ci_t(*[s[0] for s in shapes]), ci_t(*[s[1] for s in shapes]), vm,
-             vp(*[p(t) for t in wfs]), vp(*[p(t) for t in wds]), stream())
+             vp(*[p(t) for t in wfs]), vp(*[p(t) for t in wds]), vp(p(wts[0]), None, p(wts[2])), stream())
     for (a, b), a2, b2 in zip(single, wfs, wds):
         assert torch.equal(a, a2) and torch.equal(b, b2)
+    # wt: the fp32 kernel itself in wf's layout (c_out, 3 * c_in); a NULL entry is skipped
+    for k in (0, 2):
+        ci, co = shapes[k]
+        assert torch.equal(wts[k].view(co, 3, ci), ws[k].permute(2, 0, 1).contiguous())
+    assert not wts[1].any()
+    L().call("vm_prep_conv_weights_batch", 3, vp(*[p(w) for w in ws]), ci_t(*[s[0] for s in shapes]), ci_t(*[s[1] for s in shapes]), vm,
+             vp(*[p(t) for t in wfs]), vp(*[p(t) for t in wds]), None, stream())
     with pytest.raises(RuntimeError):
-        L().call("vm_prep_conv_weights_batch", 9, vp(), ci_t(), ci_t(), vm, vp(), vp(), stream())
+        L().call("vm_prep_conv_weights_batch", 9, vp(), ci_t(), ci_t(), vm, vp(), vp(), None, stream())
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 254, 128, 256), (2, 256, 32, 128), (2, 1000, 256, 384), (5, 750, 384, 512), (4, 3000, 128, 256),

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 3  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 4  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -48,15 +48,20 @@ SIGNATURES = {
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
     "vm_conv_fwd_e_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
+    "vm_fold_bn_weights": (I, [P, P, P, I, I, I, I, P, P, P]),
+    "vm_conv_fwd_fold_supported": (I, [L, L, I, I, I, I]),
+    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P]),
     "vm_conv_fwd_pool_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P]),
     "vm_conv_dgrad_bnred_rows": (L, [L]),
     "vm_conv_dgrad_bnred_supported": (I, [L, L, I, I, I]),
     "vm_conv_dgrad_bnred": (I, [P, P, L, L, I, I, I, P, P, I, P, P, P]),
-    "vm_prep_conv_weights_batch": (I, [I, P, P, P, I, P, P, P]),
+    "vm_prep_conv_weights_batch": (I, [I, P, P, P, I, P, P, P, P]),
     "vm_conv_wgrad_splits": (I, [L, L, I, I]),
     "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),
     "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),
+    "vm_conv_wgrad_fold_workspace_bytes": (L, [L, L, L, I, I]),
+    "vm_conv_wgrad_fold": (I, [P, P, L, L, L, I, I, I, P, P, P, P, P, P]),
     "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
     "vm_colreduce_workspace_bytes": (L, [I, I]),
     "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P]),
@@ -72,6 +77,7 @@ SIGNATURES = {
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),
+    "vm_du_tower_sums": (I, [P, P, L, L, L, I, I, P, P, P, P]),
     "vm_bn_drop_pool_gmax_workspace_bytes": (L, [L, I]),
     "vm_bn_drop_pool_gmax_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P, P, P]),
     "vm_global_maxpool_fwd": (I, [P, L, L, I, I, P, P, P]),

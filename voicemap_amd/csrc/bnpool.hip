@@ -828,6 +828,40 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __re
     if (k == 0) out[c] = (float)ss;
 }
 
+// vm_du_tower_sums: per tower t the column sums of du (from the apply pass's partial rows, via colreduce_stage1_kernel with one segment
+// per tower) and the three tap sums D_t[k][c] a folded weight gradient needs: the sum over the positions whose tap k lies inside the
+// window -- all of them for k = 1, all but position 0 for k = 0, all but position L - 1 for k = 2 (du: padded (n_windows, L + 2, C)).
+template <typename T>
+__global__ __launch_bounds__(256) void du_tower_sums_kernel(const double* __restrict__ ws, const T* __restrict__ du, int towers,
+                                                             int64_t wpt, int64_t L, int C, float* __restrict__ grad_b,
+                                                             float* __restrict__ dsum) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    if (c >= C) return;
+    double gb = 0.0;
+    for (int t = 0; t < towers; ++t) {
+        double ss, qq;
+        colreduce_stage2_par(ws, t, C, c, k, ss, qq);
+        double e0 = 0.0, e1 = 0.0;
+        for (int64_t w = k; w < wpt; w += 32) {
+            const T* row = du + ((int64_t)(t * wpt + w) * (L + 2)) * C + c;
+            e0 += (double)(float)row[C];
+            e1 += (double)(float)row[L * C];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            e0 += __shfl_xor(e0, o, 64);
+            e1 += __shfl_xor(e1, o, 64);
+        }
+        if (k == 0) {
+            dsum[((int64_t)t * 3 + 0) * C + c] = (float)(ss - e0);
+            dsum[((int64_t)t * 3 + 1) * C + c] = (float)ss;
+            dsum[((int64_t)t * 3 + 2) * C + c] = (float)(ss - e1);
+        }
+        gb += ss;
+    }
+    if (k == 0 && grad_b != nullptr) grad_b[c] = (float)gb;
+}
+
 static int lanes_for(int cv) {
     int p = 1;
     while (p < cv && p < 256) p <<= 1;
@@ -1055,6 +1089,21 @@ extern "C" int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const i
     VM_REQUIRE(dg && gidx, "vm_bn_pool_bwd_apply_gmax: null pointer");
     return bn_pool_bwd_apply_impl(z, nullptr, dg, gidx, scale, shift, mean, invstd, drop, c1, c2, n_windows, windows_per_tower, L,
                                   C, pool, dtype, du, part_du, stream);
+}
+
+extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C,
+                                int dtype, float* grad_b, float* dsum, void* ws, void* stream) {
+    VM_REQUIRE(part_du && du && dsum && ws, "vm_du_tower_sums: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && L > 0 && C > 0,
+               "vm_du_tower_sums: n_windows must be a positive multiple of windows_per_tower");
+    const int towers = (int)(n_windows / windows_per_tower);
+    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, part_du,
+                       (const float*)nullptr, windows_per_tower * (int64_t)BN_SEG, C, (double*)ws);
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((du_tower_sums_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                           (const T*)du, towers, windows_per_tower, L, C, grad_b, dsum);
+    });
+    return check_launch("vm_du_tower_sums");
 }
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {

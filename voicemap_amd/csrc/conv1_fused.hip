@@ -161,8 +161,9 @@ template <typename TS, int POOL, bool INFER>
 __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                               const float* __restrict__ bias, const float* __restrict__ sgn,
                                                               const float* __restrict__ shift, int64_t L, int F, int chunks,
-                                                              int splits, int cps, TS* __restrict__ out,
+                                                              int splits, int cps, TS* __restrict__ out, int e_pad,
                                                               float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+    // e_pad (training): 1 = the pool extreme is written as a padded activation tensor (n_windows, L / POOL + 2, F), rows 1 .. L / POOL
     __shared__ __attribute__((aligned(16))) F1Copies cp[2];
     __shared__ float red[4][32][2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
             if (t0 + 32 * rt >= L) break;
             const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
             if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
-                TS* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F : out + (n * Lq + (t0 + 32 * rt) / POOL) * F) + lane_off;
+                TS* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F
+                                : out + (n * (Lq + 2 * e_pad) + e_pad + (t0 + 32 * rt) / POOL) * F) + lane_off;
                 if (all_max) {
                     fast_tile(acc, ob, std::true_type{});
                 } else {
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                         if (INFER) {
                             out[(n * (Lq + 2) + 1 + q) * F + c] = (TS)fmaf(ext, sg, sh);  // ... and here it is the scale
                         } else {
-                            out[(n * Lq + q) * F + c] = (TS)ext;
+                            out[(n * (Lq + 2 * e_pad) + e_pad + q) * F + c] = (TS)ext;
                         }
                     }
                 }
@@ -591,7 +593,8 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
     VM_REQUIRE(n_windows > 0 && L > 0 && F > 0 && F % 8 == 0, "vm_conv1_fused_fwd: bad sizes");
     VM_REQUIRE(pool == 2 || pool == 4, "vm_conv1_fused_fwd: pool must be 2 or 4 (got %d)", pool);
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_conv1_fused_fwd: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
-    VM_REQUIRE(inference ? shift != nullptr : (stat_sum && stat_sq), "vm_conv1_fused_fwd: missing shift / stat buffers");
+    VM_REQUIRE(inference >= 0 && inference <= 2, "vm_conv1_fused_fwd: mode must be 0 (training), 1 (inference) or 2 (training, padded extreme)");
+    VM_REQUIRE(inference == 1 ? shift != nullptr : (stat_sum && stat_sq), "vm_conv1_fused_fwd: missing shift / stat buffers");
     const int chunks = (int)((L + F1_CHUNK - 1) / F1_CHUNK);
     const int splits = f1_splits(n_windows, chunks, g_f1_fwd_blocks);
     const int cps = (chunks + splits - 1) / splits;
@@ -600,12 +603,12 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
 #define VM_F1_FWD(POOL, INF)                                                                                              \
     hipLaunchKernelGGL((conv1_fused_fwd_kernel<T, POOL, INF>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,        \
-                       gamma_or_scale, shift, L, F, chunks, splits, cps, (T*)out, stat_sum, stat_sq)
+                       gamma_or_scale, shift, L, F, chunks, splits, cps, (T*)out, inference == 2 ? 1 : 0, stat_sum, stat_sq)
     VM_DISPATCH_16(dtype, {
         if (pool == 2) {
-            if (inference) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
+            if (inference == 1) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
         } else {
-            if (inference) VM_F1_FWD(4, true); else VM_F1_FWD(4, false);
+            if (inference == 1) VM_F1_FWD(4, true); else VM_F1_FWD(4, false);
         }
     });
 #undef VM_F1_FWD

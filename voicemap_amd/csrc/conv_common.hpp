@@ -165,7 +165,8 @@ __device__ inline void acc_to_lds(char* out_tile, int wm, int wn, int lane, cons
 }
 
 // EPI_FWD_POOL (conv_nt2r_kernel only): forward in inference mode with the BatchNorm affine and MaxPool1D(2) applied in the epilogue
-enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_FWD_POOL = 2 };
+// EPI_FWD_FOLD (conv_nt2r_kernel only): EPI_FWD on the pool extreme of the layer below with that layer's BatchNorm affine folded in
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_FWD_POOL = 2, EPI_FWD_FOLD = 3 };
 
 template <typename T>
 struct NtArgs {
@@ -191,6 +192,15 @@ struct NtArgs {
     // EPI_FWD (training, vm_conv_fwd_e): also write the pool-window extreme of the (2q, 2q + 1) position pairs -- the maximum where
     // aff_scale (= the BatchNorm gamma) is >= 0, the minimum where it is negative -- as an unpadded (n_windows, L / 2, N) tensor
     T* pool_e = nullptr;
+    int pool_e_pad = 0;  // 1: pool_e is padded like an activation tensor, (n_windows, L / 2 + 2, N) with the data in rows 1 .. L / 2
+    // EPI_FWD_FOLD = EPI_FWD with the BatchNorm affine of the layer below folded into the weights (vm_conv_fwd_fold): the
+    // input is the pool extreme e of that layer, bt holds W * scale[ci], and fold_hb (3, N) the per-tap constants
+    // hb[k][co] = sum_ci W[k][ci][co] * shift[ci].  Accumulators start at bias + hb[0] + hb[1] + hb[2]; position 0 of a window has no
+    // tap 0 and position L - 1 no tap 2 (the SAME padding pads the BatchNorm OUTPUT with zeros), so hb[0] / hb[2] come off there.
+    const float* fold_hb = nullptr;
+    // ... per tower (BatchNorm statistics are per encoder call): windows [t * tower_windows, (t + 1) * tower_windows) use the weights at
+    // bt + t * bt_tower_stride and the constants at fold_hb + t * 3 * N
+    int64_t tower_windows = 0, bt_tower_stride = 0;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -459,6 +459,29 @@ __device__ inline void n2_load_bias(const NtArgs<T>& p, f32x4 (&b4)[2][4], int c
             if (EPI != EPI_DGRAD) b4[j][g] = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 * j + 8 * g);
         }
 }
+// vm_conv_fwd_fold: tile row ``row`` is the first (which = 0) or last (which = 1) position of the window -- take the constant of the
+// tap that falls into the padding off its accumulators (lane r <-> row 32 i + r of the wave's 128, registers <-> channels)
+template <typename T>
+__device__ inline void n2_fold_edge(const NtArgs<T>& p, f32x16 (&acc)[4][2], int row, int which, int wm, int r, int c0) {
+    if ((row >> 7) != wm) return;  // wave-uniform
+    const float* hb = p.fold_hb + (which ? 2 * p.N : 0) + c0;
+    f32x4 h[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) h[j][g] = *reinterpret_cast<const f32x4*>(hb + 32 * j + 8 * g);
+    const int rw = row & 127;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // every 32-row block with a lane mask: a runtime block index would put acc into scratch
+        const float m = (32 * i + r == rw) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] -= m * h[j][g][e];
+    }
+}
 __device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -488,7 +511,8 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
     using namespace n2;
     using V8 = typename Mfma<T>::Frag;  // eight 16-bit values
     const int r = lane & 31, kh = lane >> 5;
-    const bool stats = EPI == EPI_FWD && p.stat_sum != nullptr && !(VM_ABL & 8);
+    constexpr bool FWD = EPI == EPI_FWD || EPI == EPI_FWD_FOLD;  // the training forward (statistics, optional pool extreme)
+    const bool stats = FWD && p.stat_sum != nullptr && !(VM_ABL & 8);
     const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
@@ -516,7 +540,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
                     pk[0] = lo;
                     pk[1] = hi;
                 }
-                if ((EPI == EPI_FWD || red) && partial && m >= valid) pk[0] = pk[1] = 0u;
+                if ((FWD || red) && partial && m >= valid) pk[0] = pk[1] = 0u;
                 *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
             }
         }
@@ -585,7 +609,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
         half(0, std::false_type{});
         half(1, std::false_type{});
     }
-    if (EPI == EPI_FWD && p.pool_e != nullptr) {
+    if (FWD && p.pool_e != nullptr) {
         // ---- pool-window extreme of z for the BatchNorm / pool pass that follows the statistics (it then reads a pooled-size tensor
         // instead of z: max_j fma(z_j, s, h) == fma(ext_j z, s, h), the extreme being the maximum for s >= 0 and the minimum for
         // s < 0; sign(s) = sign(gamma) is known before the statistics are).  z >= 0 after ReLU, so the packed 16-bit integer max / min
@@ -599,7 +623,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
             neg[3] = (g1[2] < 0.f ? 0xFFFFu : 0u) | (g1[3] < 0.f ? 0xFFFF0000u : 0u);
         }
         const int vq = valid >> 1;
-        T* ebase = p.pool_e + (n * (int64_t)(p.L / 2) + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
+        T* ebase = p.pool_e + (n * (int64_t)(p.L / 2 + 2 * p.pool_e_pad) + p.pool_e_pad + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
         u32x4 r0[8], r1[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -855,9 +879,25 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
     const int tl = (int)(group - nw * (unsigned)p.tilesL);
     const int64_t n = nw;
     const int t0 = tl * TROWS, n0 = tn * TN;
+    if constexpr (EPI == EPI_FWD_FOLD) {  // this window's tower: its folded weights and constants
+        const unsigned tw = nw / (unsigned)p.tower_windows;
+        p.bt += tw * p.bt_tower_stride;
+        p.fold_hb += tw * 3 * p.N;
+    }
     // forward: the bias loads go out first and are consumed (accumulator init) only after the prologue DMA has been issued
     f32x4 bias4[2][4];
     n2_load_bias<T, EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
+    // vm_conv_fwd_fold: the three per-tap constants of these channels, summed into the bias after the prologue DMA is out
+    f32x4 hb4[EPI == EPI_FWD_FOLD ? 3 : 1][2][4];
+    if constexpr (EPI == EPI_FWD_FOLD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hb4[k][j][g] = *reinterpret_cast<const f32x4*>(p.fold_hb + k * p.N + n0 + wn * 64 + 4 * (lane >> 5) + 32 * j + 8 * g);
+    }
 
     // ---- DMA sources: one instruction = 16 rows x 64 B; A block row R <-> padded input row t0 + R (clamped to the L + 2 rows) ----
     const int lrow = lane >> 2, lchunk = lane & 3;
@@ -921,6 +961,13 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
     issue_b(1, row_bytes);  // K tile 1 = (chunk 0, tap 1)
     VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
     f32x16 acc[4][2];
+    if constexpr (EPI == EPI_FWD_FOLD) {
+        __builtin_amdgcn_sched_barrier(0);  // the sums wait for their loads: keep them behind the DMA issue
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[j][g] = bias4[j][g] + ((hb4[0][j][g] + hb4[1][j][g]) + hb4[2][j][g]);
+    }
     n2_fill_acc(acc, bias4);
     int n_wait = (chunks > 1 ? 4 : 0) + 2;  // pieces issued after B(0)
     int ia_prev = 0;                        // A pieces issued in the previous iteration (after its B pieces)
@@ -1015,6 +1062,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
         a_blk = a_blk == 2 ? 0 : a_blk + 1;
     }
     VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
+    if constexpr (EPI == EPI_FWD_FOLD) {
+        const int c0 = n0 + wn * 64 + 4 * (lane >> 5), rl = p.L - 1 - t0;
+        if (t0 == 0) n2_fold_edge<T>(p, acc, 0, 0, wm, lane & 31, c0);
+        if (rl >= 0 && rl < TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
+    }
     n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, TROWS, tid, lane, w, wm, wn);
 #if defined(VM_EXPERIMENT_PROFILE)
     {
@@ -1089,7 +1141,7 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
 template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
-        if ((g_nt_n2 & (EPI == EPI_DGRAD ? 2 : 1)) && a.Ktot == 3 * a.a_c && n2r_shape(n_windows, a.L, a.a_c, a.N, EPI == EPI_FWD)) {
+        if ((g_nt_n2 & (EPI == EPI_DGRAD ? 2 : 1)) && a.Ktot == 3 * a.a_c && n2r_shape(n_windows, a.L, a.a_c, a.N, EPI == EPI_FWD || EPI == EPI_FWD_FOLD)) {
             launch_n2r<T, EPI>(a, n_windows, stream);
             return;
         }
@@ -1199,6 +1251,38 @@ extern "C" int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, 
         launch_n2r<T, EPI_FWD>(a, n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd_e");
+}
+
+// ---- training forward over the pool extreme of the layer below, that layer's BatchNorm affine folded into the weights
+// (vm_fold_bn_weights makes wf_folded and hb; conv_nt2r_kernel only).  e (optional): this layer's own pool extreme, PADDED ----
+extern "C" int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e) {
+    if (!(is16(dtype) && (g_nt_n2 & 1) && n2r_shape(n_windows, L, c_in, c_out, true))) return 0;
+    return (!with_e || (L >= 2 && !(L & 1))) ? 1 : 0;
+}
+
+extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
+                                int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z,
+                                float* stat_sum, float* stat_sq, void* e, void* stream) {
+    VM_REQUIRE(in_e && wf_folded && bias && hb && z && stat_sum && stat_sq, "vm_conv_fwd_fold: null pointer");
+    VM_REQUIRE(e == nullptr || gamma != nullptr, "vm_conv_fwd_fold: the pool extreme needs gamma (its sign picks max / min)");
+    VM_REQUIRE(n_windows > 0 && L > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
+               "vm_conv_fwd_fold: n_windows must be a positive multiple of windows_per_tower");
+    VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd_fold: window too large");
+    if (!vm_conv_fwd_fold_supported(n_windows, L, c_in, c_out, dtype, e != nullptr)) {
+        set_error("vm_conv_fwd_fold: shape/dtype/tuning not served by the 256 x 128 input-resident kernel (ask vm_conv_fwd_fold_supported)");
+        return VM_ERR_UNSUPPORTED;
+    }
+    VM_DISPATCH_16(dtype, {
+        NtArgs<T> a = fwd_args<T>(in_e, wf_folded, bias, z, stat_sum, stat_sq, L, c_in, c_out, dtype);
+        a.fold_hb = hb;
+        a.tower_windows = windows_per_tower;
+        a.bt_tower_stride = 3LL * c_in * c_out;
+        a.aff_scale = gamma;
+        a.pool_e = (T*)e;
+        a.pool_e_pad = 1;
+        launch_n2r<T, EPI_FWD_FOLD>(a, n_windows, (hipStream_t)stream);
+    });
+    return check_launch("vm_conv_fwd_fold");
 }
 
 // ---- inference forward with BatchNorm affine + MaxPool1D(2) in the epilogue (conv_nt2r_kernel only) ----

@@ -31,7 +31,24 @@ struct TnArgs {
     int xcd_remap;
     int64_t n_windows, win_per_split;
     int split = 0;  // fp32 storage only (dtype VM_F32S): split-bf16 products
+    // vm_conv_wgrad_fold: the windows come in towers of tower_windows and no slab straddles two of them (slab s belongs to tower
+    // s / splits_per_tower); the plain entry point has one "tower" of all windows
+    int64_t tower_windows = 0;
+    int splits_per_tower = 0;
 };
+
+// windows [w_begin, w_end) of split ``split``
+template <typename T>
+__device__ inline void split_windows(const TnArgs<T>& p, int split, int64_t& w_begin, int64_t& w_end) {
+    const int tw = split / p.splits_per_tower, j = split - tw * p.splits_per_tower;
+    const int64_t t0 = (int64_t)tw * p.tower_windows;
+    int64_t t1 = t0 + p.tower_windows;
+    if (t1 > p.n_windows) t1 = p.n_windows;
+    w_begin = t0 + (int64_t)j * p.win_per_split;
+    w_end = w_begin + p.win_per_split;
+    if (w_end > t1) w_end = t1;
+    if (w_begin > w_end) w_begin = w_end;
+}
 
 template <typename T, int PITCH, int SZ = (int)sizeof(T)> struct Transpose4;
 template <typename T, int PITCH> struct Transpose4<T, PITCH, 2> {
@@ -120,9 +137,8 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(TnArgs<T> p) {
         toff[it] = pg[it] * 4 * row_c + (col_ok[it] ? gcol : 0);  // element offset of this item's first row in a stage
     }
 
-    const int64_t w_begin = (int64_t)split * p.win_per_split;
-    int64_t w_end = w_begin + p.win_per_split;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    int64_t w_begin, w_end;
+    split_windows(p, split, w_begin, w_end);
     const int stages_per_win = (p.L + BKP - 1) / BKP;
     const int64_t n_stages = (w_end - w_begin) * stages_per_win;
 
@@ -236,9 +252,8 @@ __global__ __launch_bounds__(512) void conv_tn256_kernel(TnArgs<T> p) {
     const int d_toff = pg * 4 * p.c_out + (d_ok ? j0 + col0 : 0);
     const T* d_base0 = p.du + p.c_out;  // dU row t lives at padded row t+1
 
-    const int64_t w_begin = (int64_t)split * p.win_per_split;
-    int64_t w_end = w_begin + p.win_per_split;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    int64_t w_begin, w_end;
+    split_windows(p, split, w_begin, w_end);
     const int stages_per_win = (p.L + BKP - 1) / BKP;
     const int64_t n_stages = (w_end - w_begin) * stages_per_win;
 
@@ -401,9 +416,13 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<T> p) {
     const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
     const int ci0 = ti * 128, j0 = tj * 128;
 
-    const int w_begin = (int)((int64_t)split * p.win_per_split);
-    int w_end = w_begin + (int)p.win_per_split;
-    if (w_end > (int)p.n_windows) w_end = (int)p.n_windows;
+    int w_begin, w_end;
+    {
+        int64_t wb, we;
+        split_windows(p, split, wb, we);
+        w_begin = (int)wb;
+        w_end = (int)we;
+    }
     const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
     const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
 
@@ -628,7 +647,9 @@ static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_i
 // CU for the others), so the launch takes rounds = ceil(tiles * splits / slots) rounds of windows_per_split
 // windows each -- a launch of 3 rounds + 12 workgroups pays a whole 4th round -- plus the write + re-read of one fp32
 // slab per split.  Pick the split that minimises   rounds * wps * t_window  +  splits * t_slab.
-extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
+// ``tower_windows`` < n_windows (vm_conv_wgrad_fold): the same search with every tower split separately, so that a slab never holds
+// windows of two towers; returns the splits PER TOWER.
+static int wgrad_splits_per_tower(int64_t n_windows, int64_t tower_windows, int64_t L, int c_in, int c_out) {
     const bool big = tn_use_256(c_in, c_out);
     const bool xres = tn_x_shape(c_in, c_out);  // (the fp32 kernels then run with a split count tuned for the 16-bit tiling)
     const int tile = big ? 256 : 128;
@@ -636,10 +657,11 @@ extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int 
     const int64_t slots = (big || xres) ? 256 : 512;
     const double t_window = xres ? 2.0 * 384 * 128 * (double)L / 5.0e12 : 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
     const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
+    const int64_t towers = (n_windows + tower_windows - 1) / tower_windows;
     int64_t best_wps = 1;
     double best_cost = -1.0;
-    for (int64_t wps = 1; wps <= n_windows; ++wps) {
-        const int64_t splits = (n_windows + wps - 1) / wps;
+    for (int64_t wps = 1; wps <= tower_windows; ++wps) {
+        const int64_t splits = towers * ((tower_windows + wps - 1) / wps);
         const int64_t rounds = (t * splits + slots - 1) / slots;
         const double cost = (double)(rounds * wps) * t_window + (double)splits * t_slab;
         if (best_cost < 0.0 || cost < best_cost) {
@@ -647,7 +669,11 @@ extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int 
             best_wps = wps;
         }
     }
-    return (int)((n_windows + best_wps - 1) / best_wps);
+    return (int)((tower_windows + best_wps - 1) / best_wps);
+}
+
+extern "C" int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out) {
+    return wgrad_splits_per_tower(n_windows, n_windows, L, c_in, c_out);
 }
 
 extern "C" int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, int c_in, int c_out) {
@@ -655,12 +681,12 @@ extern "C" int64_t vm_conv_wgrad_workspace_bytes(int64_t n_windows, int64_t L, i
            slab_sum_part_bytes(3LL * c_in * c_out);
 }
 
-extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
-                             void* ws, float* grad_w, void* stream) {
-    VM_REQUIRE(in && du && ws && grad_w, "vm_conv_wgrad: null pointer");
-    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_wgrad: bad sizes");
-    VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_wgrad: channels must be multiples of 8");
-    const int splits = vm_conv_wgrad_splits(n_windows, L, c_in, c_out);
+// The split-K GEMM launch shared by vm_conv_wgrad and vm_conv_wgrad_fold: one fp32 slab (3 * c_in, c_out) per split into ws.
+// Returns the number of slabs.
+static int launch_wgrad(const void* in, const void* du, int64_t n_windows, int64_t tower_windows, int64_t L, int c_in, int c_out,
+                        int dtype, void* ws, hipStream_t st) {
+    const int spt = wgrad_splits_per_tower(n_windows, tower_windows, L, c_in, c_out);
+    const int splits = spt * (int)((n_windows + tower_windows - 1) / tower_windows);
     VM_DISPATCH_DTYPE(dtype, {
         TnArgs<T> a;
         a.x = (const T*)in;
@@ -679,10 +705,11 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
         a.splits = splits;
         a.xcd_remap = 1;
         a.n_windows = n_windows;
-        a.win_per_split = (n_windows + splits - 1) / splits;
+        a.tower_windows = tower_windows;
+        a.splits_per_tower = spt;
+        a.win_per_split = (tower_windows + spt - 1) / spt;
         a.split = dtype == VM_F32S;
         const dim3 grid((unsigned)((int64_t)splits * a.tilesI * a.tilesJ));
-        hipStream_t st = (hipStream_t)stream;
         if constexpr (sizeof(T) == 4) {
             if (a.split && big) {
                 hipLaunchKernelGGL((conv_tn256_kernel<T, 128, true>), grid, dim3(512), 0, st, a);
@@ -703,10 +730,115 @@ extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, 
             }
         }
     });
+    return splits;
+}
+
+extern "C" int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                             void* ws, float* grad_w, void* stream) {
+    VM_REQUIRE(in && du && ws && grad_w, "vm_conv_wgrad: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_wgrad: bad sizes");
+    VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_wgrad: channels must be multiples of 8");
+    const int splits = launch_wgrad(in, du, n_windows, n_windows, L, c_in, c_out, dtype, ws, (hipStream_t)stream);
+    if (splits < 0) return splits;  // unknown dtype
     int rc = check_launch("vm_conv_wgrad");
     if (rc) return rc;
     const int64_t n = 3LL * c_in * c_out;
     return slab_sum((const float*)ws, splits, n, grad_w, n, nullptr, (float*)ws + (int64_t)splits * n, (hipStream_t)stream);
+}
+
+// ---- weight gradient of a layer that ran on the pool extreme e of the layer below with that layer's BatchNorm affine folded into
+// its weights (vm_conv_fwd_fold).  Its true input is y = scale_t[ci] * e + shift_t[ci] inside the window and 0 in the padding (t =
+// the tower of the window: BatchNorm statistics are per encoder call), so
+//     dW[k][ci][co] = sum_t  scale_t[ci] * (sum_pos e[pos + k - 1][ci] du[pos][co])  +  shift_t[ci] * D_t[k][co]
+// with D_t[k][co] = sum of du[pos][co] over the positions whose tap k lies inside the window (vm_du_tower_sums).  The first sum is
+// the GEMM above run on e, one set of slabs per tower; this kernel adds the slabs of each tower in fp64 in a fixed order and applies
+// the two per-channel factors ----
+__global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ ws, int towers, int spt, int c_in, int c_out,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ dsum, float* __restrict__ out) {
+    const int64_t nel = 3LL * c_in * c_out;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nel) return;
+    const int co = (int)(i % c_out);
+    const int64_t r = i / c_out;
+    const int ci = (int)(r % c_in), k = (int)(r / c_in);
+    double total = 0.0;
+    for (int t = 0; t < towers; ++t) {
+        double s0 = 0.0, s1 = 0.0;
+        int j = 0;
+        for (; j + 2 <= spt; j += 2) {
+            s0 += (double)ws[(int64_t)(t * spt + j) * nel + i];
+            s1 += (double)ws[(int64_t)(t * spt + j + 1) * nel + i];
+        }
+        if (j < spt) s0 += (double)ws[(int64_t)(t * spt + j) * nel + i];
+        total += (double)scale[t * c_in + ci] * (s0 + s1) + (double)shift[t * c_in + ci] * (double)dsum[((int64_t)t * 3 + k) * c_out + co];
+    }
+    out[i] = (float)total;
+}
+
+extern "C" int64_t vm_conv_wgrad_fold_workspace_bytes(int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out) {
+    if (windows_per_tower <= 0 || n_windows <= 0) return 0;
+    const int64_t splits = (int64_t)wgrad_splits_per_tower(n_windows, windows_per_tower, L, c_in, c_out) *
+                           ((n_windows + windows_per_tower - 1) / windows_per_tower);
+    return splits * 3 * c_in * c_out * (int64_t)sizeof(float) + 64;
+}
+
+extern "C" int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in,
+                                  int c_out, int dtype, const float* scale, const float* shift, const float* dsum, void* ws,
+                                  float* grad_w, void* stream) {
+    VM_REQUIRE(in_e && du && scale && shift && dsum && ws && grad_w, "vm_conv_wgrad_fold: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
+               "vm_conv_wgrad_fold: n_windows must be a positive multiple of windows_per_tower");
+    VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_wgrad_fold: channels must be multiples of 8");
+    const int towers = (int)(n_windows / windows_per_tower);
+    const int splits = launch_wgrad(in_e, du, n_windows, windows_per_tower, L, c_in, c_out, dtype, ws, (hipStream_t)stream);
+    if (splits < 0) return splits;  // unknown dtype
+    int rc = check_launch("vm_conv_wgrad_fold");
+    if (rc) return rc;
+    const int64_t n = 3LL * c_in * c_out;
+    hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, towers,
+                       splits / towers, c_in, c_out, scale, shift, dsum, grad_w);
+    return check_launch("vm_conv_wgrad_fold");
+}
+
+// ---- the weights vm_conv_fwd_fold runs on, per tower t: wf[t][co][k * c_in + ci] = W[k][ci][co] * scale[t][ci] in the storage type,
+// and the per-tap constants hb[t][k][co] = sum_ci W[k][ci][co] * shift[t][ci] (fp64, fixed order).  Input: wt = the fp32 kernel in
+// wf's layout (vm_prep_conv_weights_batch), so that reads and writes are row-contiguous.  One wave = one (c_out, tap) row ----
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bn_weights_kernel(const float* __restrict__ wt, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int c_in, int c_out,
+                                                              T* __restrict__ wf, float* __restrict__ hb) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);  // row = co * 3 + k
+    const int t = blockIdx.y;
+    if (row >= 3 * c_out) return;
+    const float* src = wt + (int64_t)row * c_in;
+    T* dst = wf + ((int64_t)t * 3 * c_out + row) * c_in;
+    const float* sc = scale + (int64_t)t * c_in;
+    const float* sh = shift + (int64_t)t * c_in;
+    double acc = 0.0;
+    for (int ci = lane; ci < c_in; ci += 64) {
+        const float v = src[ci];
+        dst[ci] = Elem<T>::from_f(v * sc[ci]);
+        acc += (double)v * (double)sh[ci];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        const int co = row / 3, k = row - 3 * co;
+        hb[((int64_t)t * 3 + k) * c_out + co] = (float)acc;
+    }
+}
+
+extern "C" int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, int towers, int c_in, int c_out, int dtype,
+                                  void* wf_folded, float* hb, void* stream) {
+    VM_REQUIRE(wt && scale && shift && wf_folded && hb, "vm_fold_bn_weights: null pointer");
+    VM_REQUIRE(c_in > 0 && c_out > 0 && towers > 0 && towers < 65536, "vm_fold_bn_weights: bad sizes");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_fold_bn_weights: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
+    VM_DISPATCH_16(dtype, {
+        hipLaunchKernelGGL((fold_bn_weights_kernel<T>), dim3((unsigned)cdiv(3 * c_out, 4), (unsigned)towers), dim3(256), 0,
+                           (hipStream_t)stream, wt, scale, shift, c_in, c_out, (T*)wf_folded, hb);
+    });
+    return check_launch("vm_fold_bn_weights");
 }
 
 extern "C" int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream) {
@@ -726,6 +858,7 @@ struct PrepBatch {
     const float* w[PREP_MAX_LAYERS];
     void* wf[PREP_MAX_LAYERS];
     void* wd[PREP_MAX_LAYERS];
+    float* wt[PREP_MAX_LAYERS];  // optional: the fp32 kernel itself in wf's layout (the input of vm_fold_bn_weights)
     int c_in[PREP_MAX_LAYERS], c_out[PREP_MAX_LAYERS];
 };
 template <typename T>
@@ -736,6 +869,7 @@ __global__ void prep_weights_batch_kernel(PrepBatch pb) {
     const float* w = pb.w[l];
     T* wf = (T*)pb.wf[l];
     T* wd = (T*)pb.wd[l];
+    float* wt = pb.wt[l];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int co = (int)(i % c_out);
         const int64_t r = i / c_out;
@@ -744,11 +878,12 @@ __global__ void prep_weights_batch_kernel(PrepBatch pb) {
         const T v = Elem<T>::from_f(w[i]);
         wf[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = v;
         wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
+        if (wt != nullptr) wt[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = w[i];
     }
 }
 
 extern "C" int vm_prep_conv_weights_batch(int n_layers, const float* const* w, const int* c_in, const int* c_out, int dtype,
-                                          void* const* wf, void* const* wd, void* stream) {
+                                          void* const* wf, void* const* wd, float* const* wt, void* stream) {
     VM_REQUIRE(w && c_in && c_out && wf && wd, "vm_prep_conv_weights_batch: null pointer");
     VM_REQUIRE(n_layers > 0 && n_layers <= PREP_MAX_LAYERS, "vm_prep_conv_weights_batch: 1..%d layers per call (got %d)", PREP_MAX_LAYERS,
                n_layers);
@@ -759,6 +894,7 @@ extern "C" int vm_prep_conv_weights_batch(int n_layers, const float* const* w, c
         pb.w[l] = w[l];
         pb.wf[l] = wf[l];
         pb.wd[l] = wd[l];
+        pb.wt[l] = wt != nullptr ? wt[l] : nullptr;
         pb.c_in[l] = c_in[l];
         pb.c_out[l] = c_out[l];
         const int64_t n = 3LL * c_in[l] * c_out[l];

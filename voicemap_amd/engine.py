@@ -106,7 +106,9 @@ class FlatState:
 
 # entry points whose launches bench.py books under another name: (name, index of an extra argument to drop so that the leading
 # arguments line up with that entry point's)
-_TIMED_AS = {"vm_conv_dgrad_bnred": ("vm_conv_dgrad", None), "vm_conv_fwd_e": ("vm_conv_fwd", 3)}
+# entry points timed under the name (and argument positions) of the plain form: name -> (plain name, argument indices to drop)
+_TIMED_AS = {"vm_conv_dgrad_bnred": ("vm_conv_dgrad", ()), "vm_conv_fwd_e": ("vm_conv_fwd", (3,)),
+             "vm_conv_fwd_fold": ("vm_conv_fwd", (3, 4, 6)), "vm_conv_wgrad_fold": ("vm_conv_wgrad", (3,))}
 
 
 class HipEncoderEngine:
@@ -159,10 +161,13 @@ class HipEncoderEngine:
         self._init_zero_debias()
         self.wf: Dict[int, torch.Tensor] = {}
         self.wd: Dict[int, torch.Tensor] = {}
+        self.wt: Dict[int, torch.Tensor] = {}   # fp32 kernels in wf's layout: the input of the per-step BatchNorm fold (16-bit storage)
         for i in range(1, self.nb):
             cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
             self.wf[i] = torch.empty(cout * 3 * cin, dtype=self.tdt, device=dev)
             self.wd[i] = torch.empty(cin * 3 * cout, dtype=self.tdt, device=dev)
+            if self.is16 and self.nb - 1 <= 8:
+                self.wt[i] = torch.empty(cout * 3 * cin, dtype=torch.float32, device=dev)
         self._sq_ws = torch.empty(self.lib.query("vm_sqnorm_workspace_bytes", self.n_flat) // 8, dtype=torch.float64, device=dev)
         self._sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         # Adam(clipnorm=1.) defaults of the reference scripts
@@ -192,6 +197,12 @@ class HipEncoderEngine:
         # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
         # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
         self.fused_pool_extreme = False
+        # training without the BatchNorm / pool pass between blocks (dropout rate 0, 16-bit storage, one tower per launch): block i+1
+        # reads block i's pool extreme e with block i's BatchNorm affine folded into its weights (vm_fold_bn_weights + vm_conv_fwd_fold,
+        # weight gradient vm_conv_wgrad_fold) -- the pooled BatchNorm output is never written or read, and it is no longer rounded to
+        # the storage type either.  Falls back to the pass wherever a kernel does not serve a shape (_fold_ok)
+        self.fold_affine = self.is16
+        self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
@@ -243,7 +254,7 @@ class HipEncoderEngine:
     def _call(self, name, *args):
         """Enqueue one C-ABI entry point; entry points listed in ``self.timed`` are bracketed by HIP events on the
         launch stream (bench.py uses this for the per-kernel roofline figure)."""
-        as_name, drop = _TIMED_AS.get(name, (name, None))
+        as_name, drop = _TIMED_AS.get(name, (name, ()))
         rec = self.timed.get(as_name) if self.timed else None
         if rec is None:
             self.lib.call(name, *args)
@@ -252,7 +263,7 @@ class HipEncoderEngine:
         e0.record()
         self.lib.call(name, *args)
         e1.record()
-        rec.append((e0, e1, (args if drop is None else args[:drop] + args[drop + 1:]) + ((name,) if as_name != name else ())))
+        rec.append((e0, e1, tuple(a for k, a in enumerate(args) if k not in drop) + ((name,) if as_name != name else ())))
 
     def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
         if name in self.nt_off:
@@ -353,9 +364,10 @@ class HipEncoderEngine:
             self._prep_args = (vp(*[_p(self.view(f"conv{i+1}.kernel")) for i in range(1, self.nb)]),
                                ci(*[self.blocks[i - 1][1] for i in range(1, self.nb)]),
                                ci(*[self.blocks[i][1] for i in range(1, self.nb)]),
-                               vp(*[_p(self.wf[i]) for i in range(1, self.nb)]), vp(*[_p(self.wd[i]) for i in range(1, self.nb)]))
-        w, cin, cout, wf, wd = self._prep_args
-        self._call("vm_prep_conv_weights_batch", nl, w, cin, cout, self.dtype, wf, wd, self.stream())
+                               vp(*[_p(self.wf[i]) for i in range(1, self.nb)]), vp(*[_p(self.wd[i]) for i in range(1, self.nb)]),
+                               vp(*[_p(self.wt[i]) for i in range(1, self.nb)]) if self.wt else None)
+        w, cin, cout, wf, wd, wt = self._prep_args
+        self._call("vm_prep_conv_weights_batch", nl, w, cin, cout, self.dtype, wf, wd, wt, self.stream())
 
     # ------------------------------------------------------------------------------------------------
     def lengths(self, l0: int) -> List[int]:
@@ -461,6 +473,49 @@ class HipEncoderEngine:
         self._call("vm_decimate_whiten", _p(raw), int(is16), pl["n"], raw.shape[1], downsampling, int(whitening), rms,
                       windows_per_tower, _p(pl["x0"]), _p(pl["pre_ws"]), self.stream())
 
+    def _fold_ok(self, pl: dict, wpt: int, drop_masks) -> bool:
+        """Can this training forward run blocks 2.. on the pool extremes with the BatchNorm affines folded into the weights?  Asked per
+        call (the answer follows the dropout masks and vm_set_tuning)."""
+        if not (self.fold_affine and pl["training"] and self.is16 and self.fuse_block1 and self.fused_bn_reduce
+                and self.fused_sums_finalize and self.nb >= 2 and self.wt):
+            return False
+        if drop_masks is not None and any(m is not None for m in drop_masks):
+            return False   # SpatialDropout1D scales per (window, channel): not a per-channel affine
+        n, dt = pl["n"], self.dtype
+        for i in range(1, self.nb):
+            cin, c, L = self.blocks[i - 1][1], self.blocks[i][1], pl["L"][i]
+            with_e = i < self.nb - 1
+            if with_e and self.blocks[i][2] != 2:
+                return False
+            if not self.lib.query("vm_conv_fwd_fold_supported", n, L, cin, c, dt, int(with_e)):
+                return False
+            if not self.lib.query("vm_conv_dgrad_bnred_supported", n, L, cin, c, dt):
+                return False
+        return True
+
+    def _fold_bufs(self, i: int):
+        """Per tower: the folded forward weights of block i (0-based) and the per-tap constants hb (3, c_out)."""
+        if i not in self._fold:
+            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            self._fold[i] = (torch.empty(2, cout * 3 * cin, dtype=self.tdt, device=self.device),
+                             torch.empty(2, 3, cout, dtype=torch.float32, device=self.device))
+        return self._fold[i]
+
+    def _fold_plan(self, pl: dict):
+        """Buffers of the folded forward / backward, on first use: padded pool extremes (zero halo rows), tap sums, wgrad slabs."""
+        if "fold_ready" in pl:
+            return
+        n, ls, wpt = pl["n"], pl["L"], pl["wpt"]
+        for i in range(self.nb - 1):
+            c = self.blocks[i][1]
+            pl[i]["ep"] = torch.zeros(n, ls[i + 1] + 2, c, dtype=self.tdt, device=self.device)
+        for i in range(1, self.nb):
+            cin, c = self.blocks[i - 1][1], self.blocks[i][1]
+            pl[i]["dsum"] = torch.empty(2, 3, c, dtype=torch.float32, device=self.device)
+            ws = self.lib.query("vm_conv_wgrad_fold_workspace_bytes", n, wpt, ls[i], cin, c)
+            pl[i]["wgrad_ws_fold"] = torch.empty(ws // 4 + 16, dtype=torch.float32, device=self.device)
+        pl["fold_ready"] = wpt
+
     def forward(self, pl: dict, windows_per_tower: int, drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """x0 -> embeddings (pl['emb']).  Training plans use batch statistics per tower and update the moving
         statistics; inference plans use the moving statistics (Keras learning phase 0).
@@ -478,10 +533,17 @@ class HipEncoderEngine:
         assert n_towers <= 2 or not training, "at most two towers per call"
         wpt = windows_per_tower if training else n
         pl["wpt"], pl["drop"] = wpt, drop_masks
+        split = training and n_towers == 2 and self.split_towers
+        fold = training and self._fold_ok(pl, wpt, drop_masks)
+        pl["fold_now"] = fold
+        if fold:
+            if pl.get("fold_ready", wpt) != wpt:   # the slab split depends on the tower size
+                del pl["fold_ready"]
+            self._fold_plan(pl)
         if training:
             self.bn_steps += 1
             self._bn_t = self.bn_steps
-        if training and n_towers == 2 and self.split_towers:
+        if split:
             if "cr_ws_t2" not in pl:
                 pl["cr_ws_t2"] = torch.empty_like(pl["cr_ws"])
                 pl["gmax_ws_t2"] = torch.empty_like(pl["gmax_ws"])
@@ -489,21 +551,21 @@ class HipEncoderEngine:
                 pl["tower_ev"] = [torch.cuda.Event() for _ in self.blocks]
             cur = torch.cuda.current_stream(self.device)
             self.tower_stream.wait_stream(cur)   # the pre-processed windows are ready
-            self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True)
+            self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True, fold=fold)
             if self.tower_stagger and "stagger_ev" in pl:
                 self.tower_stream.wait_event(pl["stagger_ev"])
             with torch.cuda.stream(self.tower_stream):
-                self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True)
+                self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True, fold=fold)
             cur.wait_stream(self.tower_stream)
         else:
-            self._forward_range(pl, 0, n, 0, n_towers, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"])
+            self._forward_range(pl, 0, n, 0, n_towers, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], fold=fold)
         cl = self.blocks[-1][1]
         self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
                    _p(pl["emb"]), self.stream())
         return pl["emb"]
 
     def _forward_range(self, pl: dict, w0: int, nw: int, tw0: int, ntw: int, wpt: int, drop_masks, cr_ws, gmax_ws,
-                       first_of_two: bool = False, second_of_two: bool = False):
+                       first_of_two: bool = False, second_of_two: bool = False, fold: bool = False):
         """The encoder blocks for windows [w0, w0 + nw) = towers [tw0, tw0 + ntw) on the current stream."""
         st, dt, training = self.stream(), self.dtype, pl["training"]
 
@@ -542,14 +604,17 @@ class HipEncoderEngine:
             if i == 0 and self.fuse_block1:
                 w1 = _p(self.view("conv1.kernel"))
                 if training:
-                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 0, dt, W(b["e"]), ssum, ssq, st)
+                    # fold: the extreme goes out as a padded activation tensor (mode 2) and block 2 reads it as it is
+                    self._call("vm_conv1_fused_fwd", W(pl["x0"]), w1, bias, gam, None, nw, L, c, pool, 2 if fold else 0, dt,
+                               W(b["ep"] if fold else b["e"]), ssum, ssq, st)
                     if first_of_two and self.tower_stagger == 1:
                         if "stagger_ev" not in pl:
                             pl["stagger_ev"] = torch.cuda.Event()
                         pl["stagger_ev"].record()
                     finalize()
-                    self._call("vm_bn_drop_pool_fwd", W(b["e"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, pl["L"][1], c, 1, dt,
-                               W(b["act"]), st)
+                    if not fold:
+                        self._call("vm_bn_drop_pool_fwd", W(b["e"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, pl["L"][1], c, 1, dt,
+                                   W(b["act"]), st)
                     if first_of_two and self.tower_stagger == 2:
                         if "stagger_ev" not in pl:
                             pl["stagger_ev"] = torch.cuda.Event()
@@ -572,7 +637,21 @@ class HipEncoderEngine:
                                c, dt, W(b["act"]), st)
                     continue
                 b["e_now"] = False
-                if (training and self.fused_pool_extreme and pool == 2 and i < self.nb - 1
+                if fold:
+                    # the BatchNorm affine of the block below (this tower's) goes into this block's weights, the conv reads that
+                    # block's pool extreme and leaves its own; no pass in between
+                    lo = pl[i - 1]
+                    wfo, hbo = self._fold_bufs(i)
+                    with_e = i < self.nb - 1
+                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), ntw, cin, c, dt,
+                               wfo[tw0].data_ptr(), hbo[tw0].data_ptr(), st)
+                    self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
+                               nw, wpt, L, cin, c, dt, W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None, st)
+                    b["e_now"] = with_e
+                    if with_e:
+                        finalize()
+                        continue
+                elif (training and self.fused_pool_extreme and pool == 2 and i < self.nb - 1
                         and self.lib.query("vm_conv_fwd_e_supported", nw, L, cin, c, dt)):
                     # the conv epilogue also leaves the pool-window extreme of z (chosen by sign(gamma)): the BatchNorm / pool pass
                     # then reads that pooled-size tensor instead of z -- same bits -- and the backward sums are taken against it
@@ -585,7 +664,8 @@ class HipEncoderEngine:
                                W(b["act"]), st)
                     b["e_now"] = True
                     continue
-                self._call("vm_conv_fwd", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, nw, L, cin, c, dt, W(b["z"]), ssum, ssq, st)
+                else:
+                    self._call("vm_conv_fwd", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, nw, L, cin, c, dt, W(b["z"]), ssum, ssq, st)
             if training:
                 finalize()
             else:
@@ -612,6 +692,7 @@ class HipEncoderEngine:
         sync_tail = sync_tail and self.grad_sync is not None and hasattr(self.grad_sync, "begin_tail")
         lib, st, n, dt, wpt = self.lib, self.stream(), pl["n"], self.dtype, pl["wpt"]
         drop = pl["drop"]
+        fold = bool(pl.get("fold_now"))   # the forward ran blocks 2.. on pool extremes with folded BatchNorm affines
         cl, Ll = self.blocks[-1][1], pl["L"][-1]
         G = self.G
         self._call("vm_dense_bwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E,
@@ -675,11 +756,23 @@ class HipEncoderEngine:
             self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
                        wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
             side = self.overlap_wgrad and i > 0
-            if not side:
-                self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)),
-                           _p(pl["cr_ws"]), st)
+            gb = _p(self.view(f"conv{i+1}.bias", G))
             gw = _p(self.view(f"conv{i+1}.kernel", G))
+
+            def wgrad(stream, cr_ws):
+                # the conv bias gradient = column sums of du (from the apply pass's partials), then the weight gradient
+                cin = self.blocks[i - 1][1]
+                if fold:
+                    lo = pl[i - 1]
+                    self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), stream)
+                    self._call("vm_conv_wgrad_fold", _p(lo["ep"]), _p(b["du"]), n, wpt, L, cin, c, dt, _p(lo["scale"]), _p(lo["shift"]),
+                               _p(b["dsum"]), _p(b["wgrad_ws_fold"]), gw, stream)
+                else:
+                    self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, stream)
+                    self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(cr_ws), stream)
+
             if i == 0:
+                self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(pl["cr_ws"]), st)
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
             else:
                 cin = self.blocks[i - 1][1]
@@ -688,12 +781,8 @@ class HipEncoderEngine:
                     b["ev"].record()
                     with torch.cuda.stream(self.side_stream):
                         self.side_stream.wait_event(b["ev"])
-                        self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw,
-                                   self.stream())
-                        # the conv bias gradient (column sums of du, from the apply pass's partials) is nobody's input until
-                        # the optimizer: off the main stream, with its own reduction workspace
-                        self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)),
-                                   _p(pl["cr_ws_side"]), self.stream())
+                        # (the bias gradient is nobody's input until the optimizer: off the main stream, with its own workspace)
+                        wgrad(self.stream(), pl["cr_ws_side"])
                     if i == 1 and sync_tail:
                         if "sync_ev" not in pl:
                             pl["sync_ev"] = torch.cuda.Event()
@@ -704,7 +793,7 @@ class HipEncoderEngine:
                 if self.overlap_wgrad and not late:
                     side_wgrad()
                 elif not self.overlap_wgrad:
-                    self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, st)
+                    wgrad(st, pl["cr_ws"])
                     if i == 1 and sync_tail:
                         if "sync_ev" not in pl:
                             pl["sync_ev"] = torch.cuda.Event()
@@ -714,8 +803,9 @@ class HipEncoderEngine:
                 lo["bnred_now"] = self._bnred_plan(pl, i)
                 if lo["bnred_now"]:
                     use_e = (i == 1 and self.fuse_block1) or bool(lo.get("e_now"))   # the extreme itself, else the pooled output
-                    self._call("vm_conv_dgrad_bnred", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]),
-                               _p(lo["e"] if use_e else lo["act"]), 0 if use_e else 1, _p(lo["rs0"]), _p(lo["rs1"]), st)
+                    red_a, padded = (lo["ep"], 1) if fold else ((lo["e"], 0) if use_e else (lo["act"], 1))
+                    self._call("vm_conv_dgrad_bnred", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), _p(red_a), padded,
+                               _p(lo["rs0"]), _p(lo["rs1"]), st)
                 else:
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), st)
                 if late:
