@@ -60,8 +60,9 @@ def conv_launch_work(name, args, esize):
     shape = {"n_windows": n, "L": L, "c_in": cin, "c_out": cout, "fused": fused}
     extra = {"vm_conv_fwd_e": n * (L // 2) * cout, "vm_conv_dgrad_bnred": n * L * cin}.get(fused, 0)
     if fused == "vm_conv_fwd_fold" and args[base + 8] is not None:   # (in_e, wf, bias, n, L, c_in, c_out, dtype, z, sum, sq, e, ...)
-        extra = n * (L // 2) * cout
-        shape["fused"] = "vm_conv_fwd_fold+e"
+        pairs = args[base + 5] is None   # no z: the output is the (extreme, other element) pair, n * L * c_out values as z would be
+        extra = 0 if pairs else n * (L // 2) * cout
+        shape["fused"] = "vm_conv_fwd_fold+" + ("pairs" if pairs else "e")
     return (n * L * (cin + cout) + extra) * esize, 2.0 * n * L * 3 * cin * cout, shape
 
 
@@ -122,7 +123,7 @@ def main():
         return e
     eng = make_engine(a.dtype)
     ENGINE_SWITCHES = {"overlap_wgrad": bool, "pooled_reduce": bool, "split_towers": bool, "fused_bn_reduce": bool, "wgrad_after_dgrad": bool,
-                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool, "fold_affine": bool}
+                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool, "fold_affine": bool, "fold_pairs": bool}
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
         if k in ENGINE_SWITCHES:

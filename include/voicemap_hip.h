@@ -49,8 +49,8 @@ enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 const char* vm_last_error(void);
 /* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
- * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums; vm_conv1_fused_fwd mode 2; `wt` in
- * vm_prep_conv_weights_batch) (round 3). */
+ * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
+ * `wt` in vm_prep_conv_weights_batch) (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -151,13 +151,17 @@ int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float
  * rows), z / stat_* as vm_conv_fwd; e (optional) = this layer's own extreme for MaxPool1D(2), PADDED (n_windows, L/2 + 2, c_out), the
  * maximum where gamma >= 0 else the minimum.  16-bit storage, conv_nt2r_kernel shapes only (vm_conv_fwd_fold_supported).  The
  * pooled BatchNorm output is never materialised: -1 read and -1 write of it per block and no pass over z in the forward.
+ * o (optional, with e): the OTHER element of every position pair, unpadded (n_windows, L/2, c_out), with its sign bit set where the
+ * extreme is the pair's second element (z >= 0 after the ReLU: the bit is free; ties: the first element is the extreme).  (e, o)
+ * together are z, so with o given z is NOT written and may be NULL -- the epilogue stores as many bytes as a plain forward --
+ * and the backward takes the pair form (vm_bn_pool_bwd_apply_pairs).
  * vm_conv_wgrad_fold is the matching weight gradient, vm_conv_dgrad[_bnred] is unchanged (it takes the un-folded wd). */
 int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, int towers, int c_in, int c_out, int dtype,
                        void* wf_folded, float* hb, void* stream);
 int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e);
 int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                      int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z, float* stat_sum,
-                     float* stat_sq, void* e, void* stream);
+                     float* stat_sq, void* e, void* o, void* stream);
 /* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
  * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
  * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by
@@ -283,6 +287,11 @@ int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gid
                               const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
                               int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, void* du,
                               float* part_du, void* stream);
+/* vm_bn_pool_bwd_apply for pool = 2 with z given as the pair tensors of vm_conv_fwd_fold: e PADDED (n_windows, L/2 + 2, C), o
+ * (n_windows, L/2, C) with the position flag in its sign bit.  Same arithmetic and outputs.  16-bit storage, L even. */
+int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const void* dp, const float* scale, const float* shift, const float* mean,
+                               const float* invstd, const float* drop, const float* c1, const float* c2, int64_t n_windows,
+                               int64_t windows_per_tower, int64_t L, int C, int dtype, void* du, float* part_du, void* stream);
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
 /* vm_colsum of the apply pass's part_du (n_windows * vm_bn_part_rows(), C) per tower, plus what vm_conv_wgrad_fold needs:

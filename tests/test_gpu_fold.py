@@ -46,7 +46,9 @@ def test_fold_bn_weights(dtype, cin, cout):
         want = quant((w * s[t][None, :, None]).astype(np.float32), dtype).numpy()
         want1 = quant(w.astype(np.float64) * s[t][None, :, None].astype(np.float64), dtype).numpy()
         got = wf[t].to(torch.float64).cpu().numpy().reshape(cout, 3, cin).transpose(1, 2, 0)  # (c_out, 3 * c_in) -> (3, c_in, c_out)
-        assert ((got == want) | (got == want1)).all()
+        # (half: a product in the subnormal range, < 6.1e-5, may also come out flushed or one subnormal step away)
+        ok = (got == want) | (got == want1) | ((np.abs(want) < 6.2e-5) & (np.abs(got - want) < 6.2e-5))
+        assert ok.all(), (got[~ok][:8], want[~ok][:8])
         hb_ref = np.einsum("kio,i->ko", w.astype(np.float64), h[t].astype(np.float64))
         assert np.abs(hb[t].cpu().numpy() - hb_ref).max() < 1e-5 * max(1.0, np.abs(hb_ref).max())
 
@@ -90,7 +92,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
     ssq = torch.empty_like(ssum)
     eo = torch.full((n, Lw // 2 + 2, cout), 7.0, dtype=tdt, device="cuda") if with_e else None
     L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
-             vm, p(z), p(ssum), p(ssq), p(eo), stream())
+             vm, p(z), p(ssum), p(ssq), p(eo), None, stream())
     torch.cuda.synchronize()
     # the definition, with the weights the kernel multiplies by (W * scale rounded to the storage type) and exact shift terms
     zr = np.empty((n, Lw, cout))
@@ -114,6 +116,60 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
         eg = eo.to(torch.float64).cpu().numpy()
         assert np.array_equal(eg[:, 1:-1], want)
         assert (eg[:, 0] == 7.0).all() and (eg[:, -1] == 7.0).all()   # halo rows are the caller's
+        # the pair form: z is not written; (e, o) hold it -- o = the other element, sign bit = "the extreme is the second element"
+        e2, o2 = torch.zeros_like(eo), torch.empty(n, Lw // 2, cout, dtype=tdt, device="cuda")
+        ssum2, ssq2 = torch.empty_like(ssum), torch.empty_like(ssq)
+        L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)), n, wpt, Lw, cin, cout, vm, None,
+                 p(ssum2), p(ssq2), p(e2), p(o2), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(e2[:, 1:-1], eo[:, 1:-1]) and torch.equal(ssum2, ssum) and torch.equal(ssq2, ssq)
+        ob = o2.view(torch.int16).cpu().numpy().view(np.uint16)
+        second = (ob >> 15).astype(bool)
+        oth = torch.from_numpy((ob & 0x7fff).view(np.int16)).view(tdt).to(torch.float64).numpy()
+        zb = pairs.copy()                                   # rebuild the pairs and compare with the z of the first launch, bit for bit
+        zb[:, :, 0] = np.where(second, oth, want)
+        zb[:, :, 1] = np.where(second, want, oth)
+        assert np.array_equal(zb, pairs)
+        first_wins = (pairs[:, :, 0] == pairs[:, :, 1])
+        assert not second[first_wins].any()                 # ties: the first element is the extreme
+
+
+@pytest.mark.parametrize("dtype", DT16)
+def test_bn_pool_bwd_apply_pairs_equals_apply_on_z(dtype):
+    """vm_bn_pool_bwd_apply_pairs on (e, o) == vm_bn_pool_bwd_apply on the z they encode: same du, same partial column sums."""
+    vm, tdt = DTYPES[dtype]
+    r = np.random.default_rng(11)
+    n, wpt, Lw, c = 4, 2, 60, 136
+    z = quant(np.maximum(r.normal(0, 1, (n, Lw, c)), 0.0), dtype)   # post-ReLU: >= 0, with exact zeros and (rare) ties
+    z[:, 10:12] = z[:, 10:11]                                        # a tie in every channel
+    dp = quant(r.normal(0, 1, (n, Lw // 2, c)), dtype)
+    scale = (r.normal(1.0, 0.3, (2, c)) * np.where(r.random((2, c)) < 0.3, -1, 1)).astype(np.float32)
+    shift, mean = r.normal(0, 0.5, (2, c)).astype(np.float32), r.normal(0.4, 0.1, (2, c)).astype(np.float32)
+    invstd = r.uniform(0.5, 2.0, (2, c)).astype(np.float32)
+    c1, c2 = r.normal(0, 0.01, (2, c)).astype(np.float32), r.normal(0, 0.01, (2, c)).astype(np.float32)
+    zt = z.to("cuda", tdt)
+    pr = zt.view(n, Lw // 2, 2, c)
+    pos = torch.tensor(scale >= 0, device="cuda").repeat_interleave(wpt, 0)[:, None, :]       # (n, 1, c): a maximum is pooled
+    second = torch.where(pos, pr[:, :, 1] > pr[:, :, 0], pr[:, :, 1] < pr[:, :, 0])
+    ext = torch.where(second, pr[:, :, 1], pr[:, :, 0])
+    oth = torch.where(second, pr[:, :, 0], pr[:, :, 1])
+    ep = torch.zeros(n, Lw // 2 + 2, c, dtype=tdt, device="cuda")
+    ep[:, 1:-1] = ext
+    o = (oth.contiguous().view(torch.int16) | (second.to(torch.int16) << 15)).view(tdt).contiguous()
+    prow = L().query("vm_bn_part_rows")
+    outs = []
+    for pairs in (False, True):
+        du = torch.zeros(n, Lw + 2, c, dtype=tdt, device="cuda")
+        pdu = torch.empty(n * prow, c, dtype=torch.float32, device="cuda")
+        common = (p(dev(dp, tdt)), p(dev(scale)), p(dev(shift)), p(dev(mean)), p(dev(invstd)), None, p(dev(c1)), p(dev(c2)), n, wpt, Lw, c)
+        if pairs:
+            L().call("vm_bn_pool_bwd_apply_pairs", p(ep), p(o), *common, vm, p(du), p(pdu), stream())
+        else:
+            L().call("vm_bn_pool_bwd_apply", p(zt.contiguous()), *common, 2, vm, p(du), p(pdu), stream())
+        torch.cuda.synchronize()
+        outs.append((du, pdu))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].abs().sum() > 0
 
 
 @pytest.mark.parametrize("dtype", DT16)
@@ -180,11 +236,12 @@ def _fold_arch_case(seed, pairs, l0, f=128, e=64):
     return arch, p_, x1, x2, y
 
 
-def _run(arch, p_, x1, x2, y, dtype, fold, split=True, loss="contrastive"):
+def _run(arch, p_, x1, x2, y, dtype, fold, split=True, loss="contrastive", pairs=True):
     from voicemap_amd.engine import HipEncoderEngine
     eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=0.0, head="uniform_euclidean", dtype=dtype)
     eng.set_params({k: v.numpy() for k, v in p_.items()})
     eng.fold_affine = fold
+    eng.fold_pairs = pairs
     eng.split_towers = split
     pl = eng.siamese_train_step(x1, x2, y, loss=loss, drop_masks=None)
     torch.cuda.synchronize()
@@ -226,6 +283,10 @@ def test_folded_train_step_matches_oracle_and_unfolded_path(dtype, split):
         if "moving" in k:
             assert rel_err(pf[k], v.numpy()) < (3e-3 if dtype == "f16" else 2e-2), k
     assert eng_f.skipped_steps() == 0
+    # (extreme, other element) instead of (z, extreme) is a re-encoding of the same values: the whole step is bit-identical
+    eng_z, pl_z = _run(arch, p_, x1, x2, y, dtype, True, split, pairs=False)
+    assert pl_f[1]["pairs_now"] and not pl_z[1]["pairs_now"]
+    assert torch.equal(pl_z["emb"], pl_f["emb"]) and torch.equal(eng_z.G, eng_f.G)
 
 
 def test_folded_path_falls_back_with_dropout_masks_and_is_deterministic():

@@ -50,7 +50,7 @@ SIGNATURES = {
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
     "vm_fold_bn_weights": (I, [P, P, P, I, I, I, I, P, P, P]),
     "vm_conv_fwd_fold_supported": (I, [L, L, I, I, I, I]),
-    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P]),
+    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P]),
     "vm_conv_fwd_pool_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P]),
     "vm_conv_dgrad_bnred_rows": (L, [L]),
@@ -76,6 +76,7 @@ SIGNATURES = {
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_bn_pool_bwd_apply_pairs": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),
     "vm_du_tower_sums": (I, [P, P, L, L, L, I, I, P, P, P, P]),
     "vm_bn_drop_pool_gmax_workspace_bytes": (L, [L, I]),

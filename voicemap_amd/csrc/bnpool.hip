@@ -337,8 +337,11 @@ __global__ __launch_bounds__(256) void gmax_segments_kernel(const float* __restr
 // extreme wins).  Also emits the per-segment column sums of du (bias gradient of the convolution below).
 // SP: dp is given in its sparse GlobalMaxPool1D-backward form -- dp[n][q][c] = sp_dg[n][c] if q == sp_idx[n][c] else 0 --
 // instead of as a dense tensor (saves writing and re-reading it for the last block).
-template <typename T, int POOL, bool SP>
-__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ dp,
+// PAIRS (16-bit storage, POOL 2, L even): z is given as the pool extreme e = ``z`` (PADDED, (n_windows, L/2 + 2, C)) and the other
+// element of every pair ``zo`` (n_windows, L/2, C) with its sign bit set where the extreme is the pair's second element -- what
+// vm_conv_fwd_fold leaves instead of z.
+template <typename T, int POOL, bool SP, bool PAIRS = false>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ zo, const T* __restrict__ dp,
                                                                 const float* __restrict__ scale, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ drop,
                                                                 const float* __restrict__ c1, const float* __restrict__ c2,
@@ -410,10 +413,19 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 Vec16<T> zv[POOL];
                 int nrows = POOL;
                 if (!FULL && q * POOL + POOL > L) nrows = (int)(L - q * POOL);
-                const T* zp = z + (n * L + q * POOL) * C + c0;
+                if constexpr (PAIRS && sizeof(T) == 2 && POOL == 2) {
+                    typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+                    const Vec16<T> ev = load16<T>(z + (n * (Lq + 2) + 1 + q) * C + c0), ow = load16<T>(zo + (n * Lq + q) * C + c0);
+                    const u16x8 eb = __builtin_bit_cast(u16x8, ev.v), ob = __builtin_bit_cast(u16x8, ow.v);
+                    const u16x8 m = (u16x8)0 - (ob >> 15), oa = ob & (uint16_t)0x7fff;  // m: 0xffff where the extreme is element 1
+                    zv[0].v = __builtin_bit_cast(decltype(zv[0].v), (u16x8)((eb & ~m) | (oa & m)));
+                    zv[1].v = __builtin_bit_cast(decltype(zv[1].v), (u16x8)((oa & ~m) | (eb & m)));
+                } else {
+                    const T* zp = z + (n * L + q * POOL) * C + c0;
 #pragma unroll
-                for (int j = 0; j < POOL; ++j)
-                    if (FULL || j < nrows) zv[j] = load16<T>(zp + j * C);
+                    for (int j = 0; j < POOL; ++j)
+                        if (FULL || j < nrows) zv[j] = load16<T>(zp + j * C);
+                }
                 const bool has_dp = FULL || q < Lq;
                 Vec16<T> dv;
                 if (!SP && has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
@@ -1062,11 +1074,11 @@ static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp
         const int P = lanes_for(C / Elem<T>::kVec);
         if (sp_idx != nullptr) {
             hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
-                               (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                               (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
                                L, C, P, (T*)du, part_du, sp_dg, sp_idx);
         } else {
             hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
-                               (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                               (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
                                L, C, P, (T*)du, part_du, sp_dg, sp_idx);
         }
     }));
@@ -1080,6 +1092,22 @@ extern "C" int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* 
     VM_REQUIRE(dp, "vm_bn_pool_bwd_apply: null pointer");
     return bn_pool_bwd_apply_impl(z, dp, nullptr, nullptr, scale, shift, mean, invstd, drop, c1, c2, n_windows, windows_per_tower,
                                   L, C, pool, dtype, du, part_du, stream);
+}
+
+extern "C" int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const void* dp, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
+                                          int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int dtype, void* du,
+                                          float* part_du, void* stream) {
+    VM_REQUIRE(e && o && dp && scale && shift && mean && invstd && c1 && c2 && du && part_du, "vm_bn_pool_bwd_apply_pairs: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= 2 && !(L & 1) && C % 8 == 0, "vm_bn_pool_bwd_apply_pairs: L must be even, C % 8 == 0");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool_bwd_apply_pairs: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
+    VM_DISPATCH_16(dtype, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)e, (const T*)o, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                           L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr);
+    });
+    return check_launch("vm_bn_pool_bwd_apply_pairs");
 }
 
 extern "C" int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale,

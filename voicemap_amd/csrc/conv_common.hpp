@@ -193,6 +193,9 @@ struct NtArgs {
     // aff_scale (= the BatchNorm gamma) is >= 0, the minimum where it is negative -- as an unpadded (n_windows, L / 2, N) tensor
     T* pool_e = nullptr;
     int pool_e_pad = 0;  // 1: pool_e is padded like an activation tensor, (n_windows, L / 2 + 2, N) with the data in rows 1 .. L / 2
+    // with pool_e: the OTHER element of every position pair, unpadded (n_windows, L / 2, N), its sign bit set where the extreme is the
+    // second element of the pair (z >= 0 after ReLU, so the bit is free) -- (pool_e, pool_o) then hold all of z and `out` is not written
+    T* pool_o = nullptr;
     // EPI_FWD_FOLD = EPI_FWD with the BatchNorm affine of the layer below folded into the weights (vm_conv_fwd_fold): the
     // input is the pool extreme e of that layer, bt holds W * scale[ci], and fold_hb (3, N) the per-tap constants
     // hb[k][co] = sum_ci W[k][ci][co] * shift[ci].  Accumulators start at bias + hb[0] + hb[1] + hb[2]; position 0 of a window has no

@@ -602,7 +602,9 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
             if (ok && !((VM_ABL & 4) && row > 0)) *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.N) = v[jj];
         }
     };
-    if (interior) {
+    if (FWD && p.pool_o != nullptr) {
+        // (pool_e, pool_o) below carry the tile: z itself is not written
+    } else if (interior) {
         half(0, std::true_type{});
         half(1, std::true_type{});
     } else {
@@ -624,6 +626,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
         }
         const int vq = valid >> 1;
         T* ebase = p.pool_e + (n * (int64_t)(p.L / 2 + 2 * p.pool_e_pad) + p.pool_e_pad + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
+        T* obase2 = p.pool_o + (n * (int64_t)(p.L / 2) + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
         u32x4 r0[8], r1[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -634,7 +637,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int q = rg + 16 * jj;
-            u32x4 o;
+            u32x4 o, oth;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const uint32_t a = r0[jj][d], b = r1[jj][d];
@@ -643,8 +646,19 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
                 asm("v_pk_min_i16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
                 const uint32_t m = neg[d];
                 o[d] = (mx & ~m) | (mn & m);
+                if (p.pool_o != nullptr) {
+                    // the other element, flagged (bit 15) where the extreme is the pair's SECOND element: b > a where a maximum is
+                    // taken, b < a for a minimum -- the sign of the 16-bit difference of two non-negative values; ties: the first
+                    uint32_t d1, d2;
+                    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d1) : "v"(a), "v"(b));
+                    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d2) : "v"(b), "v"(a));
+                    oth[d] = (mx ^ mn ^ o[d]) | (((d1 & ~m) | (d2 & m)) & 0x80008000u);
+                }
             }
-            if (q < vq) *reinterpret_cast<u32x4*>(ebase + (int64_t)q * p.N) = o;
+            if (q < vq) {
+                *reinterpret_cast<u32x4*>(ebase + (int64_t)q * p.N) = o;
+                if (p.pool_o != nullptr) *reinterpret_cast<u32x4*>(obase2 + (int64_t)q * p.N) = oth;
+            }
         }
     }
     if (stats) {
@@ -1262,9 +1276,11 @@ extern "C" int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in
 
 extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                                 int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z,
-                                float* stat_sum, float* stat_sq, void* e, void* stream) {
-    VM_REQUIRE(in_e && wf_folded && bias && hb && z && stat_sum && stat_sq, "vm_conv_fwd_fold: null pointer");
+                                float* stat_sum, float* stat_sq, void* e, void* o, void* stream) {
+    VM_REQUIRE(in_e && wf_folded && bias && hb && stat_sum && stat_sq, "vm_conv_fwd_fold: null pointer");
     VM_REQUIRE(e == nullptr || gamma != nullptr, "vm_conv_fwd_fold: the pool extreme needs gamma (its sign picks max / min)");
+    VM_REQUIRE(o == nullptr || e != nullptr, "vm_conv_fwd_fold: o (the other element of each pair) goes with e");
+    VM_REQUIRE(z != nullptr || o != nullptr, "vm_conv_fwd_fold: z may only be NULL when (e, o) carry the output");
     VM_REQUIRE(n_windows > 0 && L > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
                "vm_conv_fwd_fold: n_windows must be a positive multiple of windows_per_tower");
     VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd_fold: window too large");
@@ -1279,6 +1295,7 @@ extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const f
         a.bt_tower_stride = 3LL * c_in * c_out;
         a.aff_scale = gamma;
         a.pool_e = (T*)e;
+        a.pool_o = (T*)o;
         a.pool_e_pad = 1;
         launch_n2r<T, EPI_FWD_FOLD>(a, n_windows, (hipStream_t)stream);
     });

@@ -108,7 +108,8 @@ class FlatState:
 # arguments line up with that entry point's)
 # entry points timed under the name (and argument positions) of the plain form: name -> (plain name, argument indices to drop)
 _TIMED_AS = {"vm_conv_dgrad_bnred": ("vm_conv_dgrad", ()), "vm_conv_fwd_e": ("vm_conv_fwd", (3,)),
-             "vm_conv_fwd_fold": ("vm_conv_fwd", (3, 4, 6)), "vm_conv_wgrad_fold": ("vm_conv_wgrad", (3,))}
+             "vm_conv_fwd_fold": ("vm_conv_fwd", (3, 4, 6, 15)), "vm_conv_wgrad_fold": ("vm_conv_wgrad", (3,)),
+             "vm_bn_pool_bwd_apply_pairs": ("vm_bn_pool_bwd_apply", (1,))}
 
 
 class HipEncoderEngine:
@@ -202,6 +203,9 @@ class HipEncoderEngine:
         # weight gradient vm_conv_wgrad_fold) -- the pooled BatchNorm output is never written or read, and it is no longer rounded to
         # the storage type either.  Falls back to the pass wherever a kernel does not serve a shape (_fold_ok)
         self.fold_affine = self.is16
+        # ... and the folded convs leave (extreme, other element + position flag) instead of (z, extreme): same bytes as a plain
+        # forward epilogue, the BatchNorm-backward apply pass reads the pair form (vm_bn_pool_bwd_apply_pairs)
+        self.fold_pairs = True
         self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
@@ -509,6 +513,8 @@ class HipEncoderEngine:
         for i in range(self.nb - 1):
             c = self.blocks[i][1]
             pl[i]["ep"] = torch.zeros(n, ls[i + 1] + 2, c, dtype=self.tdt, device=self.device)
+            if i > 0:
+                pl[i]["o"] = torch.empty(n, ls[i + 1], c, dtype=self.tdt, device=self.device)
         for i in range(1, self.nb):
             cin, c = self.blocks[i - 1][1], self.blocks[i][1]
             pl[i]["dsum"] = torch.empty(2, 3, c, dtype=torch.float32, device=self.device)
@@ -636,7 +642,7 @@ class HipEncoderEngine:
                     self._call("vm_conv_fwd_pool", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, _p(b["scale"]), _p(b["shift"]), nw, L, cin,
                                c, dt, W(b["act"]), st)
                     continue
-                b["e_now"] = False
+                b["e_now"] = b["pairs_now"] = False
                 if fold:
                     # the BatchNorm affine of the block below (this tower's) goes into this block's weights, the conv reads that
                     # block's pool extreme and leaves its own; no pass in between
@@ -645,9 +651,11 @@ class HipEncoderEngine:
                     with_e = i < self.nb - 1
                     self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), ntw, cin, c, dt,
                                wfo[tw0].data_ptr(), hbo[tw0].data_ptr(), st)
+                    pairs = with_e and self.fold_pairs
                     self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
-                               nw, wpt, L, cin, c, dt, W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None, st)
-                    b["e_now"] = with_e
+                               nw, wpt, L, cin, c, dt, None if pairs else W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None,
+                               W(b["o"]) if pairs else None, st)
+                    b["e_now"], b["pairs_now"] = with_e, pairs
                     if with_e:
                         finalize()
                         continue
@@ -734,7 +742,8 @@ class HipEncoderEngine:
             if sparse:
                 self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             elif b.get("bnred_now") and self.fused_sums_finalize:
-                self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
+                self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None if b.get("pairs_now") else _p(b["z"]),
+                           _p(b["dp"]), _p(b["scale"]),
                            _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
                            float(wpt * L), _p(b["c1"]), _p(b["c2"]), _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)),
                            _p(pl["cr_ws"]), st)
@@ -753,8 +762,12 @@ class HipEncoderEngine:
             if not fused_fin:
                 self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
                            _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
-            self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
-                       wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
+            if b.get("pairs_now") and not sparse:
+                self._call("vm_bn_pool_bwd_apply_pairs", _p(b["ep"]), _p(b["o"]), *common[1:], _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, dt,
+                           _p(b["du"]), _p(b["pdu"]), st)
+            else:
+                self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
+                           wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
             side = self.overlap_wgrad and i > 0
             gb = _p(self.view(f"conv{i+1}.bias", G))
             gw = _p(self.view(f"conv{i+1}.kernel", G))
