@@ -50,7 +50,7 @@ const char* vm_last_error(void);
 /* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
- * `wt` in vm_prep_conv_weights_batch) (round 3). */
+ * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step) (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -345,7 +345,8 @@ int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int
                    float* loss_acc, float* dlogits, float* ws, void* stream);
 
 /* ---- a5: Adam(clipnorm=1.)  (experiments/train_siamese.py:56; Keras 2.2.2 optimizers.py) -------------------
- * sqnorm: 1 fp32 on device <- sum(g^2) over the flat gradient buffer (fixed order; ws >= vm_sqnorm_workspace_bytes). */
+ * sqnorm: 1 fp32 on device <- sum(g^2) over the flat gradient buffer (fixed order; ws >= vm_sqnorm_workspace_bytes).  sqnorm may be
+ * NULL: then only the partial sums are left in ws, for vm_adam_clip_step's sqnorm_parts (one launch less). */
 int64_t vm_sqnorm_workspace_bytes(int64_t n);
 int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm, void* stream);
 /* g *= grad_prescale (e.g. 1/world after an all-reduce sum); norm = grad_prescale*sqrt(*sqnorm);
@@ -353,10 +354,12 @@ int vm_grad_sqnorm(const float* g, int64_t n, void* ws, float* sqnorm, void* str
  * (computed on the host, passed in), p -= lr_t*m/(sqrt(v)+eps).
  * skip_nonfinite != 0 (needs sqnorm): a step whose gradient norm is inf / NaN leaves p, m, v untouched (loss-scaled VM_F16
  * training: an overflowed activation gradient costs one step instead of the model) and increments the caller's running count *skipped
- * (1 int32 on the device, zeroed by the caller, may be NULL); with 0 the update is Keras' own arithmetic, NaNs included. */
+ * (1 int32 on the device, zeroed by the caller, may be NULL); with 0 the update is Keras' own arithmetic, NaNs included.
+ * sqnorm_parts (optional): the ws vm_grad_sqnorm(…, sqnorm = NULL) filled -- every workgroup then adds the partials itself (same
+ * order, same value) and *sqnorm (if not NULL) receives the sum; without it *sqnorm is read. */
 int vm_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
-                      float eps, float clipnorm, float grad_prescale, const float* sqnorm, int skip_nonfinite, int32_t* skipped,
-                      void* stream);
+                      float eps, float clipnorm, float grad_prescale, float* sqnorm, const void* sqnorm_parts, int skip_nonfinite,
+                      int32_t* skipped, void* stream);
 
 /* ---- a8: n-shot evaluation distances  (voicemap/utils.py:159-206) ------------------------------------------
  * For each task: query embedding (E) vs k class prototypes built from n support embeddings each

@@ -445,25 +445,31 @@ def test_adam_clip_step():
         ref = O.adam_step(st, {"w": torch.tensor(pv, dtype=torch.float64)}, {"w": torch.tensor(g, dtype=torch.float64)})["w"]
         t = 7
         lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
-        L().call("vm_adam_clip_step", p(P_), p(G_), p(M_), p(V_), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq), 0, None, stream())
+        L().call("vm_adam_clip_step", p(P_), p(G_), p(M_), p(V_), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq), None, 0, None, stream())
         assert max_err(P_.cpu().numpy(), ref.numpy()) < 2e-6
         assert rel_err(M_.cpu().numpy(), st.m["w"].numpy()) < 1e-5
         assert rel_err(V_.cpu().numpy(), st.v["w"].numpy()) < 1e-5
+        # the one-launch-less form: partials only, the optimizer kernel adds them (same order) and publishes the norm -- same bits
+        P3, M3, V3 = dev(pv), dev(m0), dev(v0)
+        sq3 = torch.zeros(1, device="cuda")
+        L().call("vm_grad_sqnorm", p(G_), n, p(ws), None, stream())
+        L().call("vm_adam_clip_step", p(P3), p(G_), p(M3), p(V3), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0, p(sq3), p(ws), 0, None, stream())
+        assert torch.equal(P3, P_) and torch.equal(M3, M_) and torch.equal(V3, V_) and torch.equal(sq3, sq)
         # loss-scaled form (f16 storage): G holds 4096 x the gradients, grad_prescale divides it out before the clip -- the same
         # update to rounding; skip_nonfinite with a finite norm changes nothing and reports 0
         P2, G2, M2, V2 = dev(pv), dev(g * np.float32(4096.0)), dev(m0), dev(v0)
         flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
         L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
-        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), None, 1, p(flag), stream())
         assert max_err(P2.cpu().numpy(), ref.numpy()) < 2e-6 and flag.item() == 7     # a running count: untouched by a good step
         # a non-finite gradient norm: the step is skipped on the device (p, m, v untouched) and flagged; without the switch the
         # NaN goes through like in Keras
         G2[17] = float("inf")
         before = (P2.clone(), M2.clone(), V2.clone())
         L().call("vm_grad_sqnorm", p(G2), n, p(ws), p(sq), stream())
-        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 1, p(flag), stream())
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), None, 1, p(flag), stream())
         assert flag.item() == 8 and torch.equal(P2, before[0]) and torch.equal(M2, before[1]) and torch.equal(V2, before[2])
-        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), 0, None, stream())
+        L().call("vm_adam_clip_step", p(P2), p(G2), p(M2), p(V2), n, lr_t, 0.9, 0.999, 1e-7, 1.0, 1.0 / 4096.0, p(sq), None, 0, None, stream())
         assert not torch.isfinite(P2).all()
 
 

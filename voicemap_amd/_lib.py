@@ -89,7 +89,7 @@ SIGNATURES = {
     "vm_softmax_cce": (I, [P, P, L, I, F, P, P, P, P, P]),
     "vm_sqnorm_workspace_bytes": (L, [L]),
     "vm_grad_sqnorm": (I, [P, L, P, P, P]),
-    "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, I, P, P]),
+    "vm_adam_clip_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P, I, P, P]),
     "vm_nshot_distances": (I, [P, P, L, I, I, I, I, P, P, P]),
     "vm_nshot_indexed": (I, [P, L, P, P, L, I, I, I, I, P, P, P]),
     "vm_pairdist_workspace_bytes": (L, [L, L]),

@@ -45,44 +45,40 @@ __global__ __launch_bounds__(256) void whiten_stats_kernel(const R* __restrict__
     }
 }
 
-// pass 1b: per-window mean and ONE scale per tower (utils.py:94-98).  grid = n_towers; fixed summation order.
-__global__ __launch_bounds__(256) void whiten_finalize_kernel(const double* __restrict__ psum, const double* __restrict__ psq,
-                                                              int64_t wpt, int64_t L0, float rms, double* __restrict__ mean,
-                                                              double* __restrict__ scale) {
-    __shared__ double red[4];
-    const int64_t tw = blockIdx.x;
-    double q = 0.0;
-    for (int64_t j = threadIdx.x; j < wpt * WS_SEG; j += 256) q += psq[tw * wpt * WS_SEG + j];
-    q = wave_sum_d(q);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-        scale[tw] = (double)rms / sqrt(tot / ((double)wpt * (double)L0));
-    }
-    for (int64_t j = threadIdx.x; j < wpt; j += 256) {
-        double s = 0.0;
-        for (int k = 0; k < WS_SEG; ++k) s += psum[(tw * wpt + j) * WS_SEG + k];
-        mean[tw * wpt + j] = s / (double)L0;
-    }
-}
-
-// pass 2: write (x - mean_n) * scale_tower with the halo.  grid = (ceil((L0+31)/256), n_windows).
+// pass 2: per-window mean and ONE scale per tower (utils.py:94-98) from the partials -- recomputed by every workgroup in the same
+// fixed order (1 K doubles from L2: cheaper than the launch a separate finalize kernel costs) -- then (x - mean_n) * scale_tower
+// with the halo.  grid = (WA_SPLIT, n_windows): a workgroup writes one slice of a window's row.
+constexpr int WA_SPLIT = 8;
 template <typename R>
 __global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__ raw, const int64_t* __restrict__ offsets,
-                                                           int64_t raw_len, int ds, int64_t L0, int whitening, int64_t wpt,
-                                                           const double* __restrict__ mean, const double* __restrict__ scale,
+                                                           int64_t raw_len, int ds, int64_t L0, int whitening, int64_t wpt, float rms,
+                                                           const double* __restrict__ psum, const double* __restrict__ psq,
                                                            float* __restrict__ out) {
+    __shared__ double red[4];
     const int64_t n = blockIdx.y;
     const R* r = raw + (offsets ? offsets[n] : n * raw_len);
-    const double m = whitening ? mean[n] : 0.0;
-    const double sc = whitening ? scale[n / wpt] : 1.0;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L0 + HALO) return;
-    const int64_t t = i - HALO_L;
-    float v = 0.f;
-    if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(r[t * ds]) - m) * sc);
-    out[n * (L0 + HALO) + i] = v;
+    double m = 0.0, sc = 1.0;
+    if (whitening) {
+        const int64_t tw = n / wpt;
+        double q = 0.0;
+        for (int64_t j = threadIdx.x; j < wpt * WS_SEG; j += 256) q += psq[tw * wpt * WS_SEG + j];
+        q = wave_sum_d(q);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+        __syncthreads();
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        sc = (double)rms / sqrt(tot / ((double)wpt * (double)L0));
+        double s = 0.0;
+        for (int k = 0; k < WS_SEG; ++k) s += psum[n * WS_SEG + k];
+        m = s / (double)L0;
+    }
+    const int64_t row = L0 + HALO, per = (row + WA_SPLIT - 1) / WA_SPLIT;
+    const int64_t i1 = (blockIdx.x + 1) * per < row ? (blockIdx.x + 1) * per : row;
+    for (int64_t i = blockIdx.x * per + threadIdx.x; i < i1; i += 256) {
+        const int64_t t = i - HALO_L;
+        float v = 0.f;
+        if (t >= 0 && t < L0) v = (float)(((double)raw_to_f<R>(r[t * ds]) - m) * sc);
+        out[n * row + i] = v;
+    }
 }
 
 }  // namespace vm
@@ -90,7 +86,7 @@ __global__ __launch_bounds__(256) void whiten_apply_kernel(const R* __restrict__
 using namespace vm;
 
 extern "C" int64_t vm_decimate_whiten_workspace_bytes(int64_t n_windows) {
-    return (2 * WS_SEG + 2) * n_windows * (int64_t)sizeof(double);  // partials, per-window means, per-tower scales
+    return (2 * WS_SEG + 2) * n_windows * (int64_t)sizeof(double);  // the partials (+ two rows no longer used)
 }
 
 static int decimate_whiten_impl(const char* what, const void* raw, int raw_is_i16, const int64_t* offsets, int64_t n_windows,
@@ -99,30 +95,21 @@ static int decimate_whiten_impl(const char* what, const void* raw, int raw_is_i1
     const int64_t L0 = (raw_len + downsampling - 1) / downsampling;  // len(x[::d])
     double* psum = (double*)ws;
     double* psq = psum + n_windows * WS_SEG;
-    double* mean = psq + n_windows * WS_SEG;
-    double* scale = mean + n_windows;
     const dim3 g1((unsigned)n_windows, WS_SEG);
-    const dim3 g2((unsigned)cdiv(L0 + HALO, 256), (unsigned)n_windows);
-    const unsigned towers = (unsigned)(n_windows / windows_per_tower);
+    const dim3 g2(WA_SPLIT, (unsigned)n_windows);
     hipStream_t st = (hipStream_t)stream;
     if (raw_is_i16) {
-        if (whitening) {
+        if (whitening)
             hipLaunchKernelGGL((whiten_stats_kernel<int16_t>), g1, dim3(256), 0, st, (const int16_t*)raw, offsets, raw_len,
                                downsampling, L0, psum, psq);
-            hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
-                               scale);
-        }
         hipLaunchKernelGGL((whiten_apply_kernel<int16_t>), g2, dim3(256), 0, st, (const int16_t*)raw, offsets, raw_len, downsampling,
-                           L0, whitening, windows_per_tower, mean, scale, out);
+                           L0, whitening, windows_per_tower, rms, psum, psq, out);
     } else {
-        if (whitening) {
+        if (whitening)
             hipLaunchKernelGGL((whiten_stats_kernel<float>), g1, dim3(256), 0, st, (const float*)raw, offsets, raw_len, downsampling,
                                L0, psum, psq);
-            hipLaunchKernelGGL(whiten_finalize_kernel, dim3(towers), dim3(256), 0, st, psum, psq, windows_per_tower, L0, rms, mean,
-                               scale);
-        }
         hipLaunchKernelGGL((whiten_apply_kernel<float>), g2, dim3(256), 0, st, (const float*)raw, offsets, raw_len, downsampling, L0,
-                           whitening, windows_per_tower, mean, scale, out);
+                           whitening, windows_per_tower, rms, psum, psq, out);
     }
     return check_launch(what);
 }

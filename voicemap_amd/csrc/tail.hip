@@ -128,13 +128,10 @@ __global__ __launch_bounds__(64 * DENSE_KS) void dense_fwd_kernel(const float* _
 }
 
 // grad_w[i][o] = sum_r in[r][i]*dout[r][o]; blockIdx.y = i.  The last y-row computes grad_b.
-__global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                                                    int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
-                                                                    float* __restrict__ grad_b) {
-    __shared__ float red[DENSE_KS][64];
+__device__ inline void dense_bwd_w_body(const float* __restrict__ in, const float* __restrict__ dout, int64_t rows, int n_in, int n_out,
+                                        float* __restrict__ grad_w, float* __restrict__ grad_b, int bx, int i, float (&red)[DENSE_KS][64]) {
     const int ol = threadIdx.x & 63, rq = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + ol;
-    const int i = blockIdx.y;
+    const int o = bx * 64 + ol;
     const int64_t per = (rows + DENSE_KS - 1) / DENSE_KS;
     const int64_t r0 = rq * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -174,11 +171,16 @@ __global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_w_kernel(const float*
     }
 }
 
+__global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                                    int64_t rows, int n_in, int n_out, float* __restrict__ grad_w,
+                                                                    float* __restrict__ grad_b) {
+    __shared__ float red[DENSE_KS][64];
+    dense_bwd_w_body(in, dout, rows, n_in, n_out, grad_w, grad_b, blockIdx.x, blockIdx.y, red);
+}
+
 // din[r][i] = sum_o dout[r][o]*w[i][o]; blockIdx.y = r, lanes over i (w rows are short: L2-resident).
-__global__ __launch_bounds__(64) void dense_bwd_in_kernel(const float* __restrict__ w, const float* __restrict__ dout,
-                                                          int n_in, int n_out, float* __restrict__ din) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const int64_t r = blockIdx.y;
+__device__ inline void dense_bwd_in_body(const float* __restrict__ w, const float* __restrict__ dout, int n_in, int n_out,
+                                         float* __restrict__ din, int i, int64_t r) {
     if (i >= n_in) return;
     const float* wr = w + (int64_t)i * n_out;
     const float* dr = dout + r * n_out;
@@ -190,6 +192,29 @@ __global__ __launch_bounds__(64) void dense_bwd_in_kernel(const float* __restric
     }
     for (; o < n_out; ++o) a0 = fmaf(dr[o], wr[o], a0);
     din[r * n_in + i] = a0 + a1;
+}
+
+__global__ __launch_bounds__(64) void dense_bwd_in_kernel(const float* __restrict__ w, const float* __restrict__ dout,
+                                                          int n_in, int n_out, float* __restrict__ din) {
+    dense_bwd_in_body(w, dout, n_in, n_out, din, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+}
+
+// Both halves of the dense backward in one launch (they share dout and nothing else): the first wx * (n_in + 1) workgroups are
+// dense_bwd_w_kernel's, the others take DENSE_KS rows of dense_bwd_in_kernel's grid each -- the same arithmetic per output element.
+__global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_both_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                       const float* __restrict__ dout, int64_t rows, int n_in,
+                                                                       int n_out, float* __restrict__ grad_w, float* __restrict__ grad_b,
+                                                                       float* __restrict__ din, int wx, int ix) {
+    __shared__ float red[DENSE_KS][64];
+    const int nw = wx * (n_in + 1);
+    int b = blockIdx.x;
+    if (b < nw) {
+        dense_bwd_w_body(in, dout, rows, n_in, n_out, grad_w, grad_b, b % wx, b / wx, red);
+        return;
+    }
+    b -= nw;
+    const int64_t r = (int64_t)(b / ix) * DENSE_KS + (threadIdx.x >> 6);
+    if (r < rows) dense_bwd_in_body(w, dout, n_in, n_out, din, (b % ix) * 64 + (threadIdx.x & 63), r);
 }
 
 // ---- siamese head + loss, forward and backward ----------------------------------------------------------
@@ -439,6 +464,15 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
                             float* grad_w, float* grad_b, float* din, void* stream) {
     VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
     VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
+    {
+        const int64_t wx = (n_out + 63) / 64, ix = (n_in + 63) / 64;
+        const int64_t blocks = wx * (n_in + 1) + (din != nullptr ? ix * ((rows + DENSE_KS - 1) / DENSE_KS) : 0);
+        if (din != nullptr && blocks < (1LL << 31)) {  // one launch
+            hipLaunchKernelGGL(dense_bwd_both_kernel, dim3((unsigned)blocks), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, w, dout, rows,
+                               n_in, n_out, grad_w, grad_b, din, (int)wx, (int)ix);
+            return check_launch("vm_dense_bwd");
+        }
+    }
     hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, dout, rows,
                        n_in, n_out, grad_w, grad_b);
     int rc = check_launch("vm_dense_bwd(w)");

@@ -880,7 +880,7 @@ class HipEncoderEngine:
         lib, st = self.lib, self.stream()
         skip = self.loss_scale != 1.0   # loss-scaled storage: a non-finite gradient norm skips the update on the device
         if (self.clipnorm and self.clipnorm > 0) or skip:
-            self._call("vm_grad_sqnorm", _p(self.G), self.n_flat, _p(self._sq_ws), _p(self._sqnorm), st)
+            self._call("vm_grad_sqnorm", _p(self.G), self.n_flat, _p(self._sq_ws), None, st)   # partials; the optimizer kernel adds them
         lr = self.lr
         if self.decay > 0:
             lr = lr * (1.0 / (1.0 + self.decay * self.iterations))
@@ -888,7 +888,7 @@ class HipEncoderEngine:
         lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         self._call("vm_adam_clip_step", _p(self.P), _p(self.G), _p(self.M), _p(self.V), self.n_flat, lr_t, self.beta_1,
                  self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale) / float(self.loss_scale),
-                 _p(self._sqnorm), int(skip), _p(self._skipped) if skip else None, st)
+                 _p(self._sqnorm), _p(self._sq_ws), int(skip), _p(self._skipped) if skip else None, st)
         self.iterations = t
         self.refresh_weights()
 
