@@ -260,14 +260,19 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     roof["kernel"] = a.dominant
-    roof["kernel_symbol"] = KERNEL_SYMBOL[a.dominant].format(T=CTYPE.get(a.dtype, a.dtype))
+    def symbol(nm):   # the folded forward (vm_conv_fwd_fold) is epilogue variant 3 of the same kernel
+        sym = KERNEL_SYMBOL[nm].format(T=CTYPE.get(a.dtype, a.dtype))
+        if nm == "vm_conv_fwd" and any(str(l["shape"]["fused"]).startswith("vm_conv_fwd_fold") for l in fam[nm]["launches"]):
+            sym = sym.replace(", 0>", ", 3>")
+        return sym
+    roof["kernel_symbol"] = symbol(a.dominant)
     roof["source"] = ("bench.py serial attribution pass of this run: HIP events on the launch stream around every GEMM launch, median per "
                       "launch shape; committed counterparts: profiles/r03_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
                       "serial step), profiles/r03_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
     # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense 16-bit peak) and algorithmic GB/s
-    roof["families_serial"] = {nm: {"ms_per_step": round(f["ms_per_step"], 4), "kernel_symbol": KERNEL_SYMBOL[nm].format(T=CTYPE.get(a.dtype, a.dtype)),
+    roof["families_serial"] = {nm: {"ms_per_step": round(f["ms_per_step"], 4), "kernel_symbol": symbol(nm),
                                     "frac_of_mfma_peak": round(sum(l["flops"] * l["per_step"] for l in f["launches"]) / (f["ms_per_step"] * 1e-3) / 1e12
                                                                / MFMA_16BIT_PEAK_TF, 4),
                                     "launches": [{"L": l["shape"]["L"], "c_in": l["shape"]["c_in"], "c_out": l["shape"]["c_out"], "fused": l["shape"]["fused"],

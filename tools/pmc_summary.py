@@ -14,7 +14,8 @@ def short(name):
         if key in name:
             extra = ""
             if "conv_nt" in name:   # mangled: ...ILi0E / Li1E ...; demangled: <T, 0> / <T, 1>
-                extra = "<fwd>" if ("Li0E" in name or ", 0>" in name or "(int)0>" in name) else "<dgrad>"
+                extra = ("<fwd>" if ("Li0E" in name or ", 0>" in name or "(int)0>" in name) else
+                         "<fwd+fold>" if ("Li3E" in name or ", 3>" in name or "(int)3>" in name) else "<dgrad>")
             if "bn_pool_bwd" in name:
                 extra = "<apply>" if ("Lb1E" in name or "bool, E>" in name or "apply" in name) else "<reduce>"
             return key + extra

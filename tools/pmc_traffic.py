@@ -47,17 +47,22 @@ def main(fetch_dir, write_dir, out):
            "kernels": {}}
     n = 256
     for (L, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
-        splits = lib.query("vm_conv_wgrad_splits", n, L, cin, cout)
-        grid = splits * (-(-cin // 128)) * (-(-cout // 128)) * 512  # conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
+        # slabs of the plain entry point, or of the folded one (every slab inside one of the two towers)
+        grids = []
+        for splits in (lib.query("vm_conv_wgrad_splits", n, L, cin, cout),
+                       lib.query("vm_conv_wgrad_fold_workspace_bytes", n, n // 2, L, cin, cout) // (3 * cin * cout * 4)):
+            grids.append(splits * (-(-cin // 128)) * (-(-cout // 128)) * 512)  # conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
         for (name, g), fv in fetch.items():
-            if "conv_tn8x" in name and g == grid:
+            if "conv_tn8x" in name and g in grids:
                 wv = write.get((name, g), 0.0)
                 res["kernels"]["vm_conv_wgrad|%d|%d|%d|%d" % (n, L, cin, cout)] = {
                     "fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024, "grid": g}
     # forward / dgrad launches share one grid size: told apart by dispatch order (forward: blocks 2,3,4; dgrad: 4,3,2)
     shapes = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
     # (rocprofv3 prints some instantiations demangled, with the epilogue enum elided: "<bool _Accum, int, E, 128, false>")
-    for entry, has, order in (("vm_conv_fwd", [("conv_nt2r", "Li0E"), ("conv_nt2r_kernel<", ", 0>"), ("conv_nt2r_kernel<", "(int)0>")], shapes),
+    # (Li3 = the forward on the pool extremes with the BatchNorm affine folded in, vm_conv_fwd_fold: what a default step launches)
+    for entry, has, order in (("vm_conv_fwd", [("conv_nt2r", "Li0E"), ("conv_nt2r_kernel<", ", 0>"), ("conv_nt2r_kernel<", "(int)0>"),
+                                               ("conv_nt2r", "Li3E"), ("conv_nt2r_kernel<", ", 3>"), ("conv_nt2r_kernel<", "(int)3>")], shapes),
                               ("vm_conv_dgrad", [("conv_nt2r", "Li1E"), ("conv_nt2r_kernel<", ", 1>"), ("conv_nt2r_kernel<", "(int)1>")],
                                shapes[::-1])):
         fv, wv = per_order(fetch_dir, "FETCH_SIZE", has, 3), per_order(write_dir, "WRITE_SIZE", has, 3)

@@ -199,24 +199,6 @@ __global__ __launch_bounds__(64) void dense_bwd_in_kernel(const float* __restric
     dense_bwd_in_body(w, dout, n_in, n_out, din, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
 }
 
-// Both halves of the dense backward in one launch (they share dout and nothing else): the first wx * (n_in + 1) workgroups are
-// dense_bwd_w_kernel's, the others take DENSE_KS rows of dense_bwd_in_kernel's grid each -- the same arithmetic per output element.
-__global__ __launch_bounds__(64 * DENSE_KS) void dense_bwd_both_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                                       const float* __restrict__ dout, int64_t rows, int n_in,
-                                                                       int n_out, float* __restrict__ grad_w, float* __restrict__ grad_b,
-                                                                       float* __restrict__ din, int wx, int ix) {
-    __shared__ float red[DENSE_KS][64];
-    const int nw = wx * (n_in + 1);
-    int b = blockIdx.x;
-    if (b < nw) {
-        dense_bwd_w_body(in, dout, rows, n_in, n_out, grad_w, grad_b, b % wx, b / wx, red);
-        return;
-    }
-    b -= nw;
-    const int64_t r = (int64_t)(b / ix) * DENSE_KS + (threadIdx.x >> 6);
-    if (r < rows) dense_bwd_in_body(w, dout, n_in, n_out, din, (b % ix) * 64 + (threadIdx.x & 63), r);
-}
-
 // ---- siamese head + loss, forward and backward ----------------------------------------------------------
 constexpr float KERAS_EPS = 1e-7f;
 
@@ -464,15 +446,6 @@ extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, 
                             float* grad_w, float* grad_b, float* din, void* stream) {
     VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
     VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
-    {
-        const int64_t wx = (n_out + 63) / 64, ix = (n_in + 63) / 64;
-        const int64_t blocks = wx * (n_in + 1) + (din != nullptr ? ix * ((rows + DENSE_KS - 1) / DENSE_KS) : 0);
-        if (din != nullptr && blocks < (1LL << 31)) {  // one launch
-            hipLaunchKernelGGL(dense_bwd_both_kernel, dim3((unsigned)blocks), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, w, dout, rows,
-                               n_in, n_out, grad_w, grad_b, din, (int)wx, (int)ix);
-            return check_launch("vm_dense_bwd");
-        }
-    }
     hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, dout, rows,
                        n_in, n_out, grad_w, grad_b);
     int rc = check_launch("vm_dense_bwd(w)");
