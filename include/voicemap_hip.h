@@ -50,7 +50,7 @@ const char* vm_last_error(void);
 /* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
- * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step) (round 3). */
+ * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce) (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -320,7 +320,8 @@ int vm_global_maxpool_bwd(const float* dg, const int32_t* gidx, int64_t n_window
 int vm_dense_fwd(const float* in, const float* w, const float* b, int64_t rows, int n_in, int n_out, float* out,
                  void* stream);
 /* grad_w[i][o] = sum_r in[r][i]*dout[r][o]; grad_b[o] = sum_r dout[r][o]; din[r][i] = sum_o dout[r][o]*w[i][o]
- * (din may be NULL).  Fixed summation order. */
+ * (din may be NULL; grad_w and grad_b may both be NULL: then only din -- the two halves are independent launches and a caller may
+ * put the parameter half on another stream).  Fixed summation order. */
 int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t rows, int n_in, int n_out,
                  float* grad_w, float* grad_b, float* din, void* stream);
 
@@ -333,10 +334,14 @@ int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t row
  * pred (pairs); loss_acc[0] = loss, [1] = binary accuracy; demb (2*pairs, E); grad_hw (1 or E); grad_hb (1).
  * ws: 4*pairs floats of scratch (per-pair terms, summed in fixed order by a second small launch); unused when y is NULL.
  * grad_scale: every gradient output (demb, grad_hw, grad_hb) is multiplied by it -- 1 for fp32 / bf16 storage; the loss scale of
- * VM_F16 storage, whose activation gradients would otherwise fall under half's 6e-8; loss_acc and pred are not scaled. */
+ * VM_F16 storage, whose activation gradients would otherwise fall under half's 6e-8; loss_acc and pred are not scaled.
+ * loss_acc may be NULL with y given: then only the per-pair pass runs (pred, demb, ws) and the caller enqueues vm_siamese_head_reduce
+ * (the fixed-order sums: loss_acc, grad_hw, grad_hb -- nobody's input before the optimizer) where it likes, e.g. on another stream. */
 int vm_siamese_head_loss(const float* emb, const float* head_w, const float* head_b, const float* y, int64_t pairs,
                          int E, int head_kind, int loss_kind, float grad_scale, float* pred, float* loss_acc, float* demb,
                          float* grad_hw, float* grad_hb, float* ws, void* stream);
+int vm_siamese_head_reduce(const float* emb, const float* ws, int64_t pairs, int E, int head_kind, float* loss_acc, float* grad_hw,
+                           float* grad_hb, void* stream);
 
 /* ---- a9: classifier head Dense(num_classes, softmax) + categorical CE  (experiments/train_classifier.py:112,115)
  * logits (rows, n_classes) fp32 -> prob; labels int32 (rows); loss_acc[0] = mean CE (Keras clip 1e-7), [1] = accuracy;

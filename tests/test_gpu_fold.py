@@ -308,3 +308,28 @@ def test_folded_path_falls_back_with_dropout_masks_and_is_deterministic():
     assert torch.equal(g1, eng.G)
     # all-ones masks are the identity: the two paths compute the same step up to the storage roundings they do not share
     assert rel_err(g1.cpu().numpy(), g_masked.cpu().numpy()) < 0.2
+
+
+def test_folded_classifier_step_one_tower():
+    """experiments/train_classifier.py's step (one encoder call = one tower, Dense(num_classes, softmax) + categorical CE) through the
+    folded forward at channel counts the kernels serve: probabilities, loss and gradients against the float64 oracle."""
+    from voicemap_amd.engine import HipEncoderEngine
+    nc, n, l0 = 24, 6, 4064
+    arch = O.EncoderArch.baseline(128, 64, dropout=0.0)
+    p_ = O.init_params(arch, head="classifier", num_classes=nc, seed=5)
+    r = np.random.default_rng(5)
+    x = O.whiten(r.normal(0, 0.05, (n, l0, 1))).astype(np.float32).astype(np.float64)
+    labels = r.integers(0, nc, n)
+    eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=0.0, head="classifier", dtype="f16", num_classes=nc)
+    eng.set_params({k: v.numpy() for k, v in p_.items()})
+    pl = eng.classifier_train_step(x, labels, drop_masks=None, apply_update=False)
+    torch.cuda.synchronize()
+    assert pl["fold_now"] and pl[1]["pairs_now"]
+    oh = torch.nn.functional.one_hot(torch.tensor(labels), nc).double()
+    ref = O.classifier_train_step(arch, p_, O.AdamState(), torch.tensor(x), oh)
+    assert rel_err(pl["prob"].cpu().numpy(), ref["prob"].numpy()) < 4e-3
+    assert abs(pl["loss_acc"][0].item() - ref["loss"].item()) < 4e-3 * max(1.0, abs(ref["loss"].item()))
+    grads = eng.get_grads()
+    for k, g in ref["grads"].items():
+        report("fold_classifier[f16]", "grad_rel_err_vs_fp64[%s]" % k, rel_err(grads[k], g.numpy()))
+        assert grad_close(grads[k], g.numpy(), 0.3, atol=1e-5), k

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),
     "vm_dense_bwd": (I, [P, P, P, L, I, I, P, P, P, P]),
     "vm_siamese_head_loss": (I, [P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P]),
+    "vm_siamese_head_reduce": (I, [P, P, L, I, I, P, P, P, P]),
     "vm_softmax_cce": (I, [P, P, L, I, F, P, P, P, P, P]),
     "vm_sqnorm_workspace_bytes": (L, [L]),
     "vm_grad_sqnorm": (I, [P, L, P, P, P]),

@@ -861,24 +861,43 @@ struct PrepBatch {
     float* wt[PREP_MAX_LAYERS];  // optional: the fp32 kernel itself in wf's layout (the input of vm_fold_bn_weights)
     int c_in[PREP_MAX_LAYERS], c_out[PREP_MAX_LAYERS];
 };
+// One workgroup = one 32 (c_in) x 32 (c_out) tile of one tap of one layer (blockIdx.y): the source rows run along c_out, wf / wt rows
+// along c_in, so the tile goes through LDS and both sides move whole 64..128-byte segments (the element-per-thread version wrote
+// 2-byte scatters: 10..16 us at the end of every step for 1.2 M weights); wd keeps the source's orientation.
 template <typename T>
-__global__ void prep_weights_batch_kernel(PrepBatch pb) {
+__global__ __launch_bounds__(256) void prep_weights_batch_kernel(PrepBatch pb) {
+    __shared__ float tile[32][33];
     const int l = blockIdx.y;
     const int c_in = pb.c_in[l], c_out = pb.c_out[l];
-    const int64_t total = 3LL * c_in * c_out;
+    const int ti = (c_in + 31) / 32, tj = (c_out + 31) / 32;
+    if ((int)blockIdx.x >= 3 * ti * tj) return;
+    const int k = blockIdx.x / (ti * tj), r = blockIdx.x - k * ti * tj;
+    const int ci0 = (r / tj) * 32, co0 = (r % tj) * 32;
     const float* w = pb.w[l];
     T* wf = (T*)pb.wf[l];
     T* wd = (T*)pb.wd[l];
     float* wt = pb.wt[l];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % c_out);
-        const int64_t r = i / c_out;
-        const int ci = (int)(r % c_in);
-        const int k = (int)(r / c_in);
-        const T v = Elem<T>::from_f(w[i]);
-        wf[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = v;
-        wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = v;
-        if (wt != nullptr) wt[(int64_t)co * 3 * c_in + (int64_t)k * c_in + ci] = w[i];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+        float v = 0.f;
+        if (ci < c_in && co < c_out) {
+            v = w[((int64_t)k * c_in + ci) * c_out + co];
+            wd[(int64_t)ci * 3 * c_out + (int64_t)(2 - k) * c_out + co] = Elem<T>::from_f(v);
+        }
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+        if (ci < c_in && co < c_out) {
+            const float v = tile[tx][ty + 8 * j];
+            const int64_t o = (int64_t)co * 3 * c_in + (int64_t)k * c_in + ci;
+            wf[o] = Elem<T>::from_f(v);
+            if (wt != nullptr) wt[o] = v;
+        }
     }
 }
 
@@ -897,11 +916,11 @@ extern "C" int vm_prep_conv_weights_batch(int n_layers, const float* const* w, c
         pb.wt[l] = wt != nullptr ? wt[l] : nullptr;
         pb.c_in[l] = c_in[l];
         pb.c_out[l] = c_out[l];
-        const int64_t n = 3LL * c_in[l] * c_out[l];
+        const int64_t n = 3LL * ((c_in[l] + 31) / 32) * ((c_out[l] + 31) / 32);   // tiles
         most = n > most ? n : most;
     }
     VM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((prep_weights_batch_kernel<T>), dim3((unsigned)cdiv(most, 256), (unsigned)n_layers), dim3(256), 0,
+        hipLaunchKernelGGL((prep_weights_batch_kernel<T>), dim3((unsigned)most, (unsigned)n_layers), dim3(256), 0,
                            (hipStream_t)stream, pb);
     });
     return check_launch("vm_prep_conv_weights_batch");

@@ -444,11 +444,15 @@ extern "C" int vm_dense_fwd(const float* in, const float* w, const float* b, int
 
 extern "C" int vm_dense_bwd(const float* in, const float* w, const float* dout, int64_t rows, int n_in, int n_out,
                             float* grad_w, float* grad_b, float* din, void* stream) {
-    VM_REQUIRE(in && w && dout && grad_w && grad_b && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
+    VM_REQUIRE(in && w && dout && rows > 0 && n_in > 0 && n_out > 0, "vm_dense_bwd: bad argument");
+    VM_REQUIRE((grad_w == nullptr) == (grad_b == nullptr) && (grad_w != nullptr || din != nullptr), "vm_dense_bwd: grad_w / grad_b go together; one of (grad_w, din) is needed");
     VM_REQUIRE(n_in < 65535, "vm_dense_bwd: n_in too large");
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, dout, rows,
-                       n_in, n_out, grad_w, grad_b);
-    int rc = check_launch("vm_dense_bwd(w)");
+    int rc = VM_OK;
+    if (grad_w != nullptr) {   // NULL: the input gradient only (the caller puts the parameter half on another stream)
+        hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((n_out + 63) / 64, n_in + 1), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, in, dout,
+                           rows, n_in, n_out, grad_w, grad_b);
+        rc = check_launch("vm_dense_bwd(w)");
+    }
     if (rc || din == nullptr) return rc;
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
@@ -466,14 +470,23 @@ extern "C" int vm_siamese_head_loss(const float* emb, const float* head_w, const
     VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1,
                "vm_siamese_head_loss: head_kind %d not implemented (the reference raises NotImplementedError too)", head_kind);
     VM_REQUIRE(loss_kind == VM_LOSS_CONTRASTIVE || loss_kind == VM_LOSS_BCE, "vm_siamese_head_loss: unknown loss %d", loss_kind);
-    VM_REQUIRE(y == nullptr || (loss_acc && demb && grad_hw && grad_hb && ws), "vm_siamese_head_loss: training outputs missing");
+    VM_REQUIRE(y == nullptr || (demb && ws && (loss_acc == nullptr || (grad_hw && grad_hb))), "vm_siamese_head_loss: training outputs missing");
     hipLaunchKernelGGL(siamese_head_pair_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, head_w,
                        head_b, y, pairs, E, head_kind, loss_kind, grad_scale, pred, demb, ws);
     int rc = check_launch("vm_siamese_head_loss");
-    if (rc || y == nullptr) return rc;
+    if (rc || y == nullptr || loss_acc == nullptr) return rc;   // loss_acc NULL: the caller runs vm_siamese_head_reduce itself
     hipLaunchKernelGGL(siamese_head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, (const float*)ws, pairs, E,
                        head_kind, loss_acc, grad_hw, grad_hb);
     return check_launch("vm_siamese_head_loss(reduce)");
+}
+
+extern "C" int vm_siamese_head_reduce(const float* emb, const float* ws, int64_t pairs, int E, int head_kind, float* loss_acc,
+                                      float* grad_hw, float* grad_hb, void* stream) {
+    VM_REQUIRE(emb && ws && loss_acc && grad_hw && grad_hb && pairs > 0 && E > 0, "vm_siamese_head_reduce: bad argument");
+    VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1, "vm_siamese_head_reduce: head_kind %d", head_kind);
+    hipLaunchKernelGGL(siamese_head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, ws, pairs, E, head_kind, loss_acc,
+                       grad_hw, grad_hb);
+    return check_launch("vm_siamese_head_reduce");
 }
 
 extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_t rows, int n_classes, float grad_scale, float* prob,

@@ -703,8 +703,27 @@ class HipEncoderEngine:
         fold = bool(pl.get("fold_now"))   # the forward ran blocks 2.. on pool extremes with folded BatchNorm affines
         cl, Ll = self.blocks[-1][1], pl["L"][-1]
         G = self.G
-        self._call("vm_dense_bwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E,
-                 _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), _p(pl["dgmax"]), st)
+        dense = (_p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E)
+        if self.overlap_wgrad:
+            # what only the optimizer reads -- the head's sums, the dense layer's parameter gradients -- goes to the side stream: the
+            # main stream's chain to the first BatchNorm backward is four small launches shorter
+            if "head_ev" not in pl:
+                pl["head_ev"] = torch.cuda.Event()
+            pl["head_ev"].record()
+            with torch.cuda.stream(self.side_stream):
+                self.side_stream.wait_event(pl["head_ev"])
+                if pl.get("head_pending"):
+                    self._call("vm_siamese_head_reduce", _p(pl["emb"]), _p(pl["head_ws"]), n // 2, self.E, HEADS[self.head], _p(pl["loss_acc"]),
+                               _p(self.view("head.kernel", G)), _p(self.view("head.bias", G)), self.stream())
+                    pl["head_pending"] = False
+                self._call("vm_dense_bwd", *dense, _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), None, self.stream())
+            self._call("vm_dense_bwd", *dense, None, None, _p(pl["dgmax"]), st)
+        else:
+            if pl.get("head_pending"):   # (the switch was flipped between the head and here)
+                self._call("vm_siamese_head_reduce", _p(pl["emb"]), _p(pl["head_ws"]), n // 2, self.E, HEADS[self.head], _p(pl["loss_acc"]),
+                           _p(self.view("head.kernel", G)), _p(self.view("head.bias", G)), st)
+                pl["head_pending"] = False
+            self._call("vm_dense_bwd", *dense, _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), _p(pl["dgmax"]), st)
         # GlobalMaxPool1D backward stays sparse (dgmax, gidx): the last block's BN-backward passes consume that form
         last = self.nb - 1
         for i in range(self.nb - 1, -1, -1):
@@ -851,11 +870,15 @@ class HipEncoderEngine:
         pairs = pl["n"] // 2
         G = self.G
         train = y is not None
+        # training with the side stream on: only the per-pair pass here; the fixed-order sums (loss, accuracy, head gradients --
+        # nobody's input before the optimizer) are enqueued on the side stream by backward()
+        defer = train and self.overlap_wgrad and pl["training"]
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")),
                       _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], float(self.loss_scale), _p(pl["pred"]),
-                      _p(pl["loss_acc"]) if train else None, _p(pl["demb"]) if train else None,
+                      _p(pl["loss_acc"]) if (train and not defer) else None, _p(pl["demb"]) if train else None,
                       _p(self.view("head.kernel", G)) if train else None, _p(self.view("head.bias", G)) if train else None,
                       _p(pl["head_ws"]), self.stream())
+        pl["head_pending"] = defer
         return pl["pred"][:pairs]
 
     def classifier_head(self, pl: dict, labels: Optional[torch.Tensor]):
