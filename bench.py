@@ -155,6 +155,8 @@ def main():
             e.optimizer_step()
         return step, p_
 
+    host_enqueue_s = []
+
     def time_blocks(step, n_blocks, k_steps):
         """n_blocks blocks of exactly k_steps steps, barrier + synchronize on both sides of each, max over ranks per block."""
         out, mine = [], []
@@ -164,6 +166,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(k_steps):
                 step()
+            host_enqueue_s.append(time.perf_counter() - t0)   # the host is done enqueueing: how far ahead of the GPU it runs
             torch.cuda.synchronize()
             t_local = time.perf_counter() - t0
             parallel.barrier()
@@ -194,7 +197,8 @@ def main():
                                   "decimated x4 (L=12000), Adam(clipnorm 1), %s storage" % (a.loss, pairs, a.dtype),
                       "global_pairs": pairs * n_gpus, "parallelism": "dp%d" % n_gpus, "final_loss": loss},
            "timing": {"blocks": len(block_s), "steps_per_block": a.steps, "reported": "median block",
-                      "block_ms_per_step": [round(b / a.steps * 1e3, 4) for b in block_s]}}
+                      "block_ms_per_step": [round(b / a.steps * 1e3, 4) for b in block_s],
+                      "host_enqueue_ms_per_step": round(float(np.median(host_enqueue_s)) / a.steps * 1e3, 4)}}
     if n_gpus > 1:
         import torch.distributed as dist
         gs = eng.grad_sync
