@@ -66,13 +66,22 @@ GEMM_SHAPES = [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24
                (8, 140, 64, 384), (3, 520, 256, 512), (8, 300, 64, 256), (16, 1030, 256, 256)]
 
 
-@pytest.mark.parametrize("gemm_kernels", [{}, {"nt_n2": 0, "tn_x": 0}, {"nt_n2": 0, "nt_glds": 0, "tn_x": 0, "tn_tile": 128}],
-                         indirect=True, ids=["default", "lds-dma-128+tn256", "register-staged-128"])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,l,cin,cout", GEMM_SHAPES)
-def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout, gemm_kernels):
-    """The three forward / dgrad kernels and the three wgrad kernels (see the headers of conv_gemm.hip / conv_wgrad.hip) against
+def test_conv_fwd_dgrad_wgrad(dt, n, l, cin, cout):
+    """The default dispatch of the three conv GEMM entry points (see the headers of conv_gemm.hip / conv_wgrad.hip) against
     the float64 oracle: K tails (c_in = 8, 16, 24, 96), ragged t-tiles, N tails (136), windows shorter than a tile (5)."""
+    _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
+
+
+@pytest.mark.parametrize("gemm_kernels", [{"nt_n2": 0, "tn_x": 0}, {"nt_n2": 0, "nt_glds": 0, "tn_x": 0, "tn_tile": 128}],
+                         indirect=True, ids=["lds-dma-128+tn256", "register-staged-128"])
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("n,l,cin,cout", [GEMM_SHAPES[i] for i in (1, 2, 3, 5, 7, 9)])
+def test_conv_fwd_dgrad_wgrad_fallback_kernels(dt, n, l, cin, cout, gemm_kernels):
+    """... and the kernels the default dispatch does not pick on these shapes (the fallbacks of other shapes / storage types), pinned
+    through vm_set_tuning: every selectable kernel agrees with the oracle wherever it can be selected.  (bf16 differs from f16 in
+    the MFMA instruction only, which the default-dispatch test covers.)"""
     _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
 
 

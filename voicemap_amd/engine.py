@@ -190,10 +190,12 @@ class HipEncoderEngine:
         # ... and those sums go straight into the column reduction (vm_bn_bwd_from_sums_finalize: two small launches per block instead
         # of three, no per-window partial tensors in between); False = the separate vm_bn_bwd_from_sums + vm_bn_bwd_finalize calls
         self.fused_sums_finalize = True
-        # side-stream wgrad of block i enqueued after (True) or before (False) that block's dgrad: after it the wgrad runs beside the
-        # memory-bound BatchNorm passes of the block below instead of beside another matrix-bound GEMM (-0.7 % step, 6 + 6
-        # interleaved repetitions); block 2's stays early under data parallelism, where the gradient all-reduce waits for it
-        self.wgrad_after_dgrad = True
+        # side-stream wgrad of block i enqueued after (True) or before (False) that block's dgrad.  Round 2 (BatchNorm passes in the
+        # forward, dense z in the backward): after it, beside the memory-bound passes of the block below, was 0.7 % faster.  Round 3
+        # (folded forward, pair-form apply pass): before it is 1.5 % faster -- 2.888 / 2.923 ms against 2.854 / 2.863 ms, interleaved
+        # on one box -- the weight-gradient GEMM then starts as soon as du exists and the step's tail (block-1 backward, slab sums,
+        # optimizer) no longer waits for the last of them
+        self.wgrad_after_dgrad = False
         # training option (bf16): vm_conv_fwd_e -- the conv epilogue also writes the pool-window extreme, the pool pass reads that
         # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
         # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
