@@ -201,6 +201,10 @@ int vm_conv_wgrad(const void* in, const void* du, int64_t n_windows, int64_t L, 
 int64_t vm_conv_wgrad_fold_workspace_bytes(int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out);
 int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out,
                        int dtype, const float* scale, const float* shift, const float* dsum, void* ws, float* grad_w, void* stream);
+/* dsum == NULL above leaves the slabs in ws (the GEMM needs nothing but e and du, so it can start before vm_du_tower_sums has run);
+ * this is the second half: the per-tower slab sums with the two factors applied -> grad_w. */
+int vm_conv_wgrad_fold_finish(const void* ws, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out,
+                              const float* scale, const float* shift, const float* dsum, float* grad_w, void* stream);
 /* fp32 Keras kernel (3, c_in, c_out) -> wf (c_out, 3*c_in) and wd (c_in, 3*c_out) in `dtype`. */
 int vm_prep_conv_weights(const float* w, int c_in, int c_out, int dtype, void* wf, void* wd, void* stream);
 /* the same for n_layers (<= 8) layers in ONE launch: host arrays of device pointers / channel counts, one entry per layer.  wt

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vm_conv_wgrad": (I, [P, P, L, L, I, I, I, P, P, P]),
     "vm_conv_wgrad_fold_workspace_bytes": (L, [L, L, L, I, I]),
     "vm_conv_wgrad_fold": (I, [P, P, L, L, L, I, I, I, P, P, P, P, P, P]),
+    "vm_conv_wgrad_fold_finish": (I, [P, L, L, L, I, I, P, P, P, P, P]),
     "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
     "vm_colreduce_workspace_bytes": (L, [I, I]),
     "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P]),

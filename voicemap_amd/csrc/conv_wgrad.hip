@@ -783,22 +783,32 @@ extern "C" int64_t vm_conv_wgrad_fold_workspace_bytes(int64_t n_windows, int64_t
     return splits * 3 * c_in * c_out * (int64_t)sizeof(float) + 64;
 }
 
+extern "C" int vm_conv_wgrad_fold_finish(const void* ws, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out,
+                                         const float* scale, const float* shift, const float* dsum, float* grad_w, void* stream) {
+    VM_REQUIRE(ws && scale && shift && dsum && grad_w, "vm_conv_wgrad_fold_finish: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
+               "vm_conv_wgrad_fold_finish: n_windows must be a positive multiple of windows_per_tower");
+    const int towers = (int)(n_windows / windows_per_tower);
+    const int spt = wgrad_splits_per_tower(n_windows, windows_per_tower, L, c_in, c_out);
+    const int64_t n = 3LL * c_in * c_out;
+    hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, towers, spt,
+                       c_in, c_out, scale, shift, dsum, grad_w);
+    return check_launch("vm_conv_wgrad_fold_finish");
+}
+
 extern "C" int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in,
                                   int c_out, int dtype, const float* scale, const float* shift, const float* dsum, void* ws,
                                   float* grad_w, void* stream) {
-    VM_REQUIRE(in_e && du && scale && shift && dsum && ws && grad_w, "vm_conv_wgrad_fold: null pointer");
+    VM_REQUIRE(in_e && du && ws, "vm_conv_wgrad_fold: null pointer");
+    VM_REQUIRE(dsum == nullptr || (scale && shift && grad_w), "vm_conv_wgrad_fold: scale / shift / grad_w go with dsum");
     VM_REQUIRE(n_windows > 0 && L > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
                "vm_conv_wgrad_fold: n_windows must be a positive multiple of windows_per_tower");
     VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_wgrad_fold: channels must be multiples of 8");
-    const int towers = (int)(n_windows / windows_per_tower);
     const int splits = launch_wgrad(in_e, du, n_windows, windows_per_tower, L, c_in, c_out, dtype, ws, (hipStream_t)stream);
     if (splits < 0) return splits;  // unknown dtype
     int rc = check_launch("vm_conv_wgrad_fold");
-    if (rc) return rc;
-    const int64_t n = 3LL * c_in * c_out;
-    hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, towers,
-                       splits / towers, c_in, c_out, scale, shift, dsum, grad_w);
-    return check_launch("vm_conv_wgrad_fold");
+    if (rc || dsum == nullptr) return rc;   // dsum NULL: the slabs only; vm_conv_wgrad_fold_finish later (once dsum exists)
+    return vm_conv_wgrad_fold_finish(ws, n_windows, windows_per_tower, L, c_in, c_out, scale, shift, dsum, grad_w, stream);
 }
 
 // ---- the weights vm_conv_fwd_fold runs on, per tower t: wf[t][co][k * c_in + ci] = W[k][ci][co] * scale[t][ci] in the storage type,

@@ -798,9 +798,12 @@ class HipEncoderEngine:
                 cin = self.blocks[i - 1][1]
                 if fold:
                     lo = pl[i - 1]
+                    # the GEMM first (it needs e and du only), the tap sums behind it, then the per-tower slab sums with their factors
+                    self._call("vm_conv_wgrad_fold", _p(lo["ep"]), _p(b["du"]), n, wpt, L, cin, c, dt, None, None, None,
+                               _p(b["wgrad_ws_fold"]), None, stream)
                     self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), stream)
-                    self._call("vm_conv_wgrad_fold", _p(lo["ep"]), _p(b["du"]), n, wpt, L, cin, c, dt, _p(lo["scale"]), _p(lo["shift"]),
-                               _p(b["dsum"]), _p(b["wgrad_ws_fold"]), gw, stream)
+                    self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]), _p(lo["shift"]),
+                               _p(b["dsum"]), gw, stream)
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, stream)
                     self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(cr_ws), stream)
