@@ -15,7 +15,11 @@
 
 namespace vm {
 
-constexpr int BN_SEG = 8;  // partial-sum segments per window in the backward kernels
+constexpr int BN_SEG = 8;  // partial-sum rows per window (the layout of every part_* tensor)
+// Workgroups per window of the pass kernels = gridDim.y: BN_SEG for the long windows of the 1-D encoder, 1 for short ones (the 2-D
+// variant runs 16 384 windows of 149 pooled rows x 4 channel vectors: eight workgroups per window left 70 % of their threads without a
+// row and the passes at 0.8-1.6 TB/s).  A launch with fewer segments zero-fills the partial rows it does not produce.
+static int bn_segs(int64_t Lq, int C, int vec) { return Lq * (int64_t)(C / vec) >= 8 * 256 ? BN_SEG : 1; }
 
 // VEC consecutive per-channel values (VEC = 4 or 8, 16-byte aligned) as 16-byte accesses: the kernels below run only a
 // dozen loop iterations per thread on the last block, so 5 x 8 scalar parameter loads per thread were a visible cost.
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_drop_pool_fwd_kernel(const T* __restri
         }
         const T* zrow = z + n * L * C + c0;
         T* orow = out + (n * (Lq + 2) + 1) * C + c0;
-        for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Lq; q += (int64_t)RP * BN_SEG) {
+        for (int64_t q = seg + (int64_t)rl * gridDim.y; q < Lq; q += (int64_t)RP * gridDim.y) {
             Vec16<T> v[POOL];
 #pragma unroll
             for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                 ones<VEC>(dr);
             }
             const T* zrow = z + n * L * C + c0;
-            for (int64_t q = seg + (int64_t)rl * BN_SEG; q < Lq; q += (int64_t)RP * BN_SEG) {
+            for (int64_t q = seg + (int64_t)rl * gridDim.y; q < Lq; q += (int64_t)RP * gridDim.y) {
                 Vec16<T> v[POOL];
 #pragma unroll
                 for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
@@ -301,6 +305,10 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                 }
                 part_v[row * C + c0 + i] = b;
                 part_i[row * C + c0 + i] = k;
+                for (int e = gridDim.y; seg == 0 && e < BN_SEG; ++e) {   // fewer segments than partial rows: the others are "empty"
+                    part_v[(row + e) * C + c0 + i] = -INFINITY;
+                    part_i[(row + e) * C + c0 + i] = 0x7fffffff;
+                }
             }
         }
         __syncthreads();
@@ -461,8 +469,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 for (int j = 0; j < POOL; ++j)
                     if (FULL || j < nrows) store16<T>(op + j * C, ov[j]);
             };
-            int64_t q = seg + (int64_t)rl * BN_SEG;
-            for (; q < Lq; q += (int64_t)RP * BN_SEG) body(q, std::true_type{});
+            int64_t q = seg + (int64_t)rl * gridDim.y;
+            for (; q < Lq; q += (int64_t)RP * gridDim.y) body(q, std::true_type{});
             if (q < Q) body(q, std::false_type{});  // the remainder rows of a floor pool (q == Lq)
         }
         // reduce over the RP row lanes
@@ -481,6 +489,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 for (int i = 0; i < VEC; ++i) a[i] += t[i];
             }
             storev<VEC>(part_a + row * C + c0, a);
+            if (seg == 0 && gridDim.y < BN_SEG) {   // fewer segments than partial rows: the others are zero
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+                for (int e = gridDim.y; e < BN_SEG; ++e) storev<VEC>(part_a + (row + e) * C + c0, a);
+            }
         }
         __syncthreads();
     }
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
     const int seg = blockIdx.y;
     const int64_t tw = n / wpt;
     const int64_t Lq = L / POOL;
-    const int64_t stride = (int64_t)RP * BN_SEG;
+    const int64_t stride = (int64_t)RP * gridDim.y;
     for (int cvb = 0; cvb < CV; cvb += P) {
         const int cv = cvb + pl;
         const bool cok = cv < CV;
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
                     s1[i] = fmaf(d, fmaf(pv.get(i), ra[i], rb[i]), s1[i]);
                 }
             };
-            int64_t q = seg + (int64_t)rl * BN_SEG;
+            int64_t q = seg + (int64_t)rl * gridDim.y;
             for (; q + stride < Lq; q += 2 * stride) {
                 const Vec16<T> pa = load16<T>(ab + q * C), da = load16<T>(db + q * C);
                 const Vec16<T> pc = load16<T>(ab + (q + stride) * C), dc = load16<T>(db + (q + stride) * C);
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
                     s1[i] = fmaf(d, sgn[i] * m, s1[i]);
                 }
             };
-            int64_t q = seg + (int64_t)rl * BN_SEG;
+            int64_t q = seg + (int64_t)rl * gridDim.y;
             for (; q + stride < Lq; q += 2 * stride) {
                 Vec16<T> za[POOL], zc[POOL];
 #pragma unroll
@@ -645,6 +658,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
             }
             storev<VEC>(part_a + row * C + c0, a);
             storev<VEC>(part_b + row * C + c0, b);
+            if (seg == 0 && gridDim.y < BN_SEG) {   // fewer segments than partial rows: the others are zero
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+                for (int e = gridDim.y; e < BN_SEG; ++e) {
+                    storev<VEC>(part_a + (row + e) * C + c0, a);
+                    storev<VEC>(part_b + (row + e) * C + c0, a);
+                }
+            }
         }
         __syncthreads();
     }
@@ -935,7 +956,7 @@ extern "C" int vm_bn_drop_pool_fwd(const void* z, const float* scale, const floa
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_drop_pool_fwd: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_drop_pool_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+        hipLaunchKernelGGL((bn_drop_pool_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, (T*)out);
     }));
     return check_launch("vm_bn_drop_pool_fwd");
@@ -954,7 +975,7 @@ extern "C" int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const
     int32_t* part_i = (int32_t*)(part_v + n_windows * BN_SEG * (int64_t)C);
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+        hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i);
     }));
     hipLaunchKernelGGL(gmax_segments_kernel, dim3((unsigned)((n_windows * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -971,7 +992,7 @@ extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float*
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, windows_per_tower, L, C, P,
                            part_dy, part_dyz, (const T*)nullptr, (const float*)nullptr);
     }));
@@ -987,7 +1008,7 @@ extern "C" int vm_bn_pool_bwd_reduce_pooled(const void* z, const void* act, cons
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_pool_bwd_reduce_pooled: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)z, (const T*)dp, scale, mean, invstd, drop, windows_per_tower, L, C, P,
                            part_dy, part_dyz, (const T*)act, shift);
     }));
@@ -1073,11 +1094,11 @@ static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         if (sp_idx != nullptr) {
-            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                                (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
                                L, C, P, (T*)du, part_du, sp_dg, sp_idx);
         } else {
-            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                                (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
                                L, C, P, (T*)du, part_du, sp_dg, sp_idx);
         }
@@ -1103,7 +1124,7 @@ extern "C" int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const vo
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool_bwd_apply_pairs: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     VM_DISPATCH_16(dtype, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), dim3((unsigned)n_windows, BN_SEG), dim3(256), 0,
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / 2, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)e, (const T*)o, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
                            L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr);
     });

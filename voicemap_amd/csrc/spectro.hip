@@ -115,84 +115,94 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(const void* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// element-wise helpers; V = elements per thread access (16 bytes when the channel count allows, else 1)
+// element-wise helpers.  One thread = one V-element vector (V = 16 bytes' worth when the channel count allows, else 1) of one window;
+// grid = (windows, ceil(vectors per window / 256)): no 64-bit divisions on the element path, whole-vector loads and stores.
 // ------------------------------------------------------------------------------------------------
+template <typename T, int V> struct EwVec {   // V elements moved as one unit
+    T v[V];
+};
+template <typename T, int V>
+__device__ inline EwVec<T, V> ew_load(const T* p) {
+    EwVec<T, V> r;
+    if constexpr (V * sizeof(T) == 16) {
+        *reinterpret_cast<u32x4*>(r.v) = *reinterpret_cast<const u32x4*>(p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) r.v[e] = p[e];
+    }
+    return r;
+}
+template <typename T, int V>
+__device__ inline void ew_store(T* p, const EwVec<T, V>& r) {
+    if constexpr (V * sizeof(T) == 16) {
+        *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(r.v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) p[e] = r.v[e];
+    }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void stack_windows_kernel(const T* __restrict__ x, int64_t n_clips, int M, int rows, int C, int Cs,
                                                             T* __restrict__ out) {
-    const int64_t per_row = Cs / V;
-    const int64_t total = n_clips * M * rows * per_row;
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cs = (int)(i % per_row) * V;
-        const int64_t rw = i / per_row;  // (window, row)
-        const int row = (int)(rw % rows);
-        const int64_t win = rw / rows;
-        const int m = (int)(win % M);
-        const int dm = cs / C, c = cs - dm * C;  // V divides C on the vector path: a vector never straddles two bands
-        const int ms = m + dm - 1;
-        T v[V];
+    const int per_row = Cs / V;
+    const int64_t win = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;   // (row, vector of the stacked row)
+    if (j >= rows * per_row) return;
+    const int row = j / per_row, cs = (j - row * per_row) * V;
+    const int m = (int)(win % M);
+    const int dm = cs / C, c = cs - dm * C;  // V divides C on the vector path: a vector never straddles two bands
+    const int ms = m + dm - 1;
+    EwVec<T, V> v;
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = Elem<T>::from_f(0.f);
-        if (dm < 3 && ms >= 0 && ms < M) {
-            const T* src = x + ((win - m + ms) * rows + row) * (int64_t)C + c;
-#pragma unroll
-            for (int e = 0; e < V; ++e) v[e] = src[e];
-        }
-        T* dst = out + rw * (int64_t)Cs + cs;
-#pragma unroll
-        for (int e = 0; e < V; ++e) dst[e] = v[e];
-    }
+    for (int e = 0; e < V; ++e) v.v[e] = Elem<T>::from_f(0.f);
+    if (dm < 3 && ms >= 0 && ms < M) v = ew_load<T, V>(x + ((win - m + ms) * rows + row) * (int64_t)C + c);
+    ew_store<T, V>(out + (win * rows + row) * (int64_t)Cs + cs, v);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void fold_windows_kernel(const T* __restrict__ dxs, int64_t n_clips, int M, int L, int C, int Cs,
                                                            T* __restrict__ dx) {
-    const int64_t per_row = C / V;
-    const int64_t total = n_clips * M * L * per_row;
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % per_row) * V;
-        const int64_t rw = i / per_row;
-        const int t = (int)(rw % L);
-        const int64_t win = rw / L;
-        const int m = (int)(win % M);
-        float acc[V];
+    const int per_row = C / V;
+    const int64_t win = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= L * per_row) return;
+    const int t = j / per_row, c = (j - t * per_row) * V;
+    const int m = (int)(win % M);
+    float acc[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int dm = 0; dm < 3; ++dm) {
-            const int md = m - dm + 1;  // the window whose stacked band dm is this window
-            if (md >= 0 && md < M) {
-                const T* src = dxs + ((win - m + md) * L + t) * (int64_t)Cs + dm * C + c;
+    for (int dm = 0; dm < 3; ++dm) {
+        const int md = m - dm + 1;  // the window whose stacked band dm is this window
+        if (md >= 0 && md < M) {
+            const EwVec<T, V> s = ew_load<T, V>(dxs + ((win - m + md) * L + t) * (int64_t)Cs + dm * C + c);
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(src[e]);
-            }
+            for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(s.v[e]);
         }
-        T* dst = dx + rw * (int64_t)C + c;
-#pragma unroll
-        for (int e = 0; e < V; ++e) dst[e] = Elem<T>::from_f(acc[e]);
     }
+    EwVec<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.v[e] = Elem<T>::from_f(acc[e]);
+    ew_store<T, V>(dx + (win * L + t) * (int64_t)C + c, o);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool_windows_fwd_kernel(const T* __restrict__ q, int64_t n_clips, int M, int rows, int C,
                                                                T* __restrict__ out) {
     const int Mo = M / 2;
-    const int64_t per_win = (int64_t)rows * C / V;
-    const int64_t total = n_clips * Mo * per_win;
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t e0 = (i % per_win) * V;
-        const int64_t wo = i / per_win;
-        const int64_t b = wo / Mo;
-        const int mo = (int)(wo % Mo);
-        const T* a = q + ((b * M + 2 * mo) * (int64_t)rows * C) + e0;
-        const T* c2 = a + (int64_t)rows * C;
-        T* dst = out + wo * (int64_t)rows * C + e0;
+    const int64_t wo = blockIdx.x;   // output window
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= rows * C / V) return;
+    const int64_t e0 = (int64_t)j * V;
+    const int64_t b = wo / Mo;
+    const int mo = (int)(wo - b * Mo);
+    const T* a = q + ((b * M + 2 * mo) * (int64_t)rows * C) + e0;
+    const EwVec<T, V> x0 = ew_load<T, V>(a), x1 = ew_load<T, V>(a + (int64_t)rows * C);
+    EwVec<T, V> o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float x0 = Elem<T>::to_f(a[e]), x1 = Elem<T>::to_f(c2[e]);
-            dst[e] = x0 >= x1 ? a[e] : c2[e];
-        }
-    }
+    for (int e = 0; e < V; ++e) o.v[e] = Elem<T>::to_f(x0.v[e]) >= Elem<T>::to_f(x1.v[e]) ? x0.v[e] : x1.v[e];
+    ew_store<T, V>(out + wo * (int64_t)rows * C + e0, o);
 }
 
 // q: the forward input (n_clips * M windows, L + 2 rows with halo); dout: (n_clips * (M/2), L, C); dq: (n_clips * M, L, C)
@@ -200,29 +210,28 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void pool_windows_bwd_kernel(const T* __restrict__ q, const T* __restrict__ dout, int64_t n_clips, int M,
                                                                int L, int C, T* __restrict__ dq) {
     const int Mo = M / 2;
-    const int64_t per_win = (int64_t)L * C / V;
-    const int64_t total = n_clips * M * per_win;
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t e0 = (i % per_win) * V;
-        const int64_t win = i / per_win;
-        const int64_t b = win / M;
-        const int m = (int)(win % M);
-        T* dst = dq + win * (int64_t)L * C + e0;
-        if (m >= 2 * Mo) {  // odd band count: the last band is dropped by the floor pooling
+    const int64_t win = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= L * C / V) return;
+    const int64_t e0 = (int64_t)j * V;
+    const int64_t b = win / M;
+    const int m = (int)(win - b * M);
+    T* dst = dq + win * (int64_t)L * C + e0;
+    EwVec<T, V> o;
 #pragma unroll
-            for (int e = 0; e < V; ++e) dst[e] = Elem<T>::from_f(0.f);
-            continue;
-        }
+    for (int e = 0; e < V; ++e) o.v[e] = Elem<T>::from_f(0.f);
+    if (m < 2 * Mo) {  // (odd band count: the last band is dropped by the floor pooling and gets no gradient)
         const int64_t pair = b * M + (m & ~1);
         const T* q0 = q + (pair * (L + 2) + 1) * (int64_t)C + e0;  // skip the halo row
-        const T* q1 = q0 + (int64_t)(L + 2) * C;
-        const T* g = dout + (b * Mo + (m >> 1)) * (int64_t)L * C + e0;
+        const EwVec<T, V> a0 = ew_load<T, V>(q0), a1 = ew_load<T, V>(q0 + (int64_t)(L + 2) * C);
+        const EwVec<T, V> g = ew_load<T, V>(dout + (b * Mo + (m >> 1)) * (int64_t)L * C + e0);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const bool first = Elem<T>::to_f(q0[e]) >= Elem<T>::to_f(q1[e]);
-            dst[e] = (first == ((m & 1) == 0)) ? g[e] : Elem<T>::from_f(0.f);
+            const bool first = Elem<T>::to_f(a0.v[e]) >= Elem<T>::to_f(a1.v[e]);
+            if (first == ((m & 1) == 0)) o.v[e] = g.v[e];
         }
     }
+    ew_store<T, V>(dst, o);
 }
 
 __global__ __launch_bounds__(256) void clip_max_fwd_kernel(const float* __restrict__ gmax, int64_t n_clips, int M, int Mv, int C,
@@ -255,10 +264,7 @@ __global__ __launch_bounds__(256) void clip_max_bwd_kernel(const float* __restri
     dg[i] = widx[b * C + c] == m ? dout[b * C + c] : 0.f;
 }
 
-static unsigned ew_grid(int64_t total) {
-    const int64_t g = (total + 255) / 256;
-    return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
-}
+static dim3 ew_grid(int64_t windows, int64_t vectors_per_window) { return dim3((unsigned)windows, (unsigned)((vectors_per_window + 255) / 256)); }
 
 }  // namespace vm
 
@@ -311,8 +317,7 @@ extern "C" int vm_stack_windows(const void* x, int64_t n_clips, int M, int64_t r
     VM_REQUIRE(x && out, "vm_stack_windows: null pointer");
     VM_REQUIRE(n_clips > 0 && M > 0 && rows > 0 && C > 0 && Cs >= 3 * C, "vm_stack_windows: bad sizes (Cs >= 3 C)");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
-        const int64_t total = n_clips * M * rows * (Cs / V);
-        hipLaunchKernelGGL((stack_windows_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, n_clips, M,
+        hipLaunchKernelGGL((stack_windows_kernel<T, V>), ew_grid(n_clips * M, rows * (Cs / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, n_clips, M,
                            (int)rows, C, Cs, (T*)out);
     }));
     return check_launch("vm_stack_windows");
@@ -322,8 +327,7 @@ extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t 
     VM_REQUIRE(dxs && dx, "vm_fold_windows: null pointer");
     VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && C > 0 && Cs >= 3 * C, "vm_fold_windows: bad sizes (Cs >= 3 C)");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
-        const int64_t total = n_clips * M * L * (C / V);
-        hipLaunchKernelGGL((fold_windows_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dxs, n_clips, M,
+        hipLaunchKernelGGL((fold_windows_kernel<T, V>), ew_grid(n_clips * M, L * (C / V)), dim3(256), 0, (hipStream_t)stream, (const T*)dxs, n_clips, M,
                            (int)L, C, Cs, (T*)dx);
     }));
     return check_launch("vm_fold_windows");
@@ -333,8 +337,7 @@ extern "C" int vm_pool_windows_fwd(const void* q, int64_t n_clips, int M, int64_
     VM_REQUIRE(q && out, "vm_pool_windows_fwd: null pointer");
     VM_REQUIRE(n_clips > 0 && M >= 2 && rows > 0 && C > 0, "vm_pool_windows_fwd: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, (rows * C), {
-        const int64_t total = n_clips * (M / 2) * (rows * C / V);
-        hipLaunchKernelGGL((pool_windows_fwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)q, n_clips, M,
+        hipLaunchKernelGGL((pool_windows_fwd_kernel<T, V>), ew_grid(n_clips * (M / 2), rows * C / V), dim3(256), 0, (hipStream_t)stream, (const T*)q, n_clips, M,
                            (int)rows, C, (T*)out);
     }));
     return check_launch("vm_pool_windows_fwd");
@@ -345,8 +348,7 @@ extern "C" int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_cl
     VM_REQUIRE(q && dout && dq, "vm_pool_windows_bwd: null pointer");
     VM_REQUIRE(n_clips > 0 && M >= 2 && L > 0 && C > 0, "vm_pool_windows_bwd: bad sizes");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, C, {
-        const int64_t total = n_clips * M * (L * C / V);
-        hipLaunchKernelGGL((pool_windows_bwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)q,
+        hipLaunchKernelGGL((pool_windows_bwd_kernel<T, V>), ew_grid(n_clips * M, L * C / V), dim3(256), 0, (hipStream_t)stream, (const T*)q,
                            (const T*)dout, n_clips, M, (int)L, C, (T*)dq);
     }));
     return check_launch("vm_pool_windows_bwd");

@@ -215,6 +215,7 @@ class HipEncoderEngine:
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
         self.tower_stream = torch.cuda.Stream(device=self.device)
+        self.defer_head_reduce = True   # backward() enqueues the head's sums on the side stream (engines that borrow siamese_head: no)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
         self._plans: Dict[Tuple, dict] = {}
@@ -877,7 +878,7 @@ class HipEncoderEngine:
         train = y is not None
         # training with the side stream on: only the per-pair pass here; the fixed-order sums (loss, accuracy, head gradients --
         # nobody's input before the optimizer) are enqueued on the side stream by backward()
-        defer = train and self.overlap_wgrad and pl["training"]
+        defer = train and self.overlap_wgrad and pl["training"] and getattr(self, "defer_head_reduce", False)
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")),
                       _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], float(self.loss_scale), _p(pl["pred"]),
                       _p(pl["loss_acc"]) if (train and not defer) else None, _p(pl["demb"]) if train else None,
