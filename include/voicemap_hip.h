@@ -411,6 +411,18 @@ int vm_pairdist_argmin(const float* q, const float* ref, int64_t M, int64_t N, i
 int64_t vm_stft_frames(int64_t raw_len, int win_length, int hop);
 int vm_stft_logmel(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const float* basis,
                    const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
+/* First Conv2D(3 x 3) of the variant (one input channel) on the vector ALUs instead of as a band-stacked GEMM with K = 24, N = 32:
+ * in: block input (n_clips * M, L + 2, 1) `dtype` with zero halo rows; w: the fp32 kernel (3, Cs, C) of the flat store (Cs >= 3, the
+ * entries km >= 3 are padding), rounded to `dtype` inside like the GEMM path's copy; z (n_clips * M, L, C) = relu(conv + bias);
+ * stat_sum / stat_sq (optional): the BatchNorm partial sums of the stored z, vm_conv_stat_rows(L) rows per window.  C % 8 == 0,
+ * C <= 128.  vm_conv2d_first_wgrad: the matching kernel gradient (3, Cs, C) from du (n_clips * M, L + 2, C) (padding entries 0);
+ * the layer has no input gradient. */
+int vm_conv2d_first_supported(int C, int dtype);
+int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C, int dtype,
+                        void* z, float* stat_sum, float* stat_sq, void* stream);
+int64_t vm_conv2d_first_wgrad_workspace_bytes(int64_t n_clips, int M, int C);
+int vm_conv2d_first_wgrad(const void* in, const void* du, int64_t n_clips, int M, int64_t L, int Cs, int C, int dtype, void* ws,
+                          float* grad_w, void* stream);
 /* Conv2D(3 x 3, SAME) over (T, M) = the k = 3 convolution along T (vm_conv_fwd / _dgrad / _wgrad) of the band-stacked tensor:
  * x: (n_clips * M windows, rows, C) with rows = T + 2 (halo rows included: they are copied, so they stay zero);
  * out: (n_clips * M, rows, Cs), out[(b, m)][row][dm * C + c] = x[(b, m + dm - 1)][row][c] (0 outside the clip's M bands),

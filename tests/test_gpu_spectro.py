@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import voicemap_oracle as O
-from tests.gpu_util import DTYPES, L, cosine, dev, grad_close, max_err, p, quant, rel_err, report, stream
+from tests.gpu_util import DTYPES, L, cosine, dev, grad_close, max_err, p, padded, quant, rel_err, report, stream
 from voicemap_amd import spectro as S
 
 pytestmark = pytest.mark.gpu
@@ -71,6 +71,66 @@ def test_stack_fold_windows(dt, n, M, rows, C, Cs):
                 fref[:, m] += g[:, m - dm + 1, :, dm * C:(dm + 1) * C]
     assert rel_err(dx.float().cpu().numpy().reshape(n, M, Lr, C), fref) < (1e-6 if dt == "f32" else 5e-3)
     assert abs((ref * g).sum() - (x * fref).sum()) < 1e-9 * max(1.0, abs((ref * g).sum()))   # <stack x, g> == <x, fold g>
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,M,Lw,C", [(2, 5, 298, 32), (1, 3, 130, 96), (2, 4, 37, 64), (1, 2, 256, 128), (3, 1, 5, 8)])
+def test_conv2d_first_layer_fwd_and_wgrad(dt, n, M, Lw, C):
+    """The one-input-channel Conv2D(3 x 3) on the vector ALUs (vm_conv2d_first_fwd / _wgrad) against its definition in float64: SAME
+    padding along both axes (bands outside the clip and the halo rows are zero), ReLU, BatchNorm partial sums of the STORED values
+    in vm_conv_stat_rows' layout, the kernel gradient in the flat store's (3, Cs, C) layout with zero padding entries -- and against
+    the band-stacked GEMM path it replaces (vm_stack_windows + vm_conv_fwd / vm_conv_wgrad)."""
+    vm, tdt = DTYPES[dt]
+    assert L().query("vm_conv2d_first_supported", C, vm) == 1
+    r = np.random.default_rng(n * 100 + M + Lw + C)
+    Cs = 8
+    x = quant(r.normal(0, 1, (n * M, Lw, 1)), dt).numpy()
+    w = np.zeros((3, Cs, C), np.float32)
+    w[:, :3] = r.normal(0, 0.3, (3, 3, C))
+    bias = r.normal(0, 0.1, C).astype(np.float32)
+    xin = padded(x, tdt)
+    rows = L().query("vm_conv_stat_rows", Lw)
+    z = torch.empty(n * M, Lw, C, dtype=tdt, device="cuda")
+    ssum = torch.empty(n * M * rows, C, dtype=torch.float32, device="cuda")
+    ssq = torch.empty_like(ssum)
+    L().call("vm_conv2d_first_fwd", p(xin), p(dev(w)), p(dev(bias)), n, M, Lw, Cs, C, vm, p(z), p(ssum), p(ssq), stream())
+    torch.cuda.synchronize()
+    wq = quant(w, dt).numpy()                                   # the weights the kernel multiplies by
+    img = np.zeros((n, M + 2, Lw + 2))
+    img[:, 1:-1, 1:-1] = x.reshape(n, M, Lw)
+    zr = np.zeros((n, M, Lw, C))
+    for kt in range(3):
+        for km in range(3):
+            zr += img[:, km:km + M, kt:kt + Lw, None] * wq[kt, km][None, None, None, :]
+    zr = np.maximum(zr + bias, 0.0).reshape(n * M, Lw, C)
+    zg = z.to(torch.float64).cpu().numpy()
+    assert rel_err(zg, zr) < (1e-6 if dt == "f32" else 6e-3 if dt == "bf16" else 8e-4)
+    pad = np.zeros((n * M, rows * 128, C))
+    pad[:, :Lw] = zg
+    assert np.allclose(ssum.cpu().numpy().reshape(n * M, rows, C), pad.reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    assert np.allclose(ssq.cpu().numpy().reshape(n * M, rows, C), (pad * pad).reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    # the GEMM path on the same operands: stacked bands, K = 24 of 32
+    xs = torch.zeros(n * M, Lw + 2, Cs, dtype=tdt, device="cuda")
+    L().call("vm_stack_windows", p(xin), n, M, Lw + 2, 1, Cs, vm, p(xs), stream())
+    wf, wd = torch.empty(C * 3 * Cs, dtype=tdt, device="cuda"), torch.empty(Cs * 3 * C, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), Cs, C, vm, p(wf), p(wd), stream())
+    z2 = torch.empty_like(z)
+    L().call("vm_conv_fwd", p(xs), p(wf), p(dev(bias)), n * M, Lw, Cs, C, vm, p(z2), None, None, stream())
+    torch.cuda.synchronize()
+    assert rel_err(zg, z2.to(torch.float64).cpu().numpy()) < (1e-6 if dt == "f32" else 6e-3 if dt == "bf16" else 8e-4)
+    # weight gradient
+    du = quant(r.normal(0, 1, (n * M, Lw, C)), dt).numpy()
+    ws = torch.empty(L().query("vm_conv2d_first_wgrad_workspace_bytes", n, M, C) // 4 + 16, dtype=torch.float32, device="cuda")
+    gw = torch.full((3, Cs, C), 7.0, dtype=torch.float32, device="cuda")
+    L().call("vm_conv2d_first_wgrad", p(xin), p(padded(du, tdt)), n, M, Lw, Cs, C, vm, p(ws), p(gw), stream())
+    torch.cuda.synchronize()
+    want = np.zeros((3, Cs, C))
+    dur = du.reshape(n, M, Lw, C)
+    for kt in range(3):
+        for km in range(3):
+            want[kt, km] = np.einsum("nml,nmlc->c", img[:, km:km + M, kt:kt + Lw], dur)
+    assert rel_err(gw.cpu().numpy(), want) < 2e-5
+    assert (gw[:, 3:] == 0).all()
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

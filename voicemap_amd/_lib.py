@@ -98,6 +98,10 @@ SIGNATURES = {
     "vm_pairdist_argmin": (I, [P, P, L, L, I, I, L, P, P, P, P, P]),
     "vm_stft_frames": (L, [L, I, I]),
     "vm_stft_logmel": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
+    "vm_conv2d_first_supported": (I, [I, I]),
+    "vm_conv2d_first_fwd": (I, [P, P, P, L, I, L, I, I, I, P, P, P, P]),
+    "vm_conv2d_first_wgrad_workspace_bytes": (L, [L, I, I]),
+    "vm_conv2d_first_wgrad": (I, [P, P, L, I, L, I, I, I, P, P, P]),
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),
     "vm_fold_windows": (I, [P, L, I, L, I, I, I, P, P]),
     "vm_pool_windows_fwd": (I, [P, L, I, L, I, I, P, P]),

@@ -63,11 +63,15 @@ __device__ inline void ones(float (&v)[VEC]) {
 //   stage 2: the consumer kernel adds the CR_CHUNKS doubles per (segment, channel) in a fixed (butterfly) order.
 constexpr int CR_CHUNKS = 32;
 
+// CL channels x (1024 / CL) row lanes per workgroup: 64 x 16 for the wide layers, 32 x 32 where 64 lanes would be half empty
+// (C = 32, 96: the 2-D variant, whose 131 K partial rows made this kernel 0.4 ms of its step)
+template <int CL>
 __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                  int64_t rows_per_seg, int C, double* __restrict__ ws) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int RG = 1024 / CL;
+    __shared__ double red[2][RG][CL];
+    const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl;
     const int seg = blockIdx.y / CR_CHUNKS, chunk = blockIdx.y % CR_CHUNKS;
     const int64_t per = (rows_per_seg + CR_CHUNKS - 1) / CR_CHUNKS;
     const int64_t r_lo = chunk * per;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     double s = 0.0, q = 0.0;
     if (c < C) {
         const int64_t base = (int64_t)seg * rows_per_seg;
-        for (int64_t r = r_lo + rg; r < r_hi; r += 16) {
+        for (int64_t r = r_lo + rg; r < r_hi; r += RG) {
             s += (double)a[(base + r) * C + c];
             if (b != nullptr) q += (double)b[(base + r) * C + c];
         }
@@ -87,12 +91,20 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     if (rg == 0 && c < C) {
         double ss = 0.0, qq = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < RG; ++i) {
             ss += red[0][i][cl];
             qq += red[1][i][cl];
         }
         ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
         ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+    }
+}
+
+static void launch_colreduce(const float* a, const float* b, int64_t rows_per_seg, int C, int segs, double* ws, hipStream_t st) {
+    if (C % 64 == 0 || C > 128) {
+        hipLaunchKernelGGL(colreduce_stage1_kernel<64>, dim3((C + 63) / 64, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws);
+    } else {
+        hipLaunchKernelGGL(colreduce_stage1_kernel<32>, dim3((C + 31) / 32, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws);
     }
 }
 
@@ -917,8 +929,7 @@ extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
     VM_REQUIRE(zd_biased == nullptr || (moving_mean != nullptr && zd_correction >= 1.0f), "vm_bn_finalize: zero-debias needs the moving statistics and a correction >= 1");
-    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
-                       stat_sum, stat_sq, rows_per_tower, C, (double*)ws);
+    launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
                        mean, invstd, scale, shift, zd_biased, zd_correction);
@@ -1055,8 +1066,7 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
                "vm_bn_bwd_finalize: n_windows must be a multiple of windows_per_tower");
     const int n_towers = (int)(n_windows / windows_per_tower);
-    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream,
-                       part_dy, part_dyz, windows_per_tower * BN_SEG, C, (double*)ws);
+    launch_colreduce(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
     return check_launch("vm_bn_bwd_finalize");
@@ -1146,8 +1156,7 @@ extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && L > 0 && C > 0,
                "vm_du_tower_sums: n_windows must be a positive multiple of windows_per_tower");
     const int towers = (int)(n_windows / windows_per_tower);
-    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, part_du,
-                       (const float*)nullptr, windows_per_tower * (int64_t)BN_SEG, C, (double*)ws);
+    launch_colreduce(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream);
     VM_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((du_tower_sums_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                            (const T*)du, towers, windows_per_tower, L, C, grad_b, dsum);
@@ -1157,8 +1166,7 @@ extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {
     VM_REQUIRE(part && out && ws && rows > 0 && C > 0, "vm_colsum: bad argument");
-    hipLaunchKernelGGL(colreduce_stage1_kernel, dim3((C + 63) / 64, CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, part,
-                       (const float*)nullptr, rows, C, (double*)ws);
+    launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
                        out);
     return check_launch("vm_colsum");

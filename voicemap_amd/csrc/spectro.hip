@@ -234,6 +234,193 @@ __global__ __launch_bounds__(256) void pool_windows_bwd_kernel(const T* __restri
     ew_store<T, V>(dst, o);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First Conv2D(3 x 3) of the variant: ONE input channel.  As a band-stacked k = 3 GEMM it had K = 24 of a 32-wide tile and N = 32 of
+// a 128-wide one (0.51 ms + a 0.1 ms stacking pass for 4.9 M positions); it is nine multiply-adds per output and a 312 MB store,
+// so it runs on the vector ALUs: a thread owns one position x 8 channels (4 adjacent lanes = the 32..128 channels of a position,
+// so a wave's stores are contiguous), a workgroup one 128-position statistics row of one window.
+//   z[w][t][co] = relu(bias[co] + sum_kT sum_km W[kT][km][co] * in[(b, m + km - 1)][t + kT])      w = (b, m), bands outside the clip: 0
+// The weights are rounded to the storage type first (what the GEMM path multiplies by), products and sums in fp32; the BatchNorm
+// partial sums are taken of the stored (rounded) z, one row per 128 positions: the layout of vm_conv_stat_rows.
+// W: the fp32 kernel (3, Cs, C) of the flat store, Cs >= 3 (entries km >= 3 are padding).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, int M, int L, int Cs, int C,
+                                                               T* __restrict__ z, float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+    __shared__ float red[2][4][128];   // [sum | sq][wave][channel]
+    const int CV = C / 8;              // channel vectors per position (4 .. 16)
+    const int64_t win = blockIdx.x;
+    const int chunk = blockIdx.y, rows = gridDim.y;
+    const int m = (int)(win % M);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PPB = 256 / CV;          // positions per pass of the workgroup
+    const int vec = tid % CV, pl = tid / CV;
+    float wr[9][8], bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[k][e] = Elem<T>::to_f(Elem<T>::from_f(w[((int64_t)(k / 3) * Cs + (k % 3)) * C + vec * 8 + e]));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bv[e] = bias[vec * 8 + e];
+        s1[e] = s2[e] = 0.f;
+    }
+    const T* rows_in[3];
+#pragma unroll
+    for (int km = 0; km < 3; ++km) {
+        const int ms = m + km - 1;
+        rows_in[km] = (ms >= 0 && ms < M) ? in + (win - m + ms) * (int64_t)(L + 2) : nullptr;
+    }
+    const int t_end = pl < PPB ? min(L, (chunk + 1) * 128) : 0;   // (C = 96: 252 of the 256 threads have a position)
+    for (int t = chunk * 128 + pl; t < t_end; t += PPB) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+#pragma unroll
+        for (int km = 0; km < 3; ++km) {
+            if (rows_in[km] == nullptr) continue;   // (uniform over the workgroup)
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const float x = Elem<T>::to_f(rows_in[km][t + kt]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, wr[kt * 3 + km][e], acc[e]);
+            }
+        }
+        EwVec<T, 8> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o.v[e] = Elem<T>::from_f(fmaxf(acc[e], 0.f));
+            const float r = Elem<T>::to_f(o.v[e]);
+            s1[e] += r;
+            s2[e] = fmaf(r, r, s2[e]);
+        }
+        ew_store<T, 8>(z + (win * L + t) * (int64_t)C + vec * 8, o);
+    }
+    if (stat_sum == nullptr) return;
+    // lanes that share a channel vector: the same (tid % CV).  CV divides 64 for C = 32, 64, 128; otherwise (C = 96: CV = 12) the
+    // sums go through LDS atom by atom below, in a fixed order
+    if (64 % CV == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            for (int o = CV; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        if (lane < CV) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[0][wave][lane * 8 + e] = s1[e];
+                red[1][wave][lane * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < C) {
+            const int64_t row = win * rows + chunk;
+            stat_sum[row * C + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+            stat_sq[row * C + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+        }
+    } else {
+        __shared__ float all[2][256][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            all[0][tid][e] = s1[e];
+            all[1][tid][e] = s2[e];
+        }
+        __syncthreads();
+        if (tid < C) {
+            const int v = tid / 8, e = tid % 8;
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p * CV + v < 256; ++p) {
+                a += all[0][p * CV + v][e];
+                b += all[1][p * CV + v][e];
+            }
+            const int64_t row = win * rows + chunk;
+            stat_sum[row * C + tid] = a;
+            stat_sq[row * C + tid] = b;
+        }
+    }
+}
+
+// ... and its weight gradient: dW[kT][km][co] = sum in[(b, m + km - 1)][t + kT] * du[(b, m)][t][co] over every window and position
+// (du padded like an activation tensor).  A workgroup walks `wpb` consecutive windows with the same thread map as the forward and
+// leaves one fp32 slab (9, C); slab_sum adds the slabs in a fixed order and the host scatters the nine taps into the (3, Cs, C) kernel
+// gradient.  The layer has no input gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void conv2d_first_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ du, int64_t n_windows, int M,
+                                                                 int L, int C, int wpb, float* __restrict__ slabs) {
+    __shared__ float red[4][9][128];
+    const int CV = C / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PPB = 256 / CV;
+    const int vec = tid % CV, pl = tid / CV;
+    float acc[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    const int64_t w0 = (int64_t)blockIdx.x * wpb;
+    for (int64_t win = w0; win < w0 + wpb && win < n_windows; ++win) {
+        const int m = (int)(win % M);
+        for (int t = pl; t < (pl < PPB ? L : 0); t += PPB) {
+            const EwVec<T, 8> g = ew_load<T, 8>(du + (win * (L + 2) + 1 + t) * (int64_t)C + vec * 8);
+            float gf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gf[e] = Elem<T>::to_f(g.v[e]);
+#pragma unroll
+            for (int km = 0; km < 3; ++km) {
+                const int ms = m + km - 1;
+                if (ms < 0 || ms >= M) continue;
+                const T* r = in + (win - m + ms) * (int64_t)(L + 2) + t;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const float x = Elem<T>::to_f(r[kt]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[kt * 3 + km][e] = fmaf(x, gf[e], acc[kt * 3 + km][e]);
+                }
+            }
+        }
+    }
+    // sum over the threads that share a channel vector, in a fixed order: lanes (where CV divides 64), then waves
+    const bool shfl = 64 % CV == 0;
+    __shared__ float all[256][9];   // the C = 96 path: one channel at a time
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (shfl) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float v = acc[k][e];
+                for (int o = CV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < CV) red[wave][k][lane * 8 + e] = v;
+            }
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 9; ++k) all[tid][k] = acc[k][e];
+            __syncthreads();
+            if (tid < CV * 9) {
+                const int v = tid / 9, k = tid % 9;
+                float a = 0.f;
+                for (int p = 0; p * CV + v < 256; ++p) a += all[p * CV + v][k];
+                red[0][k][v * 8 + e] = a;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * C; i += 256) {
+        const int k = i / C, c = i % C;
+        slabs[(int64_t)blockIdx.x * 9 * C + i] = shfl ? (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]) : red[0][k][c];
+    }
+}
+
+__global__ void conv2d_first_scatter_kernel(const float* __restrict__ g9, int Cs, int C, float* __restrict__ grad_w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over (3, Cs, C)
+    if (i >= 3 * Cs * C) return;
+    const int c = i % C, km = (i / C) % Cs, kt = i / (C * Cs);
+    grad_w[i] = km < 3 ? g9[(kt * 3 + km) * C + c] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void clip_max_fwd_kernel(const float* __restrict__ gmax, int64_t n_clips, int M, int Mv, int C,
                                                            float* __restrict__ out, int32_t* __restrict__ widx) {
     const int64_t i = blockIdx.x * 256LL + threadIdx.x;
@@ -352,6 +539,51 @@ extern "C" int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_cl
                            (const T*)dout, n_clips, M, (int)L, C, (T*)dq);
     }));
     return check_launch("vm_pool_windows_bwd");
+}
+
+extern "C" int vm_conv2d_first_supported(int C, int dtype) { return (C % 8 == 0 && C >= 8 && C <= 128) ? 1 : 0; }
+
+extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C,
+                                   int dtype, void* z, float* stat_sum, float* stat_sq, void* stream) {
+    VM_REQUIRE(in && w && bias && z, "vm_conv2d_first_fwd: null pointer");
+    VM_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "vm_conv2d_first_fwd: stat_sum / stat_sq must both be set or NULL");
+    VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && Cs >= 3 && vm_conv2d_first_supported(C, dtype), "vm_conv2d_first_fwd: bad sizes (C % 8 == 0, C <= 128, Cs >= 3)");
+    const int64_t rows = (L + 127) / 128;
+    VM_REQUIRE(rows < 65536, "vm_conv2d_first_fwd: window too long");
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((conv2d_first_fwd_kernel<T>), dim3((unsigned)(n_clips * M), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)in, w, bias, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq);
+    });
+    return check_launch("vm_conv2d_first_fwd");
+}
+
+static int64_t c2f_blocks(int64_t n_windows) { return n_windows < 2048 ? n_windows : 2048; }
+
+extern "C" int64_t vm_conv2d_first_wgrad_workspace_bytes(int64_t n_clips, int M, int C) {
+    const int64_t nel = 9LL * C;
+    return (c2f_blocks(n_clips * M) + 1) * nel * (int64_t)sizeof(float) + slab_sum_part_bytes(nel) + 64;
+}
+
+extern "C" int vm_conv2d_first_wgrad(const void* in, const void* du, int64_t n_clips, int M, int64_t L, int Cs, int C, int dtype, void* ws,
+                                     float* grad_w, void* stream) {
+    VM_REQUIRE(in && du && ws && grad_w, "vm_conv2d_first_wgrad: null pointer");
+    VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && Cs >= 3 && vm_conv2d_first_supported(C, dtype), "vm_conv2d_first_wgrad: bad sizes");
+    const int64_t nw = n_clips * M, blocks = c2f_blocks(nw), nel = 9LL * C;
+    const int wpb = (int)((nw + blocks - 1) / blocks);
+    const int64_t used = (nw + wpb - 1) / wpb;
+    float* slabs = (float*)ws;
+    float* g9 = slabs + used * nel;
+    VM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((conv2d_first_wgrad_kernel<T>), dim3((unsigned)used), dim3(256), 0, (hipStream_t)stream, (const T*)in, (const T*)du,
+                           nw, M, (int)L, C, wpb, slabs);
+    });
+    int rc = check_launch("vm_conv2d_first_wgrad");
+    if (rc) return rc;
+    rc = slab_sum(slabs, used, nel, g9, nel, nullptr, g9 + nel, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv2d_first_scatter_kernel, dim3((unsigned)((3 * Cs * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g9, Cs, C,
+                       grad_w);
+    return check_launch("vm_conv2d_first_wgrad(scatter)");
 }
 
 extern "C" int vm_clip_max_fwd(const float* gmax, int64_t n_clips, int M, int M_valid, int C, float* out, int32_t* widx, void* stream) {

@@ -96,6 +96,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.iterations = 0
         self.last_infer_l0 = 0
         self.overlap_wgrad = True
+        # block 1 (one input channel) on the vector ALUs (vm_conv2d_first_fwd / _wgrad) instead of as a band-stacked GEMM
+        self.first_layer_direct = bool(self.lib.query("vm_conv2d_first_supported", self.chan[0], self.dtype))
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None
         self.grad_prescale = 1.0
@@ -278,11 +280,15 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         for i, c in enumerate(self.chan):
             b, L, Mi = pl[i], pl["T"][i], pl["M"][i]
             nw, wpt = b["nw"], cpt * Mi
-            self._call("vm_stack_windows", _p(b["in"]), n, Mi, L + 2, self.cin[i], self.cs[i], dt, _p(b["xs"]), st)
             ssum = _p(b["ssum"]) if training else None
             ssq = _p(b["ssq"]) if training else None
-            self._call("vm_conv_fwd", _p(b["xs"]), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), nw, L, self.cs[i], c, dt, _p(b["z"]),
-                       ssum, ssq, st)
+            if i == 0 and self.first_layer_direct:
+                self._call("vm_conv2d_first_fwd", _p(b["in"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n, Mi, L,
+                           self.cs[0], c, dt, _p(b["z"]), ssum, ssq, st)
+            else:
+                self._call("vm_stack_windows", _p(b["in"]), n, Mi, L + 2, self.cin[i], self.cs[i], dt, _p(b["xs"]), st)
+                self._call("vm_conv_fwd", _p(b["xs"]), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), nw, L, self.cs[i], c, dt, _p(b["z"]),
+                           ssum, ssq, st)
             gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
             mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
             if training:
@@ -333,13 +339,23 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                        _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), nw, wpt, L, c, 2, dt, _p(b["du"]), _p(b["pdu"]), st)
             self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]), st)
             gw = _p(self.view(f"conv{i+1}.kernel", G))
+
+            def wgrad(stream):
+                if i == 0 and self.first_layer_direct:
+                    if "c2f_ws" not in b:
+                        b["c2f_ws"] = torch.empty(self.lib.query("vm_conv2d_first_wgrad_workspace_bytes", n, Mi, c) // 4 + 16,
+                                                  dtype=torch.float32, device=self.device)
+                    self._call("vm_conv2d_first_wgrad", _p(b["in"]), _p(b["du"]), n, Mi, L, self.cs[0], c, dt, _p(b["c2f_ws"]), gw, stream)
+                else:
+                    self._call("vm_conv_wgrad", _p(b["xs"]), _p(b["du"]), nw, L, self.cs[i], c, dt, _p(b["wgrad_ws"]), gw, stream)
+
             if self.overlap_wgrad:
                 b["ev"].record()
                 with torch.cuda.stream(self.side_stream):
                     self.side_stream.wait_event(b["ev"])
-                    self._call("vm_conv_wgrad", _p(b["xs"]), _p(b["du"]), nw, L, self.cs[i], c, dt, _p(b["wgrad_ws"]), gw, self.stream())
+                    wgrad(self.stream())
             else:
-                self._call("vm_conv_wgrad", _p(b["xs"]), _p(b["du"]), nw, L, self.cs[i], c, dt, _p(b["wgrad_ws"]), gw, st)
+                wgrad(st)
             if i == 1 and sync_tail:
                 if "sync_ev" not in pl:
                     pl["sync_ev"] = torch.cuda.Event()
