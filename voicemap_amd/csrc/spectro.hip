@@ -249,97 +249,104 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const T* __restri
                                                                const float* __restrict__ bias, int M, int L, int Cs, int C,
                                                                T* __restrict__ z, float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
     __shared__ float red[2][4][128];   // [sum | sq][wave][channel]
-    const int CV = C / 8;              // channel vectors per position (4 .. 16)
-    const int64_t win = blockIdx.x;
-    const int chunk = blockIdx.y, rows = gridDim.y;
+    __shared__ float wl[9][128], all[2][256][8];
+    const int CV = C / 8;              // channel vectors per position (1 .. 16)
+    const int64_t win = blockIdx.x;    // a workgroup walks the statistics rows (128 positions each) of one window
+    const int rows = (L + 127) / 128;
     const int m = (int)(win % M);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int PPB = 256 / CV;          // positions per pass of the workgroup
     const int vec = tid % CV, pl = tid / CV;
-    float wr[9][8], bv[8], s1[8], s2[8];
+    for (int i = tid; i < 9 * C; i += 256) {   // the nine taps, rounded to the storage type, once per workgroup
+        const int k = i / C, c = i - k * C;
+        wl[k][c] = Elem<T>::to_f(Elem<T>::from_f(w[((int64_t)(k / 3) * Cs + (k % 3)) * C + c]));
+    }
+    __syncthreads();
+    float wr[9][8], bv[8];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wr[k][e] = Elem<T>::to_f(Elem<T>::from_f(w[((int64_t)(k / 3) * Cs + (k % 3)) * C + vec * 8 + e]));
+        for (int e = 0; e < 8; ++e) wr[k][e] = wl[k][vec * 8 + e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bv[e] = bias[vec * 8 + e];
-        s1[e] = s2[e] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) bv[e] = bias[vec * 8 + e];
     const T* rows_in[3];
 #pragma unroll
     for (int km = 0; km < 3; ++km) {
         const int ms = m + km - 1;
         rows_in[km] = (ms >= 0 && ms < M) ? in + (win - m + ms) * (int64_t)(L + 2) : nullptr;
     }
-    const int t_end = pl < PPB ? min(L, (chunk + 1) * 128) : 0;   // (C = 96: 252 of the 256 threads have a position)
-    for (int t = chunk * 128 + pl; t < t_end; t += PPB) {
-        float acc[8];
+    for (int chunk = 0; chunk < rows; ++chunk) {
+        float s1[8], s2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+        const int t_end = pl < PPB ? min(L, (chunk + 1) * 128) : 0;   // (C = 96: 252 of the 256 threads have a position)
+        for (int t = chunk * 128 + pl; t < t_end; t += PPB) {
+            float acc[8];
 #pragma unroll
-        for (int km = 0; km < 3; ++km) {
-            if (rows_in[km] == nullptr) continue;   // (uniform over the workgroup)
+            for (int e = 0; e < 8; ++e) acc[e] = bv[e];
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                const float x = Elem<T>::to_f(rows_in[km][t + kt]);
+            for (int km = 0; km < 3; ++km) {
+                if (rows_in[km] == nullptr) continue;   // (uniform over the workgroup)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, wr[kt * 3 + km][e], acc[e]);
+                for (int kt = 0; kt < 3; ++kt) {
+                    const float x = Elem<T>::to_f(rows_in[km][t + kt]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, wr[kt * 3 + km][e], acc[e]);
+                }
             }
-        }
-        EwVec<T, 8> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o.v[e] = Elem<T>::from_f(fmaxf(acc[e], 0.f));
-            const float r = Elem<T>::to_f(o.v[e]);
-            s1[e] += r;
-            s2[e] = fmaf(r, r, s2[e]);
-        }
-        ew_store<T, 8>(z + (win * L + t) * (int64_t)C + vec * 8, o);
-    }
-    if (stat_sum == nullptr) return;
-    // lanes that share a channel vector: the same (tid % CV).  CV divides 64 for C = 32, 64, 128; otherwise (C = 96: CV = 12) the
-    // sums go through LDS atom by atom below, in a fixed order
-    if (64 % CV == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            for (int o = CV; o < 64; o <<= 1) {
-                s1[e] += __shfl_xor(s1[e], o, 64);
-                s2[e] += __shfl_xor(s2[e], o, 64);
-            }
-        }
-        if (lane < CV) {
+            EwVec<T, 8> o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[0][wave][lane * 8 + e] = s1[e];
-                red[1][wave][lane * 8 + e] = s2[e];
+                o.v[e] = Elem<T>::from_f(fmaxf(acc[e], 0.f));
+                const float r = Elem<T>::to_f(o.v[e]);
+                s1[e] += r;
+                s2[e] = fmaf(r, r, s2[e]);
             }
+            ew_store<T, 8>(z + (win * L + t) * (int64_t)C + vec * 8, o);
         }
-        __syncthreads();
-        if (tid < C) {
-            const int64_t row = win * rows + chunk;
-            stat_sum[row * C + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-            stat_sq[row * C + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
-        }
-    } else {
-        __shared__ float all[2][256][8];
+        if (stat_sum == nullptr) continue;
+        const int64_t row = win * rows + chunk;
+        // lanes that share a channel vector: the same (tid % CV).  CV divides 64 for C = 8 .. 128 except 96 (CV = 12), whose sums go
+        // through LDS thread by thread, in a fixed order
+        if (64 % CV == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            all[0][tid][e] = s1[e];
-            all[1][tid][e] = s2[e];
-        }
-        __syncthreads();
-        if (tid < C) {
-            const int v = tid / 8, e = tid % 8;
-            float a = 0.f, b = 0.f;
-            for (int p = 0; p * CV + v < 256; ++p) {
-                a += all[0][p * CV + v][e];
-                b += all[1][p * CV + v][e];
+            for (int e = 0; e < 8; ++e) {
+                for (int o = CV; o < 64; o <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], o, 64);
+                    s2[e] += __shfl_xor(s2[e], o, 64);
+                }
             }
-            const int64_t row = win * rows + chunk;
-            stat_sum[row * C + tid] = a;
-            stat_sq[row * C + tid] = b;
+            if (lane < CV) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[0][wave][lane * 8 + e] = s1[e];
+                    red[1][wave][lane * 8 + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            if (tid < C) {
+                stat_sum[row * C + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+                stat_sq[row * C + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                all[0][tid][e] = s1[e];
+                all[1][tid][e] = s2[e];
+            }
+            __syncthreads();
+            if (tid < C) {
+                const int v = tid / 8, e = tid % 8;
+                float a = 0.f, b = 0.f;
+                for (int p = 0; p * CV + v < 256; ++p) {
+                    a += all[0][p * CV + v][e];
+                    b += all[1][p * CV + v][e];
+                }
+                stat_sum[row * C + tid] = a;
+                stat_sq[row * C + tid] = b;
+            }
         }
+        __syncthreads();   // red / all are rewritten by the next statistics row
     }
 }
 
@@ -551,7 +558,7 @@ extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* 
     const int64_t rows = (L + 127) / 128;
     VM_REQUIRE(rows < 65536, "vm_conv2d_first_fwd: window too long");
     VM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((conv2d_first_fwd_kernel<T>), dim3((unsigned)(n_clips * M), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((conv2d_first_fwd_kernel<T>), dim3((unsigned)(n_clips * M)), dim3(256), 0, (hipStream_t)stream,
                            (const T*)in, w, bias, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq);
     });
     return check_launch("vm_conv2d_first_fwd");
