@@ -429,8 +429,9 @@ int vm_conv2d_first_wgrad(const void* in, const void* du, int64_t n_clips, int M
  * channels [3 C, Cs) = 0 (Cs >= 3 C, a multiple of 8 for the convolution kernels).  W2d[kt][km][ci][co] = W1d[kt][km * C + ci][co]. */
 int vm_stack_windows(const void* x, int64_t n_clips, int M, int64_t rows, int C, int Cs, int dtype, void* out, void* stream);
 /* adjoint of vm_stack_windows on un-padded rows: dxs (n_clips * M, L, Cs) -> dx (n_clips * M, L, C),
- * dx[(b, m)][t][c] = sum_dm dxs[(b, m - dm + 1)][t][dm * C + c]. */
-int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int dtype, void* dx, void* stream);
+ * dx[(b, m)][t][c] = sum_dm dxs[(b, m - dm + 1)][t][dm * C + c].  src_padded != 0: dxs is (n_clips * M, L + 2, Cs) and rows 1 .. L of a
+ * window are read -- the layout a dgrad over a clip's concatenated windows leaves (its outputs at the halo positions are not used). */
+int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded, int dtype, void* dx, void* stream);
 /* mel half of MaxPool2D(2, 2): out[(b, m')][row][c] = max(q[(b, 2m')], q[(b, 2m'+1)]) over (n_clips * M, rows, C) -> (n_clips *
  * (M / 2), rows, C) (floor: an odd last band is dropped); backward: q as in the forward (rows = L + 2 with halo), dout (n_clips *
  * (M / 2), L, C), dq (n_clips * M, L, C) = dout routed to the first maximum of each pair. */

@@ -63,7 +63,12 @@ def test_stack_fold_windows(dt, n, M, rows, C, Cs):
     Lr = rows
     g = quant(r.normal(0, 1, (n, M, Lr, Cs)), dt).numpy()
     dx = torch.empty(n * M, Lr, C, dtype=tdt, device="cuda")
-    L().call("vm_fold_windows", p(dev(g, tdt)), n, M, Lr, C, Cs, vm, p(dx), stream())
+    L().call("vm_fold_windows", p(dev(g, tdt)), n, M, Lr, C, Cs, 0, vm, p(dx), stream())
+    gp = np.full((n, M, Lr + 2, Cs), 5.0)            # the padded-source form reads rows 1 .. L of every window and nothing else
+    gp[:, :, 1:-1] = g
+    dx2 = torch.empty_like(dx)
+    L().call("vm_fold_windows", p(dev(gp, tdt)), n, M, Lr, C, Cs, 1, vm, p(dx2), stream())
+    assert torch.equal(dx, dx2)
     fref = np.zeros((n, M, Lr, C))
     for dm in range(3):
         for m in range(M):

@@ -103,7 +103,7 @@ SIGNATURES = {
     "vm_conv2d_first_wgrad_workspace_bytes": (L, [L, I, I]),
     "vm_conv2d_first_wgrad": (I, [P, P, L, I, L, I, I, I, P, P, P]),
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),
-    "vm_fold_windows": (I, [P, L, I, L, I, I, I, P, P]),
+    "vm_fold_windows": (I, [P, L, I, L, I, I, I, I, P, P]),
     "vm_pool_windows_fwd": (I, [P, L, I, L, I, I, P, P]),
     "vm_pool_windows_bwd": (I, [P, P, L, I, L, I, I, P, P]),
     "vm_clip_max_fwd": (I, [P, L, I, I, I, P, P, P]),

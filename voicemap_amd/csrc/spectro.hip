@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void stack_windows_kernel(const T* __restrict_
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void fold_windows_kernel(const T* __restrict__ dxs, int64_t n_clips, int M, int L, int C, int Cs,
-                                                           T* __restrict__ dx) {
+                                                           int src_pad, T* __restrict__ dx) {
     const int per_row = C / V;
     const int64_t win = blockIdx.x;
     const int j = blockIdx.y * 256 + threadIdx.x;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void fold_windows_kernel(const T* __restrict__
     for (int dm = 0; dm < 3; ++dm) {
         const int md = m - dm + 1;  // the window whose stacked band dm is this window
         if (md >= 0 && md < M) {
-            const EwVec<T, V> s = ew_load<T, V>(dxs + ((win - m + md) * L + t) * (int64_t)Cs + dm * C + c);
+            const EwVec<T, V> s = ew_load<T, V>(dxs + ((win - m + md) * (L + 2 * src_pad) + src_pad + t) * (int64_t)Cs + dm * C + c);
 #pragma unroll
             for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(s.v[e]);
         }
@@ -517,12 +517,13 @@ extern "C" int vm_stack_windows(const void* x, int64_t n_clips, int M, int64_t r
     return check_launch("vm_stack_windows");
 }
 
-extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int dtype, void* dx, void* stream) {
+extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded, int dtype, void* dx,
+                               void* stream) {
     VM_REQUIRE(dxs && dx, "vm_fold_windows: null pointer");
     VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && C > 0 && Cs >= 3 * C, "vm_fold_windows: bad sizes (Cs >= 3 C)");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
         hipLaunchKernelGGL((fold_windows_kernel<T, V>), ew_grid(n_clips * M, L * (C / V)), dim3(256), 0, (hipStream_t)stream, (const T*)dxs, n_clips, M,
-                           (int)L, C, Cs, (T*)dx);
+                           (int)L, C, Cs, src_padded ? 1 : 0, (T*)dx);
     }));
     return check_launch("vm_fold_windows");
 }

@@ -98,6 +98,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.overlap_wgrad = True
         # block 1 (one input channel) on the vector ALUs (vm_conv2d_first_fwd / _wgrad) instead of as a band-stacked GEMM
         self.first_layer_direct = bool(self.lib.query("vm_conv2d_first_supported", self.chan[0], self.dtype))
+        self.flat_dgrad = True   # dgrad over a clip's concatenated windows (see backward)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None
         self.grad_prescale = 1.0
@@ -222,7 +223,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                                             device=dev)
                 b["ev"] = torch.cuda.Event()
                 if i > 0:
-                    b["dxs"] = torch.empty(nw, L, self.cs[i], dtype=tdt, device=dev)   # dgrad output (gradient of xs)
+                    b["dxs"] = torch.empty(nw, L + 2 * int(self.flat_dgrad), self.cs[i], dtype=tdt, device=dev)   # dgrad output (gradient of xs)
                     b["din"] = torch.empty(nw, L, self.cin[i], dtype=tdt, device=dev)  # folded: gradient of the block input
             pl[i] = b
         cl, nwl = self.chan[-1], n_clips * Ms[3]
@@ -362,8 +363,16 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 pl["sync_ev"].record()
                 self.grad_sync.begin_tail(self, pl["sync_ev"])
             if i > 0:
-                self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), nw, L, self.cs[i], c, dt, _p(b["dxs"]), st)
-                self._call("vm_fold_windows", _p(b["dxs"]), n, Mi, L, self.cin[i], self.cs[i], dt, _p(b["din"]), st)
+                flat = self.flat_dgrad and nw * (L + 2) * max(c, self.cs[i]) < 2 ** 31
+                if flat:
+                    # all windows, each with its own zero halo rows in du, are ONE window of nw (L + 2) - 2 positions for the k = 3
+                    # dgrad: full 128-row tiles instead of windows of 149 .. 37 rows.  Output row p lands on padded row p + 1 of dxs,
+                    # so a window's rows 1 .. L are what the per-window launch computes and its halo rows take the junk
+                    self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), 1, nw * (L + 2) - 2, self.cs[i], c, dt,
+                               b["dxs"].data_ptr() + self.cs[i] * b["dxs"].element_size(), st)
+                else:   # per window, un-padded rows (the buffer is large enough either way)
+                    self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), nw, L, self.cs[i], c, dt, _p(b["dxs"]), st)
+                self._call("vm_fold_windows", _p(b["dxs"]), n, Mi, L, self.cin[i], self.cs[i], int(flat), dt, _p(b["din"]), st)
                 # gradient of the previous block's pooled output -> gradient of its time-pooled tensor q
                 self._call("vm_pool_windows_bwd", _p(pl[i - 1]["q"]), _p(b["din"]), n, pl["M"][i - 1], L, self.cin[i], dt,
                            _p(pl[i - 1]["dp"]), st)
