@@ -219,8 +219,14 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                     b["dp"] = torch.empty(nw, Ts[i + 1], c, dtype=tdt, device=dev)    # gradient of q (un-padded)
                 for nm in ("pa", "pb", "pdu"):
                     b[nm] = torch.empty(nw * prow, c, dtype=f32, device=dev)
-                b["wgrad_ws"] = torch.empty(self.lib.query("vm_conv_wgrad_workspace_bytes", nw, L, self.cs[i], c) // 4 + 16, dtype=f32,
-                                            device=dev)
+                # the weight gradient is a sum over positions, and consecutive windows -- each with its own zero halo rows in xs and
+                # du -- are one window of g (L + 2) - 2 positions for vm_conv_wgrad (a halo row multiplies by zero, no tap reaches
+                # across two of them): the same sum (1e-6, the order of fp32 partial sums) from fewer, longer reductions.  g = 8 is
+                # the best of tools/probe/wgrad_merge_probe.py on the three GEMM-shaped layers (452 -> 372 us together)
+                g = 8 if nw % 8 == 0 else 1
+                b["wg_n"], b["wg_L"] = nw // g, g * (L + 2) - 2
+                b["wgrad_ws"] = torch.empty(self.lib.query("vm_conv_wgrad_workspace_bytes", b["wg_n"], b["wg_L"], self.cs[i], c) // 4 + 16,
+                                            dtype=f32, device=dev)
                 b["ev"] = torch.cuda.Event()
                 if i > 0:
                     b["dxs"] = torch.empty(nw, L + 2 * int(self.flat_dgrad), self.cs[i], dtype=tdt, device=dev)   # dgrad output (gradient of xs)
@@ -348,7 +354,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                                                   dtype=torch.float32, device=self.device)
                     self._call("vm_conv2d_first_wgrad", _p(b["in"]), _p(b["du"]), n, Mi, L, self.cs[0], c, dt, _p(b["c2f_ws"]), gw, stream)
                 else:
-                    self._call("vm_conv_wgrad", _p(b["xs"]), _p(b["du"]), nw, L, self.cs[i], c, dt, _p(b["wgrad_ws"]), gw, stream)
+                    self._call("vm_conv_wgrad", _p(b["xs"]), _p(b["du"]), b["wg_n"], b["wg_L"], self.cs[i], c, dt, _p(b["wgrad_ws"]), gw, stream)
 
             if self.overlap_wgrad:
                 b["ev"].record()
