@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const T* __restri
                                                                const float* __restrict__ bias, int M, int L, int Cs, int C,
                                                                T* __restrict__ z, float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
     __shared__ float red[2][4][128];   // [sum | sq][wave][channel]
-    __shared__ float wl[9][128], all[2][256][8];
+    __shared__ __attribute__((aligned(16))) float wl[9][128];
+    __shared__ float all[2][256][8];
     const int CV = C / 8;              // channel vectors per position (1 .. 16)
     const int64_t win = blockIdx.x;    // a workgroup walks the statistics rows (128 positions each) of one window
     const int rows = (L + 127) / 128;
@@ -262,11 +263,9 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const T* __restri
         wl[k][c] = Elem<T>::to_f(Elem<T>::from_f(w[((int64_t)(k / 3) * Cs + (k % 3)) * C + c]));
     }
     __syncthreads();
-    float wr[9][8], bv[8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wr[k][e] = wl[k][vec * 8 + e];
+    // (the 72 weights of a thread stay in LDS -- broadcast reads, 4 addresses per wave -- instead of in registers: 136 -> ~70 VGPRs,
+    // twice the waves per SIMD for a kernel that waits on its nine 2-byte loads per position)
+    float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = bias[vec * 8 + e];
     const T* rows_in[3];
@@ -290,8 +289,13 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const T* __restri
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const float x = Elem<T>::to_f(rows_in[km][t + kt]);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[kt * 3 + km][vec * 8]);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wl[kt * 3 + km][vec * 8 + 4]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, wr[kt * 3 + km][e], acc[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        acc[e] = fmaf(x, w0[e], acc[e]);
+                        acc[4 + e] = fmaf(x, w1[e], acc[4 + e]);
+                    }
                 }
             }
             EwVec<T, 8> o;
