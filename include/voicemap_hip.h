@@ -50,7 +50,8 @@ const char* vm_last_error(void);
 /* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
- * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce) (round 3). */
+ * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce; vm_conv_fwd_flat, vm_conv2d_first_*,
+ * `src_padded` in vm_fold_windows) (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -131,6 +132,14 @@ int vm_conv1_fused_bwd(const float* x, const float* w, const float* bias, const 
 int64_t vm_conv_stat_rows(int64_t L);
 int vm_conv_fwd(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in,
                 int c_out, int dtype, void* z, float* stat_sum, float* stat_sq, void* stream);
+/* vm_conv_fwd for windows too short to fill a tile (the 2-D variant: 149 .. 37 positions): every window of `in` carries its own zero
+ * halo rows, so the concatenation of all windows is one valid k = 3 sequence; it is run as ONE window on the 128-row kernels and the
+ * epilogue drops the halo positions (their results are junk) and writes the rest to the same un-padded z (n_windows, L, c_out) --
+ * bit-identical to vm_conv_fwd.  stat_sum / stat_sq: vm_conv_flat_stat_rows(n_windows, L) rows in all (one per 128 rows of the
+ * concatenation) instead of vm_conv_stat_rows(L) per window: a caller with BatchNorm statistics per tower launches once per tower. */
+int64_t vm_conv_flat_stat_rows(int64_t n_windows, int64_t L);
+int vm_conv_fwd_flat(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
+                     void* z, float* stat_sum, float* stat_sq, void* stream);
 /* vm_conv_fwd (training form: statistics required) that also writes the pool-window extreme of z for MaxPool1D(2):
  * e[n][q][c] = max(z[n][2q][c], z[n][2q+1][c]) where gamma[c] >= 0, the min where gamma[c] < 0 -- the element the max-pool of the
  * BatchNorm output will select, known before the statistics are (sign(scale) = sign(gamma)).  e: unpadded (n_windows, L/2, c_out).

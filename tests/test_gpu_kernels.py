@@ -1035,3 +1035,37 @@ def test_conv_fwd_e_pool_extreme(n, l, cin, cout, dt16):
     L().call("vm_bn_drop_pool_fwd", p(z0), p(scale), p(shift), p(drop), n, n, l, cout, 2, vm, p(a0), stream())
     L().call("vm_bn_drop_pool_fwd", p(e), p(scale), p(shift), p(drop), n, n, lq, cout, 1, vm, p(a1), stream())
     assert torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,l,cin,cout", [(40, 37, 96, 64), (7, 149, 192, 96), (64, 5, 24, 128), (3, 300, 32, 32)])
+def test_conv_fwd_flat_equals_per_window_forward(dt, n, l, cin, cout):
+    """vm_conv_fwd_flat -- many short windows, each with its own zero halo rows, run as one sequence on full 128-row tiles with the
+    halo positions dropped by the epilogue -- gives vm_conv_fwd's z bit for bit (the same products in the same order per output) and
+    the same BatchNorm sums over all windows (one partial row per tile of the concatenation instead of per window)."""
+    vm, tdt = DTYPES[dt]
+    r = rng(n + l)
+    x = quant(r.normal(0, 1, (n, l, cin)), dt).numpy()
+    w = r.normal(0, 0.3 / np.sqrt(3 * cin), (3, cin, cout)).astype(np.float32)
+    bias = r.normal(0, 0.1, cout).astype(np.float32)
+    xin = padded(x, tdt)
+    wf, wd = torch.empty(cout * 3 * cin, dtype=tdt, device="cuda"), torch.empty(cin * 3 * cout, dtype=tdt, device="cuda")
+    L().call("vm_prep_conv_weights", p(dev(w)), cin, cout, vm, p(wf), p(wd), stream())
+    rows = L().query("vm_conv_stat_rows", l)
+    z1 = torch.empty(n, l, cout, dtype=tdt, device="cuda")
+    s1, q1 = torch.empty(n * rows, cout, device="cuda"), torch.empty(n * rows, cout, device="cuda")
+    L().call("vm_conv_fwd", p(xin), p(wf), p(dev(bias)), n, l, cin, cout, vm, p(z1), p(s1), p(q1), stream())
+    frows = L().query("vm_conv_flat_stat_rows", n, l)
+    assert frows == -(-(n * (l + 2) - 2) // 128)
+    z2 = torch.full((n, l, cout), 7.0, dtype=tdt, device="cuda")
+    s2, q2 = torch.empty(frows, cout, device="cuda"), torch.empty(frows, cout, device="cuda")
+    L().call("vm_conv_fwd_flat", p(xin), p(wf), p(dev(bias)), n, l, cin, cout, vm, p(z2), p(s2), p(q2), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2)
+    assert np.allclose(s1.sum(0).cpu().numpy(), s2.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert np.allclose(q1.sum(0).cpu().numpy(), q2.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # inference form: no statistics
+    z3 = torch.empty_like(z2)
+    L().call("vm_conv_fwd_flat", p(xin), p(wf), p(dev(bias)), n, l, cin, cout, vm, p(z3), None, None, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z3)

@@ -46,6 +46,8 @@ SIGNATURES = {
     "vm_conv_stat_rows": (L, [L]),
     "vm_conv_fwd": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_dgrad": (I, [P, P, L, L, I, I, I, P, P]),
+    "vm_conv_flat_stat_rows": (L, [L, L]),
+    "vm_conv_fwd_flat": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_fwd_e_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
     "vm_fold_bn_weights": (I, [P, P, P, I, I, I, I, P, P, P]),

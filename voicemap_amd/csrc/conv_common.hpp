@@ -204,6 +204,11 @@ struct NtArgs {
     // ... per tower (BatchNorm statistics are per encoder call): windows [t * tower_windows, (t + 1) * tower_windows) use the weights at
     // bt + t * bt_tower_stride and the constants at fold_hb + t * 3 * N
     int64_t tower_windows = 0, bt_tower_stride = 0;
+    // vm_conv_fwd_flat (the 128-row kernels' epilogues): the input is the concatenation of windows of flat_valid positions, each with
+    // its two zero halo rows (flat_period = flat_valid + 2 rows per window), run as ONE window; tile row t belongs to window
+    // t / flat_period, position t % flat_period, and rows with position >= flat_valid -- the halo positions, whose results are junk --
+    // are neither stored nor counted; the others go to the UN-padded output row window * flat_valid + position.  0 = off.
+    int flat_period = 0, flat_valid = 0;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -161,7 +161,14 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
         for (int j = 0; j < 8; ++j) {
             const int row = rg + 16 * j;
             const int t = t0 + row;
-            if (cok && t < p.L) {
+            int64_t orow = n * p.L + t;
+            bool rok = t < p.L;
+            if (p.flat_period) {   // vm_conv_fwd_flat: (window, position) of this flat row; halo positions are dropped
+                const int wq = t / p.flat_period, loc = t - wq * p.flat_period;
+                rok = rok && loc < p.flat_valid;
+                orow = (int64_t)wq * p.flat_valid + loc;
+            }
+            if (cok && rok) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
                 const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(NtArgs<T> p, int64_t n_gro
                         o1.set(i - 4, x);
                     }
                 }
-                T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+                T* dst = p.out + orow * (int64_t)p.N + ncol;
                 store16<T>(dst, o0);
                 if (sizeof(T) == 4) store16<T>(dst + 4, o1);
             }
@@ -280,7 +287,14 @@ __device__ inline void nt_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
     for (int j = 0; j < 8; ++j) {
         const int row = rg + 16 * j;
         const int t = t0 + row;
-        if (cok && t < p.L) {
+        int64_t orow = n * p.L + t;
+        bool rok = t < p.L;
+        if (p.flat_period) {   // vm_conv_fwd_flat: (window, position) of this flat row; halo positions are dropped
+            const int wq = t / p.flat_period, loc = t - wq * p.flat_period;
+            rok = rok && loc < p.flat_valid;
+            orow = (int64_t)wq * p.flat_valid + loc;
+        }
+        if (cok && rok) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + row * OUT_PITCH + c8 * 32 + 16);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -303,7 +317,7 @@ __device__ inline void nt_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
                     o1.set(i - 4, x);
                 }
             }
-            T* dst = p.out + (n * p.L + t) * (int64_t)p.N + ncol;
+            T* dst = p.out + orow * (int64_t)p.N + ncol;
             store16<T>(dst, o0);
             if (sizeof(T) == 4) store16<T>(dst + 4, o1);
         }
@@ -1155,7 +1169,7 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
 template <typename T, int EPI>
 static void launch_nt(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
-        if ((g_nt_n2 & (EPI == EPI_DGRAD ? 2 : 1)) && a.Ktot == 3 * a.a_c && n2r_shape(n_windows, a.L, a.a_c, a.N, EPI == EPI_FWD || EPI == EPI_FWD_FOLD)) {
+        if (!a.flat_period && (g_nt_n2 & (EPI == EPI_DGRAD ? 2 : 1)) && a.Ktot == 3 * a.a_c && n2r_shape(n_windows, a.L, a.a_c, a.N, EPI == EPI_FWD || EPI == EPI_FWD_FOLD)) {
             launch_n2r<T, EPI>(a, n_windows, stream);
             return;
         }
@@ -1242,6 +1256,29 @@ extern "C" int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, 
         launch_nt<T, EPI_DGRAD>(dgrad_args<T>(du, wd, dx, L, c_in, c_out, dtype), n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad");
+}
+
+// ---- vm_conv_fwd over windows too short for a tile: their concatenation (every window carries its own zero halo rows) run as one
+// sequence on the 128-row kernels, the halo positions dropped by the epilogue.  Same z, bit for bit; the statistics rows are per
+// 128-row tile of the concatenation (vm_conv_flat_stat_rows rows in all) instead of per window ----
+extern "C" int64_t vm_conv_flat_stat_rows(int64_t n_windows, int64_t L) { return (n_windows * (L + 2) - 2 + BM - 1) / BM; }
+
+extern "C" int vm_conv_fwd_flat(const void* in, const void* wf, const float* bias, int64_t n_windows, int64_t L, int c_in, int c_out,
+                                int dtype, void* z, float* stat_sum, float* stat_sq, void* stream) {
+    VM_REQUIRE(in && wf && bias && z, "vm_conv_fwd_flat: null pointer");
+    VM_REQUIRE(n_windows > 0 && L > 0 && c_in > 0 && c_out > 0, "vm_conv_fwd_flat: bad sizes");
+    VM_REQUIRE(c_in % 8 == 0 && c_out % 8 == 0, "vm_conv_fwd_flat: channels must be multiples of 8 (got %d, %d)", c_in, c_out);
+    VM_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "vm_conv_fwd_flat: stat_sum/stat_sq must both be set or NULL");
+    const int64_t Lf = n_windows * (L + 2) - 2;
+    VM_REQUIRE((Lf + 2) * (int64_t)(c_in > c_out ? c_in : c_out) < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31),
+               "vm_conv_fwd_flat: the concatenated windows exceed 2^31 elements (launch fewer windows per call)");
+    VM_DISPATCH_DTYPE(dtype, {
+        NtArgs<T> a = fwd_args<T>(in, wf, bias, z, stat_sum, stat_sq, Lf, c_in, c_out, dtype);
+        a.flat_period = (int)(L + 2);
+        a.flat_valid = (int)L;
+        launch_nt<T, EPI_FWD>(a, 1, (hipStream_t)stream);
+    });
+    return check_launch("vm_conv_fwd_flat");
 }
 
 // ---- training forward that also emits the pool-window extreme (conv_nt2r_kernel only) ----

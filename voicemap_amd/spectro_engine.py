@@ -98,7 +98,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.overlap_wgrad = True
         # block 1 (one input channel) on the vector ALUs (vm_conv2d_first_fwd / _wgrad) instead of as a band-stacked GEMM
         self.first_layer_direct = bool(self.lib.query("vm_conv2d_first_supported", self.chan[0], self.dtype))
-        self.flat_dgrad = True   # dgrad over a clip's concatenated windows (see backward)
+        self.flat_dgrad = True   # dgrad over the concatenated windows (see backward)
+        self.flat_fwd = True     # ... and the forward of the GEMM-shaped layers (vm_conv_fwd_flat)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None
         self.grad_prescale = 1.0
@@ -289,18 +290,37 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             nw, wpt = b["nw"], cpt * Mi
             ssum = _p(b["ssum"]) if training else None
             ssq = _p(b["ssq"]) if training else None
+            stat_rows_per_tower = wpt * b["stat_rows"]
             if i == 0 and self.first_layer_direct:
                 self._call("vm_conv2d_first_fwd", _p(b["in"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n, Mi, L,
                            self.cs[0], c, dt, _p(b["z"]), ssum, ssq, st)
             else:
                 self._call("vm_stack_windows", _p(b["in"]), n, Mi, L + 2, self.cin[i], self.cs[i], dt, _p(b["xs"]), st)
-                self._call("vm_conv_fwd", _p(b["xs"]), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), nw, L, self.cs[i], c, dt, _p(b["z"]),
-                           ssum, ssq, st)
+                flat = self.flat_fwd and wpt * (L + 2) * max(c, self.cs[i]) < 2 ** 31
+                if flat:
+                    # a tower's windows -- each with its own zero halo rows in xs -- as ONE sequence on full 128-row tiles; the epilogue
+                    # drops the halo positions and writes the same un-padded z.  The statistics rows are then per tile of the
+                    # concatenation: one launch per tower keeps them per tower
+                    srows = self.lib.query("vm_conv_flat_stat_rows", wpt, L)
+                    if training and b.get("flat_rows") != (n_towers, srows):
+                        b["ssum_f"] = torch.empty(n_towers * srows, c, dtype=torch.float32, device=self.device)
+                        b["ssq_f"] = torch.empty_like(b["ssum_f"])
+                        b["flat_rows"] = (n_towers, srows)
+                    for tw in range(n_towers):
+                        self._call("vm_conv_fwd_flat", b["xs"][tw * wpt:].data_ptr(), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), wpt, L,
+                                   self.cs[i], c, dt, b["z"][tw * wpt:].data_ptr(),
+                                   b["ssum_f"][tw * srows:].data_ptr() if training else None,
+                                   b["ssq_f"][tw * srows:].data_ptr() if training else None, st)
+                    if training:
+                        ssum, ssq, stat_rows_per_tower = _p(b["ssum_f"]), _p(b["ssq_f"]), srows
+                else:
+                    self._call("vm_conv_fwd", _p(b["xs"]), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), nw, L, self.cs[i], c, dt, _p(b["z"]),
+                               ssum, ssq, st)
             gam, bet = _p(self.view(f"bn{i+1}.gamma")), _p(self.view(f"bn{i+1}.beta"))
             mm, mv = _p(self.view(f"bn{i+1}.moving_mean")), _p(self.view(f"bn{i+1}.moving_variance"))
             if training:
                 zd, zc = self._zd(i)
-                self._call("vm_bn_finalize", ssum, ssq, wpt * b["stat_rows"], n_towers, c, float(wpt * L), gam, bet, self.bn_eps,
+                self._call("vm_bn_finalize", ssum, ssq, stat_rows_per_tower, n_towers, c, float(wpt * L), gam, bet, self.bn_eps,
                            self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]), _p(b["scale"]), _p(b["shift"]),
                            _p(pl["cr_ws"]), zd, zc, st)
             else:
