@@ -80,10 +80,29 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     double s = 0.0, q = 0.0;
     if (c < C) {
         const int64_t base = (int64_t)seg * rows_per_seg;
-        for (int64_t r = r_lo + rg; r < r_hi; r += RG) {
-            s += (double)a[(base + r) * C + c];
-            if (b != nullptr) q += (double)b[(base + r) * C + c];
+        // four rows in flight per thread (a thread of the 2-D variant's launches walks 64 rows: one dependent load after the other
+        // made this kernel 25-34 us for 17 MB), combined in a fixed order
+        double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t r = r_lo + rg;
+        for (; r + 3 * RG < r_hi; r += 4 * RG) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = a[(base + r + u * RG) * C + c];
+                vb[u] = b != nullptr ? b[(base + r + u * RG) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s4[u] += (double)va[u];
+                q4[u] += (double)vb[u];
+            }
         }
+        for (; r < r_hi; r += RG) {
+            s4[0] += (double)a[(base + r) * C + c];
+            if (b != nullptr) q4[0] += (double)b[(base + r) * C + c];
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     }
     red[0][rg][cl] = s;
     red[1][rg][cl] = q;
