@@ -249,7 +249,9 @@ int vm_bn_drop_pool_fwd(const void* z, const float* scale, const float* shift, c
                         void* out, void* stream);
 /* backward, pass 1: partials of sum(dy) and sum(dy*zhat) over the pooled positions, where dy is dp routed to
  * the first maximum of each pool window.  dp: (n_windows, L/pool, C).
- * part_*: (n_windows * vm_bn_part_rows(), C) fp32 (a fixed number of segments per window). */
+ * part_*: (n_windows * vm_bn_part_rows(), C) fp32: every pass kernel fills all vm_bn_part_rows() rows of a window -- one per
+ * workgroup of the window for long windows; for short ones (pooled rows x channel vectors < 2 048: the 2-D variant) one workgroup
+ * takes the whole window, writes row 0 and zero-fills the others -- so a consumer simply adds all rows. */
 int vm_bn_part_rows(void);
 int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
