@@ -422,6 +422,15 @@ int vm_pairdist_argmin(const float* q, const float* ref, int64_t M, int64_t N, i
 int64_t vm_stft_frames(int64_t raw_len, int win_length, int hop);
 int vm_stft_logmel(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const float* basis,
                    const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
+/* vm_stft_logmel with the DFT on the f16 matrix pipe: the windowed basis and the (x 256) samples are split into two f16 halves each
+ * (22 significand bits) and the three significant products accumulated in fp32 -- ~2^-21 relative per product against fp32's 2^-24, at
+ * 1/5 of the matrix time (an fp32 MFMA moves K = 2 per 64 clocks).  Meant for the 16-bit storage modes, whose log-mel image is rounded
+ * to 11 / 8 significand bits anyway; the fp32-storage mode keeps vm_stft_logmel.  basis16: vm_stft_split_basis_bytes(win_length) bytes
+ * filled ONCE by vm_stft_split_basis from the fp32 basis; everything else as vm_stft_logmel. */
+int64_t vm_stft_split_basis_bytes(int win_length);
+int vm_stft_split_basis(const float* basis, int win_length, void* basis16, void* stream);
+int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const void* basis16,
+                        const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
 /* First Conv2D(3 x 3) of the variant (one input channel) on the vector ALUs instead of as a band-stacked GEMM with K = 24, N = 32:
  * in: block input (n_clips * M, L + 2, 1) `dtype` with zero halo rows; w: the fp32 kernel (3, Cs, C) of the flat store (Cs >= 3, the
  * entries km >= 3 are padding), rounded to `dtype` inside like the GEMM path's copy; z (n_clips * M, L, C) = relu(conv + bias);

@@ -43,6 +43,19 @@ def test_stft_logmel(i16, n, raw_len, n_mels):
         assert np.all(o[:, :, 0] == 0) and np.all(o[:, :, -1] == 0)      # halo rows untouched
         got = o[:, :, 1:-1].transpose(0, 2, 1)
         assert max_err(got, ref) < tol * max(1.0, np.abs(ref).max()), dt    # log domain: absolute error
+    # the f16-split DFT (hi / lo halves of basis and samples on the f16 matrix pipe): ~2^-21 per product instead of 2^-24
+    b16 = torch.empty(L().query("vm_stft_split_basis_bytes", S.WIN_LENGTH) // 2, dtype=torch.float16, device="cuda")
+    L().call("vm_stft_split_basis", p(basis), S.WIN_LENGTH, p(b16), stream())
+    for dt, tol in (("f32", 5e-4), ("f16", 4e-3)):
+        vm, tdt = DTYPES[dt]
+        out = torch.zeros(n * n_mels, T + 2, 1, dtype=tdt, device="cuda")
+        L().call("vm_stft_logmel_f16s", p(rd), int(i16), n, raw_len, S.WIN_LENGTH, S.HOP, p(b16), p(melw), n_mels, S.LOG_FLOOR, vm, p(out),
+                 stream())
+        o = out.float().cpu().numpy().reshape(n, n_mels, T + 2)
+        assert np.all(o[:, :, 0] == 0) and np.all(o[:, :, -1] == 0)
+        got = o[:, :, 1:-1].transpose(0, 2, 1)
+        report("stft_logmel_f16s[%s]" % dt, "max_abs_log_err[n%d len%d mels%d i16=%d]" % (n, raw_len, n_mels, int(i16)), max_err(got, ref))
+        assert max_err(got, ref) < tol * max(1.0, np.abs(ref).max()), dt
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

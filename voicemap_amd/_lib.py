@@ -100,6 +100,9 @@ SIGNATURES = {
     "vm_pairdist_argmin": (I, [P, P, L, L, I, I, L, P, P, P, P, P]),
     "vm_stft_frames": (L, [L, I, I]),
     "vm_stft_logmel": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
+    "vm_stft_split_basis_bytes": (L, [I]),
+    "vm_stft_split_basis": (I, [P, I, P, P]),
+    "vm_stft_logmel_f16s": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
     "vm_conv2d_first_supported": (I, [I, I]),
     "vm_conv2d_first_fwd": (I, [P, P, P, L, I, L, I, I, I, P, P, P, P]),
     "vm_conv2d_first_wgrad_workspace_bytes": (L, [L, I, I]),

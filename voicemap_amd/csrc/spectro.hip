@@ -115,6 +115,116 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(const void* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same front-end with GEMM 1 on the f16 matrix pipe (16-bit storage modes; the fp32-storage mode keeps the exact kernel above).
+// An fp32 MFMA moves K = 2 per 64 clocks, v_mfma_f32_32x32x16_f16 K = 16 per 32: the DFT is 0.43 ms of fp32 MFMA time per 256 clips, the
+// whole kernel ran at 87 % of that.  Both operands are split into two halves (v = hi + lo, both f16: 22 significand bits) and the three
+// significant products accumulated in fp32: bh*xh + bl*xh + bh*xl -- 3 MFMAs per K = 16 instead of 8 per K = 16: 5.3 x less matrix time at
+// ~2^-21 relative per product (fp32: 2^-24).  The samples are scaled by 256 before the split (raw audio is ~0.05: its low halves would
+// be subnormal in half) and the power by 2^-16 afterwards (exact).  basis16: [hi | lo][512 rows: re bins, im bins][Kp] f16, Kp = win
+// rounded up to 16 (vm_stft_split_basis).  Power, mel GEMM (fp32 MFMA, registers as operand), log: as above.
+// ------------------------------------------------------------------------------------------------
+template <typename TOUT, int NMB>
+__global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __restrict__ raw, int is_int16, int64_t raw_len, int win, int hop,
+                                                               int T, const f16* __restrict__ basis16, int Kp,
+                                                               const float* __restrict__ melw, float log_floor, TOUT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pitch = Kp + 8;   // halves: a row is 2 Kp + 16 bytes, the 16-byte operand reads of 32 frames x 2 K-halves are conflict-free
+    f16* xh = reinterpret_cast<f16*>(smem);
+    f16* xl = xh + SF_FRAMES * pitch;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t clip = blockIdx.y;
+    const int f0 = blockIdx.x * SF_FRAMES;
+    const float* rf = reinterpret_cast<const float*>(raw) + clip * raw_len;
+    const int16_t* ri = reinterpret_cast<const int16_t*>(raw) + clip * raw_len;
+    for (int i = tid; i < SF_FRAMES * Kp; i += 256) {
+        const int f = i / Kp, n = i - f * Kp;
+        float v = 0.f;
+        if (f0 + f < T && n < win) {
+            const int64_t sidx = (int64_t)(f0 + f) * hop + n;
+            v = is_int16 ? (float)ri[sidx] * (256.0f / 32768.0f) : rf[sidx] * 256.0f;
+        }
+        const f16 h = (f16)v;
+        xh[f * pitch + n] = h;
+        xl[f * pitch + n] = (f16)(v - (float)h);
+    }
+    __syncthreads();
+
+    const int col = lane & 31, kh = lane >> 5;
+    f32x16 re[2], im[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) re[c][e] = im[c][e] = 0.f;
+    const f16* bh = basis16 + (int64_t)(64 * w + col) * Kp + 8 * kh;   // row blocks: +0 re, +32 rows re', +256 im, +288 im'
+    const f16* bl = bh + (int64_t)512 * Kp;
+    const f16* xhr = xh + col * pitch + 8 * kh;
+    const f16* xlr = xl + col * pitch + 8 * kh;
+    for (int n0 = 0; n0 < Kp; n0 += 16) {
+        const f16x8 vxh = *reinterpret_cast<const f16x8*>(xhr + n0), vxl = *reinterpret_cast<const f16x8*>(xlr + n0);
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t ro = (int64_t)((q & 1) * 32 + (q >> 1) * 256) * Kp + n0;
+            ah[q] = *reinterpret_cast<const f16x8*>(bh + ro);
+            al[q] = *reinterpret_cast<const f16x8*>(bl + ro);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x16& acc = q < 2 ? re[q] : im[q - 2];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], vxh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q], vxh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], vxl, acc, 0, 0, 0);
+        }
+    }
+    f32x16 mel[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mel[mb][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pw = (re[c][r] * re[c][r] + im[c][r] * im[c][r]) * (1.0f / 65536.0f);   // the samples were scaled by 256
+            const int bin = 64 * w + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float* wrow = melw + (int64_t)bin * (32 * NMB) + col;
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) mel[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * mb], pw, mel[mb], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the frame matrices
+    float* red = reinterpret_cast<float*>(smem);  // [4][32 * NMB][32]
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            red[(w * 32 * NMB + m) * 32 + col] = mel[mb][r];
+        }
+    __syncthreads();
+    const int n_mels = 32 * NMB;
+    for (int i = tid; i < n_mels * 32; i += 256) {
+        const int m = i >> 5, f = i & 31;
+        if (f0 + f < T) {
+            const float sum = (red[(0 * n_mels + m) * 32 + f] + red[(1 * n_mels + m) * 32 + f]) +
+                              (red[(2 * n_mels + m) * 32 + f] + red[(3 * n_mels + m) * 32 + f]);
+            out[((int64_t)clip * n_mels + m) * (T + 2) + 1 + f0 + f] = Elem<TOUT>::from_f(logf(sum + log_floor));
+        }
+    }
+}
+
+// basis [win][512] fp32 -> [hi | lo][512][Kp] f16 (K-contiguous rows: 16-byte operand loads), zero beyond win
+__global__ void stft_split_basis_kernel(const float* __restrict__ basis, int win, int Kp, f16* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 512 * Kp) return;
+    const int row = i / Kp, k = i - row * Kp;
+    const float b = k < win ? basis[(int64_t)k * 512 + row] : 0.f;
+    const f16 h = (f16)b;
+    out[i] = h;
+    out[(int64_t)512 * Kp + i] = (f16)(b - (float)h);
+}
+
+// ------------------------------------------------------------------------------------------------
 // element-wise helpers.  One thread = one V-element vector (V = 16 bytes' worth when the channel count allows, else 1) of one window;
 // grid = (windows, ceil(vectors per window / 256)): no 64-bit divisions on the element path, whole-vector loads and stores.
 // ------------------------------------------------------------------------------------------------
@@ -498,6 +608,44 @@ extern "C" int vm_stft_logmel(const void* raw, int is_int16, int64_t n_clips, in
     });
 #undef VM_LAUNCH_SF
     return check_launch("vm_stft_logmel");
+}
+
+extern "C" int64_t vm_stft_split_basis_bytes(int win_length) { return 2LL * 512 * ((win_length + 15) / 16 * 16) * 2; }
+
+extern "C" int vm_stft_split_basis(const float* basis, int win_length, void* basis16, void* stream) {
+    VM_REQUIRE(basis && basis16 && win_length >= 2 && win_length <= 512, "vm_stft_split_basis: bad argument");
+    const int Kp = (win_length + 15) / 16 * 16;
+    hipLaunchKernelGGL(stft_split_basis_kernel, dim3((unsigned)((512 * Kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, basis, win_length, Kp,
+                       (f16*)basis16);
+    return check_launch("vm_stft_split_basis");
+}
+
+extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
+                                   const void* basis16, const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream) {
+    VM_REQUIRE(raw && basis16 && melw && out, "vm_stft_logmel_f16s: null pointer");
+    VM_REQUIRE(n_clips > 0 && n_clips < 65536 && win_length >= 2 && win_length <= 512 && hop > 0 && raw_len >= win_length,
+               "vm_stft_logmel_f16s: bad sizes (n_fft is 512: win_length <= 512)");
+    VM_REQUIRE(n_mels == 32 || n_mels == 64 || n_mels == 96 || n_mels == 128, "vm_stft_logmel_f16s: n_mels must be 32, 64, 96 or 128");
+    VM_REQUIRE(log_floor > 0.f, "vm_stft_logmel_f16s: log_floor must be positive");
+    const int n_frames = (int)vm_stft_frames(raw_len, win_length, hop);
+    const int Kp = (win_length + 15) / 16 * 16;
+    const dim3 grid((unsigned)((n_frames + SF_FRAMES - 1) / SF_FRAMES), (unsigned)n_clips);
+    size_t lds = (size_t)2 * SF_FRAMES * (Kp + 8) * 2;
+    const size_t red = (size_t)4 * n_mels * 32 * 4;
+    if (red > lds) lds = red;
+#define VM_LAUNCH_SF16(TT, NMB)                                                                                                       \
+    hipLaunchKernelGGL((stft_logmel_f16s_kernel<TT, NMB>), grid, dim3(256), lds, (hipStream_t)stream, raw, is_int16, raw_len, win_length, \
+                       hop, n_frames, (const f16*)basis16, Kp, melw, log_floor, (TT*)out)
+    VM_DISPATCH_DTYPE(dtype, {
+        switch (n_mels / 32) {
+            case 1: VM_LAUNCH_SF16(T, 1); break;
+            case 2: VM_LAUNCH_SF16(T, 2); break;
+            case 3: VM_LAUNCH_SF16(T, 3); break;
+            default: VM_LAUNCH_SF16(T, 4); break;
+        }
+    });
+#undef VM_LAUNCH_SF16
+    return check_launch("vm_stft_logmel_f16s");
 }
 
 #define VM_DISPATCH_VEC(T, C, ...)                       \

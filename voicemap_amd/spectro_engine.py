@@ -109,6 +109,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self._init_zero_debias()
         self.basis = torch.from_numpy(spectro.dft_basis(self.win_length)).to(dev)
         self.melw = torch.from_numpy(spectro.mel_filterbank(self.n_mels)).to(dev)
+        # 16-bit storage: the DFT on the f16 matrix pipe from hi / lo halves of basis and samples (vm_stft_logmel_f16s)
+        self.stft_split = self.is16
+        self.basis16 = torch.empty(self.lib.query("vm_stft_split_basis_bytes", self.win_length) // 2, dtype=torch.float16, device=dev)
+        self._call("vm_stft_split_basis", _p(self.basis), self.win_length, _p(self.basis16), self.stream())
         self.init_params(seed)
 
     # ---- parameters: the flat store keeps Conv2D kernels as (3, Cs, C_out) = (kT, [kM x C_in, zero padding], C_out) ----------------
@@ -260,8 +264,12 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         if not is16:
             raw = raw.to(torch.float32)
         assert raw.shape[1] == pl["raw_len"]
-        self._call("vm_stft_logmel", _p(raw), int(is16), pl["n"], pl["raw_len"], self.win_length, self.hop, _p(self.basis), _p(self.melw),
-                   self.n_mels, self.log_floor, self.dtype, _p(pl[0]["in"]), self.stream())
+        if self.stft_split:
+            self._call("vm_stft_logmel_f16s", _p(raw), int(is16), pl["n"], pl["raw_len"], self.win_length, self.hop, _p(self.basis16),
+                       _p(self.melw), self.n_mels, self.log_floor, self.dtype, _p(pl[0]["in"]), self.stream())
+        else:
+            self._call("vm_stft_logmel", _p(raw), int(is16), pl["n"], pl["raw_len"], self.win_length, self.hop, _p(self.basis), _p(self.melw),
+                       self.n_mels, self.log_floor, self.dtype, _p(pl[0]["in"]), self.stream())
         pl["_raw_keepalive"] = raw
 
     def make_drop_masks(self, n_clips: int, generator: Optional[torch.Generator] = None):
