@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) re[c][e] = im[c][e] = 0.f;
-    const f16* bh = basis16 + (int64_t)(64 * w + col) * Kp + 8 * kh;   // row blocks: +0 re, +32 rows re', +256 im, +288 im'
+    // basis16 is stored in operand order: [hi | lo][K step][16 row blocks][lane][8 halves] -- one operand load of a wave is 1 KB
+    // contiguous (8 whole cache lines; K-contiguous rows touched 32 lines for 32 bytes each and refetched them every step)
+    const f16* bh = basis16 + (int64_t)(2 * w) * 512 + lane * 8;   // row blocks: +0 re, +1 re', +8 im, +9 im'
     const f16* bl = bh + (int64_t)512 * Kp;
     const f16* xhr = xh + col * pitch + 8 * kh;
     const f16* xlr = xl + col * pitch + 8 * kh;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
         f16x8 ah[4], al[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t ro = (int64_t)((q & 1) * 32 + (q >> 1) * 256) * Kp + n0;
+            const int64_t ro = (int64_t)n0 * 512 + ((q & 1) + (q >> 1) * 8) * 512;
             ah[q] = *reinterpret_cast<const f16x8*>(bh + ro);
             al[q] = *reinterpret_cast<const f16x8*>(bl + ro);
         }
@@ -181,18 +183,30 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) mel[mb][e] = 0.f;
+    // This wave's 64 rows of the mel matrix go through LDS (the frame matrices are done with): 16 bulk loads per lane up front instead of
+    // 64 NMB dependent scalar loads from L2, one in front of every MFMA below (they were most of this kernel's time)
+    __syncthreads();
+    float* mw = reinterpret_cast<float*>(smem) + w * 64 * (32 * NMB);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(melw + (int64_t)64 * w * (32 * NMB));
+        f32x4* dst = reinterpret_cast<f32x4*>(mw);
+#pragma unroll
+        for (int i = 0; i < 64 * 32 * NMB / 4 / 64; ++i) dst[i * 64 + lane] = src[i * 64 + lane];
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // (the wave reads only what it wrote itself)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float pw = (re[c][r] * re[c][r] + im[c][r] * im[c][r]) * (1.0f / 65536.0f);   // the samples were scaled by 256
-            const int bin = 64 * w + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const float* wrow = melw + (int64_t)bin * (32 * NMB) + col;
+            const int lbin = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;   // row of this wave's slice
+            const float* wrow = mw + lbin * (32 * NMB) + col;
 #pragma unroll
             for (int mb = 0; mb < NMB; ++mb) mel[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * mb], pw, mel[mb], 0, 0, 0);
         }
     }
-    __syncthreads();  // every wave is done with the frame matrices
+    __syncthreads();  // every wave is done with its slice
     float* red = reinterpret_cast<float*>(smem);  // [4][32 * NMB][32]
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -213,11 +227,13 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     }
 }
 
-// basis [win][512] fp32 -> [hi | lo][512][Kp] f16 (K-contiguous rows: 16-byte operand loads), zero beyond win
+// basis [win][512] fp32 -> [hi | lo][Kp / 16 steps][16 row blocks][64 lanes][8] f16 (lane = row % 32 + 32 * (K half of the step): the
+// A operand of v_mfma_f32_32x32x16_f16 as it sits in registers), zero beyond win
 __global__ void stft_split_basis_kernel(const float* __restrict__ basis, int win, int Kp, f16* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 512 * Kp) return;
-    const int row = i / Kp, k = i - row * Kp;
+    const int e = i & 7, lane = (i >> 3) & 63, rb = (i >> 9) & 15, step = i >> 13;
+    const int row = 32 * rb + (lane & 31), k = 16 * step + 8 * (lane >> 5) + e;
     const float b = k < win ? basis[(int64_t)k * 512 + row] : 0.f;
     const f16 h = (f16)b;
     out[i] = h;
@@ -631,8 +647,9 @@ extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clip
     const int Kp = (win_length + 15) / 16 * 16;
     const dim3 grid((unsigned)((n_frames + SF_FRAMES - 1) / SF_FRAMES), (unsigned)n_clips);
     size_t lds = (size_t)2 * SF_FRAMES * (Kp + 8) * 2;
-    const size_t red = (size_t)4 * n_mels * 32 * 4;
+    const size_t red = (size_t)4 * n_mels * 32 * 4, mws = (size_t)4 * 64 * n_mels * 4;   // partial mel sums; the mel matrix, a slice per wave
     if (red > lds) lds = red;
+    if (mws > lds) lds = mws;
 #define VM_LAUNCH_SF16(TT, NMB)                                                                                                       \
     hipLaunchKernelGGL((stft_logmel_f16s_kernel<TT, NMB>), grid, dim3(256), lds, (hipStream_t)stream, raw, is_int16, raw_len, win_length, \
                        hop, n_frames, (const f16*)basis16, Kp, melw, log_floor, (TT*)out)
