@@ -136,16 +136,27 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     const int f0 = blockIdx.x * SF_FRAMES;
     const float* rf = reinterpret_cast<const float*>(raw) + clip * raw_len;
     const int16_t* ri = reinterpret_cast<const int16_t*>(raw) + clip * raw_len;
-    for (int i = tid; i < SF_FRAMES * Kp; i += 256) {
-        const int f = i / Kp, n = i - f * Kp;
-        float v = 0.f;
-        if (f0 + f < T && n < win) {
-            const int64_t sidx = (int64_t)(f0 + f) * hop + n;
-            v = is_int16 ? (float)ri[sidx] * (256.0f / 32768.0f) : rf[sidx] * 256.0f;
+    // a wave per frame, 64 consecutive samples per load, a frame's (up to 8) loads all in flight before the first conversion: with a
+    // run-time trip count every load was waited for on its own -- 50 L2 latencies in a row per workgroup, longer than its GEMM
+    for (int f = w; f < SF_FRAMES; f += 4) {
+        const bool fok = f0 + f < T;
+        const int64_t s0 = (int64_t)(f0 + f) * hop;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            v[j] = 0.f;
+            if (fok && n < win) v[j] = is_int16 ? (float)ri[s0 + n] * (256.0f / 32768.0f) : rf[s0 + n] * 256.0f;
         }
-        const f16 h = (f16)v;
-        xh[f * pitch + n] = h;
-        xl[f * pitch + n] = (f16)(v - (float)h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            if (n < Kp) {
+                const f16 h = (f16)v[j];
+                xh[f * pitch + n] = h;
+                xl[f * pitch + n] = (f16)(v[j] - (float)h);
+            }
+        }
     }
     __syncthreads();
 
@@ -161,21 +172,31 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     const f16* bl = bh + (int64_t)512 * Kp;
     const f16* xhr = xh + col * pitch + 8 * kh;
     const f16* xlr = xl + col * pitch + 8 * kh;
+    f16x8 ah[4], al[4];   // the next step's basis operands are in flight under this step's MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t ro = (int64_t)((q & 1) + (q >> 1) * 8) * 512;
+        ah[q] = *reinterpret_cast<const f16x8*>(bh + ro);
+        al[q] = *reinterpret_cast<const f16x8*>(bl + ro);
+    }
     for (int n0 = 0; n0 < Kp; n0 += 16) {
         const f16x8 vxh = *reinterpret_cast<const f16x8*>(xhr + n0), vxl = *reinterpret_cast<const f16x8*>(xlr + n0);
-        f16x8 ah[4], al[4];
+        f16x8 ch[4], cl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ch[q] = ah[q]; cl[q] = al[q]; }
+        const int n1 = n0 + 16 < Kp ? n0 + 16 : n0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t ro = (int64_t)n0 * 512 + ((q & 1) + (q >> 1) * 8) * 512;
+            const int64_t ro = (int64_t)n1 * 512 + ((q & 1) + (q >> 1) * 8) * 512;
             ah[q] = *reinterpret_cast<const f16x8*>(bh + ro);
             al[q] = *reinterpret_cast<const f16x8*>(bl + ro);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x16& acc = q < 2 ? re[q] : im[q - 2];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], vxh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q], vxh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], vxl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[q], vxh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[q], vxh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[q], vxl, acc, 0, 0, 0);
         }
     }
     f32x16 mel[NMB];
@@ -183,30 +204,19 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) mel[mb][e] = 0.f;
-    // This wave's 64 rows of the mel matrix go through LDS (the frame matrices are done with): 16 bulk loads per lane up front instead of
-    // 64 NMB dependent scalar loads from L2, one in front of every MFMA below (they were most of this kernel's time)
-    __syncthreads();
-    float* mw = reinterpret_cast<float*>(smem) + w * 64 * (32 * NMB);
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(melw + (int64_t)64 * w * (32 * NMB));
-        f32x4* dst = reinterpret_cast<f32x4*>(mw);
-#pragma unroll
-        for (int i = 0; i < 64 * 32 * NMB / 4 / 64; ++i) dst[i * 64 + lane] = src[i * 64 + lane];
-    }
-    __builtin_amdgcn_s_waitcnt(0);   // (the wave reads only what it wrote itself)
-    __builtin_amdgcn_wave_barrier();
+    // (the mel matrix operands come straight from global: staging this wave's rows through LDS first measured 0.25 against 0.21 ms)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float pw = (re[c][r] * re[c][r] + im[c][r] * im[c][r]) * (1.0f / 65536.0f);   // the samples were scaled by 256
-            const int lbin = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;   // row of this wave's slice
-            const float* wrow = mw + lbin * (32 * NMB) + col;
+            const int bin = 64 * w + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float* wrow = melw + (int64_t)bin * (32 * NMB) + col;
 #pragma unroll
             for (int mb = 0; mb < NMB; ++mb) mel[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * mb], pw, mel[mb], 0, 0, 0);
         }
     }
-    __syncthreads();  // every wave is done with its slice
+    __syncthreads();  // every wave is done with the frame matrices
     float* red = reinterpret_cast<float*>(smem);  // [4][32 * NMB][32]
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -647,9 +657,8 @@ extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clip
     const int Kp = (win_length + 15) / 16 * 16;
     const dim3 grid((unsigned)((n_frames + SF_FRAMES - 1) / SF_FRAMES), (unsigned)n_clips);
     size_t lds = (size_t)2 * SF_FRAMES * (Kp + 8) * 2;
-    const size_t red = (size_t)4 * n_mels * 32 * 4, mws = (size_t)4 * 64 * n_mels * 4;   // partial mel sums; the mel matrix, a slice per wave
+    const size_t red = (size_t)4 * n_mels * 32 * 4;
     if (red > lds) lds = red;
-    if (mws > lds) lds = mws;
 #define VM_LAUNCH_SF16(TT, NMB)                                                                                                       \
     hipLaunchKernelGGL((stft_logmel_f16s_kernel<TT, NMB>), grid, dim3(256), lds, (hipStream_t)stream, raw, is_int16, raw_len, win_length, \
                        hop, n_frames, (const f16*)basis16, Kp, melw, log_floor, (TT*)out)
