@@ -561,6 +561,213 @@ __global__ __launch_bounds__(256) void conv2d_first_wgrad_kernel(const T* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer on the matrix pipe (16-bit storage, C % 32 == 0).  The vector-ALU form above issues ~600 vector instructions per
+// 32 positions x 32 channels and kept the vector pipes 77 % and the LDS 68 % busy (SQ counters, profiles/r03_logmel_pmc_*.csv): its
+// 0.22 ms were arithmetic, not the 312 MB store.  As a GEMM tile the nine taps are K = 9 of ONE v_mfma_f32_32x32x16:
+//   A = the 3 x 3 patches of 32 positions (gathered with 2-byte loads: the input has one channel, 10 MB, cache-resident),
+//   B = the nine weights of 32 channels (registers, once per wave), accumulator start = bias.
+// A wave owns one statistics row (128 positions of one window = 4 tiles).  D puts a channel in a lane and the positions in its
+// registers, so the BatchNorm partial sums are in-lane adds (no cross-lane reduction until the row ends); the tile reaches memory
+// through a wave-private LDS transpose: 2-byte writes [position][channel], 16-byte reads, 1 KB contiguous per store instruction.
+// Tap order k = kT * 3 + km as above; same rounding points (weights to the storage type, fp32 accumulation, statistics of the stored z).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    using Frag = f16x8;
+    __device__ static inline f32x16 run32(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static inline f32x4 run16(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma16<bf16> {
+    using Frag = bf16x8;
+    __device__ static inline f32x16 run32(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static inline f32x4 run16(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, int CB>   // CB = C / 32
+__global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, int64_t n_rows, int M, int L, int Cs,
+                                                                    T* __restrict__ z, float* __restrict__ stat_sum,
+                                                                    float* __restrict__ stat_sq) {
+    constexpr int C = 32 * CB;
+    using Frag = typename Mma16<T>::Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int rows = (L + 127) / 128;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // statistics row = (window, 128-position chunk); no workgroup barrier below
+    if (row >= n_rows) return;
+    const int64_t win = row / rows;
+    const int chunk = (int)(row - win * rows);
+    const int m = (int)(win % M);
+    T* tile = reinterpret_cast<T*>(smem) + wave * 32 * C;   // [32 positions][C]
+
+    // this lane's eight K slots: taps 8 kh .. 8 kh + 7 (taps >= 9: zero)
+    Frag wb[CB];
+    float bv[CB];
+    int off[8];
+    unsigned ok = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kh + e, kt = k / 3, km = k - 3 * kt, ms = m + km - 1;
+        off[e] = (km - 1) * (L + 2) + kt;
+        if (k < 9 && ms >= 0 && ms < M) ok |= 1u << e;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            wb[cb][e] = Elem<T>::from_f(k < 9 ? w[((int64_t)kt * Cs + km) * C + 32 * cb + col] : 0.f);
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bv[cb] = bias[32 * cb + col];
+    const T* base = in + win * (int64_t)(L + 2);
+    float s1[CB], s2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) s1[cb] = s2[cb] = 0.f;
+
+    for (int ti = 0; ti < 4; ++ti) {
+        const int t0 = chunk * 128 + ti * 32;
+        if (t0 >= L) break;
+        const int t = t0 + col;
+        Frag a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            T v = Elem<T>::from_f(0.f);
+            if (((ok >> e) & 1u) && t < L) v = base[off[e] + t];
+            a[e] = v;
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bv[cb];
+            acc = Mma16<T>::run32(a, wb[cb], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const T h = Elem<T>::from_f(fmaxf(acc[r], 0.f));
+                const float rf = Elem<T>::to_f(h);
+                if (t0 + pl < L) {
+                    s1[cb] += rf;
+                    s2[cb] = fmaf(rf, rf, s2[cb]);
+                }
+                tile[pl * C + 32 * cb + col] = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private tile: the LDS serves a wave's accesses in order)
+        const int nbytes = (L - t0 < 32 ? L - t0 : 32) * C * 2;
+        char* dst = reinterpret_cast<char*>(z + (win * L + t0) * (int64_t)C);
+#pragma unroll
+        for (int i = 0; i < 2 * CB; ++i) {
+            const int bo = (i * 64 + lane) * 16;
+            if (bo < nbytes) *reinterpret_cast<u32x4*>(dst + bo) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + bo);
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (stat_sum != nullptr) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const float a = s1[cb] + __shfl_xor(s1[cb], 32, 64), b = s2[cb] + __shfl_xor(s2[cb], 32, 64);
+            if (kh == 0) {
+                stat_sum[row * C + 32 * cb + col] = a;
+                stat_sq[row * C + 32 * cb + col] = b;
+            }
+        }
+    }
+}
+
+// ... and the weight gradient as v_mfma_f32_16x16x32 tiles: dW[tap][co] = sum over positions of patch[position][tap] * du[position][co] is a
+// GEMM with the POSITIONS as K.  A (16 tap rows x 32 positions): a lane's eight K slots are eight consecutive samples of one band --
+// one 16-byte load; B (32 positions x 16 channels): eight 2-byte loads a channel block (du is channel-contiguous).  A wave walks
+// (window, 32-position block) items of its workgroup's `wpb` windows; the four waves' tiles meet in LDS in a fixed order.  Same
+// slab layout as above.  Positions past the window: du is read as zero there (the A samples beside them belong to the next band: finite).
+template <typename T, int CB16>   // CB16 = C / 16
+__global__ __launch_bounds__(256) void conv2d_first_wgrad_mfma_kernel(const T* __restrict__ in, const T* __restrict__ du, int64_t n_windows,
+                                                                      int M, int L, int wpb, float* __restrict__ slabs) {
+    constexpr int C = 16 * CB16;
+    using Frag = typename Mma16<T>::Frag;
+    __shared__ float red[4][9][C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kg = lane >> 4;
+    const int kt = i / 3, km = i - 3 * kt;   // tap i = kT * 3 + km (rows 9 .. 15 of A: zero)
+    f32x4 acc[CB16];
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nblk = (L + 31) / 32;
+    const int64_t w0 = (int64_t)blockIdx.x * wpb;
+    const int nwin = (int)(n_windows - w0 < wpb ? n_windows - w0 : wpb);
+    for (int item = wave; item < nwin * nblk; item += 4) {
+        const int wi = item / nblk, blk = item - wi * nblk;
+        const int64_t win = w0 + wi;
+        const int m = (int)(win % M), ms = m + km - 1;
+        const int p0 = blk * 32 + kg * 8;   // this lane's K slots: positions p0 .. p0 + 7
+        Frag a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = Elem<T>::from_f(0.f);
+        if (i < 9 && ms >= 0 && ms < M) {
+            const T* src = in + (win + km - 1) * (int64_t)(L + 2) + p0 + kt;
+            if (p0 + kt + 8 <= L + 2) {
+                __builtin_memcpy(&a, src, 16);   // 2-byte aligned
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (p0 + kt + j < L + 2) a[j] = src[j];
+            }
+        }
+        const T* g = du + ((win * (L + 2) + 1 + p0) * (int64_t)C + i);
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            Frag b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                T v = Elem<T>::from_f(0.f);
+                if (p0 + j < L) v = g[(int64_t)j * C + 16 * cb];
+                b[j] = v;
+            }
+            acc[cb] = Mma16<T>::run16(a, b, acc[cb]);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tap = 4 * kg + r;
+            if (tap < 9) red[wave][tap][16 * cb + i] = acc[cb][r];
+        }
+    __syncthreads();
+    for (int q = tid; q < 9 * C; q += 256) {
+        const int k = q / C, c = q % C;
+        slabs[(int64_t)blockIdx.x * 9 * C + q] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+    }
+}
+
+template <typename T>
+static void launch_c2f_mfma(const T* in, const float* w, const float* bias, int64_t n_rows, int M, int L, int Cs, int C, T* z, float* stat_sum,
+                            float* stat_sq, hipStream_t stream) {
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+    const size_t lds = (size_t)4 * 32 * C * 2;
+#define VM_LAUNCH_C2F(CB) \
+    hipLaunchKernelGGL((conv2d_first_fwd_mfma_kernel<T, CB>), grid, dim3(256), lds, stream, in, w, bias, n_rows, M, L, Cs, z, stat_sum, stat_sq)
+    switch (C / 32) {
+        case 1: VM_LAUNCH_C2F(1); break;
+        case 2: VM_LAUNCH_C2F(2); break;
+        case 3: VM_LAUNCH_C2F(3); break;
+        default: VM_LAUNCH_C2F(4); break;
+    }
+#undef VM_LAUNCH_C2F
+}
+
+template <typename T>
+static void launch_c2w_mfma(const T* in, const T* du, int64_t nw, int M, int L, int C, int wpb, float* slabs, unsigned blocks, hipStream_t stream) {
+#define VM_LAUNCH_C2W(CB16) \
+    hipLaunchKernelGGL((conv2d_first_wgrad_mfma_kernel<T, CB16>), dim3(blocks), dim3(256), 0, stream, in, du, nw, M, L, wpb, slabs)
+    switch (C / 32) {
+        case 1: VM_LAUNCH_C2W(2); break;
+        case 2: VM_LAUNCH_C2W(4); break;
+        case 3: VM_LAUNCH_C2W(6); break;
+        default: VM_LAUNCH_C2W(8); break;
+    }
+#undef VM_LAUNCH_C2W
+}
+
 __global__ void conv2d_first_scatter_kernel(const float* __restrict__ g9, int Cs, int C, float* __restrict__ grad_w) {
     const int i = blockIdx.x * 256 + threadIdx.x;   // over (3, Cs, C)
     if (i >= 3 * Cs * C) return;
@@ -737,6 +944,14 @@ extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* 
     const int64_t rows = (L + 127) / 128;
     VM_REQUIRE(rows < 65536, "vm_conv2d_first_fwd: window too long");
     VM_DISPATCH_DTYPE(dtype, {
+        if constexpr (sizeof(T) == 2) {
+            if (C % 32 == 0) {   // 16-bit storage: the matrix-pipe form, one wave per statistics row
+                const int64_t n_rows = n_clips * M * rows;
+                VM_REQUIRE(n_rows / 4 + 1 < (1LL << 31), "vm_conv2d_first_fwd: too many windows");
+                launch_c2f_mfma<T>((const T*)in, w, bias, n_rows, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq, (hipStream_t)stream);
+                return check_launch("vm_conv2d_first_fwd");
+            }
+        }
         hipLaunchKernelGGL((conv2d_first_fwd_kernel<T>), dim3((unsigned)(n_clips * M)), dim3(256), 0, (hipStream_t)stream,
                            (const T*)in, w, bias, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq);
     });
@@ -760,8 +975,16 @@ extern "C" int vm_conv2d_first_wgrad(const void* in, const void* du, int64_t n_c
     float* slabs = (float*)ws;
     float* g9 = slabs + used * nel;
     VM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((conv2d_first_wgrad_kernel<T>), dim3((unsigned)used), dim3(256), 0, (hipStream_t)stream, (const T*)in, (const T*)du,
-                           nw, M, (int)L, C, wpb, slabs);
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (C % 32 == 0) {
+                launch_c2w_mfma<T>((const T*)in, (const T*)du, nw, M, (int)L, C, wpb, slabs, (unsigned)used, (hipStream_t)stream);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((conv2d_first_wgrad_kernel<T>), dim3((unsigned)used), dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                               (const T*)du, nw, M, (int)L, C, wpb, slabs);
     });
     int rc = check_launch("vm_conv2d_first_wgrad");
     if (rc) return rc;
