@@ -602,19 +602,23 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
     const int m = (int)(win % M);
     T* tile = reinterpret_cast<T*>(smem) + wave * 32 * C;   // [32 positions][C]
 
-    // this lane's eight K slots: taps 8 kh .. 8 kh + 7 (taps >= 9: zero)
+    // this lane's K slots: the lower half-wave carries taps 0 .. 4 in slots 0 .. 4, the upper one taps 5 .. 8 in slots 0 .. 3 (five
+    // gather instructions a tile, not eight); the other slots are zero in both operands
     Frag wb[CB];
     float bv[CB];
-    int off[8];
+    int off[5];
     unsigned ok = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int k = 8 * kh + e, kt = k / 3, km = k - 3 * kt, ms = m + km - 1;
-        off[e] = (km - 1) * (L + 2) + kt;
-        if (k < 9 && ms >= 0 && ms < M) ok |= 1u << e;
+        const int k = 5 * kh + e, kt = k / 3, km = k - 3 * kt, ms = m + km - 1;
+        const bool slot = e < 5 - kh;
+        if (e < 5) {
+            off[e] = (km - 1) * (L + 2) + kt;
+            if (slot && ms >= 0 && ms < M) ok |= 1u << e;
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
-            wb[cb][e] = Elem<T>::from_f(k < 9 ? w[((int64_t)kt * Cs + km) * C + 32 * cb + col] : 0.f);
+            wb[cb][e] = Elem<T>::from_f(slot ? w[((int64_t)kt * Cs + km) * C + 32 * cb + col] : 0.f);
     }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bv[cb] = bias[32 * cb + col];
@@ -631,25 +635,34 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             T v = Elem<T>::from_f(0.f);
-            if (((ok >> e) & 1u) && t < L) v = base[off[e] + t];
+            if (e < 5)
+                if (((ok >> e) & 1u) && t < L) v = base[off[e] + t];
             a[e] = v;
         }
+        const bool whole = t0 + 32 <= L;   // (uniform) every position of the tile counts in the statistics
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bv[cb];
             acc = Mma16<T>::run32(a, wb[cb], acc);
+            float rf[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pl = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const T h = Elem<T>::from_f(fmaxf(acc[r], 0.f));
-                const float rf = Elem<T>::to_f(h);
-                if (t0 + pl < L) {
-                    s1[cb] += rf;
-                    s2[cb] = fmaf(rf, rf, s2[cb]);
-                }
+                rf[r] = Elem<T>::to_f(h);
                 tile[pl * C + 32 * cb + col] = h;
+            }
+            if (!whole) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t0 + (r & 3) + 8 * (r >> 2) + 4 * kh >= L) rf[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s1[cb] += rf[r];
+                s2[cb] = fmaf(rf[r], rf[r], s2[cb]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private tile: the LDS serves a wave's accesses in order)
@@ -712,17 +725,21 @@ __global__ __launch_bounds__(256) void conv2d_first_wgrad_mfma_kernel(const T* _
                     if (p0 + kt + j < L + 2) a[j] = src[j];
             }
         }
-        const T* g = du + ((win * (L + 2) + 1 + p0) * (int64_t)C + i);
+        // channel blocks in pairs: lane i carries channels 32 q + 2 i (block 2 q) and 32 q + 2 i + 1 (block 2 q + 1) -- one 4-byte load
+        const T* g = du + ((win * (L + 2) + 1 + p0) * (int64_t)C + 2 * i);
 #pragma unroll
-        for (int cb = 0; cb < CB16; ++cb) {
-            Frag b;
+        for (int q = 0; q < CB16 / 2; ++q) {
+            Frag b0, b1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                T v = Elem<T>::from_f(0.f);
-                if (p0 + j < L) v = g[(int64_t)j * C + 16 * cb];
-                b[j] = v;
+                uint32_t v = 0;
+                if (p0 + j < L) v = *reinterpret_cast<const uint32_t*>(g + (int64_t)j * C + 32 * q);
+                const uint16_t lo = (uint16_t)(v & 0xffffu), hi = (uint16_t)(v >> 16);
+                b0[j] = __builtin_bit_cast(T, lo);
+                b1[j] = __builtin_bit_cast(T, hi);
             }
-            acc[cb] = Mma16<T>::run16(a, b, acc[cb]);
+            acc[2 * q] = Mma16<T>::run16(a, b0, acc[2 * q]);
+            acc[2 * q + 1] = Mma16<T>::run16(a, b1, acc[2 * q + 1]);
         }
     }
 #pragma unroll
@@ -730,7 +747,7 @@ __global__ __launch_bounds__(256) void conv2d_first_wgrad_mfma_kernel(const T* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tap = 4 * kg + r;
-            if (tap < 9) red[wave][tap][16 * cb + i] = acc[cb][r];
+            if (tap < 9) red[wave][tap][32 * (cb >> 1) + 2 * i + (cb & 1)] = acc[cb][r];
         }
     __syncthreads();
     for (int q = tid; q < 9 * C; q += 256) {
