@@ -431,7 +431,9 @@ int64_t vm_stft_split_basis_bytes(int win_length);
 int vm_stft_split_basis(const float* basis, int win_length, void* basis16, void* stream);
 int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const void* basis16,
                         const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
-/* First Conv2D(3 x 3) of the variant (one input channel) on the vector ALUs instead of as a band-stacked GEMM with K = 24, N = 32:
+/* First Conv2D(3 x 3) of the variant (one input channel) with its own kernels instead of as a band-stacked GEMM with K = 24, N = 32
+ * (16-bit storage and C % 32 == 0: one v_mfma_f32_32x32x16 per 32 positions x 32 channels, the nine taps as K, and
+ * v_mfma_f32_16x16x32 tiles with the positions as K for the gradient; otherwise on the vector ALUs):
  * in: block input (n_clips * M, L + 2, 1) `dtype` with zero halo rows; w: the fp32 kernel (3, Cs, C) of the flat store (Cs >= 3, the
  * entries km >= 3 are padding), rounded to `dtype` inside like the GEMM path's copy; z (n_clips * M, L, C) = relu(conv + bias);
  * stat_sum / stat_sq (optional): the BatchNorm partial sums of the stored z, vm_conv_stat_rows(L) rows per window.  C % 8 == 0,

@@ -694,7 +694,7 @@ def test_conv_cfgA_geometry_default_dispatch(dt, l, cin, cout):
 
 
 def _window_slices(n):
-    return sorted({0, 1, n // 2 - 1, n // 2, n - 1})
+    return sorted({0, n // 2, n - 1})   # first / last window and the first window of the second tower
 
 
 @pytest.mark.parametrize("dt", ["f32", "f32s", "bf16", "f16"])

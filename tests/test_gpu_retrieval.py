@@ -117,7 +117,7 @@ def test_cached_evaluation_matches_the_oracle_on_the_cached_embeddings_and_the_t
     emb = cache.emb.cpu().numpy()
     for dist, k, n in (("euclidean", 5, 1), ("cosine", 4, 3), ("dot_product", 6, 2)):
         np.random.seed(11)
-        q, s = R.draw_tasks_reference(ds, 60, k, n)
+        q, s = R.draw_tasks_reference(ds, 30, k, n)
         got, pred = R.evaluate_tasks(cache, q, s, k, n, dist, return_pred=True)
         want = sum(int(np.argmin(O.n_shot_prediction(emb[q[t]], emb[s[t]], n, k, dist)) == 0) for t in range(len(q)))
         assert got == want, (dist, got, want)
@@ -128,18 +128,18 @@ def test_cached_evaluation_matches_the_oracle_on_the_cached_embeddings_and_the_t
         assert (classes == classes[:, :, :1]).all() and all(len(set(c[:, 0])) == k for c in classes)
         # same seed through the wrapper (which embeds the corpus itself when no cache is passed)
         np.random.seed(11)
-        assert R.n_shot_task_evaluation_cached(net, ds, pre, 60, n, k, "siamese", dist, cache=cache) == got
+        assert R.n_shot_task_evaluation_cached(net, ds, pre, 30, n, k, "siamese", dist, cache=cache) == got
     # against the reference-faithful task-by-task evaluation on the SAME tasks (same seed): the only difference is the whitening
     # scalar of the support windows (per task batch there, per window here), so the accuracies are close, not equal
     np.random.seed(3)
-    faithful = VU.n_shot_task_evaluation(net, ds, pre, 60, 5, 5, network_type="siamese", distance="euclidean")
+    faithful = VU.n_shot_task_evaluation(net, ds, pre, 30, 5, 5, network_type="siamese", distance="euclidean")
     np.random.seed(3)
-    cached = R.n_shot_task_evaluation_cached(net, ds, pre, 60, 5, 5, "siamese", "euclidean", cache=cache)
-    report("cached_eval", "acc_task_by_task_5way_5shot", faithful / 60.0)
-    report("cached_eval", "acc_cached_5way_5shot", cached / 60.0)
+    cached = R.n_shot_task_evaluation_cached(net, ds, pre, 30, 5, 5, "siamese", "euclidean", cache=cache)
+    report("cached_eval", "acc_task_by_task_5way_5shot", faithful / 30.0)
+    report("cached_eval", "acc_cached_5way_5shot", cached / 30.0)
     # (untrained net on synthetic speakers of very different loudness: 0.51 vs 0.77 measured -- batch-level whitening keeps the
     # loudness differences between a task's support windows, per-window whitening removes them; both must beat chance = 0.2)
-    assert faithful > 0.3 * 60 and cached > 0.3 * 60
+    assert faithful > 0.3 * 30 and cached > 0.3 * 30
 
 
 def test_device_task_sampler_draws_valid_tasks_with_the_reference_distribution():
