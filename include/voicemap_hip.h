@@ -47,11 +47,12 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 4.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
+/* 5.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
  * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce; vm_conv_fwd_flat, vm_conv2d_first_*,
- * `src_padded` in vm_fold_windows) (round 3). */
+ * `src_padded` in vm_fold_windows) (round 3); 5 = vm_bn_pool2d_stack_fwd, vm_fold_pool_windows_bwd, the operand-order basis of
+ * vm_stft_split_basis (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
 int vm_check_device(void);
@@ -459,6 +460,17 @@ int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t L, int C, i
  * (M / 2), L, C), dq (n_clips * M, L, C) = dout routed to the first maximum of each pair. */
 int vm_pool_windows_fwd(const void* q, int64_t n_clips, int M, int64_t rows, int C, int dtype, void* out, void* stream);
 int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M, int64_t L, int C, int dtype, void* dq, void* stream);
+/* One block boundary of the 2-D variant in one pass (round 3; bit-identical to the three / two passes they replace):
+ * vm_bn_pool2d_stack_fwd = vm_bn_drop_pool_fwd(pool 2) -> vm_pool_windows_fwd -> vm_stack_windows.  z (n_clips * M, L, C), scale / shift
+ * (towers, C) with `clips_per_tower` clips a tower, drop (n_clips * M, C) or NULL; writes q (n_clips * M, L / 2 + 2, C) rows 1 .. L / 2
+ * (kept for the backward) and the stacked block input xs (n_clips * (M / 2), L / 2 + 2, Cs).  NEITHER tensor's halo rows, out-of-clip band
+ * slots or channels [3 C, Cs) are written: zero both once after allocation.  C, Cs multiples of the 16-byte vector.
+ * vm_fold_pool_windows_bwd = vm_fold_windows -> vm_pool_windows_bwd: dxs (n_clips * (M / 2), L (+ 2 if src_padded), Cs) and q as above
+ * (L = its un-padded rows) -> dq (n_clips * M, L, C). */
+int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
+                           int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);
+int vm_fold_pool_windows_bwd(const void* dxs, const void* q, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded, int dtype,
+                             void* dq, void* stream);
 /* mel half of GlobalMaxPool2D: out[b][c] = max over m < M_valid of gmax[(b, m)][c] (fp32; first maximum -> widx[b][c]);
  * backward: dg[(b, m)][c] = dout[b][c] if m == widx[b][c] else 0. */
 int vm_clip_max_fwd(const float* gmax, int64_t n_clips, int M, int M_valid, int C, float* out, int32_t* widx, void* stream);

@@ -175,6 +175,43 @@ def test_pool_windows(dt, n, M, Lq, C):
     assert np.array_equal(dq.float().cpu().numpy().reshape(n, M, Lq, C), dref)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,cpt,M,Lz,C,Cs,drop", [(4, 2, 4, 10, 32, 96, True), (2, 2, 5, 7, 8, 24, False), (2, 1, 2, 298, 64, 192, True),
+                                                  (3, 3, 8, 37, 96, 288, False), (2, 1, 3, 5, 16, 56, True)])
+def test_fused_block_boundary_equals_the_separate_passes(dt, n, cpt, M, Lz, C, Cs, drop):
+    """vm_bn_pool2d_stack_fwd == vm_bn_drop_pool_fwd -> vm_pool_windows_fwd -> vm_stack_windows and vm_fold_pool_windows_bwd ==
+    vm_fold_windows -> vm_pool_windows_bwd, bit for bit (q, the stacked block input, the gradient of q): odd band counts (the last band
+    is dropped), odd lengths, two towers with their own affine, dropout masks, padded stacked widths, both source layouts of the fold."""
+    vm, tdt = DTYPES[dt]
+    r = np.random.default_rng(n * 1000 + M * 100 + Lz + C)
+    nw, Lq, Mo = n * M, Lz // 2, M // 2
+    z = dev(quant(np.round(r.normal(0, 1, (nw, Lz, C)) * 8) / 8, dt).numpy(), tdt)     # coarse values: ties between the bands occur
+    towers = n // cpt
+    scale = dev(r.normal(0, 1, (towers, C)).astype(np.float32))
+    shift = dev(r.normal(0, 0.5, (towers, C)).astype(np.float32))
+    dm = dev(((r.random((nw, C)) > 0.3) / 0.7).astype(np.float32)) if drop else None
+    q_ref = torch.zeros(nw, Lq + 2, C, dtype=tdt, device="cuda")
+    L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), p(dm) if drop else None, nw, cpt * M, Lz, C, 2, vm, p(q_ref), stream())
+    pooled = torch.zeros(n * Mo, Lq + 2, C, dtype=tdt, device="cuda")
+    L().call("vm_pool_windows_fwd", p(q_ref), n, M, Lq + 2, C, vm, p(pooled), stream())
+    xs_ref = torch.full((n * Mo, Lq + 2, Cs), 3.0, dtype=tdt, device="cuda")
+    L().call("vm_stack_windows", p(pooled), n, Mo, Lq + 2, C, Cs, vm, p(xs_ref), stream())
+    q = torch.zeros_like(q_ref)
+    xs = torch.zeros_like(xs_ref)
+    L().call("vm_bn_pool2d_stack_fwd", p(z), p(scale), p(shift), p(dm) if drop else None, n, M, cpt, Lz, C, Cs, vm, p(q), p(xs), stream())
+    assert torch.equal(q, q_ref)
+    assert torch.equal(xs, xs_ref)
+    for padded_src in (0, 1):
+        g = dev(quant(r.normal(0, 1, (n * Mo, Lq + 2 * padded_src, Cs)), dt).numpy(), tdt)
+        din = torch.empty(n * Mo, Lq, C, dtype=tdt, device="cuda")
+        L().call("vm_fold_windows", p(g), n, Mo, Lq, C, Cs, padded_src, vm, p(din), stream())
+        dq_ref = torch.full((nw, Lq, C), 9.0, dtype=tdt, device="cuda")
+        L().call("vm_pool_windows_bwd", p(q_ref), p(din), n, M, Lq, C, vm, p(dq_ref), stream())
+        dq = torch.full((nw, Lq, C), 5.0, dtype=tdt, device="cuda")
+        L().call("vm_fold_pool_windows_bwd", p(g), p(q_ref), n, M, Lq, C, Cs, padded_src, vm, p(dq), stream())
+        assert torch.equal(dq, dq_ref)
+
+
 def test_clip_max():
     r = rng(4)
     n, M, Mv, C = 3, 5, 4, 24

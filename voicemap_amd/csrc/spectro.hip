@@ -341,6 +341,123 @@ __global__ __launch_bounds__(256) void pool_windows_fwd_kernel(const T* __restri
     ew_store<T, V>(out + wo * (int64_t)rows * C + e0, o);
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm affine + dropout + MaxPool2D(2, 2) + band stacking of one block boundary in ONE pass over z: what vm_bn_drop_pool_fwd ->
+// vm_pool_windows_fwd -> vm_stack_windows do in three (z read once instead of z, q, the pooled tensor three times; the pooled tensor
+// itself is never written).  Same arithmetic and rounding points, bit-identical outputs:
+//   q[(b, m)][1 + t'][c]  = max_j drop * (scale * z[(b, m)][2 t' + j][c] + shift)            (kept: the backward routes through it)
+//   p                     = q[(b, 2 mo)] >= q[(b, 2 mo + 1)] ? the first : the second          (of the stored values)
+//   xs[(b, mo + 1 - dm)][1 + t'][dm * C + c] = p  for dm = 0, 1, 2 inside the clip
+// The halo rows of q and xs, the out-of-clip band slots and the channels [3 C, Cs) of xs are never written: the caller zeroes both
+// tensors once.  A workgroup owns one band pair of one clip: threads = (channel vector, row lane), rows walked with stride 256 / CV.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool2d_stack_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ drop,
+                                                                  int64_t wpt, int M, int L, int C, int Cs, T* __restrict__ q,
+                                                                  T* __restrict__ xs) {
+    constexpr int V = Elem<T>::kVec;
+    const int CV = C / V, RP = 256 / CV;
+    const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+    if (rl >= RP) return;
+    const int Mo = M / 2, Mh = (M + 1) / 2;
+    const int64_t b = blockIdx.x / Mh;
+    const int mo = (int)(blockIdx.x - b * Mh);
+    const int64_t n0 = b * M + 2 * mo;
+    const bool pair = 2 * mo + 1 < M;   // (odd band count: the last band has no partner and is dropped by the floor pooling)
+    const int64_t tw = n0 / wpt;
+    const int c0 = cv * V, Lq = L / 2;
+    float sc[V], sh[V], d0[V], d1[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        sc[i] = scale[tw * C + c0 + i];
+        sh[i] = shift[tw * C + c0 + i];
+        d0[i] = drop ? drop[n0 * C + c0 + i] : 1.f;
+        d1[i] = (drop && pair) ? drop[(n0 + 1) * C + c0 + i] : 1.f;
+    }
+    const T* z0 = z + n0 * (int64_t)L * C + c0;
+    const T* z1 = z0 + (int64_t)L * C;
+    T* q0 = q + (n0 * (Lq + 2) + 1) * (int64_t)C + c0;
+    T* q1 = q0 + (int64_t)(Lq + 2) * C;
+    const int64_t xrow = (int64_t)(Lq + 2) * Cs;
+    T* x1 = xs + ((b * Mo + mo) * (int64_t)(Lq + 2) + 1) * Cs + c0;
+    for (int t = rl; t < Lq; t += RP) {
+        const Vec16<T> a0 = load16<T>(z0 + (int64_t)(2 * t) * C), a1 = load16<T>(z0 + (int64_t)(2 * t + 1) * C);
+        Vec16<T> o0, o1;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float y0 = fmaf(a0.get(i), sc[i], sh[i]) * d0[i], y1 = fmaf(a1.get(i), sc[i], sh[i]) * d0[i];
+            o0.set(i, y1 > y0 ? y1 : y0);
+        }
+        store16<T>(q0 + (int64_t)t * C, o0);
+        if (!pair) continue;
+        const Vec16<T> b0 = load16<T>(z1 + (int64_t)(2 * t) * C), b1 = load16<T>(z1 + (int64_t)(2 * t + 1) * C);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float y0 = fmaf(b0.get(i), sc[i], sh[i]) * d1[i], y1 = fmaf(b1.get(i), sc[i], sh[i]) * d1[i];
+            o1.set(i, y1 > y0 ? y1 : y0);
+        }
+        store16<T>(q1 + (int64_t)t * C, o1);
+        Vec16<T> pm;
+#pragma unroll
+        for (int i = 0; i < V; ++i) pm.set(i, o0.get(i) >= o1.get(i) ? o0.get(i) : o1.get(i));
+        T* xr = x1 + (int64_t)t * Cs;
+        store16<T>(xr + C, pm);                                   // this band: the middle slot of its own window
+        if (mo + 1 < Mo) store16<T>(xr + xrow, pm);               // band mo + 1 sees it as its lower neighbour (dm = 0)
+        if (mo >= 1) store16<T>(xr - xrow + 2 * C, pm);           // band mo - 1 as its upper neighbour (dm = 2)
+    }
+}
+
+// vm_fold_windows + vm_pool_windows_bwd in one pass: the gradient of the pooled block input, summed over the three stacked slots it was
+// copied to, goes to the band of the pair that held the maximum (first maximum wins), zero to the other.  dxs: the dgrad output
+// (n_clips * Mo, L (+ 2), Cs); q: (n_clips * M, L + 2, C) as in the forward; dq: (n_clips * M, L, C).  Same rounding as the two passes.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void fold_pool_windows_bwd_kernel(const T* __restrict__ dxs, const T* __restrict__ q, int64_t n_clips, int M,
+                                                                    int L, int C, int Cs, int src_pad, T* __restrict__ dq) {
+    const int Mo = M / 2, Mh = (M + 1) / 2;
+    const int per_row = C / V;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= L * per_row) return;
+    const int t = j / per_row, c = (j - t * per_row) * V;
+    const int64_t b = blockIdx.x / Mh;
+    const int mo = (int)(blockIdx.x - b * Mh);
+    const int64_t n0 = b * M + 2 * mo;
+    EwVec<T, V> zero;
+#pragma unroll
+    for (int e = 0; e < V; ++e) zero.v[e] = Elem<T>::from_f(0.f);
+    T* d0 = dq + (n0 * L + t) * (int64_t)C + c;
+    if (2 * mo + 1 >= M) {   // the dropped last band of an odd count
+        ew_store<T, V>(d0, zero);
+        return;
+    }
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dm = 0; dm < 3; ++dm) {
+        const int md = mo - dm + 1;  // the window whose stacked band dm is this pooled band
+        if (md >= 0 && md < Mo) {
+            const EwVec<T, V> sv = ew_load<T, V>(dxs + ((b * Mo + md) * (int64_t)(L + 2 * src_pad) + src_pad + t) * Cs + dm * C + c);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(sv.v[e]);
+        }
+    }
+    const T* qa = q + (n0 * (L + 2) + 1 + t) * (int64_t)C + c;
+    const EwVec<T, V> a0 = ew_load<T, V>(qa), a1 = ew_load<T, V>(qa + (int64_t)(L + 2) * C);
+    EwVec<T, V> o0 = zero, o1 = zero;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const T g = Elem<T>::from_f(acc[e]);
+        if (Elem<T>::to_f(a0.v[e]) >= Elem<T>::to_f(a1.v[e])) {
+            o0.v[e] = g;
+        } else {
+            o1.v[e] = g;
+        }
+    }
+    ew_store<T, V>(d0, o0);
+    ew_store<T, V>(d0 + (int64_t)L * C, o1);
+}
+
 // q: the forward input (n_clips * M windows, L + 2 rows with halo); dout: (n_clips * (M/2), L, C); dq: (n_clips * M, L, C)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool_windows_bwd_kernel(const T* __restrict__ q, const T* __restrict__ dout, int64_t n_clips, int M,
@@ -928,6 +1045,31 @@ extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t 
                            (int)L, C, Cs, src_padded ? 1 : 0, (T*)dx);
     }));
     return check_launch("vm_fold_windows");
+}
+
+extern "C" int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
+                                      int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream) {
+    VM_REQUIRE(z && scale && shift && q && xs, "vm_bn_pool2d_stack_fwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M >= 2 && clips_per_tower > 0 && L >= 2 && C > 0 && Cs >= 3 * C, "vm_bn_pool2d_stack_fwd: bad sizes (Cs >= 3 C)");
+    VM_REQUIRE(n_clips * ((M + 1) / 2) < (1LL << 31), "vm_bn_pool2d_stack_fwd: too many windows");
+    VM_DISPATCH_DTYPE(dtype, {
+        VM_REQUIRE(C % Elem<T>::kVec == 0 && Cs % Elem<T>::kVec == 0 && C / Elem<T>::kVec <= 256,
+                   "vm_bn_pool2d_stack_fwd: C and Cs must be multiples of the 16-byte vector, C / vector <= 256");
+        hipLaunchKernelGGL((bn_pool2d_stack_fwd_kernel<T>), dim3((unsigned)(n_clips * ((M + 1) / 2))), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)z, scale, shift, drop, clips_per_tower * M, M, (int)L, C, Cs, (T*)q, (T*)xs);
+    });
+    return check_launch("vm_bn_pool2d_stack_fwd");
+}
+
+extern "C" int vm_fold_pool_windows_bwd(const void* dxs, const void* q, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded,
+                                        int dtype, void* dq, void* stream) {
+    VM_REQUIRE(dxs && q && dq, "vm_fold_pool_windows_bwd: null pointer");
+    VM_REQUIRE(n_clips > 0 && M >= 2 && L > 0 && C > 0 && Cs >= 3 * C, "vm_fold_pool_windows_bwd: bad sizes (Cs >= 3 C)");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
+        hipLaunchKernelGGL((fold_pool_windows_bwd_kernel<T, V>), ew_grid(n_clips * ((M + 1) / 2), L * (C / V)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dxs, (const T*)q, n_clips, M, (int)L, C, Cs, src_padded ? 1 : 0, (T*)dq);
+    }));
+    return check_launch("vm_fold_pool_windows_bwd");
 }
 
 extern "C" int vm_pool_windows_fwd(const void* q, int64_t n_clips, int M, int64_t rows, int C, int dtype, void* out, void* stream) {

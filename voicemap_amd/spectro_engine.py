@@ -100,6 +100,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.first_layer_direct = bool(self.lib.query("vm_conv2d_first_supported", self.chan[0], self.dtype))
         self.flat_dgrad = True   # dgrad over the concatenated windows (see backward)
         self.flat_fwd = True     # ... and the forward of the GEMM-shaped layers (vm_conv_fwd_flat)
+        self.fuse_boundary = True   # BatchNorm + 2 x 2 pooling + band stacking as one pass per block boundary, and its adjoint
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None
         self.grad_prescale = 1.0
@@ -185,6 +186,13 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         for i in range(4):
             self._call("vm_prep_conv_weights", _p(self.view(f"conv{i+1}.kernel")), self.cs[i], self.chan[i], self.dtype, _p(self.wf[i]),
                        _p(self.wd[i]), self.stream())
+
+    def _fused_boundary(self, i: int) -> bool:
+        """Is the boundary between blocks i and i + 1 one pass each way (vm_bn_pool2d_stack_fwd / vm_fold_pool_windows_bwd)?"""
+        if not self.fuse_boundary or i < 0 or i >= 3:
+            return False
+        vec = 4 if self.dtype in (_lib.VM_F32, _lib.VM_F32S) else 8
+        return self.chan[i] % vec == 0 and self.cs[i + 1] % vec == 0
 
     # ---- geometry --------------------------------------------------------------------------------------------------------------
     def geometry(self, raw_len: int):
@@ -303,7 +311,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 self._call("vm_conv2d_first_fwd", _p(b["in"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n, Mi, L,
                            self.cs[0], c, dt, _p(b["z"]), ssum, ssq, st)
             else:
-                self._call("vm_stack_windows", _p(b["in"]), n, Mi, L + 2, self.cin[i], self.cs[i], dt, _p(b["xs"]), st)
+                if not self._fused_boundary(i - 1):   # (else the previous block's pooling pass wrote xs itself)
+                    self._call("vm_stack_windows", _p(b["in"]), n, Mi, L + 2, self.cin[i], self.cs[i], dt, _p(b["xs"]), st)
                 flat = self.flat_fwd and wpt * (L + 2) * max(c, self.cs[i]) < 2 ** 31
                 if flat:
                     # a tower's windows -- each with its own zero halo rows in xs -- as ONE sequence on full 128-row tiles; the epilogue
@@ -341,6 +350,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 self._call("vm_bn_drop_pool_gmax_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), nw, wpt, L, c, 2, dt,
                            _p(pl["gmax_w"]), _p(pl["gidx"]), _p(pl["gmax_ws"]), st)
                 self._call("vm_clip_max_fwd", _p(pl["gmax_w"]), n, Mi, 2 * (Mi // 2), c, _p(pl["gmax"]), _p(pl["widx"]), st)
+            elif self._fused_boundary(i):
+                # BatchNorm affine + dropout + MaxPool2D(2, 2) + the next block's band stacking in one pass over z
+                self._call("vm_bn_pool2d_stack_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, Mi, cpt, L, c, self.cs[i + 1], dt,
+                           _p(b["q"]), _p(pl[i + 1]["xs"]), st)
             else:
                 self._call("vm_bn_drop_pool_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), nw, wpt, L, c, 2, dt, _p(b["q"]), st)
                 self._call("vm_pool_windows_fwd", _p(b["q"]), n, Mi, pl["T"][i + 1] + 2, c, dt, _p(pl[i + 1]["in"]), st)
@@ -406,10 +419,15 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                                b["dxs"].data_ptr() + self.cs[i] * b["dxs"].element_size(), st)
                 else:   # per window, un-padded rows (the buffer is large enough either way)
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), nw, L, self.cs[i], c, dt, _p(b["dxs"]), st)
-                self._call("vm_fold_windows", _p(b["dxs"]), n, Mi, L, self.cin[i], self.cs[i], int(flat), dt, _p(b["din"]), st)
-                # gradient of the previous block's pooled output -> gradient of its time-pooled tensor q
-                self._call("vm_pool_windows_bwd", _p(pl[i - 1]["q"]), _p(b["din"]), n, pl["M"][i - 1], L, self.cin[i], dt,
-                           _p(pl[i - 1]["dp"]), st)
+                if self._fused_boundary(i - 1):
+                    # adjoint of the stacking + the mel half of the pooling backward in one pass: dxs -> gradient of the previous block's q
+                    self._call("vm_fold_pool_windows_bwd", _p(b["dxs"]), _p(pl[i - 1]["q"]), n, pl["M"][i - 1], L, self.cin[i], self.cs[i],
+                               int(flat), dt, _p(pl[i - 1]["dp"]), st)
+                else:
+                    self._call("vm_fold_windows", _p(b["dxs"]), n, Mi, L, self.cin[i], self.cs[i], int(flat), dt, _p(b["din"]), st)
+                    # gradient of the previous block's pooled output -> gradient of its time-pooled tensor q
+                    self._call("vm_pool_windows_bwd", _p(pl[i - 1]["q"]), _p(b["din"]), n, pl["M"][i - 1], L, self.cin[i], dt,
+                               _p(pl[i - 1]["dp"]), st)
         if self.overlap_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
 
