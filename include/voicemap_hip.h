@@ -466,11 +466,14 @@ int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M,
  * (kept for the backward) and the stacked block input xs (n_clips * (M / 2), L / 2 + 2, Cs).  NEITHER tensor's halo rows, out-of-clip band
  * slots or channels [3 C, Cs) are written: zero both once after allocation.  C, Cs multiples of the 16-byte vector.
  * vm_fold_pool_windows_bwd = vm_fold_windows -> vm_pool_windows_bwd: dxs (n_clips * (M / 2), L (+ 2 if src_padded), Cs) and q as above
- * (L = its un-padded rows) -> dq (n_clips * M, L, C). */
+ * (L = its un-padded rows) -> dq (n_clips * M, L, C).  s0 / sa (optional, both or neither; (n_clips * M * vm_fold_pool_windows_rows(...), C)
+ * fp32): the sums of dq and of dq * q per window and workgroup row -- what vm_bn_bwd_from_sums_finalize(..., rows_per_window =
+ * vm_fold_pool_windows_rows, a_is_act = 1) turns into the BatchNorm-backward constants of the block below without a pass over (z, dq). */
 int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
                            int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);
+int64_t vm_fold_pool_windows_rows(int64_t L, int C, int Cs, int dtype);
 int vm_fold_pool_windows_bwd(const void* dxs, const void* q, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded, int dtype,
-                             void* dq, void* stream);
+                             void* dq, float* s0, float* sa, void* stream);
 /* mel half of GlobalMaxPool2D: out[b][c] = max over m < M_valid of gmax[(b, m)][c] (fp32; first maximum -> widx[b][c]);
  * backward: dg[(b, m)][c] = dout[b][c] if m == widx[b][c] else 0. */
 int vm_clip_max_fwd(const float* gmax, int64_t n_clips, int M, int M_valid, int C, float* out, int32_t* widx, void* stream);

@@ -208,8 +208,19 @@ def test_fused_block_boundary_equals_the_separate_passes(dt, n, cpt, M, Lz, C, C
         dq_ref = torch.full((nw, Lq, C), 9.0, dtype=tdt, device="cuda")
         L().call("vm_pool_windows_bwd", p(q_ref), p(din), n, M, Lq, C, vm, p(dq_ref), stream())
         dq = torch.full((nw, Lq, C), 5.0, dtype=tdt, device="cuda")
-        L().call("vm_fold_pool_windows_bwd", p(g), p(q_ref), n, M, Lq, C, Cs, padded_src, vm, p(dq), stream())
+        rows = L().query("vm_fold_pool_windows_rows", Lq, C, Cs, vm)
+        s0 = torch.full((nw * rows, C), 7.0, device="cuda")
+        sa = torch.full((nw * rows, C), 7.0, device="cuda")
+        L().call("vm_fold_pool_windows_bwd", p(g), p(q_ref), n, M, Lq, C, Cs, padded_src, vm, p(dq), p(s0), p(sa), stream())
         assert torch.equal(dq, dq_ref)
+        # the sums of dq and dq * q per window (over its workgroup rows) against float64
+        d64, q64 = dq_ref.double(), q_ref[:, 1:-1].double()
+        tol = 1e-5
+        assert rel_err(s0.view(nw, rows, C).sum(1).cpu().numpy(), d64.sum(1).cpu().numpy()) < tol
+        assert rel_err(sa.view(nw, rows, C).sum(1).cpu().numpy(), (d64 * q64).sum(1).cpu().numpy()) < tol
+        dq2 = torch.full((nw, Lq, C), 5.0, dtype=tdt, device="cuda")
+        L().call("vm_fold_pool_windows_bwd", p(g), p(q_ref), n, M, Lq, C, Cs, padded_src, vm, p(dq2), None, None, stream())
+        assert torch.equal(dq2, dq_ref)
 
 
 def test_clip_max():

@@ -110,7 +110,8 @@ SIGNATURES = {
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),
     "vm_fold_windows": (I, [P, L, I, L, I, I, I, I, P, P]),
     "vm_bn_pool2d_stack_fwd": (I, [P, P, P, P, L, I, L, L, I, I, I, P, P, P]),
-    "vm_fold_pool_windows_bwd": (I, [P, P, L, I, L, I, I, I, I, P, P]),
+    "vm_fold_pool_windows_rows": (L, [L, I, I, I]),
+    "vm_fold_pool_windows_bwd": (I, [P, P, L, I, L, I, I, I, I, P, P, P, P]),
     "vm_pool_windows_fwd": (I, [P, L, I, L, I, I, P, P]),
     "vm_pool_windows_bwd": (I, [P, P, L, I, L, I, I, P, P]),
     "vm_clip_max_fwd": (I, [P, L, I, I, I, P, P, P]),

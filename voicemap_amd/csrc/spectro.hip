@@ -413,49 +413,77 @@ __global__ __launch_bounds__(256) void bn_pool2d_stack_fwd_kernel(const T* __res
 // (n_clips * Mo, L (+ 2), Cs); q: (n_clips * M, L + 2, C) as in the forward; dq: (n_clips * M, L, C).  Same rounding as the two passes.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void fold_pool_windows_bwd_kernel(const T* __restrict__ dxs, const T* __restrict__ q, int64_t n_clips, int M,
-                                                                    int L, int C, int Cs, int src_pad, T* __restrict__ dq) {
+                                                                    int L, int C, int Cs, int src_pad, T* __restrict__ dq,
+                                                                    float* __restrict__ s0, float* __restrict__ sa) {
+    // A workgroup owns one band pair of one clip; threads = (channel vector, row lane), rows walked with stride 256 / per_row.
+    // s0 / sa (optional): per window the sums of dq and dq * q -- the two sums the BatchNorm backward of the block below needs
+    // (vm_bn_bwd_from_sums_finalize, one row per window, a_is_act = 1), taken here from registers instead of by a pass over (z, dq)
+    __shared__ float red[4][256][V];
     const int Mo = M / 2, Mh = (M + 1) / 2;
-    const int per_row = C / V;
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    if (j >= L * per_row) return;
-    const int t = j / per_row, c = (j - t * per_row) * V;
+    const int per_row = C / V, RP = 256 / per_row;
+    const int tid = threadIdx.x;
+    const int cvi = tid % per_row, rl = tid / per_row, c = cvi * V;
     const int64_t b = blockIdx.x / Mh;
     const int mo = (int)(blockIdx.x - b * Mh);
     const int64_t n0 = b * M + 2 * mo;
-    EwVec<T, V> zero;
+    const bool pair = 2 * mo + 1 < M;   // else: the dropped last band of an odd count
+    float sum[4][V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) zero.v[e] = Elem<T>::from_f(0.f);
-    T* d0 = dq + (n0 * L + t) * (int64_t)C + c;
-    if (2 * mo + 1 >= M) {   // the dropped last band of an odd count
-        ew_store<T, V>(d0, zero);
-        return;
-    }
-    float acc[V];
+    for (int w = 0; w < 4; ++w)
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int e = 0; e < V; ++e) sum[w][e] = 0.f;
+    const int64_t srow = (int64_t)(L + 2 * src_pad) * Cs;
+    const T* src = dxs + ((b * Mo + mo) * (int64_t)(L + 2 * src_pad) + src_pad) * Cs + c;   // this band's own window, slot dm = 1 at + C
+    const T* qa = q + (n0 * (L + 2) + 1) * (int64_t)C + c;
+    T* d0 = dq + n0 * (int64_t)L * C + c;
+    for (int t = rl < RP ? rl : L; t < L; t += RP) {
+        EwVec<T, V> o0, o1;
 #pragma unroll
-    for (int dm = 0; dm < 3; ++dm) {
-        const int md = mo - dm + 1;  // the window whose stacked band dm is this pooled band
-        if (md >= 0 && md < Mo) {
-            const EwVec<T, V> sv = ew_load<T, V>(dxs + ((b * Mo + md) * (int64_t)(L + 2 * src_pad) + src_pad + t) * Cs + dm * C + c);
+        for (int e = 0; e < V; ++e) o0.v[e] = o1.v[e] = Elem<T>::from_f(0.f);
+        if (pair) {
+            float acc[V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(sv.v[e]);
+            for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int dm = 0; dm < 3; ++dm) {
+                const int md = mo - dm + 1;  // the window whose stacked band dm is this pooled band
+                if (md >= 0 && md < Mo) {
+                    const EwVec<T, V> sv = ew_load<T, V>(src + (1 - dm) * srow + (int64_t)t * Cs + dm * C);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(sv.v[e]);
+                }
+            }
+            const EwVec<T, V> a0 = ew_load<T, V>(qa + (int64_t)t * C), a1 = ew_load<T, V>(qa + (int64_t)(L + 2 + t) * C);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T g = Elem<T>::from_f(acc[e]);
+                const float gf = Elem<T>::to_f(g), q0 = Elem<T>::to_f(a0.v[e]), q1 = Elem<T>::to_f(a1.v[e]);
+                if (q0 >= q1) {
+                    o0.v[e] = g;
+                    sum[0][e] += gf;
+                    sum[1][e] = fmaf(gf, q0, sum[1][e]);
+                } else {
+                    o1.v[e] = g;
+                    sum[2][e] += gf;
+                    sum[3][e] = fmaf(gf, q1, sum[3][e]);
+                }
+            }
+            ew_store<T, V>(d0 + (int64_t)(L + t) * C, o1);
         }
+        ew_store<T, V>(d0 + (int64_t)t * C, o0);
     }
-    const T* qa = q + (n0 * (L + 2) + 1 + t) * (int64_t)C + c;
-    const EwVec<T, V> a0 = ew_load<T, V>(qa), a1 = ew_load<T, V>(qa + (int64_t)(L + 2) * C);
-    EwVec<T, V> o0 = zero, o1 = zero;
+    if (s0 == nullptr) return;
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        const T g = Elem<T>::from_f(acc[e]);
-        if (Elem<T>::to_f(a0.v[e]) >= Elem<T>::to_f(a1.v[e])) {
-            o0.v[e] = g;
-        } else {
-            o1.v[e] = g;
-        }
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[w][tid][e] = sum[w][e];
+    __syncthreads();
+    for (int k = tid; k < (pair ? 4 : 2) * C; k += 256) {   // the row lanes of a channel vector, in lane order
+        const int which = k / C, cc = k - which * C, cv = cc / V, e = cc - cv * V;
+        float tot = 0.f;
+        for (int r = 0; r < RP; ++r) tot += red[which][r * per_row + cv][e];
+        ((which & 1) ? sa : s0)[(n0 + (which >> 1)) * C + cc] = tot;
     }
-    ew_store<T, V>(d0, o0);
-    ew_store<T, V>(d0 + (int64_t)L * C, o1);
 }
 
 // q: the forward input (n_clips * M windows, L + 2 rows with halo); dout: (n_clips * (M/2), L, C); dq: (n_clips * M, L, C)
@@ -1061,13 +1089,18 @@ extern "C" int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const f
     return check_launch("vm_bn_pool2d_stack_fwd");
 }
 
+extern "C" int64_t vm_fold_pool_windows_rows(int64_t L, int C, int Cs, int dtype) { return 1; }   // one row of sums per window
+
 extern "C" int vm_fold_pool_windows_bwd(const void* dxs, const void* q, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded,
-                                        int dtype, void* dq, void* stream) {
+                                        int dtype, void* dq, float* s0, float* sa, void* stream) {
     VM_REQUIRE(dxs && q && dq, "vm_fold_pool_windows_bwd: null pointer");
+    VM_REQUIRE((s0 == nullptr) == (sa == nullptr), "vm_fold_pool_windows_bwd: s0 / sa must both be set or NULL");
     VM_REQUIRE(n_clips > 0 && M >= 2 && L > 0 && C > 0 && Cs >= 3 * C, "vm_fold_pool_windows_bwd: bad sizes (Cs >= 3 C)");
+    VM_REQUIRE(s0 == nullptr || C <= 256, "vm_fold_pool_windows_bwd: the sums need C <= 256");
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_VEC(T, ((C % Elem<T>::kVec) || (Cs % Elem<T>::kVec)) ? 1 : C, {
-        hipLaunchKernelGGL((fold_pool_windows_bwd_kernel<T, V>), ew_grid(n_clips * ((M + 1) / 2), L * (C / V)), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)dxs, (const T*)q, n_clips, M, (int)L, C, Cs, src_padded ? 1 : 0, (T*)dq);
+        VM_REQUIRE(C / V <= 256, "vm_fold_pool_windows_bwd: too many channels");
+        hipLaunchKernelGGL((fold_pool_windows_bwd_kernel<T, V>), dim3((unsigned)(n_clips * ((M + 1) / 2))), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dxs, (const T*)q, n_clips, M, (int)L, C, Cs, src_padded ? 1 : 0, (T*)dq, s0, sa);
     }));
     return check_launch("vm_fold_pool_windows_bwd");
 }

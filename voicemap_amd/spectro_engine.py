@@ -101,6 +101,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.flat_dgrad = True   # dgrad over the concatenated windows (see backward)
         self.flat_fwd = True     # ... and the forward of the GEMM-shaped layers (vm_conv_fwd_flat)
         self.fuse_boundary = True   # BatchNorm + 2 x 2 pooling + band stacking as one pass per block boundary, and its adjoint
+        self.fused_bn_sums = True   # ... which also leaves the two BatchNorm-backward sums of the block below (no reduce pass)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.grad_sync = None
         self.grad_prescale = 1.0
@@ -230,6 +231,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 b["du"] = torch.zeros(nw, L + 2, c, dtype=tdt, device=dev)
                 if i < 3:
                     b["dp"] = torch.empty(nw, Ts[i + 1], c, dtype=tdt, device=dev)    # gradient of q (un-padded)
+                    if self._fused_boundary(i):   # the BatchNorm-backward sums vm_fold_pool_windows_bwd leaves per (window, workgroup row)
+                        b["fs_rows"] = self.lib.query("vm_fold_pool_windows_rows", Ts[i + 1], c, self.cs[i + 1], self.dtype)
+                        b["fs0"] = torch.empty(nw * b["fs_rows"], c, dtype=f32, device=dev)
+                        b["fsa"] = torch.empty_like(b["fs0"])
                 for nm in ("pa", "pb", "pdu"):
                     b[nm] = torch.empty(nw * prow, c, dtype=f32, device=dev)
                 # the weight gradient is a sum over positions, and consecutive windows -- each with its own zero halo rows in xs and
@@ -373,16 +378,24 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             c, b, L, Mi = self.chan[i], pl[i], pl["T"][i], pl["M"][i]
             nw, wpt = b["nw"], cpt * Mi
             dm = _p(pl["drop_w"][i])
+            bn_grads = (_p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)))
             if i == 3:
                 head = (_p(b["z"]), _p(pl["dgmax_w"]), _p(pl["gidx"]))
                 self._call("vm_bn_pool_bwd_reduce_gmax", *head, _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, nw, wpt,
                            L, c, 2, dt, _p(b["pa"]), _p(b["pb"]), st)
             else:
                 head = (_p(b["z"]), _p(b["dp"]))
-                self._call("vm_bn_pool_bwd_reduce", *head, _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, nw, wpt, L, c,
-                           2, dt, _p(b["pa"]), _p(b["pb"]), st)
-            self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), nw, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                       _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
+                if not (self.fused_bn_sums and "fs0" in b):
+                    self._call("vm_bn_pool_bwd_reduce", *head, _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, nw, wpt, L,
+                               c, 2, dt, _p(b["pa"]), _p(b["pb"]), st)
+            if i < 3 and self.fused_bn_sums and "fs0" in b:
+                # sum dp and sum dp * q came out of vm_fold_pool_windows_bwd (q = this block's pooled BatchNorm output): no pass over (z, dp)
+                self._call("vm_bn_bwd_from_sums_finalize", _p(b["fs0"]), _p(b["fsa"]), b["fs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
+                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, nw, wpt, L, c, 2, dt, 1, float(wpt * L), _p(b["c1"]),
+                           _p(b["c2"]), *bn_grads, _p(pl["cr_ws"]), st)
+            else:
+                self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), nw, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]), *bn_grads,
+                           _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply_gmax" if i == 3 else "vm_bn_pool_bwd_apply", *head, _p(b["scale"]), _p(b["shift"]),
                        _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), nw, wpt, L, c, 2, dt, _p(b["du"]), _p(b["pdu"]), st)
             self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]), st)
@@ -421,8 +434,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), nw, L, self.cs[i], c, dt, _p(b["dxs"]), st)
                 if self._fused_boundary(i - 1):
                     # adjoint of the stacking + the mel half of the pooling backward in one pass: dxs -> gradient of the previous block's q
+                    sums = self.fused_bn_sums and "fs0" in pl[i - 1]
                     self._call("vm_fold_pool_windows_bwd", _p(b["dxs"]), _p(pl[i - 1]["q"]), n, pl["M"][i - 1], L, self.cin[i], self.cs[i],
-                               int(flat), dt, _p(pl[i - 1]["dp"]), st)
+                               int(flat), dt, _p(pl[i - 1]["dp"]), _p(pl[i - 1]["fs0"]) if sums else None,
+                               _p(pl[i - 1]["fsa"]) if sums else None, st)
                 else:
                     self._call("vm_fold_windows", _p(b["dxs"]), n, Mi, L, self.cin[i], self.cs[i], int(flat), dt, _p(b["din"]), st)
                     # gradient of the previous block's pooled output -> gradient of its time-pooled tensor q
