@@ -51,7 +51,7 @@ const char* vm_last_error(void);
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
  * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce; vm_conv_fwd_flat, vm_conv2d_first_*,
- * `src_padded` in vm_fold_windows) (round 3); 5 = vm_bn_pool2d_stack_fwd, vm_fold_pool_windows_bwd, the operand-order basis of
+ * `src_padded` in vm_fold_windows) (round 3); 5 = vm_bn_pool2d_stack_fwd, vm_fold_pool_windows_bwd, vm_colsum_strided, the operand-order basis of
  * vm_stft_split_basis (round 3). */
 int vm_abi_version(void);
 /* device smoke: hipGetDeviceProperties gcnArchName must start with "gfx950". */
@@ -310,6 +310,11 @@ int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const void* dp, con
                                int64_t windows_per_tower, int64_t L, int C, int dtype, void* du, float* part_du, void* stream);
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
+/* The part_* tensors have vm_bn_part_rows() rows per window; a pass over short windows (the 2-D variant) fills only the first
+ * vm_bn_part_rows_used(L, C, pool, dtype) of them and zeroes the rest.  vm_colsum_strided sums rows 0, row_step, 2 row_step, ...
+ * (`rows` of them) -- with row_step = vm_bn_part_rows() the one live row per window instead of eight. */
+int vm_bn_part_rows_used(int64_t L, int C, int pool, int dtype);
+int vm_colsum_strided(const float* part, int64_t rows, int row_step, int C, float* out, void* ws, void* stream);
 /* vm_colsum of the apply pass's part_du (n_windows * vm_bn_part_rows(), C) per tower, plus what vm_conv_wgrad_fold needs:
  * dsum[t][k][c] = sum over the windows of tower t and the positions whose tap k lies inside the window of du[n][pos][c] (k = 1: all
  * positions; k = 0: all but position 0; k = 2: all but position L - 1; du: padded (n_windows, L + 2, C) `dtype`).  grad_b (optional,

@@ -223,6 +223,26 @@ def test_fused_block_boundary_equals_the_separate_passes(dt, n, cpt, M, Lz, C, C
         assert torch.equal(dq2, dq_ref)
 
 
+def test_colsum_strided_reads_the_live_partial_rows():
+    """vm_colsum_strided over the one live row per window == vm_colsum over all vm_bn_part_rows() rows (the rest are zeros), and
+    vm_bn_part_rows_used says when a pass leaves only that row: short windows (the 2-D variant), not the 1-D encoder's."""
+    prow = L().query("vm_bn_part_rows")
+    assert L().query("vm_bn_part_rows_used", 298, 32, 2, DTYPES["f16"][0]) == 1
+    assert L().query("vm_bn_part_rows_used", 3000, 256, 2, DTYPES["bf16"][0]) == prow
+    r = rng(9)
+    nw, C = 3000, 96
+    part = np.zeros((nw, prow, C), np.float32)
+    part[:, 0] = r.normal(0, 1, (nw, C))
+    pd = dev(part.reshape(nw * prow, C))
+    ws = torch.empty(L().query("vm_colreduce_workspace_bytes", 2, C) // 8, dtype=torch.float64, device="cuda")
+    a = torch.empty(C, device="cuda")
+    b = torch.empty(C, device="cuda")
+    L().call("vm_colsum", p(pd), nw * prow, C, p(a), p(ws), stream())
+    L().call("vm_colsum_strided", p(pd), nw, prow, C, p(b), p(ws), stream())
+    want = part.astype(np.float64).sum((0, 1))
+    assert rel_err(a.cpu().numpy(), want) < 1e-6 and rel_err(b.cpu().numpy(), want) < 1e-6
+
+
 def test_clip_max():
     r = rng(4)
     n, M, Mv, C = 3, 5, 4, 24

@@ -68,7 +68,7 @@ def main():
            "algorithmic_mb_per_step": nbytes / 1e6, "hbm_frac_of_8TBs": nbytes / (ms * 1e-3) / 8e12,
            "mfma_frac_of_2.5PF": flops / (ms * 1e-3) / 2.5e15, "ms_at_hbm_roofline": nbytes / 8e12 * 1e3}
     if a.breakdown:
-        names = ["vm_stft_logmel", "vm_stft_logmel_f16s", "vm_conv2d_first_fwd", "vm_conv2d_first_wgrad", "vm_stack_windows", "vm_bn_pool2d_stack_fwd", "vm_fold_pool_windows_bwd", "vm_bn_bwd_from_sums_finalize", "vm_fold_windows", "vm_pool_windows_fwd", "vm_pool_windows_bwd", "vm_clip_max_fwd", "vm_clip_max_bwd",
+        names = ["vm_stft_logmel", "vm_stft_logmel_f16s", "vm_conv2d_first_fwd", "vm_conv2d_first_wgrad", "vm_stack_windows", "vm_bn_pool2d_stack_fwd", "vm_fold_pool_windows_bwd", "vm_bn_bwd_from_sums_finalize", "vm_colsum_strided", "vm_fold_windows", "vm_pool_windows_fwd", "vm_pool_windows_bwd", "vm_clip_max_fwd", "vm_clip_max_bwd",
                  "vm_conv_fwd", "vm_conv_fwd_flat", "vm_conv_dgrad", "vm_conv_wgrad", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd", "vm_bn_pool_bwd_reduce",
                  "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply", "vm_bn_pool_bwd_apply_gmax", "vm_colsum",
                  "vm_dense_fwd", "vm_dense_bwd", "vm_siamese_head_loss", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights", "vm_fill_zero"]

@@ -81,6 +81,8 @@ SIGNATURES = {
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_pairs": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),
+    "vm_bn_part_rows_used": (I, [L, I, I, I]),
+    "vm_colsum_strided": (I, [P, L, I, I, P, P, P]),
     "vm_du_tower_sums": (I, [P, P, L, L, L, I, I, P, P, P, P]),
     "vm_bn_drop_pool_gmax_workspace_bytes": (L, [L, I]),
     "vm_bn_drop_pool_gmax_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P, P, P]),

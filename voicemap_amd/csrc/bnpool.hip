@@ -67,7 +67,8 @@ constexpr int CR_CHUNKS = 32;
 // (C = 32, 96: the 2-D variant, whose 131 K partial rows made this kernel 0.4 ms of its step)
 template <int CL>
 __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                                 int64_t rows_per_seg, int C, double* __restrict__ ws) {
+                                                                 int64_t rows_per_seg, int C, double* __restrict__ ws, int row_step) {
+    // row_step > 1 (vm_colsum_strided): only every row_step-th row of the matrix is read (the others are known to be zero)
     constexpr int RG = 1024 / CL;
     __shared__ double red[2][RG][CL];
     const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     double s = 0.0, q = 0.0;
     if (c < C) {
         const int64_t base = (int64_t)seg * rows_per_seg;
+        const int64_t rc = (int64_t)row_step * C;
         // four rows in flight per thread (a thread of the 2-D variant's launches walks 64 rows: one dependent load after the other
         // made this kernel 25-34 us for 17 MB), combined in a fixed order
         double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
             float va[4], vb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                va[u] = a[(base + r + u * RG) * C + c];
-                vb[u] = b != nullptr ? b[(base + r + u * RG) * C + c] : 0.f;
+                va[u] = a[(base + r + u * RG) * rc + c];
+                vb[u] = b != nullptr ? b[(base + r + u * RG) * rc + c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
             }
         }
         for (; r < r_hi; r += RG) {
-            s4[0] += (double)a[(base + r) * C + c];
-            if (b != nullptr) q4[0] += (double)b[(base + r) * C + c];
+            s4[0] += (double)a[(base + r) * rc + c];
+            if (b != nullptr) q4[0] += (double)b[(base + r) * rc + c];
         }
         s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
@@ -119,11 +121,14 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
     }
 }
 
-static void launch_colreduce(const float* a, const float* b, int64_t rows_per_seg, int C, int segs, double* ws, hipStream_t st) {
+static void launch_colreduce(const float* a, const float* b, int64_t rows_per_seg, int C, int segs, double* ws, hipStream_t st,
+                             int row_step = 1) {
     if (C % 64 == 0 || C > 128) {
-        hipLaunchKernelGGL(colreduce_stage1_kernel<64>, dim3((C + 63) / 64, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws);
+        hipLaunchKernelGGL(colreduce_stage1_kernel<64>, dim3((C + 63) / 64, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
+                           row_step);
     } else {
-        hipLaunchKernelGGL(colreduce_stage1_kernel<32>, dim3((C + 31) / 32, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws);
+        hipLaunchKernelGGL(colreduce_stage1_kernel<32>, dim3((C + 31) / 32, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
+                           row_step);
     }
 }
 
@@ -1181,6 +1186,19 @@ extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_
                            (const T*)du, towers, windows_per_tower, L, C, grad_b, dsum);
     });
     return check_launch("vm_du_tower_sums");
+}
+
+extern "C" int vm_bn_part_rows_used(int64_t L, int C, int pool, int dtype) {
+    const int vec = (dtype == VM_F32 || dtype == VM_F32S) ? 4 : 8;
+    return (pool < 1 || C < vec) ? BN_SEG : bn_segs(L / pool, C, vec);
+}
+
+extern "C" int vm_colsum_strided(const float* part, int64_t rows, int row_step, int C, float* out, void* ws, void* stream) {
+    VM_REQUIRE(part && out && ws && rows > 0 && row_step >= 1 && C > 0, "vm_colsum_strided: bad argument");
+    launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, row_step);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
+                       out);
+    return check_launch("vm_colsum_strided");
 }
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {

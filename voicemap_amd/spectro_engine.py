@@ -237,6 +237,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                         b["fsa"] = torch.empty_like(b["fs0"])
                 for nm in ("pa", "pb", "pdu"):
                     b[nm] = torch.empty(nw * prow, c, dtype=f32, device=dev)
+                b["pdu_used"] = self.lib.query("vm_bn_part_rows_used", L, c, 2, self.dtype)
                 # the weight gradient is a sum over positions, and consecutive windows -- each with its own zero halo rows in xs and
                 # du -- are one window of g (L + 2) - 2 positions for vm_conv_wgrad (a halo row multiplies by zero, no tap reaches
                 # across two of them): the same sum (1e-6, the order of fp32 partial sums) from fewer, longer reductions.  g = 8 is
@@ -398,7 +399,11 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                            _p(pl["cr_ws"]), st)
             self._call("vm_bn_pool_bwd_apply_gmax" if i == 3 else "vm_bn_pool_bwd_apply", *head, _p(b["scale"]), _p(b["shift"]),
                        _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), nw, wpt, L, c, 2, dt, _p(b["du"]), _p(b["pdu"]), st)
-            self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]), st)
+            if b["pdu_used"] == 1:   # short windows: one live partial row per window, the other seven are zeros
+                self._call("vm_colsum_strided", _p(b["pdu"]), nw, b["pdu"].shape[0] // nw, c, _p(self.view(f"conv{i+1}.bias", G)),
+                           _p(pl["cr_ws"]), st)
+            else:
+                self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, _p(self.view(f"conv{i+1}.bias", G)), _p(pl["cr_ws"]), st)
             gw = _p(self.view(f"conv{i+1}.kernel", G))
 
             def wgrad(stream):
