@@ -100,6 +100,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.first_layer_direct = bool(self.lib.query("vm_conv2d_first_supported", self.chan[0], self.dtype))
         self.flat_dgrad = True   # dgrad over the concatenated windows (see backward)
         self.flat_fwd = True     # ... and the forward of the GEMM-shaped layers (vm_conv_fwd_flat)
+        self.towers_concurrent = True   # forward: the two towers' GEMM launches of the small blocks side by side on two streams
         self.fuse_boundary = True   # BatchNorm + 2 x 2 pooling + band stacking as one pass per block boundary, and its adjoint
         self.fused_bn_sums = True   # ... which also leaves the two BatchNorm-backward sums of the block below (no reduce pass)
         self.side_stream = torch.cuda.Stream(device=self.device)
@@ -329,11 +330,24 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                         b["ssum_f"] = torch.empty(n_towers * srows, c, dtype=torch.float32, device=self.device)
                         b["ssq_f"] = torch.empty_like(b["ssum_f"])
                         b["flat_rows"] = (n_towers, srows)
-                    for tw in range(n_towers):
-                        self._call("vm_conv_fwd_flat", b["xs"][tw * wpt:].data_ptr(), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), wpt, L,
-                                   self.cs[i], c, dt, b["z"][tw * wpt:].data_ptr(),
-                                   b["ssum_f"][tw * srows:].data_ptr() if training else None,
-                                   b["ssq_f"][tw * srows:].data_ptr() if training else None, st)
+                    # the second tower's launch goes to the side stream where one tower does not fill the chip (blocks 3, 4: a few
+                    # hundred 128-row tiles a tower)
+                    two = self.towers_concurrent and training and n_towers == 2 and wpt * (L + 2) < 128 * 2048
+                    if two:
+                        b["ev"].record()   # the stacked input is complete here
+                    for tw in reversed(range(n_towers)):
+                        args = (b["xs"][tw * wpt:].data_ptr(), _p(self.wf[i]), _p(self.view(f"conv{i+1}.bias")), wpt, L,
+                                self.cs[i], c, dt, b["z"][tw * wpt:].data_ptr(),
+                                b["ssum_f"][tw * srows:].data_ptr() if training else None,
+                                b["ssq_f"][tw * srows:].data_ptr() if training else None)
+                        if two and tw == 1:
+                            with torch.cuda.stream(self.side_stream):
+                                self.side_stream.wait_event(b["ev"])
+                                self._call("vm_conv_fwd_flat", *args, self.stream())
+                        else:
+                            self._call("vm_conv_fwd_flat", *args, st)
+                    if two:
+                        torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
                     if training:
                         ssum, ssq, stat_rows_per_tower = _p(b["ssum_f"]), _p(b["ssq_f"]), srows
                 else:
