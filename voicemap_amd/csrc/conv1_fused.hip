@@ -381,7 +381,15 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x2 za, zb2;
-            f1_relu4(acc, g, bv2, za, zb2);
+            if (ALLMAX) {
+                // no ReLU here: the pre-activation v = conv + bias serves.  Among positive values max-pooling v or relu(v) picks the
+                // same first maximum; where every v of a window is <= 0 the choice differs but every du of the window is masked to
+                // zero either way; and gc * relu(v) + [v > 0] a == [v > 0] (gc * v + a).  Four v_max fewer per group, same bits.
+                za = f32x2{acc[4 * g], acc[4 * g + 1]} + bv2;
+                zb2 = f32x2{acc[4 * g + 2], acc[4 * g + 3]} + bv2;
+            } else {
+                f1_relu4(acc, g, bv2, za, zb2);
+            }
             const float z[4] = {za[0], za[1], zb2[0], zb2[1]};
             float gz[4];
 #pragma unroll
@@ -424,7 +432,14 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                     for (int j = 0; j < POOL; ++j) a[j] = j == arg ? gb1 : gb0;
                 }
 #pragma unroll
-                for (int j = 0; j < POOL; ++j) gz[pw * POOL + j] = fmaf(gc, zw[j], zw[j] > 0.f ? a[j] : 0.f);
+                for (int j = 0; j < POOL; ++j) {
+                    if (ALLMAX) {
+                        const float t = fmaf(gc, zw[j], a[j]);
+                        gz[pw * POOL + j] = zw[j] > 0.f ? t : 0.f;
+                    } else {
+                        gz[pw * POOL + j] = fmaf(gc, zw[j], zw[j] > 0.f ? a[j] : 0.f);
+                    }
+                }
             }
             dub[2 * g] = __builtin_convertvector(f32x2{gz[0], gz[1]}, bf16x2);
             dub[2 * g + 1] = __builtin_convertvector(f32x2{gz[2], gz[3]}, bf16x2);
