@@ -46,14 +46,40 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(const void* __restrict
     const int f0 = blockIdx.x * SF_FRAMES;
     const float* rf = reinterpret_cast<const float*>(raw) + clip * raw_len;
     const int16_t* ri = reinterpret_cast<const int16_t*>(raw) + clip * raw_len;
-    for (int i = tid; i < SF_FRAMES * win; i += 256) {
-        const int f = i / win, n = i - f * win;
-        float v = 0.f;
-        if (f0 + f < T) {
-            const int64_t s = (int64_t)(f0 + f) * hop + n;
-            v = is_int16 ? (float)ri[s] * (1.0f / 32768.0f) : rf[s];
+    // a wave per frame, 64 consecutive samples per load, every load of the wave's eight frames unconditional (clamped indices) and in
+    // flight before the first store -- see stft_logmel_f16s_kernel: one load per branch was half of a wave's lifetime there
+    {
+        constexpr int FPW = SF_FRAMES / 4;
+        float v[FPW][8];
+        auto fetch = [&](auto* src, float scale) {
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) {
+                int fr = f0 + w + 4 * i;
+                fr = fr < T ? fr : T - 1;
+                const auto* p0 = src + (int64_t)fr * hop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = lane + 64 * j;
+                    v[i][j] = (float)p0[n < win ? n : win - 1] * scale;
+                }
+            }
+        };
+        if (is_int16) {
+            fetch(ri, 1.0f / 32768.0f);
+        } else {
+            fetch(rf, 1.0f);
         }
-        xs[f * pitch + n] = v;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) {
+            const int f = w + 4 * i;
+            const bool fok = f0 + f < T;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = lane + 64 * j;
+                if (n < win) xs[f * pitch + n] = fok ? v[i][j] : 0.f;
+            }
+        }
     }
     __syncthreads();
 
