@@ -13,14 +13,19 @@ __global__ __launch_bounds__(256) void slab_stage1_kernel(const float* __restric
     const int64_t lo = blockIdx.y * per;
     int64_t hi = lo + per;
     if (hi > slabs) hi = slabs;
-    double s0 = 0.0, s1 = 0.0;
+    // eight slabs in flight per thread (the block-1 weight gradient: 1024 slabs, 16 per thread -- two at a time was eight memory round
+    // trips in a row on the step's tail), summed in a fixed order
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int64_t k = lo;
-    for (; k + 2 <= hi; k += 2) {
-        s0 += (double)ws[k * nel + i];
-        s1 += (double)ws[(k + 1) * nel + i];
+    for (; k + 8 <= hi; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(k + u) * nel + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += (double)v[u];
     }
-    if (k < hi) s0 += (double)ws[k * nel + i];
-    part[(int64_t)blockIdx.y * nel + i] = s0 + s1;
+    for (; k < hi; ++k) s[0] += (double)ws[k * nel + i];
+    part[(int64_t)blockIdx.y * nel + i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // one stage: few slabs and enough elements to fill the chip on their own
