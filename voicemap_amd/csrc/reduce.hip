@@ -54,8 +54,17 @@ __global__ __launch_bounds__(256) void slab_stage2_kernel(const double* __restri
                                                           float* __restrict__ out0, float* __restrict__ out1) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nel) return;
-    double s = 0.0;
-    for (int k = 0; k < rch; ++k) s += part[(int64_t)k * nel + i];
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // eight partials in flight, fixed order
+    int k = 0;
+    for (; k + 8 <= rch; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + u) * nel + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[u];
+    }
+    for (; k < rch; ++k) s8[0] += part[(int64_t)k * nel + i];
+    const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     if (i < n0) {
         out0[i] = (float)s;
     } else {
