@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 import numpy as np
 import torch
+import torch.distributed
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_16BIT_PEAK_TF = 2500.0  # dense bf16 / f16 MFMA peak
@@ -87,6 +88,58 @@ def restore(eng, s):
     eng.refresh_weights()
 
 
+def fail(msg, code=2):
+    """A loud failure: one JSON error line on stdout (so a record of the run says why there is no number) and a non-zero exit."""
+    print(json.dumps({"error": msg, "metric": None, "value": None}), flush=True)
+    sys.stderr.write("bench.py: " + msg + "\n")
+    sys.stderr.flush()
+    os._exit(code)
+
+
+class Watchdog:
+    """Turns a hang of the rendezvous or of the first collective into an error line: ``arm(what)`` starts a timer that, unless
+    ``disarm()`` comes first, reports ``what`` and ends the process (a hung RCCL call cannot be interrupted from Python)."""
+
+    def __init__(self, seconds):
+        self.seconds = seconds
+        self._timer = None
+
+    def arm(self, what):
+        import threading
+        self.disarm()
+        self._timer = threading.Timer(self.seconds, fail, args=("watchdog: no progress in %.0f s during %s (rank %s)"
+                                                                % (self.seconds, what, os.environ.get("RANK", "0")), 3))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a torchrun environment: re-exec this very command line under
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` (the driver's own launch form), one rank per GPU over RCCL.
+    Fewer than N visible devices is an error unless the transport is the gloo rehearsal (ranks then share devices)."""
+    import socket
+    import subprocess
+    if os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo":
+        have = torch.cuda.device_count()
+        if have < n:
+            fail("bench.py --gpus %d: only %d device(s) visible on this node -- refusing to report a smaller run as n_gpus %d"
+                 % (n, have, n))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,11 +160,24 @@ def main():
     ap.add_argument("--allow-nonfinite", action="store_true", help="timing experiments with ablated builds (tools/build_variant.sh): results are wrong by design")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain ``python bench.py --gpus N``: become the launcher of N ranks (one per GPU) -- never a silent 1-GPU run
+        sys.exit(self_launch(a.gpus))
+
     from voicemap_amd import parallel
     from voicemap_amd.engine import HipEncoderEngine
-    rank, world, local = parallel.init_distributed()
-    assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    # (the rendezvous gets twice the collectives' limit: ranks of a fresh box finish ``import torch`` at different times)
+    watchdog = Watchdog(2 * float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "60")))
+    watchdog.arm("torch.distributed rendezvous / init_process_group (world %s)" % os.environ.get("WORLD_SIZE", "1"))
+    rank, world, local = parallel.init_distributed(timeout_s=watchdog.seconds)
+    watchdog.disarm()
+    watchdog.seconds = float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "60"))
+    if world != a.gpus:
+        fail("bench.py --gpus %d was started with WORLD_SIZE=%d: launch with --nproc-per-node == --gpus (or without torchrun: "
+             "bench.py spawns the ranks itself)" % (a.gpus, world))
     n_gpus = world
+    if n_gpus > 1 and os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo" and torch.cuda.device_count() < n_gpus:
+        fail("bench.py --gpus %d: only %d device(s) visible on this node" % (n_gpus, torch.cuda.device_count()))
     if os.environ.get("VOICEMAP_DIST_BACKEND") == "gloo":   # rehearsal: more ranks than GPUs, the replicas share devices
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -131,7 +197,13 @@ def main():
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))
     parallel.attach(eng, n_gpus)
+    if n_gpus > 1:
+        watchdog.arm("the first collectives (barrier + state broadcast, backend %s)" % torch.distributed.get_backend())
+        parallel.barrier()
     parallel.broadcast_state(eng)
+    if n_gpus > 1:
+        torch.cuda.synchronize()
+        watchdog.disarm()
 
     # synthetic raw windows, a different shard per rank, resident in HBM
     pairs = a.pairs
@@ -176,9 +248,12 @@ def main():
         return out, mine
 
     step, pl = make_step(eng)
+    if n_gpus > 1:
+        watchdog.arm("the warm-up steps (first gradient all-reduce)")
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    watchdog.disarm()
     if n_gpus > 1 and eng.grad_sync is not None:
         eng.grad_sync.time_wait = True
     block_s, mine_s = time_blocks(step, max(1, a.blocks), a.steps)

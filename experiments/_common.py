@@ -36,6 +36,10 @@ def base_parser(description, **defaults):
     p.add_argument("--device-data", metavar="DIR", default="",
                    help="decode the TRAINING set once into int16 shards under DIR (reused if present), keep them resident in HBM and "
                         "crop/decimate/whiten on the GPU; the host only draws pair offsets (voicemap_amd/shards.py)")
+    p.add_argument("--shard-speakers", action="store_true",
+                   help="with --device-data under torchrun: every rank keeps only 1/world of the speakers resident and draws its "
+                        "different-speaker pairs among them (a different negative distribution from the reference's whole-corpus "
+                        "sampling: opt-in; the default keeps the whole corpus on every rank)")
     p.add_argument("--training-set", nargs="+", default=["train-clean-100", "train-clean-360"])
     p.add_argument("--validation-set", default="dev-clean")
     return p
@@ -59,8 +63,10 @@ def device_resident(a, train):
         shards.write_shards(train, a.device_data)
     from voicemap_amd import parallel
     rank, world = parallel.rank_world()
-    # under torchrun every rank keeps 1 / world of the speakers resident (shards.ShardedSpeechDataset speaker_shard)
-    ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False, speaker_shard=(rank, world) if world > 1 else None)
+    # default: the whole corpus on every rank, pairs sampled over all speakers as the reference does (librispeech.py:139-177);
+    # --shard-speakers: 1 / world of the speakers per rank (shards.ShardedSpeechDataset speaker_shard) -- opt-in, ADVICE r3
+    shard = (rank, world) if (world > 1 and getattr(a, "shard_speakers", False)) else None
+    ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False, speaker_shard=shard)
     ds.to_device("cuda")
     return ds
 

@@ -37,11 +37,17 @@ def test_bench_single_process_line_contract():
     assert set(roof["families_serial"]) == {"vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"}
 
 
-def test_bench_two_ranks_over_gloo():
+@pytest.mark.parametrize("launch", ["self", "torchrun"])
+def test_bench_two_ranks_over_gloo(launch):
+    """``self``: plain ``python bench.py --gpus 2`` -- no RANK in the environment, bench.py spawns the two ranks itself (what a driver
+    that does not wrap the command gets); ``torchrun``: the driver's documented N > 1 form.  The line must say n_gpus 2 either way."""
     env = dict(os.environ, VOICEMAP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     port = str(29500 + (os.getpid() + 13) % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", port, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--pairs", "16"]
+    tail = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--pairs", "16"]
+    cmd = [sys.executable] + ([] if launch == "self" else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                           "--master-addr", "127.0.0.1", "--master-port", port]) + tail
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json_line(r.stdout)
@@ -52,3 +58,15 @@ def test_bench_two_ranks_over_gloo():
     assert abs(dp["collectives_per_step"] - 2.0) < 1e-9 and dp["flat_gradient_bytes"] > 4_000_000
     assert "extras" not in out and "cpu_baseline" not in out     # rank 0 at N = 1 only
     assert r.stdout.count('"metric"') == 1                        # ONE line, from rank 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """``--gpus`` beyond the visible devices (RCCL transport) is an error line and a non-zero exit, never an n_gpus-1 record."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VOICEMAP_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    out = _last_json_line(r.stdout)
+    assert out["value"] is None and "device" in out["error"]

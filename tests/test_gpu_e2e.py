@@ -189,6 +189,38 @@ def test_f16_overflowing_step_is_skipped_not_applied():
     assert eng.adjust_loss_scale() == 8192.0             # ... and the fourth doubles the scale
 
 
+def test_f16_loss_scale_recovers_inside_a_plain_train_on_batch_loop():
+    """loops that call the step directly (siamese_contrastive_loss.py, the DDP bench) never called adjust_loss_scale.
+    The scale is now driven from optimizer_step: an overflowing scale is halved away within a few polls without any caller help,
+    skipped steps do not advance Adam's step counter, the value 1.0 is a scale like any other (non-finite steps are still skipped
+    there, and the scale grows back)."""
+    import warnings
+    arch, p, x1, x2, y, _, _ = _tiny_case(seed=1, dropout=0.0)
+    eng = _engine(arch, p, "uniform_euclidean", "f16")
+    eng.scale_poll_every, eng.scale_poll_lag = 2, 1
+    eng.loss_scale = 2.0 ** 26
+    before = eng.P.clone()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(40):
+            eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None)
+    skipped = eng.skipped_steps()
+    assert 0 < skipped < 40 and eng.loss_scale < 2.0 ** 20 and any("skipped" in str(m.message) for m in w)
+    assert eng.iterations == 40 - eng._skip_seen and eng._skip_seen >= skipped - 2   # the last poll may still be in flight
+    assert not torch.equal(eng.P, before) and torch.isfinite(eng.P).all()
+    # scale 1.0: still a scaled mode (skips stay armed), and it grows back after scale_grow_after clean steps
+    eng.loss_scale, eng.scale_grow_after, eng._clean_steps = 1.0, 4, 0
+    n0 = eng.skipped_steps()
+    for _ in range(8):
+        eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None)
+    assert eng.loss_scale > 1.0 and eng.skipped_steps() == n0
+    eng.G.fill_(float("inf"))
+    pb = eng.P.clone()
+    eng.loss_scale = 1.0
+    eng.optimizer_step()
+    assert torch.equal(eng.P, pb) and eng.skipped_steps() == n0 + 1
+
+
 def test_two_steps_fp32_keep_tracking_oracle():
     """Second step exercises the Adam slots, the refreshed GEMM weight copies and the moving statistics."""
     arch, p, x1, x2, y, m1, m2 = _tiny_case(seed=3, dropout=0.0)

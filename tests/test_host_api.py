@@ -393,7 +393,11 @@ def test_sharded_dataset_speaker_shard_partitions_the_corpus(tmp_path):
     assert sum(len(s) for s in seen) == 9 and set().union(*seen) == set(whole.df['speaker_id'].unique())
     assert sum(len(p) for p in parts) == len(whole)
     for p in parts:
+        #  the offsets describe the compact per-rank buffer from construction on, not only after to_device()
+        before = p.global_offset.copy()
+        assert before[0] == 0 and np.array_equal(before[1:], np.cumsum(p.file_length)[:-1])
         audio = p.to_device("cpu").numpy()
+        assert np.array_equal(p.global_offset, before)
         assert len(audio) == int(p.file_length.sum())
         for i in (0, len(p) - 1):
             o = int(p.global_offset[i])
@@ -403,3 +407,5 @@ def test_sharded_dataset_speaker_shard_partitions_the_corpus(tmp_path):
             assert p.datasetid_to_speaker_id[a] == p.datasetid_to_speaker_id[b]
         o1, o2, y = p.build_verification_batch_offsets(4)
         assert o1.max() + p.fragment_length <= len(audio) and o2.max() + p.fragment_length <= len(audio)
+    with pytest.raises(ValueError):   # 9 speakers over 8 ranks: rank 1..7 would hold one speaker -- no different-speaker pairs
+        shards.ShardedSpeechDataset(str(tmp_path), 3, stochastic=False, speaker_shard=(1, 8))

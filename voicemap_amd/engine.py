@@ -227,9 +227,17 @@ class HipEncoderEngine:
         it), the flat gradient buffer G then holds loss_scale x the gradients and the optimizer kernel divides it out again
         (grad_prescale) before the clip; a step whose scaled gradients overflowed (non-finite norm) is skipped on the device and
         counted in ``skipped_steps()``.  1.0 for the other storage types: their arithmetic is untouched."""
-        self.loss_scale = DEFAULT_F16_LOSS_SCALE if self.dtype == VM_F16 else 1.0
+        self.loss_scaled = (self.dtype == VM_F16)   # the switch for scaling / skipping -- NOT the scale's value (ADVICE r3)
+        self.loss_scale = DEFAULT_F16_LOSS_SCALE if self.loss_scaled else 1.0
         self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)   # running count, incremented by the optimizer kernel
         self._skip_seen, self._clean_checks = 0, 0
+        # dynamic scale driven from optimizer_step (every train_on_batch loop gets it, not only fit_generator): every
+        # ``scale_poll_every`` steps the count is copied to pinned memory behind the step; ``scale_poll_lag`` steps later -- a fixed
+        # lag, so data-parallel replicas change their scale at the same step -- it is read (the copy is long done: no drain)
+        self.scale_poll_every, self.scale_poll_lag = 16, 8
+        self.scale_grow_after, self.scale_max, self.scale_min = 2000, 65536.0, 1.0
+        self._opt_calls, self._clean_steps, self._poll = 0, 0, None
+        self._skip_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.loss_scaled else None
 
     def _init_zero_debias(self):
         """Keras 2.2.2 BatchNormalization updates its moving statistics with TF 1.10's assign_moving_average(zero_debias=True)
@@ -336,24 +344,59 @@ class HipEncoderEngine:
         """Optimizer steps skipped because the loss-scaled gradients were not finite (f16 storage only; synchronises)."""
         return int(self._skipped.item())
 
-    def adjust_loss_scale(self, grow_after: int = 4, max_scale: float = 32768.0) -> float:
-        """Dynamic loss scaling at the caller's cadence (``fit_generator`` calls it once per epoch: one device read, no per-step
-        synchronisation): steps were skipped since the last call -> halve the scale once per skipped step (at most 2^-4); none for
-        ``grow_after`` calls in a row -> double it (an overflow it may cause costs one skipped step and is halved away at the next
-        call).  No-op for the storage types that do not scale."""
-        if self.loss_scale == 1.0:
-            return 1.0
-        total = self.skipped_steps()
+    def _account_skips(self, total: int) -> int:
+        """``total`` skipped steps so far: the new ones are taken off ``iterations`` again (a skipped step is not an Adam step: its
+        bias correction and lr decay must not advance) and reported once."""
         new, self._skip_seen = total - self._skip_seen, total
         if new > 0:
-            self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), 1.0)
-            self._clean_checks = 0
+            self.iterations = max(0, self.iterations - new)
+            import warnings
+            warnings.warn("f16 storage: %d optimizer step(s) skipped (non-finite loss-scaled gradients, scale %g); %d in total"
+                          % (new, self.loss_scale, total), RuntimeWarning, stacklevel=3)
+        return new
+
+    def adjust_loss_scale(self, grow_after: int = 4, max_scale: float = 65536.0) -> float:
+        """Dynamic loss scaling at the caller's cadence (one device read per call; ``optimizer_step`` does the same on its own
+        without a read on the critical path, see ``_poll_loss_scale``): steps were skipped since the last look -> halve the scale
+        once per skipped step (at most 2^-4); none for ``grow_after`` calls in a row -> double it.  No-op for the storage types
+        that do not scale.  The scale may reach ``scale_min`` (1.0) and grows back from there."""
+        if not self.loss_scaled:
+            return 1.0
+        new = self._account_skips(self.skipped_steps())
+        if new > 0:
+            self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), self.scale_min)
+            self._clean_checks = self._clean_steps = 0
         else:
             self._clean_checks += 1
             if self._clean_checks >= grow_after:
                 self.loss_scale = min(self.loss_scale * 2.0, max_scale)
                 self._clean_checks = 0
         return self.loss_scale
+
+    def _poll_loss_scale(self):
+        """Called once per optimizer step (f16 storage).  Step k with k % scale_poll_every == 0 enqueues a copy of the device's skip
+        count to pinned memory; step k + scale_poll_lag consumes it."""
+        k = self._opt_calls
+        self._opt_calls += 1
+        if self._poll is not None and k >= self._poll[0] + self.scale_poll_lag:
+            k0, ev = self._poll
+            self._poll = None
+            ev.synchronize()   # enqueued scale_poll_lag steps ago
+            new = self._account_skips(int(self._skip_host[0]))
+            if new > 0:
+                self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), self.scale_min)
+                self._clean_steps = 0
+            else:
+                self._clean_steps += self.scale_poll_every
+                if self._clean_steps >= self.scale_grow_after:
+                    self.loss_scale = min(self.loss_scale * 2.0, self.scale_max)
+                    self._clean_steps = 0
+        if self._poll is None and k % self.scale_poll_every == 0:
+            with torch.cuda.stream(torch.cuda.current_stream(self.device)):
+                self._skip_host.copy_(self._skipped, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._poll = (k, ev)
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
@@ -907,7 +950,7 @@ class HipEncoderEngine:
         if self.grad_sync is not None:
             self.grad_sync(self.G)
         lib, st = self.lib, self.stream()
-        skip = self.loss_scale != 1.0   # loss-scaled storage: a non-finite gradient norm skips the update on the device
+        skip = self.loss_scaled   # loss-scaled storage: a non-finite gradient norm skips the update on the device
         if (self.clipnorm and self.clipnorm > 0) or skip:
             self._call("vm_grad_sqnorm", _p(self.G), self.n_flat, _p(self._sq_ws), None, st)   # partials; the optimizer kernel adds them
         lr = self.lr
@@ -919,6 +962,8 @@ class HipEncoderEngine:
                  self.beta_2, self.adam_eps, float(self.clipnorm or 0.0), float(self.grad_prescale) / float(self.loss_scale),
                  _p(self._sqnorm), _p(self._sq_ws), int(skip), _p(self._skipped) if skip else None, st)
         self.iterations = t
+        if skip:
+            self._poll_loss_scale()   # after the launch: the copy it may enqueue sees this step's count
         self.refresh_weights()
 
     # ------------------------------------------------------------------------------------------------

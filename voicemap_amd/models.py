@@ -298,9 +298,7 @@ class _TrainableModel:
                     print("Epoch %d/%d - %.0fs - %s" % (epoch + 1, epochs, time.time() - t0,
                                                        " - ".join("%s: %.4f" % kv for kv in logs.items())))
                 K.run_callbacks(cbs, "on_epoch_end", epoch, logs)
-                eng_ = getattr(self, "engine", None)
-                if eng_ is not None and hasattr(eng_, "adjust_loss_scale"):
-                    eng_.adjust_loss_scale()   # f16 storage: dynamic loss scale, one device read per epoch (a no-op otherwise)
+                # (f16 storage: the dynamic loss scale is driven by the engine's optimizer_step itself, every 16 steps)
                 if self.stop_training:
                     break
         finally:

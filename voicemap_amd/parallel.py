@@ -33,8 +33,9 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
-    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*)."""
+def init_distributed(backend: str | None = None, timeout_s: float | None = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).  ``timeout_s`` bounds the
+    rendezvous (and, for gloo, every collective): a rank that never shows up is an exception, not a hang."""
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -44,7 +45,11 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
             backend = os.environ.get("VOICEMAP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -199,4 +204,7 @@ def weighted_mean_logs(sums: Dict[str, float], weight: float, device=None) -> Di
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":   # name the device: no guess from the rank number at the communicator's first use
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

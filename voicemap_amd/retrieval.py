@@ -233,15 +233,50 @@ def evaluate_tasks(cache: EmbeddingCache, query_idx, support_idx, k: int, n: int
     return (n_correct, pred) if return_pred else n_correct
 
 
+def _siamese_head_engine(model):
+    """The engine of a siamese net that owns the verification head's weights (None for a bare encoder)."""
+    if hasattr(model, "_ensure_engine") and hasattr(model, "layers") and len(getattr(model, "layers", [])) > 2:
+        eng = model._ensure_engine()
+        if "head.kernel" in getattr(eng, "offsets", {}) and getattr(eng, "head", None) in ("uniform_euclidean", "weighted_l1"):
+            return eng
+    return None
+
+
+def evaluate_tasks_head(eng, cache: EmbeddingCache, query_idx, support_idx, k: int, return_pred: bool = False):
+    """1-shot tasks ranked the way voicemap/utils.py:121-137 ranks them for a siamese network: the model's own verification head on
+    the k (query, support) pairs of every task -- ``vm_siamese_head_loss`` in its predict-only form on rows of the cached matrix --
+    and correct iff the smallest output is the first pair's (:137).  n_correct (and optionally the (tasks, k) outputs)."""
+    from .engine import HEADS, _p
+    dev = cache.emb.device
+    q = torch.as_tensor(query_idx).to(dev, torch.int64).reshape(-1)
+    s = torch.as_tensor(support_idx).to(dev, torch.int64).reshape(-1)
+    tasks = int(q.numel())
+    if tasks == 0:
+        return (0, None) if return_pred else 0
+    assert s.numel() == tasks * k
+    if int(torch.minimum(q.min(), s.min())) < 0 or int(torch.maximum(q.max(), s.max())) >= cache.n:
+        raise IndexError("task indices outside the cached matrix (0 .. %d)" % (cache.n - 1))
+    pairs = tasks * k
+    both = torch.empty(2 * pairs, cache.E, dtype=torch.float32, device=dev)   # rows [0, pairs): the query k times per task; then the supports
+    torch.index_select(cache.emb, 0, q.repeat_interleave(k), out=both[:pairs])
+    torch.index_select(cache.emb, 0, s, out=both[pairs:])
+    pred = torch.empty(pairs, dtype=torch.float32, device=dev)
+    eng.lib.call("vm_siamese_head_loss", _p(both), _p(eng.view("head.kernel")), _p(eng.view("head.bias")), None, pairs, cache.E,
+                 HEADS[eng.head], 0, 1.0, _p(pred), None, None, None, None, None, torch.cuda.current_stream(dev).cuda_stream)
+    p = pred.reshape(tasks, k).cpu().numpy()
+    n_correct = int((np.argmin(p, axis=1) == 0).sum())
+    return (n_correct, p) if return_pred else n_correct
+
+
 def n_shot_task_evaluation_cached(model, dataset, preprocessor, num_tasks, n, k, network_type="siamese", distance="euclidean",
                                   cache: Optional[EmbeddingCache] = None, sampler="reference"):
     """``n_shot_task_evaluation`` (voicemap/utils.py:104-216: same arguments, same return value ``n_correct``) on a cached embedding
     matrix: the corpus is embedded once (or ``cache`` re-used: experiments/k_way_accuracy.py sweeps 38 (k, n) cells over one model),
     tasks are row indices, all of them go through one launch.  ``sampler``: "reference" draws them with the reference's
-    ``np.random`` sequence (``draw_tasks_reference``), a ``DeviceTaskSampler`` draws them on the GPU.  Always the embedding route
-    (prototype distances, :138-212): for a siamese net with n = 1 the reference ranks by the verification head's output instead
-    (:121-137) -- a monotone function of the euclidean distance for the ``uniform_euclidean`` head with a positive weight, i.e. the same
-    argmin with distance='euclidean'.  Under torchrun tasks are sharded over ranks and the counts summed."""
+    ``np.random`` sequence (``draw_tasks_reference``), a ``DeviceTaskSampler`` draws them on the GPU.  For a siamese net with n = 1
+    the reference ranks the k candidates by the verification HEAD's output, whatever ``distance`` says (:121-137): so does this
+    (``evaluate_tasks_head``: the head kernel on the cached embedding pairs); every other cell takes the embedding route
+    (prototype distances, :138-212).  Under torchrun tasks are sharded over ranks and the counts summed."""
     if n < 1:
         raise ValueError("n must be >= 1")
     if network_type not in ("siamese", "classifier"):
@@ -257,7 +292,11 @@ def n_shot_task_evaluation_cached(model, dataset, preprocessor, num_tasks, n, k,
             q, s = sampler.draw(hi - lo, k, n)
         else:
             q, s = draw_tasks_reference(dataset, hi - lo, k, n)
-        local = evaluate_tasks(cache, q, s, k, n, distance)
+        head_eng = _siamese_head_engine(model) if (network_type == "siamese" and n == 1) else None
+        if head_eng is not None:
+            local = evaluate_tasks_head(head_eng, cache, q, s, k)
+        else:
+            local = evaluate_tasks(cache, q, s, k, n, distance)
     else:
         local = 0
     return int(round(parallel.sum_over_ranks(float(local)))) if world > 1 else local

@@ -105,7 +105,9 @@ class ShardedSpeechDataset(LibriSpeechDataset):
         ``world`` -- the data-parallel form of the resident corpus: every rank draws its pairs among its own 1 / world of the
         speakers and ``to_device`` uploads only their recordings (train-clean-100 + 360: ~52 GB as int16 -> 6.5 GB per rank of 8
         instead of 52 GB on each).  Same-speaker pairs are unaffected; different-speaker pairs are drawn within the rank's speakers
-        (1172 / 8 = 146 of them), and the gradient all-reduce mixes the ranks' batches as before."""
+        (1172 / 8 = 146 of them) -- a DIFFERENT training distribution from the reference's whole-corpus negatives
+        (librispeech.py:159-177), which is why it is an explicit opt-in (``--shard-speakers`` of the experiment scripts) and the
+        default keeps the whole corpus on every rank (52 GB of 288 GB).  A shard needs at least two speakers."""
         assert label in ('sex', 'speaker'), 'Label type must be one of (\'sex\', \'speaker\')'
         self.subset = shard_dir
         self.fragment_seconds = seconds
@@ -118,6 +120,9 @@ class ShardedSpeechDataset(LibriSpeechDataset):
             rank, world = int(speaker_shard[0]), int(speaker_shard[1])
             speakers = np.sort(df['id'].unique())
             mine = set(speakers[rank::world].tolist())
+            if len(mine) < 2:
+                raise ValueError('speaker_shard %r leaves %d speaker(s) on this rank: different-speaker pairs need two'
+                                 % ((rank, world), len(mine)))
             df = df[df['id'].isin(mine)].reset_index(drop=True)
             self.speaker_shard = (rank, world)
         self._finalise(df)
@@ -127,6 +132,11 @@ class ShardedSpeechDataset(LibriSpeechDataset):
         # start of every file in the concatenation of all shards (the layout of the device buffer)
         self.global_offset = (base[self.df['shard'].values] + self.df['offset'].values).astype(np.int64)
         self.file_length = self.df['length'].values.astype(np.int64)
+        if self.speaker_shard is not None:
+            # the device buffer of a speaker shard holds only this rank's recordings, back to back in index order: the offsets are
+            # those of THAT layout from the start (host reads go through the shard / offset columns, never through global_offset)
+            self.global_offset = np.concatenate([[0], np.cumsum(self.file_length)[:-1]]).astype(np.int64) if len(self.df) \
+                else np.zeros(0, dtype=np.int64)
         self.device_audio = None
 
     def _pcm(self, index):
@@ -144,9 +154,8 @@ class ShardedSpeechDataset(LibriSpeechDataset):
             if self.speaker_shard is None:
                 parts = [torch.from_numpy(np.array(m, dtype=np.int16, copy=True)) for m in self._maps]
             else:
-                # only this rank's recordings, back to back in index order: global_offset is re-based onto the compact buffer
+                # only this rank's recordings, back to back in index order (the layout global_offset describes since __init__)
                 parts = [torch.from_numpy(np.array(self._pcm(i), dtype=np.int16, copy=True)) for i in range(len(self.df))]
-                self.global_offset = np.concatenate([[0], np.cumsum(self.file_length)[:-1]]).astype(np.int64)
             self.device_audio = torch.cat(parts).to(device) if parts else torch.zeros(0, dtype=torch.int16, device=device)
         return self.device_audio
 
