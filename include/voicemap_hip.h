@@ -9,8 +9,8 @@
  *
  * Conventions (every function):
  *   - plain pointers are DEVICE pointers unless named host_*; sizes are explicit; no torch types.
- *   - `dtype` selects the storage type of activations / GEMM operands: VM_F32 or VM_BF16.  Accumulation,
- *     batch statistics, the tail (global max -> dense -> head -> loss) and the optimizer are always fp32.
+ *   - `dtype` selects the storage type of activations / GEMM operands: VM_F32, VM_F32S, VM_BF16 or VM_F16 (the enum below).
+ *     Accumulation, batch statistics, the tail (global max -> dense -> head -> loss) and the optimizer are always fp32.
  *   - enqueue-only on `stream` (a hipStream_t passed as void*); no host sync, no allocation; re-entrant per
  *     stream.  The ONE piece of process-global mutable state is the kernel-selection table behind vm_set_tuning
  *     (below): every selectable kernel computes the same result (each is parity-tested against the oracle), so
@@ -47,7 +47,8 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 5.  History: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
+/* 6.  History: 6 = packed weights (vm_pack_nt_weights; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+ * vm_conv_dgrad_bnred) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
  * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce; vm_conv_fwd_flat, vm_conv2d_first_*,
@@ -171,7 +172,16 @@ int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, 
 int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e);
 int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                      int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z, float* stat_sum,
-                     float* stat_sq, void* e, void* o, void* stream);
+                     float* stat_sq, void* e, void* o, const void* wf_packed, void* stream);
+/* The k = 3 GEMM weights in the order the matrix cores consume them (round 4).  bt: `towers` matrices (n_rows, 3 * a_c) `dtype` back
+ * to back -- wf (n_rows = c_out, a_c = c_in), wd (n_rows = c_in, a_c = c_out) of vm_prep_conv_weights, wf_folded of
+ * vm_fold_bn_weights; packed: the same elements as [tower][n_rows / 64][K tile = (channel chunk of 32, tap)][32-row half][16-channel
+ * half][64 lanes][8 values], i.e. every 1 KB piece is one v_mfma_f32_32x32x16 operand fragment of a wave and a wave's stream through a
+ * K loop is contiguous.  The entry points that take a `*_packed` argument (vm_conv_fwd_fold, vm_conv_fwd_pool, vm_conv_dgrad_bnred)
+ * then load the weights from L2 straight into registers (conv_nt3_kernel) instead of staging them in LDS; NULL there = the staged
+ * kernel.  Same results bit for bit (the same products in the same order).  16-bit storage, n_rows % 128 == 0, a_c % 32 == 0. */
+int vm_pack_nt_weights_supported(int n_rows, int a_c, int dtype);
+int vm_pack_nt_weights(const void* bt, int towers, int n_rows, int a_c, int dtype, void* packed, void* stream);
 /* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
  * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
  * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by
@@ -179,7 +189,7 @@ int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias,
  * vm_conv_fwd_pool_supported() says whether a shape is, VM_ERR_UNSUPPORTED otherwise. */
 int vm_conv_fwd_pool_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
 int vm_conv_fwd_pool(const void* in, const void* wf, const float* bias, const float* scale, const float* shift,
-                     int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, void* stream);
+                     int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, const void* wf_packed, void* stream);
 /* dgrad: dx[n][t][ci] = sum_{k,co} du[n][t+1-k][co] * W[k][ci][co].  du padded (n_windows, L+2, c_out);
  * wd: (c_in, 3*c_out) `dtype` tap-flipped copy from vm_prep_conv_weights; dx: (n_windows, L, c_in). */
 int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
@@ -196,7 +206,8 @@ int vm_conv_dgrad(const void* du, const void* wd, int64_t n_windows, int64_t L, 
 int64_t vm_conv_dgrad_bnred_rows(int64_t L);
 int vm_conv_dgrad_bnred_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype);
 int vm_conv_dgrad_bnred(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
-                        void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, void* stream);
+                        void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, const void* wd_packed,
+                        void* stream);
 /* wgrad: dW[k][ci][co] = sum_{n,t} in[n][t+k][ci] * du[n][t+1][co] (both padded).  Split over windows into
  * vm_conv_wgrad_splits() slabs in ws (fp32), then summed in fixed order into grad_w (3, c_in, c_out). */
 int vm_conv_wgrad_splits(int64_t n_windows, int64_t L, int c_in, int c_out);

@@ -93,8 +93,20 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
     ssq = torch.empty_like(ssum)
     eo = torch.full((n, Lw // 2 + 2, cout), 7.0, dtype=tdt, device="cuda") if with_e else None
     L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
-             vm, p(z), p(ssum), p(ssq), p(eo), None, stream())
+             vm, p(z), p(ssum), p(ssq), p(eo), None, None, stream())
     torch.cuda.synchronize()
+    if L().query("vm_pack_nt_weights_supported", cout, cin, vm):
+        # round 4: the same launch with the weights in fragment order (conv_nt3_kernel where the channel count has a written-out K
+        # loop: L2 -> registers, no weight stage in LDS, one barrier per channel chunk) -- the same products in the same order, so
+        # every output is bit-identical to the staged kernel's
+        wfp = torch.empty_like(wf)
+        L().call("vm_pack_nt_weights", p(wf), towers, cout, cin, vm, p(wfp), stream())
+        z3, ssum3, ssq3 = torch.empty_like(z), torch.empty_like(ssum), torch.empty_like(ssq)
+        eo3 = torch.full_like(eo, 7.0) if with_e else None
+        L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
+                 vm, p(z3), p(ssum3), p(ssq3), p(eo3), None, p(wfp), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(z3, z) and torch.equal(ssum3, ssum) and torch.equal(ssq3, ssq) and (not with_e or torch.equal(eo3, eo))
     # the definition, with the weights the kernel multiplies by (W * scale rounded to the storage type) and exact shift terms
     zr = np.empty((n, Lw, cout))
     for t in range(towers):
@@ -121,7 +133,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
         e2, o2 = torch.zeros_like(eo), torch.empty(n, Lw // 2, cout, dtype=tdt, device="cuda")
         ssum2, ssq2 = torch.empty_like(ssum), torch.empty_like(ssq)
         L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)), n, wpt, Lw, cin, cout, vm, None,
-                 p(ssum2), p(ssq2), p(e2), p(o2), stream())
+                 p(ssum2), p(ssq2), p(e2), p(o2), None, stream())
         torch.cuda.synchronize()
         assert torch.equal(e2[:, 1:-1], eo[:, 1:-1]) and torch.equal(ssum2, ssum) and torch.equal(ssq2, ssq)
         ob = o2.view(torch.int16).cpu().numpy().view(np.uint16)

@@ -827,8 +827,15 @@ def test_conv_dgrad_bnred(n, l, cin, cout, padded_a, dt16):
     s0 = torch.full((n * rows, cin), float("nan"), device="cuda")
     s1 = torch.full((n * rows, cin), float("nan"), device="cuda")
     dx = torch.empty(n, l, cin, dtype=tdt, device="cuda")
-    L().call("vm_conv_dgrad_bnred", p(dup), p(wd), n, l, cin, cout, vm, p(dx), p(ap), int(padded_a), p(s0), p(s1), stream())
+    L().call("vm_conv_dgrad_bnred", p(dup), p(wd), n, l, cin, cout, vm, p(dx), p(ap), int(padded_a), p(s0), p(s1), None, stream())
     assert torch.equal(dx, dx0)
+    if L().query("vm_pack_nt_weights_supported", cin, cout, vm):
+        # packed weights (conv_nt3_kernel for 128 / 256 / 384 / 512 channels on the K side): bit-identical dx and partial rows
+        wdp = torch.empty_like(wd)
+        L().call("vm_pack_nt_weights", p(wd), 1, cin, cout, vm, p(wdp), stream())
+        dx3, s03, s13 = torch.empty_like(dx), torch.full_like(s0, float("nan")), torch.full_like(s1, float("nan"))
+        L().call("vm_conv_dgrad_bnred", p(dup), p(wd), n, l, cin, cout, vm, p(dx3), p(ap), int(padded_a), p(s03), p(s13), p(wdp), stream())
+        assert torch.equal(dx3, dx) and torch.equal(s03, s0) and torch.equal(s13, s1)
     d64, a64 = dx.double(), a.double()
     ref0, ref1 = d64.sum(1).cpu().numpy(), (d64 * a64).sum(1).cpu().numpy()
     got0, got1 = s0.view(n, rows, cin).double().sum(1).cpu().numpy(), s1.view(n, rows, cin).double().sum(1).cpu().numpy()
@@ -839,6 +846,25 @@ def test_conv_dgrad_bnred(n, l, cin, cout, padded_a, dt16):
     assert np.abs(got1 - ref1).max() < 2e-6 * scale1
 
 
+@pytest.mark.parametrize("towers,rows,ac", [(1, 128, 32), (2, 256, 128), (1, 384, 256), (1, 512, 384)])
+@pytest.mark.parametrize("dt16", ["bf16", "f16"])
+def test_pack_nt_weights_is_the_fragment_permutation(towers, rows, ac, dt16):
+    """vm_pack_nt_weights: (towers, rows, 3 * a_c) -> [tower][rows / 64][K tile = 3 * chunk + tap][32-row half j][16-channel half ks]
+    [lane = 32 * kh + r][8 values], element (row, tap * a_c + c) with row = 64 b + 32 j + r, c = 32 chunk + 16 ks + 8 kh + e."""
+    vm, tdt = DTYPES[dt16]
+    assert L().query("vm_pack_nt_weights_supported", rows, ac, vm) == 1
+    assert L().query("vm_pack_nt_weights_supported", rows + 64, ac, vm) == 0 and L().query("vm_pack_nt_weights_supported", rows, ac + 8, vm) == 0
+    assert L().query("vm_pack_nt_weights_supported", rows, ac, DTYPES["f32"][0]) == 0
+    src = torch.arange(towers * rows * 3 * ac, device="cuda").remainder(2039).to(tdt).view(towers, rows, 3, ac)   # exact in both types
+    out = torch.empty(towers * rows * 3 * ac, dtype=tdt, device="cuda")
+    L().call("vm_pack_nt_weights", p(src), towers, rows, ac, vm, p(out), stream())
+    want = (src.view(towers, rows // 64, 2, 32, 3, ac // 32, 2, 2, 8)      # t, b, j, r, tap, chunk, ks, kh, e
+            .permute(0, 1, 5, 4, 2, 6, 7, 3, 8).contiguous().view(-1))    # t, b, chunk, tap, j, ks, kh, r, e
+    assert torch.equal(out, want)
+    with pytest.raises(RuntimeError):
+        L().call("vm_pack_nt_weights", p(src), towers, rows, ac + 8, vm, p(out), stream())
+
+
 def test_conv_dgrad_bnred_refuses_unserved_shapes():
     vm, _ = DTYPES["bf16"]
     assert L().query("vm_conv_dgrad_bnred_supported", 2, 300, 136, 64, vm) == 0  # c_in not a multiple of 128
@@ -847,7 +873,7 @@ def test_conv_dgrad_bnred_refuses_unserved_shapes():
     assert L().query("vm_conv_dgrad_bnred_supported", 2, 500, 128, 64, vm) == 1
     d = torch.zeros(16, device="cuda")
     with pytest.raises(RuntimeError):
-        L().call("vm_conv_dgrad_bnred", p(d), p(d), 2, 300, 136, 64, vm, p(d), p(d), 1, p(d), p(d), stream())
+        L().call("vm_conv_dgrad_bnred", p(d), p(d), 2, 300, 136, 64, vm, p(d), p(d), 1, p(d), p(d), None, stream())
 
 
 @pytest.mark.parametrize("n,wpt,l,cin,cout,pool,use_drop", [(4, 2, 508, 128, 256, 2, True), (2, 1, 1016, 256, 128, 4, False),
@@ -880,7 +906,7 @@ def test_bn_bwd_from_sums_equals_pooled_reduce(n, wpt, l, cin, cout, pool, use_d
     rows2 = L().query("vm_conv_dgrad_bnred_rows", lq)
     s0, s1 = (torch.empty(n * rows2, cin, device="cuda") for _ in range(2))
     dp = torch.empty(n, lq, cin, dtype=tdt, device="cuda")
-    L().call("vm_conv_dgrad_bnred", p(dup), p(wd), n, lq, cin, cout, vm, p(dp), p(act), 1, p(s0), p(s1), stream())
+    L().call("vm_conv_dgrad_bnred", p(dup), p(wd), n, lq, cin, cout, vm, p(dp), p(act), 1, p(s0), p(s1), None, stream())
     rows = L().query("vm_bn_part_rows")
     pa0, pb0, pa1, pb1 = (torch.zeros(n * rows, cin, device="cuda") for _ in range(4))
     L().call("vm_bn_pool_bwd_reduce_pooled", p(z), p(act), p(dp), p(scale), p(shift), p(mean), p(invstd), p(drop), n, wpt, l, cin,
@@ -971,7 +997,13 @@ def test_conv_fwd_pool_equals_two_kernel_inference_path(n, l, cin, cout, dt16):
     a0 = torch.zeros(n, lq + 2, cout, dtype=tdt, device="cuda")
     L().call("vm_bn_drop_pool_fwd", p(z), p(scale), p(shift), None, n, n, l, cout, 2, vm, p(a0), stream())
     a1 = torch.full((n, lq + 2, cout), 7.0, dtype=tdt, device="cuda")
-    L().call("vm_conv_fwd_pool", p(xp), p(wf), p(dev(b)), p(scale), p(shift), n, l, cin, cout, vm, p(a1), stream())
+    L().call("vm_conv_fwd_pool", p(xp), p(wf), p(dev(b)), p(scale), p(shift), n, l, cin, cout, vm, p(a1), None, stream())
+    if L().query("vm_pack_nt_weights_supported", cout, cin, vm):   # packed weights: the same bits
+        wfp = torch.empty_like(wf)
+        L().call("vm_pack_nt_weights", p(wf), 1, cout, cin, vm, p(wfp), stream())
+        a3 = torch.full((n, lq + 2, cout), 7.0, dtype=tdt, device="cuda")
+        L().call("vm_conv_fwd_pool", p(xp), p(wf), p(dev(b)), p(scale), p(shift), n, l, cin, cout, vm, p(a3), p(wfp), stream())
+        assert torch.equal(a3, a1)
     if 2 * ((l + 253) // 254) == (l + 127) // 128:
         # vm_conv_fwd runs the same kernel (conv_nt2r_kernel: the same K walk, the same accumulation order) -- every cfg-A layer
         assert torch.equal(a1[:, 1:lq + 1], a0[:, 1:lq + 1])
@@ -993,7 +1025,7 @@ def test_conv_fwd_pool_refuses_unserved_shapes():
     assert L().query("vm_conv_fwd_pool_supported", 2, 300, 128, 128, DTYPES["f32"][0]) == 0
     d = torch.zeros(16, device="cuda")
     with pytest.raises(RuntimeError):
-        L().call("vm_conv_fwd_pool", p(d), p(d), p(d), p(d), p(d), 2, 301, 128, 128, vm, p(d), stream())
+        L().call("vm_conv_fwd_pool", p(d), p(d), p(d), p(d), p(d), 2, 301, 128, 128, vm, p(d), None, stream())
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 508, 128, 256), (2, 254, 32, 128), (2, 1016, 256, 384), (4, 3000, 128, 256), (4, 1500, 256, 384)])

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 5  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 6  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -52,12 +52,14 @@ SIGNATURES = {
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
     "vm_fold_bn_weights": (I, [P, P, P, I, I, I, I, P, P, P]),
     "vm_conv_fwd_fold_supported": (I, [L, L, I, I, I, I]),
-    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P]),
+    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P, P]),
+    "vm_pack_nt_weights_supported": (I, [I, I, I]),
+    "vm_pack_nt_weights": (I, [P, I, I, I, I, P, P]),
     "vm_conv_fwd_pool_supported": (I, [L, L, I, I, I]),
-    "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P]),
+    "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P, P]),
     "vm_conv_dgrad_bnred_rows": (L, [L]),
     "vm_conv_dgrad_bnred_supported": (I, [L, L, I, I, I]),
-    "vm_conv_dgrad_bnred": (I, [P, P, L, L, I, I, I, P, P, I, P, P, P]),
+    "vm_conv_dgrad_bnred": (I, [P, P, L, L, I, I, I, P, P, I, P, P, P, P]),
     "vm_prep_conv_weights_batch": (I, [I, P, P, P, I, P, P, P, P]),
     "vm_conv_wgrad_splits": (I, [L, L, I, I]),
     "vm_conv_wgrad_workspace_bytes": (L, [L, L, I, I]),

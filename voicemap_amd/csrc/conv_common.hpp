@@ -209,6 +209,8 @@ struct NtArgs {
     // t / flat_period, position t % flat_period, and rows with position >= flat_valid -- the halo positions, whose results are junk --
     // are neither stored nor counted; the others go to the UN-padded output row window * flat_valid + position.  0 = off.
     int flat_period = 0, flat_valid = 0;
+    // conv_nt3_kernel: bt in MFMA fragment order (vm_pack_nt_weights; all towers).  NULL: conv_nt2r_kernel streams bt through LDS.
+    const T* bt_packed = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -1115,6 +1115,366 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv_nt3_kernel (round 4): the tile of conv_nt2r_kernel with the WEIGHT operand taken from L2 straight into registers.
+//
+// conv_nt2r_kernel's K loop runs at 1 340 .. 1 410 clocks per K tile against 1 024 of MFMA issue (two waves share a SIMD), and its
+// ablation put 13 % of forward + dgrad on the in-loop weight LDS-DMA alone: a K tile costs a wave 2 weight pieces + 1.3 input pieces of
+// LDS-DMA (~250 clocks of issue each under load), 4 of its 12 fragment reads, and a workgroup barrier whose only purpose is the reuse
+// of the 8 KB weight stages.  The weights are small (0.2 .. 1.2 MB per layer), read by every workgroup and therefore L2-resident.
+// Here vm_pack_nt_weights lays them out in MFMA fragment order -- [tower][64-channel block][K tile][j][k-step][lane][8 values], so
+// that one global_load_dwordx4 of a wave IS one 32 x 16 B fragment, 1 KB contiguous, and a wave's stream is 4 KB per K tile in the
+// order the loop walks -- and the loop keeps three register sets of four fragments: K tile kt multiplies out of set kt % 3 while the
+// loads of K tile kt + 2 fill set (kt + 2) % 3.  What is left in LDS is the input operand: a ring of FOUR 16 KB blocks (256 rows x
+// 32 channels, the layout and swizzle of conv_nt2r_kernel; c_in = 128 -- the block-2 forward -- is resident outright), block
+// c + 3 requested during chunk c, and ONE barrier per chunk (48 MFMAs per wave) instead of one per K tile:
+//   RAW  A(c) was issued three chunks earlier, B(kt) two K tiles earlier; loads return in order, so the counted wait for B(kt) at the
+//        top of iteration kt covers both; the barrier at tap 0 makes the other waves' pieces of A(c) visible.
+//   WAR  A(c + 3) overwrites the block read during chunk c - 1; it is issued after the barrier of chunk c, which a wave passes only
+//        with its chunk c - 1 reads consumed.  Register set (kt + 2) % 3 was consumed by the MFMAs of iteration kt - 1.
+// The global loads are inline asm: beside an LDS-DMA hipcc waits vmcnt(0) before the first use of any ordinary load's result (and it
+// cannot count asm loads at all), so every wait is written by hand from the issue schedule:
+//   iteration kt:  B(kt + 2) [4 loads]  ->  s_waitcnt vmcnt(N)  ->  barrier (tap 0)  ->  A pieces [2; taps 0, 1]  ->  8 ds_read + 16 MFMA
+//   N = loads issued after B(kt) = A pieces of kt - 2  +  B(kt + 1)  +  A pieces of kt - 1  +  B(kt + 2)
+// The epilogue is conv_nt2r_kernel's (n2_epilogue).  Same requirements: a_c % 32 == 0, Ktot == 3 * a_c, N % 128 == 0.
+// ------------------------------------------------------------------------------------------------
+namespace n3 {
+constexpr int NBLK = 4;
+constexpr int A_BLK = 256 * 64;
+static_assert(NBLK * A_BLK <= n2::LDS_BYTES, "the input ring fits under the epilogue tile");
+constexpr int KT_BYTES = 4096;  // one wave's weight fragments of one K tile: [j 2][k-step 2][lane 64][16 B]
+}  // namespace n3
+
+// one fragment: lane l gets the 16 bytes at sbase + imm + l * 16 (voff = l * 16); the result is valid after the counted wait that
+// names the register
+#define VM_GLOAD_FRAG(dst, voff, sbase, imm) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+
+template <int N>
+__device__ inline void n3_wait_b(u32x4 (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+// The issue schedule of conv_nt3_kernel, replayed at compile time: the number of vector-memory operations a wave has issued after
+// the last fragment of B(kt) when it reaches the wait of iteration kt -- the N of that iteration's s_waitcnt vmcnt(N).
+//   prologue   A(0) [4]   B(0) [4]   A(1) [4, chunks > 1]   B(1) [4]   A(2) [4, chunks > 2]
+//   iteration i = 3 c + tap:   B(i + 2) [4, i + 2 < nk]   WAIT   (barrier, tap 0)   A(c + 3) pieces [2, tap < 2 and c + 3 < chunks]
+//   PIPE (the interleaved loop): iteration i:   WAIT   B(i + 2) [4, inside the first eight MFMAs]   A pieces [2, inside the last eight]
+constexpr int n3_nwait(int kt, int chunks, bool pipe = false) {
+    const int nk = 3 * chunks;
+    int after = -1;  // operations issued since B(kt) completed its issue; -1: B(kt) not issued yet
+    auto issue = [&](int count, bool is_bkt) {
+        if (is_bkt) {
+            after = 0;
+        } else if (after >= 0) {
+            after += count;
+        }
+    };
+    issue(4, false);                       // A(0)
+    issue(4, kt == 0);                     // B(0)
+    if (chunks > 1) issue(4, false);       // A(1)
+    issue(4, kt == 1);                     // B(1)
+    if (chunks > 2) issue(4, false);       // A(2)
+    for (int i = 0; i <= kt; ++i) {
+        if (pipe && i == kt) break;        // PIPE: the wait opens the iteration
+        if (i + 2 < nk) issue(4, i + 2 == kt);
+        if (i == kt) break;                // the wait of iteration kt
+        const int c = i / 3, tap = i - 3 * c;
+        if (tap < 2 && c + 3 < chunks) issue(2, false);
+    }
+    return after;
+}
+static_assert(n3_nwait(0, 4) == 16 && n3_nwait(1, 4) == 14 && n3_nwait(2, 4) == 12 && n3_nwait(11, 4) == 0 && n3_nwait(10, 4) == 4,
+              "conv_nt3_kernel wait schedule");
+
+static_assert(n3_nwait(0, 4, true) == 12 && n3_nwait(1, 4, true) == 10 && n3_nwait(2, 4, true) == 8 && n3_nwait(11, 4, true) == 0 &&
+              n3_nwait(5, 8, true) == 8, "conv_nt3_kernel wait schedule (interleaved loop)");
+
+// PIPE: the interleaved K loop (below, VM_KTILE_P); false: the block-structured loop of the first version (kept for the A/B)
+template <typename T, int EPI, int CHUNKS, bool PIPE>
+__global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n_groups) {
+    using namespace n2;
+    using V8 = typename Mfma<T>::Frag;
+    constexpr int A_BLK = n3::A_BLK, NK = 3 * CHUNKS;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+
+    unsigned group;
+    int tn;
+    {
+        const unsigned v = blockIdx.x, tiles_n = (unsigned)p.tilesN;
+        if ((n_groups & 7) == 0) {
+            const unsigned j = v >> 3, q = j / tiles_n;
+            tn = (int)(j - q * tiles_n);
+            group = q * 8 + (v & 7);
+        } else {
+            group = v / tiles_n;
+            tn = (int)(v - group * tiles_n);
+        }
+    }
+    const unsigned nw = group / (unsigned)p.tilesL;
+    const int tl = (int)(group - nw * (unsigned)p.tilesL);
+    const int64_t n = nw;
+    const int t0 = tl * n2r::TROWS, n0 = tn * TN;
+    unsigned tw = 0;
+    if constexpr (EPI == EPI_FWD_FOLD) {  // this window's tower: its folded weights and constants
+        tw = nw / (unsigned)p.tower_windows;
+        p.fold_hb += tw * 3 * p.N;
+    }
+    f32x4 bias4[2][4];
+    n2_load_bias<T, EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
+    f32x4 hb4[EPI == EPI_FWD_FOLD ? 3 : 1][2][4];
+    if constexpr (EPI == EPI_FWD_FOLD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hb4[k][j][g] = *reinterpret_cast<const f32x4*>(p.fold_hb + k * p.N + n0 + wn * 64 + 4 * (lane >> 5) + 32 * j + 8 * g);
+    }
+
+    // ---- input DMA sources (as conv_nt2r_kernel): one instruction = 16 rows x 64 B ----
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const char* a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w + 4 * i) * 16 + lrow;
+        int pr = t0 + row;
+        pr = pr < p.L + 2 ? pr : p.L + 1;
+        a_src[i] = reinterpret_cast<const char*>(p.a + n * p.a_win_stride + (int64_t)pr * p.a_c) + ((lchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    auto issue_a = [&](int blk, int chunk, int i0) {  // pieces i0, i0 + 1 of this wave's four
+        char* base = lds + blk * A_BLK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(a_src[i0 + i] + chunk * KB, base + __builtin_amdgcn_readfirstlane((w + 4 * (i0 + i)) * 1024));
+    };
+    auto issue_a1 = [&](int blk, int chunk, int i) {  // piece i of this wave's four
+        glds16(a_src[i] + chunk * KB, lds + blk * A_BLK + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
+    };
+    // ---- weight stream of this wave: (tower, 64-channel block n0 / 64 + wn), NK x 4 KB, base in SGPRs ----
+    uint64_t bbase;
+    {
+        const uint64_t q = (uint64_t)(uintptr_t)p.bt_packed +
+                           ((uint64_t)tw * (unsigned)(p.N >> 6) + (unsigned)((n0 >> 6) + wn)) * (uint64_t)(NK * n3::KT_BYTES);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        bbase = ((uint64_t)hi << 32) | lo;
+    }
+    const uint32_t bvoff = lane * 16;
+    u32x4 bs[3][4];  // register sets of K tiles kt % 3 = 0, 1, 2: fragments (j, k-step) = 00, 01, 10, 11 (constant indices only)
+#define VM_LOAD_SET(KT)                                                           \
+    {                                                                             \
+        const uint64_t sb_ = bbase + (uint64_t)((KT) * n3::KT_BYTES);             \
+        VM_GLOAD_FRAG(bs[(KT) % 3][0], bvoff, sb_, 0);                            \
+        VM_GLOAD_FRAG(bs[(KT) % 3][1], bvoff, sb_, 1024);                         \
+        VM_GLOAD_FRAG(bs[(KT) % 3][2], bvoff, sb_, 2048);                         \
+        VM_GLOAD_FRAG(bs[(KT) % 3][3], bvoff, sb_, 3072);                         \
+    }
+
+    const int r = lane & 31, kh = lane >> 5;
+    int a_addr[3][2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int row = wm * 128 + r + tap;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_addr[tap][ks] = row * KB + (((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#else
+    const uint32_t lds0 = 0;
+#endif
+
+    // ---- prologue: A(0), B(0), A(1), B(1), A(2) ----
+    issue_a(0, 0, 0);
+    issue_a(0, 0, 2);
+    VM_LOAD_SET(0);
+    if constexpr (CHUNKS > 1) {
+        issue_a(1, 1, 0);
+        issue_a(1, 1, 2);
+    }
+    VM_LOAD_SET(1);
+    if constexpr (CHUNKS > 2) {
+        issue_a(2, 2, 0);
+        issue_a(2, 2, 2);
+    }
+    f32x16 acc[4][2];
+    if constexpr (EPI == EPI_FWD_FOLD) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[j][g] = bias4[j][g] + ((hb4[0][j][g] + hb4[1][j][g]) + hb4[2][j][g]);
+    }
+    n2_fill_acc(acc, bias4);
+#define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
+    // one K tile; KT is a literal: every index, every wait count and every branch below is a compile-time constant, the loop is straight-
+    // line code and no register that a load is still writing ever meets a phi (the rolled form made hipcc copy them)
+#define VM_KTILE(KT)                                                                                                                  \
+    if constexpr ((KT) < NK) {                                                                                                        \
+        constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, ablk_ = c_ % 4;                                  \
+        if constexpr (kt_ + 2 < NK) VM_LOAD_SET(kt_ + 2);                                                                             \
+        n3_wait_b<n3_nwait(kt_, CHUNKS)>(bs[cur_]);                                                                                   \
+        if constexpr (tap_ == 0) __builtin_amdgcn_s_barrier();                                                                        \
+        if constexpr (tap_ < 2 && c_ + 3 < CHUNKS) issue_a((c_ + 3) % 4, c_ + 3, 2 * tap_);                                           \
+        const uint32_t aa0 = lds0 + ablk_ * A_BLK + a_addr[tap_][0], aa1 = lds0 + ablk_ * A_BLK + a_addr[tap_][1];                     \
+        u32x4 f0[4], f1[4];                                                                                                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f0[0]) : "v"(aa0));                                                                 \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f0[1]) : "v"(aa0));                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f0[2]) : "v"(aa0));                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f0[3]) : "v"(aa0));                                                     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f1[0]) : "v"(aa1));                                                                 \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f1[1]) : "v"(aa1));                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f1[2]) : "v"(aa1));                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f1[3]) : "v"(aa1));                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f0[0]));                                                                           \
+        VM_MM(f0[0], bs[cur_][0], 0, 0);                                                                                              \
+        VM_MM(f0[0], bs[cur_][2], 0, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f0[1]));                                                                           \
+        VM_MM(f0[1], bs[cur_][0], 1, 0);                                                                                              \
+        VM_MM(f0[1], bs[cur_][2], 1, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f0[2]));                                                                           \
+        VM_MM(f0[2], bs[cur_][0], 2, 0);                                                                                              \
+        VM_MM(f0[2], bs[cur_][2], 2, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f0[3]));                                                                           \
+        VM_MM(f0[3], bs[cur_][0], 3, 0);                                                                                              \
+        VM_MM(f0[3], bs[cur_][2], 3, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[0]));                                                                           \
+        VM_MM(f1[0], bs[cur_][1], 0, 0);                                                                                              \
+        VM_MM(f1[0], bs[cur_][3], 0, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f1[1]));                                                                           \
+        VM_MM(f1[1], bs[cur_][1], 1, 0);                                                                                              \
+        VM_MM(f1[1], bs[cur_][3], 1, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f1[2]));                                                                           \
+        VM_MM(f1[2], bs[cur_][1], 2, 0);                                                                                              \
+        VM_MM(f1[2], bs[cur_][3], 2, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[3]));                                                                           \
+        VM_MM(f1[3], bs[cur_][1], 3, 0);                                                                                              \
+        VM_MM(f1[3], bs[cur_][3], 3, 1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    }
+    // ---- the interleaved loop.  Every memory operation of a K tile sits INSIDE its MFMA stream, one per pair of MFMAs: the
+    // k-step-1 fragments of this tile and the weight fragments of tile kt + 2 under the k-step-0 MFMAs, the k-step-0 fragments of the
+    // NEXT tile (their registers are free by then) and the input DMA pieces under the k-step-1 MFMAs.  An LDS read has eight MFMAs
+    // (256 clocks) to return, a wave never has an issue-only phase, and LDS returns in order with exactly three reads younger than
+    // the one an MFMA pair needs: every wait is lgkmcnt(3) until the last tile drains.  The chunk barrier moves to the middle of
+    // tap 2 (before the first read of the next block), behind lgkmcnt(0): all reads of this chunk's block have RETURNED when a wave
+    // passes it, so the DMA pieces that recycle the block -- issued at least one tile later -- cannot overtake a read.
+    u32x4 f0[4], f1[4];
+#define VM_FRAG_READ(dst, base, I)                                                              \
+    if constexpr ((I) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(base));          \
+    if constexpr ((I) == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(dst) : "v"(base));
+#define VM_P_STEP0(I)                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f0[I]));                                                                               \
+    VM_MM(f0[I], bs[cur_][0], I, 0);                                                                                                  \
+    VM_MM(f0[I], bs[cur_][2], I, 1);                                                                                                  \
+    VM_FRAG_READ(f1[I], aa1_, I)                                                                                                      \
+    if constexpr (kt_ + 2 < NK) {                                                                                                     \
+        if constexpr ((I) == 0) VM_GLOAD_FRAG(bs[nxt_][0], bvoff, sb_, 0);                                                            \
+        if constexpr ((I) == 1) VM_GLOAD_FRAG(bs[nxt_][1], bvoff, sb_, 1024);                                                         \
+        if constexpr ((I) == 2) VM_GLOAD_FRAG(bs[nxt_][2], bvoff, sb_, 2048);                                                         \
+        if constexpr ((I) == 3) VM_GLOAD_FRAG(bs[nxt_][3], bvoff, sb_, 3072);                                                         \
+    }                                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define VM_P_STEP1(I)                                                                                                                 \
+    if constexpr (kt_ + 1 < NK) {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[I]));                                                                           \
+    } else {                                                                                                                          \
+        if constexpr ((I) == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[I]));                                                   \
+        if constexpr ((I) == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f1[I]));                                                   \
+        if constexpr ((I) == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f1[I]));                                                   \
+        if constexpr ((I) == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[I]));                                                   \
+    }                                                                                                                                 \
+    VM_MM(f1[I], bs[cur_][1], I, 0);                                                                                                  \
+    VM_MM(f1[I], bs[cur_][3], I, 1);                                                                                                  \
+    if constexpr (kt_ + 1 < NK) { VM_FRAG_READ(f0[I], an0_, I) }                                                                      \
+    if constexpr ((I) < 2 && tap_ < 2 && c_ + 3 < CHUNKS) issue_a1((c_ + 3) % 4, c_ + 3, 2 * tap_ + (I));                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define VM_KTILE_P(KT)                                                                                                                \
+    if constexpr ((KT) < NK) {                                                                                                        \
+        constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, nxt_ = (kt_ + 2) % 3, ablk_ = c_ % 4;             \
+        constexpr int nc_ = (kt_ + 1) / 3, ntap_ = (kt_ + 1) - 3 * nc_;   /* chunk and tap of the next tile */                          \
+        n3_wait_b<n3_nwait(kt_, CHUNKS, true)>(bs[cur_]);                                                                             \
+        if constexpr (kt_ == 0) {                                                                                                     \
+            __builtin_amdgcn_s_barrier();                                                                                             \
+            const uint32_t a00_ = lds0 + a_addr[0][0];                                                                                \
+            VM_FRAG_READ(f0[0], a00_, 0) VM_FRAG_READ(f0[1], a00_, 1) VM_FRAG_READ(f0[2], a00_, 2) VM_FRAG_READ(f0[3], a00_, 3)         \
+        }                                                                                                                             \
+        const uint32_t aa1_ = lds0 + ablk_ * A_BLK + a_addr[tap_][1];                                                                  \
+        const uint32_t an0_ = lds0 + (nc_ % 4) * A_BLK + a_addr[ntap_][0];                                                             \
+        const uint64_t sb_ = bbase + (uint64_t)((kt_ + 2) * n3::KT_BYTES);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        VM_P_STEP0(0) VM_P_STEP0(1) VM_P_STEP0(2) VM_P_STEP0(3)                                                                       \
+        if constexpr (tap_ == 2 && kt_ + 1 < NK) {                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));                                 \
+            __builtin_amdgcn_s_barrier();                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        }                                                                                                                             \
+        VM_P_STEP1(0) VM_P_STEP1(1) VM_P_STEP1(2) VM_P_STEP1(3)                                                                       \
+    }
+#define VM_CHUNK(C)                                                              \
+    if constexpr (PIPE) {                                                        \
+        VM_KTILE_P(3 * (C)) VM_KTILE_P(3 * (C) + 1) VM_KTILE_P(3 * (C) + 2)      \
+    } else {                                                                     \
+        VM_KTILE(3 * (C)) VM_KTILE(3 * (C) + 1) VM_KTILE(3 * (C) + 2)            \
+    }
+    VM_CHUNK(0) VM_CHUNK(1) VM_CHUNK(2) VM_CHUNK(3) VM_CHUNK(4) VM_CHUNK(5) VM_CHUNK(6) VM_CHUNK(7)
+    VM_CHUNK(8) VM_CHUNK(9) VM_CHUNK(10) VM_CHUNK(11) VM_CHUNK(12) VM_CHUNK(13) VM_CHUNK(14) VM_CHUNK(15)
+    static_assert(CHUNKS <= 16, "conv_nt3_kernel: at most 16 channel chunks are written out");
+#undef VM_CHUNK
+#undef VM_KTILE
+#undef VM_KTILE_P
+#undef VM_P_STEP0
+#undef VM_P_STEP1
+#undef VM_FRAG_READ
+#undef VM_MM
+#undef VM_LOAD_SET
+    if constexpr (EPI == EPI_FWD_FOLD) {
+        const int c0 = n0 + wn * 64 + 4 * (lane >> 5), rl = p.L - 1 - t0;
+        if (t0 == 0) n2_fold_edge<T>(p, acc, 0, 0, wm, lane & 31, c0);
+        if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
+    }
+    n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+}
+
+// (N, 3 * a_c) row-major GEMM-layout weights (vm_prep_conv_weights' wf / wd, vm_fold_bn_weights' wf_folded; `towers` of them back to
+// back) -> the fragment order conv_nt3_kernel streams: one thread per 16-byte piece of the OUTPUT (coalesced writes; the reads are
+// 16-byte gathers out of L2).  out piece index = ((((t * N/64 + b64) * nk + kt) * 2 + j) * 2 + ks) * 64 + lane.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nt_weights_kernel(const T* __restrict__ bt, int towers, int N, int a_c, T* __restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nk = 3 * (a_c / 32);
+    const int64_t total = (int64_t)towers * N * 3 * a_c / 8;
+    if (o >= total) return;
+    const int lane = (int)(o & 63);
+    int64_t q = o >> 6;
+    const int ks = (int)(q & 1);
+    q >>= 1;
+    const int j = (int)(q & 1);
+    q >>= 1;
+    const int kt = (int)(q % nk);
+    q /= nk;
+    const int b64 = (int)(q % (N / 64));
+    const int t = (int)(q / (N / 64));
+    const int nrow = b64 * 64 + j * 32 + (lane & 31);
+    const int chunk = kt / 3, tap = kt - 3 * chunk;
+    const int col = tap * a_c + chunk * 32 + ks * 16 + (lane >> 5) * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(bt + ((int64_t)t * N + nrow) * (3 * (int64_t)a_c) + col);
+    *reinterpret_cast<u32x4*>(out + o * 8) = v;
+}
+
 #if defined(VM_EXPERIMENT_PROFILE)
 extern "C" int vm_debug_prof_read(unsigned int* out, int n_slots) {  // out: n_slots x 4 host values
     hipDeviceSynchronize();
@@ -1135,6 +1495,8 @@ extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 // switches exist so that the tests can pin the fallback kernels on shapes the default dispatch would give to conv_nt2r_kernel ----
 namespace vm {
 int g_nt_n2 = 3;       // conv_nt2r_kernel for 16-bit storage: bit 0 forward, bit 1 dgrad; vm_set_tuning("nt_n2", 0..3)
+int g_nt3 = 3;         // conv_nt3_kernel (weights L2 -> registers) where the caller supplies packed weights: bit 0 forward, bit 1 dgrad
+int g_nt3_pipe = 3;    // conv_nt3_kernel's interleaved K loop: bit 0 forward, bit 1 dgrad (0: the block-structured loop; A/B only)
 int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0, else register staging; vm_set_tuning("nt_glds", 0 | 1)
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
 extern int g_tn_x, g_tn_tile;  // conv_wgrad.hip
@@ -1155,6 +1517,8 @@ static bool n2r_shape(int64_t n_windows, int64_t L, int ck, int n, bool stats_la
     return n_windows * t254 * (n / n2::TN) < (1LL << 31);
 }
 
+static bool nt3_chunks(int a_c) { return a_c == 128 || a_c == 256 || a_c == 384 || a_c == 512; }
+
 template <typename T, int EPI>
 static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
@@ -1162,6 +1526,21 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
         b.tilesN = a.N / n2::TN;
         b.tilesL = (a.L + n2r::TROWS - 1) / n2r::TROWS;
         const int64_t n_groups = n_windows * b.tilesL;
+        if constexpr (EPI != EPI_FWD) {  // the entry points that take packed weights (vm_pack_nt_weights)
+            if (b.bt_packed != nullptr && (g_nt3 & (EPI == EPI_DGRAD ? 2 : 1)) && nt3_chunks(a.a_c)) {
+                const dim3 grid((unsigned)(n_groups * b.tilesN));
+#define VM_NT3(CH, PIPE) hipLaunchKernelGGL((conv_nt3_kernel<T, EPI, CH, PIPE>), grid, dim3(256), 0, stream, b, n_groups)
+                const bool pipe = (g_nt3_pipe & (EPI == EPI_DGRAD ? 2 : 1)) != 0;
+                switch (a.a_c / 32) {  // the K loop is written out per channel count: 128, 256, 384, 512 channels on the K side
+                    case 4: if (pipe) VM_NT3(4, true); else VM_NT3(4, false); break;
+                    case 8: if (pipe) VM_NT3(8, true); else VM_NT3(8, false); break;
+                    case 12: if (pipe) VM_NT3(12, true); else VM_NT3(12, false); break;
+                    default: if (pipe) VM_NT3(16, true); else VM_NT3(16, false); break;
+                }
+#undef VM_NT3
+                return;
+            }
+        }
         hipLaunchKernelGGL((conv_nt2r_kernel<T, EPI>), dim3((unsigned)(n_groups * b.tilesN)), dim3(256), 0, stream, b, n_groups);
     }
 }
@@ -1313,7 +1692,7 @@ extern "C" int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in
 
 extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                                 int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z,
-                                float* stat_sum, float* stat_sq, void* e, void* o, void* stream) {
+                                float* stat_sum, float* stat_sq, void* e, void* o, const void* wf_packed, void* stream) {
     VM_REQUIRE(in_e && wf_folded && bias && hb && stat_sum && stat_sq, "vm_conv_fwd_fold: null pointer");
     VM_REQUIRE(e == nullptr || gamma != nullptr, "vm_conv_fwd_fold: the pool extreme needs gamma (its sign picks max / min)");
     VM_REQUIRE(o == nullptr || e != nullptr, "vm_conv_fwd_fold: o (the other element of each pair) goes with e");
@@ -1334,6 +1713,7 @@ extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const f
         a.pool_e = (T*)e;
         a.pool_o = (T*)o;
         a.pool_e_pad = 1;
+        a.bt_packed = (const T*)wf_packed;
         launch_n2r<T, EPI_FWD_FOLD>(a, n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd_fold");
@@ -1345,7 +1725,8 @@ extern "C" int vm_conv_fwd_pool_supported(int64_t n_windows, int64_t L, int c_in
 }
 
 extern "C" int vm_conv_fwd_pool(const void* in, const void* wf, const float* bias, const float* scale, const float* shift,
-                                int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, void* stream) {
+                                int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, void* act, const void* wf_packed,
+                                void* stream) {
     VM_REQUIRE(in && wf && bias && scale && shift && act, "vm_conv_fwd_pool: null pointer");
     VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_fwd_pool: bad sizes");
     VM_REQUIRE((L + 2) * (int64_t)c_in < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_fwd_pool: window too large");
@@ -1357,6 +1738,7 @@ extern "C" int vm_conv_fwd_pool(const void* in, const void* wf, const float* bia
         NtArgs<T> a = fwd_args<T>(in, wf, bias, act, nullptr, nullptr, L, c_in, c_out, dtype);
         a.aff_scale = scale;
         a.aff_shift = shift;
+        a.bt_packed = (const T*)wf_packed;
         launch_n2r<T, EPI_FWD_POOL>(a, n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd_pool");
@@ -1370,7 +1752,8 @@ extern "C" int vm_conv_dgrad_bnred_supported(int64_t n_windows, int64_t L, int c
 }
 
 extern "C" int vm_conv_dgrad_bnred(const void* du, const void* wd, int64_t n_windows, int64_t L, int c_in, int c_out, int dtype,
-                                   void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, void* stream) {
+                                   void* dx, const void* red_a, int red_a_padded, float* red_s0, float* red_s1, const void* wd_packed,
+                                   void* stream) {
     VM_REQUIRE(du && wd && dx && red_a && red_s0 && red_s1, "vm_conv_dgrad_bnred: null pointer");
     VM_REQUIRE(n_windows > 0 && L > 0, "vm_conv_dgrad_bnred: bad sizes");
     VM_REQUIRE((L + 2) * (int64_t)c_out < (1LL << 31) && 3LL * c_in * c_out < (1LL << 31), "vm_conv_dgrad_bnred: window too large");
@@ -1385,15 +1768,36 @@ extern "C" int vm_conv_dgrad_bnred(const void* du, const void* wd, int64_t n_win
         a.red_a = (const T*)red_a;
         a.red_a_win_stride = (L + (red_a_padded ? 2 : 0)) * (int64_t)c_in;
         a.red_a_row0 = red_a_padded ? 1 : 0;
+        a.bt_packed = (const T*)wd_packed;
         launch_n2r<T, EPI_DGRAD>(a, n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_dgrad_bnred");
 }
 
+// ---- (rows, 3 * a_c) GEMM-layout weights -> the fragment order of conv_nt3_kernel (same bytes, permuted) ----
+extern "C" int vm_pack_nt_weights_supported(int n_rows, int a_c, int dtype) {
+    return (is16(dtype) && n_rows > 0 && a_c > 0 && n_rows % n2::TN == 0 && a_c % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int vm_pack_nt_weights(const void* bt, int towers, int n_rows, int a_c, int dtype, void* packed, void* stream) {
+    VM_REQUIRE(bt && packed, "vm_pack_nt_weights: null pointer");
+    VM_REQUIRE(towers > 0, "vm_pack_nt_weights: bad sizes");
+    if (!vm_pack_nt_weights_supported(n_rows, a_c, dtype)) {
+        set_error("vm_pack_nt_weights: 16-bit storage, rows %% 128 == 0 and channels %% 32 == 0 only (ask vm_pack_nt_weights_supported)");
+        return VM_ERR_UNSUPPORTED;
+    }
+    const int64_t pieces = (int64_t)towers * n_rows * 3 * a_c / 8;
+    VM_DISPATCH_16(dtype, {
+        hipLaunchKernelGGL((pack_nt_weights_kernel<T>), dim3((unsigned)cdiv(pieces, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)bt, towers, n_rows, a_c, (T*)packed);
+    });
+    return check_launch("vm_pack_nt_weights");
+}
+
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_pipe", &g_nt3_pipe, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;

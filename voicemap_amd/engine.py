@@ -169,6 +169,17 @@ class HipEncoderEngine:
             self.wd[i] = torch.empty(cin * 3 * cout, dtype=self.tdt, device=dev)
             if self.is16 and self.nb - 1 <= 8:
                 self.wt[i] = torch.empty(cout * 3 * cin, dtype=torch.float32, device=dev)
+        # round 4: the same weights in MFMA fragment order (vm_pack_nt_weights) -- the forward / dgrad GEMMs then take them from L2
+        # straight into registers (conv_nt3_kernel) instead of staging them in LDS; only where the library serves the shape
+        self.packed_weights = self.is16
+        self.wfp: Dict[int, torch.Tensor] = {}   # packed wf (inference forward)
+        self.wdp: Dict[int, torch.Tensor] = {}   # packed wd (dgrad)
+        for i in range(1, self.nb):
+            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            if self.is16 and self.lib.query("vm_pack_nt_weights_supported", cout, cin, self.dtype):
+                self.wfp[i] = torch.empty(cout * 3 * cin, dtype=self.tdt, device=dev)
+            if self.is16 and self.lib.query("vm_pack_nt_weights_supported", cin, cout, self.dtype):
+                self.wdp[i] = torch.empty(cin * 3 * cout, dtype=self.tdt, device=dev)
         self._sq_ws = torch.empty(self.lib.query("vm_sqnorm_workspace_bytes", self.n_flat) // 8, dtype=torch.float64, device=dev)
         self._sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         # Adam(clipnorm=1.) defaults of the reference scripts
@@ -408,6 +419,7 @@ class HipEncoderEngine:
                 cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
                 self._call("vm_prep_conv_weights", _p(self.view(f"conv{i+1}.kernel")), cin, cout, self.dtype,
                            _p(self.wf[i]), _p(self.wd[i]), self.stream())
+            self._pack_weights()
             return
         if getattr(self, "_prep_args", None) is None:  # the flat buffers never move: build the pointer tables once
             vp, ci = ctypes.c_void_p * nl, ctypes.c_int * nl
@@ -418,6 +430,18 @@ class HipEncoderEngine:
                                vp(*[_p(self.wt[i]) for i in range(1, self.nb)]) if self.wt else None)
         w, cin, cout, wf, wd, wt = self._prep_args
         self._call("vm_prep_conv_weights_batch", nl, w, cin, cout, self.dtype, wf, wd, wt, self.stream())
+        self._pack_weights()
+
+    def _pack_weights(self):
+        """wf / wd -> their fragment-order copies (after every refresh of the GEMM-layout copies)."""
+        if not getattr(self, "packed_weights", False):
+            return
+        for i in range(1, self.nb):
+            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            if i in self.wfp:
+                self._call("vm_pack_nt_weights", _p(self.wf[i]), 1, cout, cin, self.dtype, _p(self.wfp[i]), self.stream())
+            if i in self.wdp:
+                self._call("vm_pack_nt_weights", _p(self.wd[i]), 1, cin, cout, self.dtype, _p(self.wdp[i]), self.stream())
 
     # ------------------------------------------------------------------------------------------------
     def lengths(self, l0: int) -> List[int]:
@@ -547,8 +571,10 @@ class HipEncoderEngine:
         """Per tower: the folded forward weights of block i (0-based) and the per-tap constants hb (3, c_out)."""
         if i not in self._fold:
             cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
+            packed = self.packed_weights and self.lib.query("vm_pack_nt_weights_supported", cout, cin, self.dtype)
             self._fold[i] = (torch.empty(2, cout * 3 * cin, dtype=self.tdt, device=self.device),
-                             torch.empty(2, 3, cout, dtype=torch.float32, device=self.device))
+                             torch.empty(2, 3, cout, dtype=torch.float32, device=self.device),
+                             torch.empty(2, cout * 3 * cin, dtype=self.tdt, device=self.device) if packed else None)
         return self._fold[i]
 
     def _fold_plan(self, pl: dict):
@@ -686,21 +712,24 @@ class HipEncoderEngine:
                     # two-kernel path below); the last block's GlobalMaxPool1D then runs on its pooled tensor
                     self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
                     self._call("vm_conv_fwd_pool", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, _p(b["scale"]), _p(b["shift"]), nw, L, cin,
-                               c, dt, W(b["act"]), st)
+                               c, dt, W(b["act"]), _p(self.wfp.get(i)) if self.packed_weights else None, st)
                     continue
                 b["e_now"] = b["pairs_now"] = False
                 if fold:
                     # the BatchNorm affine of the block below (this tower's) goes into this block's weights, the conv reads that
                     # block's pool extreme and leaves its own; no pass in between
                     lo = pl[i - 1]
-                    wfo, hbo = self._fold_bufs(i)
+                    wfo, hbo, wfp = self._fold_bufs(i)
                     with_e = i < self.nb - 1
                     self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), ntw, cin, c, dt,
                                wfo[tw0].data_ptr(), hbo[tw0].data_ptr(), st)
+                    use_packed = wfp is not None and self.packed_weights
+                    if use_packed:
+                        self._call("vm_pack_nt_weights", wfo[tw0].data_ptr(), ntw, c, cin, dt, wfp[tw0].data_ptr(), st)
                     pairs = with_e and self.fold_pairs
                     self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
                                nw, wpt, L, cin, c, dt, None if pairs else W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None,
-                               W(b["o"]) if pairs else None, st)
+                               W(b["o"]) if pairs else None, wfp[tw0].data_ptr() if use_packed else None, st)
                     b["e_now"], b["pairs_now"] = with_e, pairs
                     if with_e:
                         finalize()
@@ -886,7 +915,7 @@ class HipEncoderEngine:
                     use_e = (i == 1 and self.fuse_block1) or bool(lo.get("e_now"))   # the extreme itself, else the pooled output
                     red_a, padded = (lo["ep"], 1) if fold else ((lo["e"], 0) if use_e else (lo["act"], 1))
                     self._call("vm_conv_dgrad_bnred", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), _p(red_a), padded,
-                               _p(lo["rs0"]), _p(lo["rs1"]), st)
+                               _p(lo["rs0"]), _p(lo["rs1"]), _p(self.wdp.get(i)) if self.packed_weights else None, st)
                 else:
                     self._call("vm_conv_dgrad", _p(b["du"]), _p(self.wd[i]), n, L, cin, c, dt, _p(lo["dp"]), st)
                 if late:
