@@ -157,8 +157,11 @@ int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float
  *     hb[k][co] = sum_ci W[k][ci][co] * shift[ci];   tap 0 is outside the window at t = 0, tap 2 at t = L - 1 (SAME pads y with 0).
  * BatchNorm statistics are per encoder call ("tower": windows [t * windows_per_tower, (t + 1) * windows_per_tower)), so there is one
  * set of folded weights per tower.  vm_fold_bn_weights: wt = the fp32 kernel in wf's layout (c_out, 3 * c_in) (the `wt` output of
- * vm_prep_conv_weights_batch) + scale / shift (towers, c_in) -> wf_folded (towers, c_out, 3 * c_in) `dtype` and hb (towers, 3, c_out)
- * fp32.  vm_conv_fwd_fold: in_e = padded extreme (n_windows, L + 2, c_in) of the layer below (zero halo
+ * vm_prep_conv_weights_batch) + scale / shift (towers, c_in) + the layer's bias (c_out) -> wf_folded (towers, c_out, 3 * c_in) `dtype`
+ * and / or wf_packed (the same values in vm_pack_nt_weights' fragment order; either may be NULL) and hb (towers, 4, c_out) fp32: rows
+ * 0..2 the per-tap constants, row 3 = bias + their sum (what the accumulators of vm_conv_fwd_fold start from).  vm_conv_fwd_fold: hb
+ * as written by vm_fold_bn_weights (its `bias` argument is not read: row 3 of hb carries it); wf_packed (optional): the fragment-
+ * order copy, used where the shape has a conv_nt3_kernel (128 / 256 / 384 / 512 input channels);  in_e = padded extreme (n_windows, L + 2, c_in) of the layer below (zero halo
  * rows), z / stat_* as vm_conv_fwd; e (optional) = this layer's own extreme for MaxPool1D(2), PADDED (n_windows, L/2 + 2, c_out), the
  * maximum where gamma >= 0 else the minimum.  16-bit storage, conv_nt2r_kernel shapes only (vm_conv_fwd_fold_supported).  The
  * pooled BatchNorm output is never materialised: -1 read and -1 write of it per block and no pass over z in the forward.
@@ -167,8 +170,8 @@ int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float
  * together are z, so with o given z is NOT written and may be NULL -- the epilogue stores as many bytes as a plain forward --
  * and the backward takes the pair form (vm_bn_pool_bwd_apply_pairs).
  * vm_conv_wgrad_fold is the matching weight gradient, vm_conv_dgrad[_bnred] is unchanged (it takes the un-folded wd). */
-int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, int towers, int c_in, int c_out, int dtype,
-                       void* wf_folded, float* hb, void* stream);
+int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, const float* bias, int towers, int c_in, int c_out,
+                       int dtype, void* wf_folded, void* wf_packed, float* hb, void* stream);
 int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e);
 int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                      int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z, float* stat_sum,
@@ -182,6 +185,9 @@ int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias,
  * kernel.  Same results bit for bit (the same products in the same order).  16-bit storage, n_rows % 128 == 0, a_c % 32 == 0. */
 int vm_pack_nt_weights_supported(int n_rows, int a_c, int dtype);
 int vm_pack_nt_weights(const void* bt, int towers, int n_rows, int a_c, int dtype, void* packed, void* stream);
+/* the same for n (<= 8) matrices in ONE launch: host arrays, one entry per matrix. */
+int vm_pack_nt_weights_batch(int n, const void* const* bt, const int* towers, const int* n_rows, const int* a_c, int dtype,
+                             void* const* packed, void* stream);
 /* inference-mode forward of a whole block in one launch: Conv1D + bias + ReLU, the BatchNorm affine (scale / shift per channel from
  * vm_bn_infer_affine: (c_out) floats each) and MaxPool1D(2), models.py:22-35 with learning_phase 0.  act: padded pooled output
  * (n_windows, L/2 + 2, c_out), halo rows untouched; the conv output z is never written.  Bit-identical to vm_conv_fwd followed by

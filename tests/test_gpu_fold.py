@@ -18,18 +18,21 @@ pytestmark = pytest.mark.gpu
 DT16 = ["f16", "bf16"]
 
 
-def _fold_weights(w, s, h, dtype):
-    """w (3, c_in, c_out) Keras kernel, s / h (towers, c_in) or (c_in,) -> wf (towers, c_out, 3 * c_in), hb (towers, 3, c_out)."""
+def _fold_weights(w, s, h, dtype, bias=None, packed=False):
+    """w (3, c_in, c_out) Keras kernel, s / h (towers, c_in) or (c_in,) -> wf (towers, c_out, 3 * c_in), hb (towers, 4, c_out): rows
+    0..2 the per-tap constants, row 3 = bias + their sum (``packed``: also the fragment-order copy vm_fold_bn_weights writes itself)."""
     vm, tdt = DTYPES[dtype]
     cin, cout = w.shape[1], w.shape[2]
     s, h = np.atleast_2d(s), np.atleast_2d(h)
     towers = s.shape[0]
+    bias = np.zeros(cout, np.float32) if bias is None else bias
     wt = np.ascontiguousarray(w.transpose(2, 0, 1).reshape(cout, 3 * cin))   # the `wt` output of vm_prep_conv_weights_batch
     wf = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda")
-    hb = torch.empty(towers, 3, cout, dtype=torch.float32, device="cuda")
-    L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), towers, cin, cout, vm, p(wf), p(hb), stream())
+    wfp = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda") if packed else None
+    hb = torch.empty(towers, 4, cout, dtype=torch.float32, device="cuda")
+    L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), p(dev(bias)), towers, cin, cout, vm, p(wf), p(wfp), p(hb), stream())
     torch.cuda.synchronize()
-    return wf, hb
+    return (wf, hb, wfp) if packed else (wf, hb)
 
 
 @pytest.mark.parametrize("dtype", DT16)
@@ -39,7 +42,8 @@ def test_fold_bn_weights(dtype, cin, cout):
     w = r.normal(0, 0.1, (3, cin, cout)).astype(np.float32)
     s = r.normal(0, 2.0, (2, cin)).astype(np.float32)
     h = r.normal(0, 1.0, (2, cin)).astype(np.float32)
-    wf, hb = _fold_weights(w, s, h, dtype)
+    bias = r.normal(0, 0.3, cout).astype(np.float32)
+    wf, hb = _fold_weights(w, s, h, dtype, bias)
     for t in range(2):
         # the fp32 product rounded to the storage type, or -- where the compiler picks a mixed-precision fma (v_fma_mixlo_f16) -- the
         # exact product rounded once; the two differ only on double-rounding ties
@@ -51,7 +55,15 @@ def test_fold_bn_weights(dtype, cin, cout):
         ulp = (2.0 ** -10 if dtype == "f16" else 2.0 ** -7) * np.abs(want)
         assert ok.mean() > 0.999 and (np.abs(got - want) <= ulp + 6.2e-5).all(), (got[~ok][:8], want[~ok][:8], want1[~ok][:8])
         hb_ref = np.einsum("kio,i->ko", w.astype(np.float64), h[t].astype(np.float64))
-        assert np.abs(hb[t].cpu().numpy() - hb_ref).max() < 1e-5 * max(1.0, np.abs(hb_ref).max())
+        hbt = hb[t].cpu().numpy()
+        assert np.abs(hbt[:3] - hb_ref).max() < 1e-5 * max(1.0, np.abs(hb_ref).max())
+        assert np.array_equal(hbt[3], bias + ((hbt[0] + hbt[1]) + hbt[2]))      # the accumulators' start value, in the kernel's own order
+    if L().query("vm_pack_nt_weights_supported", cout, cin, DTYPES[dtype][0]):
+        # the fragment-order copy written by the fold kernel itself == vm_pack_nt_weights of its row-major output
+        wf2, hb2, wfp = _fold_weights(w, s, h, dtype, bias, packed=True)
+        want = torch.empty_like(wf2)
+        L().call("vm_pack_nt_weights", p(wf2), 2, cout, cin, DTYPES[dtype][0], p(want), stream())
+        assert torch.equal(wf2, wf) and torch.equal(hb2, hb) and torch.equal(wfp.view(-1), want.view(-1))
 
 
 def _fold_case(r, n, Lw, cin, cout, dtype):
@@ -86,7 +98,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
     wpt = n // towers
     s = np.stack([s, (s * r.normal(1.0, 0.2, cin)).astype(np.float32)][:towers])
     h = np.stack([h, (h + r.normal(0.0, 0.3, cin)).astype(np.float32)][:towers])
-    wf, hb = _fold_weights(w, s, h, dtype)
+    wf, hb = _fold_weights(w, s, h, dtype, bias)
     rows = L().query("vm_conv_stat_rows", Lw)
     z = torch.empty(n, Lw, cout, dtype=tdt, device="cuda")
     ssum = torch.empty(n * rows, cout, dtype=torch.float32, device="cuda")

@@ -50,11 +50,12 @@ SIGNATURES = {
     "vm_conv_fwd_flat": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_fwd_e_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
-    "vm_fold_bn_weights": (I, [P, P, P, I, I, I, I, P, P, P]),
+    "vm_fold_bn_weights": (I, [P, P, P, P, I, I, I, I, P, P, P, P]),
     "vm_conv_fwd_fold_supported": (I, [L, L, I, I, I, I]),
     "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P, P]),
     "vm_pack_nt_weights_supported": (I, [I, I, I]),
     "vm_pack_nt_weights": (I, [P, I, I, I, I, P, P]),
+    "vm_pack_nt_weights_batch": (I, [I, P, P, P, P, I, P, P]),
     "vm_conv_fwd_pool_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_pool": (I, [P, P, P, P, P, L, L, I, I, I, P, P, P]),
     "vm_conv_dgrad_bnred_rows": (L, [L]),

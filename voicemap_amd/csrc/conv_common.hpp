@@ -197,12 +197,13 @@ struct NtArgs {
     // second element of the pair (z >= 0 after ReLU, so the bit is free) -- (pool_e, pool_o) then hold all of z and `out` is not written
     T* pool_o = nullptr;
     // EPI_FWD_FOLD = EPI_FWD with the BatchNorm affine of the layer below folded into the weights (vm_conv_fwd_fold): the
-    // input is the pool extreme e of that layer, bt holds W * scale[ci], and fold_hb (3, N) the per-tap constants
-    // hb[k][co] = sum_ci W[k][ci][co] * shift[ci].  Accumulators start at bias + hb[0] + hb[1] + hb[2]; position 0 of a window has no
-    // tap 0 and position L - 1 no tap 2 (the SAME padding pads the BatchNorm OUTPUT with zeros), so hb[0] / hb[2] come off there.
+    // input is the pool extreme e of that layer, bt holds W * scale[ci], and fold_hb (4, N) the per-tap constants
+    // hb[k][co] = sum_ci W[k][ci][co] * shift[ci] (rows 0..2) and row 3 = bias + hb[0] + hb[1] + hb[2], which the accumulators start
+    // at; position 0 of a window has no tap 0 and position L - 1 no tap 2 (the SAME padding pads the BatchNorm OUTPUT with zeros), so
+    // hb[0] / hb[2] come off there.
     const float* fold_hb = nullptr;
     // ... per tower (BatchNorm statistics are per encoder call): windows [t * tower_windows, (t + 1) * tower_windows) use the weights at
-    // bt + t * bt_tower_stride and the constants at fold_hb + t * 3 * N
+    // bt + t * bt_tower_stride and the constants at fold_hb + t * 4 * N
     int64_t tower_windows = 0, bt_tower_stride = 0;
     // vm_conv_fwd_flat (the 128-row kernels' epilogues): the input is the concatenation of windows of flat_valid positions, each with
     // its two zero halo rows (flat_period = flat_valid + 2 rows per window), run as ONE window; tile row t belongs to window

@@ -910,22 +910,12 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
     if constexpr (EPI == EPI_FWD_FOLD) {  // this window's tower: its folded weights and constants
         const unsigned tw = nw / (unsigned)p.tower_windows;
         p.bt += tw * p.bt_tower_stride;
-        p.fold_hb += tw * 3 * p.N;
+        p.fold_hb += tw * 4 * p.N;
     }
     // forward: the bias loads go out first and are consumed (accumulator init) only after the prologue DMA has been issued
     f32x4 bias4[2][4];
+    if constexpr (EPI == EPI_FWD_FOLD) p.bias = p.fold_hb + 3 * p.N;  // row 3 of hb: bias + the three per-tap constants (vm_fold_bn_weights)
     n2_load_bias<T, EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
-    // vm_conv_fwd_fold: the three per-tap constants of these channels, summed into the bias after the prologue DMA is out
-    f32x4 hb4[EPI == EPI_FWD_FOLD ? 3 : 1][2][4];
-    if constexpr (EPI == EPI_FWD_FOLD) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hb4[k][j][g] = *reinterpret_cast<const f32x4*>(p.fold_hb + k * p.N + n0 + wn * 64 + 4 * (lane >> 5) + 32 * j + 8 * g);
-    }
 
     // ---- DMA sources: one instruction = 16 rows x 64 B; A block row R <-> padded input row t0 + R (clamped to the L + 2 rows) ----
     const int lrow = lane >> 2, lchunk = lane & 3;
@@ -989,13 +979,6 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
     issue_b(1, row_bytes);  // K tile 1 = (chunk 0, tap 1)
     VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
     f32x16 acc[4][2];
-    if constexpr (EPI == EPI_FWD_FOLD) {
-        __builtin_amdgcn_sched_barrier(0);  // the sums wait for their loads: keep them behind the DMA issue
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bias4[j][g] = bias4[j][g] + ((hb4[0][j][g] + hb4[1][j][g]) + hb4[2][j][g]);
-    }
     n2_fill_acc(acc, bias4);
     int n_wait = (chunks > 1 ? 4 : 0) + 2;  // pieces issued after B(0)
     int ia_prev = 0;                        // A pieces issued in the previous iteration (after its B pieces)
@@ -1194,6 +1177,7 @@ static_assert(n3_nwait(0, 4, true) == 12 && n3_nwait(1, 4, true) == 10 && n3_nwa
 // PIPE: the interleaved K loop (below, VM_KTILE_P); false: the block-structured loop of the first version (kept for the A/B)
 template <typename T, int EPI, int CHUNKS, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n_groups) {
+    VM_PROF(const long long pt_start = __builtin_amdgcn_s_memtime(); long long pt_first = 0, pt_bar = 0;)
     using namespace n2;
     using V8 = typename Mfma<T>::Frag;
     constexpr int A_BLK = n3::A_BLK, NK = 3 * CHUNKS;
@@ -1221,20 +1205,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     unsigned tw = 0;
     if constexpr (EPI == EPI_FWD_FOLD) {  // this window's tower: its folded weights and constants
         tw = nw / (unsigned)p.tower_windows;
-        p.fold_hb += tw * 3 * p.N;
+        p.fold_hb += tw * 4 * p.N;
     }
     f32x4 bias4[2][4];
+    if constexpr (EPI == EPI_FWD_FOLD) p.bias = p.fold_hb + 3 * p.N;  // row 3 of hb: bias + the three per-tap constants (vm_fold_bn_weights)
     n2_load_bias<T, EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
-    f32x4 hb4[EPI == EPI_FWD_FOLD ? 3 : 1][2][4];
-    if constexpr (EPI == EPI_FWD_FOLD) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hb4[k][j][g] = *reinterpret_cast<const f32x4*>(p.fold_hb + k * p.N + n0 + wn * 64 + 4 * (lane >> 5) + 32 * j + 8 * g);
-    }
 
     // ---- input DMA sources (as conv_nt2r_kernel): one instruction = 16 rows x 64 B ----
     const int lrow = lane >> 2, lchunk = lane & 3;
@@ -1287,6 +1262,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     const uint32_t lds0 = 0;
 #endif
 
+    VM_PROF(const long long pt_s2 = __builtin_amdgcn_s_memtime();)
     // ---- prologue: A(0), B(0), A(1), B(1), A(2) ----
     issue_a(0, 0, 0);
     issue_a(0, 0, 2);
@@ -1300,14 +1276,8 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         issue_a(2, 2, 0);
         issue_a(2, 2, 2);
     }
+    VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
     f32x16 acc[4][2];
-    if constexpr (EPI == EPI_FWD_FOLD) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bias4[j][g] = bias4[j][g] + ((hb4[0][j][g] + hb4[1][j][g]) + hb4[2][j][g]);
-    }
     n2_fill_acc(acc, bias4);
 #define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
     // one K tile; KT is a literal: every index, every wait count and every branch below is a compile-time constant, the loop is straight-
@@ -1409,6 +1379,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         n3_wait_b<n3_nwait(kt_, CHUNKS, true)>(bs[cur_]);                                                                             \
         if constexpr (kt_ == 0) {                                                                                                     \
             __builtin_amdgcn_s_barrier();                                                                                             \
+            VM_PROF(pt_bar = __builtin_amdgcn_s_memtime();)                                                                           \
             const uint32_t a00_ = lds0 + a_addr[0][0];                                                                                \
             VM_FRAG_READ(f0[0], a00_, 0) VM_FRAG_READ(f0[1], a00_, 1) VM_FRAG_READ(f0[2], a00_, 2) VM_FRAG_READ(f0[3], a00_, 3)         \
         }                                                                                                                             \
@@ -1423,6 +1394,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
             __builtin_amdgcn_sched_barrier(0);                                                                                        \
         }                                                                                                                             \
         VM_P_STEP1(0) VM_P_STEP1(1) VM_P_STEP1(2) VM_P_STEP1(3)                                                                       \
+        VM_PROF(if (kt_ == 0) pt_first = __builtin_amdgcn_s_memtime();)                                                               \
     }
 #define VM_CHUNK(C)                                                              \
     if constexpr (PIPE) {                                                        \
@@ -1446,14 +1418,42 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         if (t0 == 0) n2_fold_edge<T>(p, acc, 0, 0, wm, lane & 31, c0);
         if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
     }
+    VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
     n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+#if defined(VM_EXPERIMENT_PROFILE)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long pt_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
+            q[0] = (unsigned int)(pt_end - pt_start);    // the whole wave-tile (incl. the drain of its stores)
+            q[1] = (unsigned int)(pt_first - pt_start);  // start -> end of the first K tile
+            q[2] = (unsigned int)(pt_loop - pt_first);   // the other nk - 1 K tiles
+            q[3] = (unsigned int)(pt_end - pt_loop);     // epilogue + store drain
+            q[4] = (unsigned int)(pt_s2 - pt_start);     // tile coordinates, bias loads, DMA / fragment addresses
+            q[5] = (unsigned int)(pt_s3 - pt_s2);        // issue of the prologue DMA / weight loads
+            q[6] = (unsigned int)(pt_bar - pt_s3);       // accumulator init, first data wait, first barrier
+            q[7] = (unsigned int)(pt_first - pt_bar);    // fragment reads + 16 MFMAs of the first K tile
+        }
+    }
+#endif
 }
 
 // (N, 3 * a_c) row-major GEMM-layout weights (vm_prep_conv_weights' wf / wd, vm_fold_bn_weights' wf_folded; `towers` of them back to
 // back) -> the fragment order conv_nt3_kernel streams: one thread per 16-byte piece of the OUTPUT (coalesced writes; the reads are
 // 16-byte gathers out of L2).  out piece index = ((((t * N/64 + b64) * nk + kt) * 2 + j) * 2 + ks) * 64 + lane.
+constexpr int PACK_MAX = 8;
+struct PackBatch {   // several matrices in one launch (blockIdx.y): the wd copies of an encoder after every optimizer step
+    const void* bt[PACK_MAX];
+    void* out[PACK_MAX];
+    int towers[PACK_MAX], rows[PACK_MAX], a_c[PACK_MAX];
+};
 template <typename T>
-__global__ __launch_bounds__(256) void pack_nt_weights_kernel(const T* __restrict__ bt, int towers, int N, int a_c, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack_nt_weights_kernel(PackBatch pb) {
+    const int m = blockIdx.y;
+    const T* __restrict__ bt = (const T*)pb.bt[m];
+    T* __restrict__ out = (T*)pb.out[m];
+    const int towers = pb.towers[m], N = pb.rows[m], a_c = pb.a_c[m];
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int nk = 3 * (a_c / 32);
     const int64_t total = (int64_t)towers * N * 3 * a_c / 8;
@@ -1787,11 +1787,42 @@ extern "C" int vm_pack_nt_weights(const void* bt, int towers, int n_rows, int a_
         return VM_ERR_UNSUPPORTED;
     }
     const int64_t pieces = (int64_t)towers * n_rows * 3 * a_c / 8;
+    PackBatch pb;
+    pb.bt[0] = bt;
+    pb.out[0] = packed;
+    pb.towers[0] = towers;
+    pb.rows[0] = n_rows;
+    pb.a_c[0] = a_c;
     VM_DISPATCH_16(dtype, {
-        hipLaunchKernelGGL((pack_nt_weights_kernel<T>), dim3((unsigned)cdiv(pieces, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)bt, towers, n_rows, a_c, (T*)packed);
+        hipLaunchKernelGGL((pack_nt_weights_kernel<T>), dim3((unsigned)cdiv(pieces, 256), 1), dim3(256), 0, (hipStream_t)stream, pb);
     });
     return check_launch("vm_pack_nt_weights");
+}
+
+extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int* towers, const int* n_rows, const int* a_c, int dtype,
+                                        void* const* packed, void* stream) {
+    VM_REQUIRE(bt && towers && n_rows && a_c && packed, "vm_pack_nt_weights_batch: null pointer");
+    VM_REQUIRE(n > 0 && n <= PACK_MAX, "vm_pack_nt_weights_batch: 1..%d matrices per call (got %d)", PACK_MAX, n);
+    PackBatch pb;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        VM_REQUIRE(bt[i] && packed[i] && towers[i] > 0, "vm_pack_nt_weights_batch: bad matrix %d", i);
+        if (!vm_pack_nt_weights_supported(n_rows[i], a_c[i], dtype)) {
+            set_error("vm_pack_nt_weights_batch: matrix %d: 16-bit storage, rows %% 128 == 0 and channels %% 32 == 0 only", i);
+            return VM_ERR_UNSUPPORTED;
+        }
+        pb.bt[i] = bt[i];
+        pb.out[i] = packed[i];
+        pb.towers[i] = towers[i];
+        pb.rows[i] = n_rows[i];
+        pb.a_c[i] = a_c[i];
+        const int64_t pieces = (int64_t)towers[i] * n_rows[i] * 3 * a_c[i] / 8;
+        most = pieces > most ? pieces : most;
+    }
+    VM_DISPATCH_16(dtype, {
+        hipLaunchKernelGGL((pack_nt_weights_kernel<T>), dim3((unsigned)cdiv(most, 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, pb);
+    });
+    return check_launch("vm_pack_nt_weights_batch");
 }
 
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.

@@ -812,41 +812,77 @@ extern "C" int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_wi
 }
 
 // ---- the weights vm_conv_fwd_fold runs on, per tower t: wf[t][co][k * c_in + ci] = W[k][ci][co] * scale[t][ci] in the storage type,
-// and the per-tap constants hb[t][k][co] = sum_ci W[k][ci][co] * shift[t][ci] (fp64, fixed order).  Input: wt = the fp32 kernel in
-// wf's layout (vm_prep_conv_weights_batch), so that reads and writes are row-contiguous.  One wave = one (c_out, tap) row ----
+// and the per-tap constants hb[t][k][co] = sum_ci W[k][ci][co] * shift[t][ci] (fp64, fixed order), k = 0..2, plus row 3 = bias[co] +
+// hb[t][0][co] + hb[t][1][co] + hb[t][2][co]: the value the forward's accumulators start from (one vector load per lane instead of
+// four).  Input: wt = the fp32 kernel in wf's layout (vm_prep_conv_weights_batch), so that reads and writes are row-contiguous.
+// One wave = one output channel (its three tap rows); a lane moves 8 consecutive input channels at a time: one 16-byte piece of wf
+// and / or of the fragment-order copy conv_nt3_kernel streams (vm_pack_nt_weights' layout, written here directly) ----
 template <typename T>
 __global__ __launch_bounds__(256) void fold_bn_weights_kernel(const float* __restrict__ wt, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int c_in, int c_out,
-                                                              T* __restrict__ wf, float* __restrict__ hb) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);  // row = co * 3 + k
+                                                              const float* __restrict__ shift, const float* __restrict__ bias, int c_in,
+                                                              int c_out, T* __restrict__ wf, T* __restrict__ wfp, float* __restrict__ hb) {
+    const int lane = threadIdx.x & 63, co = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t = blockIdx.y;
-    if (row >= 3 * c_out) return;
-    const float* src = wt + (int64_t)row * c_in;
-    T* dst = wf + ((int64_t)t * 3 * c_out + row) * c_in;
+    if (co >= c_out) return;
     const float* sc = scale + (int64_t)t * c_in;
     const float* sh = shift + (int64_t)t * c_in;
-    double acc = 0.0;
-    for (int ci = lane; ci < c_in; ci += 64) {
-        const float v = src[ci];
-        dst[ci] = Elem<T>::from_f(v * sc[ci]);
-        acc += (double)v * (double)sh[ci];
+    const int ppr = c_in / 8;  // 16-byte pieces per tap row
+    const int nk = 3 * (c_in / 32);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int idx = lane; idx < 3 * ppr; idx += 64) {
+        const int k = idx / ppr, ci = (idx - k * ppr) * 8;
+        const float* src = wt + ((int64_t)co * 3 + k) * c_in + ci;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + ci), s1 = *reinterpret_cast<const f32x4*>(sc + ci + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + ci), h1 = *reinterpret_cast<const f32x4*>(sh + ci + 4);
+        Vec16<T> o;
+        double a = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o.set(e, v0[e] * s0[e]);
+            o.set(4 + e, v1[e] * s1[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a += (double)v0[e] * (double)h0[e];   // ascending input channel, as the scalar loop did per lane
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a += (double)v1[e] * (double)h1[e];
+        acc[0] += k == 0 ? a : 0.0;
+        acc[1] += k == 1 ? a : 0.0;
+        acc[2] += k == 2 ? a : 0.0;
+        if (wf != nullptr) store16<T>(wf + (((int64_t)t * c_out + co) * 3 + k) * c_in + ci, o);
+        if (wfp != nullptr) {
+            // element (row co, column k * c_in + ci .. + 7) of tower t in fragment order (see vm_pack_nt_weights)
+            const int chunk = ci >> 5, ks = (ci >> 4) & 1, kh = (ci >> 3) & 1;
+            const int64_t piece = (((((int64_t)t * (c_out >> 6) + (co >> 6)) * nk + 3 * chunk + k) * 2 + ((co >> 5) & 1)) * 2 + ks) * 64 +
+                                  kh * 32 + (co & 31);
+            store16<T>(wfp + piece * 8, o);
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
     if (lane == 0) {
-        const int co = row / 3, k = row - 3 * co;
-        hb[((int64_t)t * 3 + k) * c_out + co] = (float)acc;
+        float* h = hb + (int64_t)t * 4 * c_out + co;
+        const float f0 = (float)acc[0], f1 = (float)acc[1], f2 = (float)acc[2];
+        h[0] = f0;
+        h[c_out] = f1;
+        h[2 * c_out] = f2;
+        h[3 * c_out] = bias[co] + ((f0 + f1) + f2);   // the sum conv_nt2r_kernel used to form per lane
     }
 }
 
-extern "C" int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, int towers, int c_in, int c_out, int dtype,
-                                  void* wf_folded, float* hb, void* stream) {
-    VM_REQUIRE(wt && scale && shift && wf_folded && hb, "vm_fold_bn_weights: null pointer");
+extern "C" int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, const float* bias, int towers, int c_in,
+                                  int c_out, int dtype, void* wf_folded, void* wf_packed, float* hb, void* stream) {
+    VM_REQUIRE(wt && scale && shift && bias && hb && (wf_folded || wf_packed), "vm_fold_bn_weights: null pointer");
     VM_REQUIRE(c_in > 0 && c_out > 0 && towers > 0 && towers < 65536, "vm_fold_bn_weights: bad sizes");
+    VM_REQUIRE(c_in % 8 == 0, "vm_fold_bn_weights: c_in must be a multiple of 8 (got %d)", c_in);
+    VM_REQUIRE(wf_packed == nullptr || (c_in % 32 == 0 && c_out % 128 == 0),
+               "vm_fold_bn_weights: the fragment-order copy needs c_in %% 32 == 0 and c_out %% 128 == 0 (vm_pack_nt_weights_supported)");
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_fold_bn_weights: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     VM_DISPATCH_16(dtype, {
-        hipLaunchKernelGGL((fold_bn_weights_kernel<T>), dim3((unsigned)cdiv(3 * c_out, 4), (unsigned)towers), dim3(256), 0,
-                           (hipStream_t)stream, wt, scale, shift, c_in, c_out, (T*)wf_folded, hb);
+        hipLaunchKernelGGL((fold_bn_weights_kernel<T>), dim3((unsigned)cdiv(c_out, 4), (unsigned)towers), dim3(256), 0,
+                           (hipStream_t)stream, wt, scale, shift, bias, c_in, c_out, (T*)wf_folded, (T*)wf_packed, hb);
     });
     return check_launch("vm_fold_bn_weights");
 }

@@ -433,15 +433,36 @@ class HipEncoderEngine:
         self._pack_weights()
 
     def _pack_weights(self):
-        """wf / wd -> their fragment-order copies (after every refresh of the GEMM-layout copies)."""
-        if not getattr(self, "packed_weights", False):
+        """wd -> its fragment-order copy after every refresh of the GEMM-layout copies (one launch for all layers); the packed wf is
+        only read by the inference forward (vm_conv_fwd_pool) and is re-made lazily (``_ensure_wfp``)."""
+        self._wfp_stale = True
+        if not getattr(self, "packed_weights", False) or not self.wdp:
             return
-        for i in range(1, self.nb):
-            cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
-            if i in self.wfp:
-                self._call("vm_pack_nt_weights", _p(self.wf[i]), 1, cout, cin, self.dtype, _p(self.wfp[i]), self.stream())
-            if i in self.wdp:
-                self._call("vm_pack_nt_weights", _p(self.wd[i]), 1, cin, cout, self.dtype, _p(self.wdp[i]), self.stream())
+        if getattr(self, "_pack_args", None) is None:
+            ids = sorted(self.wdp)
+            k = len(ids)
+            vp, ci = ctypes.c_void_p * k, ctypes.c_int * k
+            self._pack_args = (k, vp(*[_p(self.wd[i]) for i in ids]), ci(*[1] * k), ci(*[self.blocks[i - 1][1] for i in ids]),
+                               ci(*[self.blocks[i][1] for i in ids]), vp(*[_p(self.wdp[i]) for i in ids]))
+        k, bt, tw, rows, ac, out = self._pack_args
+        if k <= 8:
+            self._call("vm_pack_nt_weights_batch", k, bt, tw, rows, ac, self.dtype, out, self.stream())
+        else:
+            for i in sorted(self.wdp):
+                self._call("vm_pack_nt_weights", _p(self.wd[i]), 1, self.blocks[i - 1][1], self.blocks[i][1], self.dtype, _p(self.wdp[i]), self.stream())
+
+    def _ensure_wfp(self):
+        """The packed forward weights of the inference path, re-made when the parameters changed since the last inference forward."""
+        if not getattr(self, "_wfp_stale", True) or not self.packed_weights or not self.wfp:
+            return
+        ids = sorted(self.wfp)
+        for j in range(0, len(ids), 8):
+            part = ids[j:j + 8]
+            k = len(part)
+            vp, ci = ctypes.c_void_p * k, ctypes.c_int * k
+            self._call("vm_pack_nt_weights_batch", k, vp(*[_p(self.wf[i]) for i in part]), ci(*[1] * k), ci(*[self.blocks[i][1] for i in part]),
+                       ci(*[self.blocks[i - 1][1] for i in part]), self.dtype, vp(*[_p(self.wfp[i]) for i in part]), self.stream())
+        self._wfp_stale = False
 
     # ------------------------------------------------------------------------------------------------
     def lengths(self, l0: int) -> List[int]:
@@ -573,7 +594,7 @@ class HipEncoderEngine:
             cin, cout = self.blocks[i - 1][1], self.blocks[i][1]
             packed = self.packed_weights and self.lib.query("vm_pack_nt_weights_supported", cout, cin, self.dtype)
             self._fold[i] = (torch.empty(2, cout * 3 * cin, dtype=self.tdt, device=self.device),
-                             torch.empty(2, 3, cout, dtype=torch.float32, device=self.device),
+                             torch.empty(2, 4, cout, dtype=torch.float32, device=self.device),   # rows 0..2 per tap, row 3 = bias + their sum
                              torch.empty(2, cout * 3 * cin, dtype=self.tdt, device=self.device) if packed else None)
         return self._fold[i]
 
@@ -621,6 +642,8 @@ class HipEncoderEngine:
         if training:
             self.bn_steps += 1
             self._bn_t = self.bn_steps
+        else:
+            self._ensure_wfp()
         if split:
             if "cr_ws_t2" not in pl:
                 pl["cr_ws_t2"] = torch.empty_like(pl["cr_ws"])
@@ -721,11 +744,9 @@ class HipEncoderEngine:
                     lo = pl[i - 1]
                     wfo, hbo, wfp = self._fold_bufs(i)
                     with_e = i < self.nb - 1
-                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), ntw, cin, c, dt,
-                               wfo[tw0].data_ptr(), hbo[tw0].data_ptr(), st)
                     use_packed = wfp is not None and self.packed_weights
-                    if use_packed:
-                        self._call("vm_pack_nt_weights", wfo[tw0].data_ptr(), ntw, c, cin, dt, wfp[tw0].data_ptr(), st)
+                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), bias, ntw, cin, c, dt,
+                               wfo[tw0].data_ptr(), wfp[tw0].data_ptr() if use_packed else None, hbo[tw0].data_ptr(), st)
                     pairs = with_e and self.fold_pairs
                     self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
                                nw, wpt, L, cin, c, dt, None if pairs else W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None,
