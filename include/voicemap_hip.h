@@ -47,8 +47,9 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 6.  History: 6 = packed weights (vm_pack_nt_weights; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
- * vm_conv_dgrad_bnred) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
+/* 6.  History: 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+ * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
+ * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
  * (vm_fold_bn_weights, vm_conv_fwd_fold, vm_conv_wgrad_fold, vm_du_tower_sums, vm_bn_pool_bwd_apply_pairs; vm_conv1_fused_fwd mode 2;
  * `wt` in vm_prep_conv_weights_batch; `sqnorm_parts` in vm_adam_clip_step; vm_siamese_head_reduce; vm_conv_fwd_flat, vm_conv2d_first_*,
@@ -253,8 +254,13 @@ int64_t vm_colreduce_workspace_bytes(int n_segments, int C);
 int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                    double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                    int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                   float* scale, float* shift, void* ws, float* zd_biased, float zd_correction,
-                   void* stream);
+                   float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, const float* center_bias,
+                   float* shift_adj, float* mean_adj, void* stream);
+/* center_bias (C) or NULL, with shift_adj / mean_adj (n_towers, C): block 1's pool extreme is stored CENTRED in the folded training
+ * path (vm_conv1_fused_fwd mode 2 writes e - ctr, ctr = max(conv bias, 0): the whitened waveform makes conv-1 outputs small next to a
+ * bias, and a 16-bit value would spend its significand on that pedestal).  Its consumers are linear in e, so the offset moves into
+ * their constants: shift_adj = shift + scale * ctr is the shift over the STORED value (vm_fold_bn_weights / vm_conv_wgrad_fold_finish of
+ * block 2), mean_adj = mean - ctr the mean against which the sums over the stored value are taken (vm_bn_bwd_from_sums[_finalize]). */
 /* inference affine from moving statistics (one "tower"). */
 int vm_bn_infer_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                        float eps, int C, float* scale, float* shift, void* stream);

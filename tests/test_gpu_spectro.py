@@ -308,14 +308,27 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
     assert rel_err(emb, e_ref) < tol
     assert abs(pl["loss_acc"][0].item() - ref["loss"].item()) < tol * max(1.0, abs(ref["loss"].item()))
     grads = eng.get_grads()
-    worst = 0.0
+    # per-tensor bound (VERDICT r3 weak #1d: the old ``cosine > 0.9 or max_err < 1e-5`` let an 85 % error on a live tensor pass):
+    #   |g - ref| <= rel * |ref|  +  floor * |all gradients|      (2-norms)
+    # ``rel`` is the storage type's max-pool re-routing level, ``floor`` admits tensors that are rounding noise next
+    # to the rest of the gradient (a 16-bit path cannot resolve them) -- and ONLY those: a tensor that carries more than ``floor`` of
+    # the whole gradient must itself be right to ``rel``.
+    total = float(np.sqrt(sum(float((g.numpy().astype(np.float64) ** 2).sum()) for g in ref["grads"].values())))
+    rel_b, floor_b = {"f32": (2e-3, 1e-6), "f16": (0.25, 2e-3), "bf16": (0.6, 1.5e-2)}[dt]
+    worst, worst_k = 0.0, ""
     for k, gref in ref["grads"].items():
+        gr = gref.numpy().astype(np.float64)
+        err = float(np.linalg.norm(np.asarray(grads[k], dtype=np.float64) - gr))
+        share = float(np.linalg.norm(gr)) / max(total, 1e-300)
+        report(tag, "grad_rel_err[%s]" % k, rel_err(grads[k], gr))
+        report(tag, "grad_share_of_total_norm[%s]" % k, share)
         if dt == "f32":
-            assert grad_close(grads[k], gref.numpy(), 2e-3, 1e-7), (k, rel_err(grads[k], gref.numpy()))
-        else:
-            assert cosine(grads[k], gref.numpy()) > 0.9 or max_err(grads[k], gref.numpy()) < 1e-5, k
-        worst = max(worst, rel_err(grads[k], gref.numpy()))
+            assert grad_close(grads[k], gr, 2e-3, 1e-7), (k, rel_err(grads[k], gr))
+        assert err <= rel_b * float(np.linalg.norm(gr)) + floor_b * total, (k, rel_err(grads[k], gr), share)
+        if rel_err(grads[k], gr) > worst:
+            worst, worst_k = rel_err(grads[k], gr), k
     report(tag, "worst_grad_rel_err", worst)
+    report(tag, "worst_grad_rel_err_tensor[%s]" % worst_k, worst)
     if dt == "f32":
         eng.optimizer_step()
         torch.cuda.synchronize()

@@ -124,3 +124,50 @@ def test_n_shot_prediction_modes():
     assert np.allclose(O.n_shot_prediction(q, s, n, k, "cosine"), cdist(q[None], mu, "cosine")[0])
     with pytest.raises(ValueError):
         O.n_shot_prediction(q, s, n, k, "manhattan")
+
+
+def _close(got, want, rtol, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(float(np.abs(want).max()), 1e-300)
+    err = float(np.abs(got - want).max()) / scale
+    assert err < rtol, (what, err)
+
+
+@pytest.mark.parametrize("case", ["tiny", "cfgCK"])
+def test_oracle_reproduces_committed_step_vectors(case, golden_dir):
+    """SURVEY 8c item 4 / VERDICT r3 missing #4: the oracle's TRAINING step -- per-block activations and batch statistics, embeddings,
+    loss, all 20 gradients, the weights after 1 and 3 Adam(clipnorm 1) steps, the zero-debiased BatchNorm moving statistics -- against
+    the vectors committed by tests/golden/make_oracle_step_vectors.py.  A change of the oracle's arithmetic now fails here instead of
+    silently moving every parity target."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_vec", os.path.join(golden_dir, "make_oracle_step_vectors.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(golden_dir, "oracle_vectors_step_%s.npz" % case))
+    if case == "tiny":
+        arch, _, _, _, _ = mk.tiny_case()
+        runs = []
+        for loss, head in (("contrastive", "uniform_euclidean"), ("bce", "weighted_l1")):
+            p = {k[len(loss) + 9:]: torch.tensor(g[k]) for k in g.files if k.startswith(loss + "/params0/")}
+            p = {k: p[k] for k in O.init_params(arch, head=head, seed=7)}          # the oracle's parameter order
+            runs.append((loss + "/", mk.run_steps(arch, p, g["x1"], g["x2"], g["y"], loss, head), 1e-9))
+    else:
+        arch, p = O.params_from_checkpoint(np.load(os.path.join(golden_dir, "ckpt_cfgCK_weights.npz")))
+        h, v = np.load(os.path.join(golden_dir, "clips_human_eval.npz")), np.load(os.path.join(golden_dir, "clips_embedding_vis.npz"))
+        f = lambda c: c.astype(np.float64) / 32768.0
+        left = np.stack([f(h["query"]), f(h["support"][0]), f(h["support"][1]), f(v["clips"][0])])[:, :, None]
+        right = np.stack([f(h["support"][4]), f(h["support"][2]), f(h["support"][3]), f(v["clips"][1])])[:, :, None]
+        pre = O.preprocess_instances(4)
+        runs = [("", mk.run_steps(arch, p, pre(left), pre(right), g["y"], "bce", "weighted_l1"), 1e-9)]
+    checked = 0
+    for prefix, out, rtol in runs:
+        for k, val in out.items():
+            want = g[prefix + k]
+            # the big cfg-CK arrays are committed as float32: half an ulp of the largest element
+            _close(val, want, rtol if want.dtype == np.float64 else 1e-7, prefix + k)
+            checked += 1
+    assert checked >= (2 * 60 if case == "tiny" else 60)
+    # the moving statistics are the zero-debiased form: after ONE step they equal the (last tower's) batch statistic itself
+    key = "contrastive/" if case == "tiny" else ""
+    assert not np.allclose(g[key + "params_after_1/bn1.moving_mean"], 0.0)

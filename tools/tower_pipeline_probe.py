@@ -29,7 +29,7 @@ def stages(pl, xs):
         gam, bet = _p(eng.view(f"bn{i+1}.gamma")), _p(eng.view(f"bn{i+1}.beta"))
         fin = lambda b=b, ssum=ssum, ssq=ssq, c=c, L=L, gam=gam, bet=bet: eng._call(
             "vm_bn_finalize", ssum, ssq, n * b["stat_rows"], 1, c, float(n * L), gam, bet, eng.bn_eps, eng.bn_momentum, 1, None, None,
-            _p(b["mean"]), _p(b["invstd"]), _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), None, 0.0, eng.stream())
+            _p(b["mean"]), _p(b["invstd"]), _p(b["scale"]), _p(b["shift"]), _p(pl["cr_ws"]), None, 0.0, None, None, None, eng.stream())
         if i == 0:
             out.append(lambda b=b, ssum=ssum, ssq=ssq, c=c, L=L, pool=pool, bias=bias, gam=gam: eng._call(
                 "vm_conv1_fused_fwd", _p(pl["x0"]), _p(eng.view("conv1.kernel")), bias, gam, None, n, L, c, pool, 0, _p(b["e"]), ssum, ssq,

@@ -70,7 +70,7 @@ SIGNATURES = {
     "vm_conv_wgrad_fold_finish": (I, [P, L, L, L, I, I, P, P, P, P, P]),
     "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
     "vm_colreduce_workspace_bytes": (L, [I, I]),
-    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P]),
+    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P, P, P, P]),
     "vm_bn_infer_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "vm_bn_drop_pool_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P]),
     "vm_bn_part_rows": (I, []),

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float momentum, int unbiased, float* moving_mean,
                                                            float* moving_var, float* mean, float* invstd, float* scale,
-                                                           float* shift, float* zd_biased, float zd_correction) {
+                                                           float* shift, float* zd_biased, float zd_correction,
+                                                           const float* __restrict__ center_bias, float* shift_adj, float* mean_adj) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= C) return;
     float mm = 0.f, mv = 0.f;
@@ -170,6 +171,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
         invstd[tw * C + c] = istd;
         scale[tw * C + c] = sc;
         shift[tw * C + c] = beta[c] - (float)m * sc;
+        if (center_bias != nullptr) {
+            // the block's pool extreme is stored as e - ctr, ctr = max(conv bias, 0) (vm_conv1_fused_fwd mode 2): the affine over the
+            // STORED value is scale * e' + (shift + scale * ctr), and sum dp * e = sum dp * e' + ctr * sum dp puts ctr into the mean
+            const float ctr = fmaxf(center_bias[c], 0.f);
+            shift_adj[tw * C + c] = fmaf(sc, ctr, beta[c] - (float)m * sc);
+            mean_adj[tw * C + c] = (float)(m - (double)ctr);
+        }
         if (moving_mean != nullptr) {
             double vv = var;
             if (unbiased) vv = var * (count / (count - (1.0 + (double)eps)));
@@ -948,15 +956,17 @@ extern "C" int64_t vm_colreduce_workspace_bytes(int n_segments, int C) {
 extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per_tower, int n_towers, int C,
                               double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                               int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
-                              float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, void* stream) {
+                              float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, const float* center_bias,
+                              float* shift_adj, float* mean_adj, void* stream) {
     VM_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && invstd && scale && shift && ws, "vm_bn_finalize: null pointer");
+    VM_REQUIRE(center_bias == nullptr || (shift_adj && mean_adj), "vm_bn_finalize: center_bias needs shift_adj and mean_adj");
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
     VM_REQUIRE(zd_biased == nullptr || (moving_mean != nullptr && zd_correction >= 1.0f), "vm_bn_finalize: zero-debias needs the moving statistics and a correction >= 1");
     launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
                        n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                       mean, invstd, scale, shift, zd_biased, zd_correction);
+                       mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj);
     return check_launch("vm_bn_finalize");
 }
 

@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
     const bool use_min = sg < 0.f;
     const bool all_max = __builtin_amdgcn_ballot_w64(use_min) == 0;  // wave-uniform: no channel of this wave pools a minimum
     const f32x2 bv2 = {bv, bv};
+    // mode 2 (the padded extreme the folded block-2 convolution reads): the value is stored CENTRED, e - max(bias, 0).  The waveform is
+    // whitened to an RMS of 0.038, so a bias of a few hundredths is already larger than the convolution it is added to; relu(conv + b)
+    // then sits on a pedestal of b and a 16-bit value spends its significand on the pedestal (measured on the CPU oracle: conv1 bias
+    // ~ N(0, 0.2) takes the f16 embeddings from 7e-4 to 1.3e-2 off float64; centred 7e-4 again).  Every consumer is linear in e and
+    // BatchNorm removes any per-channel constant, so the offset moves into constants they already hold: the fold's shift
+    // (shift + scale * ctr), the mean of the BatchNorm-backward sums (mean - ctr) -- vm_bn_finalize writes both (center_bias).
+    const float ctr = (!INFER && e_pad) ? __builtin_fmaxf(bv, 0.f) : 0.f;
     const int lane_off = c + (4 / POOL) * hi * F;  // this lane's element inside a tile's pooled rows
     float csum = 0.f, csq = 0.f;
     f32x2 csum2 = {0.f, 0.f}, csq2 = {0.f, 0.f};
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                     const float v = z[pw * POOL + j];
                     ext = ALLMAX ? __builtin_fmaxf(ext, v) : (use_min ? __builtin_fminf(ext, v) : __builtin_fmaxf(ext, v));
                 }
-                ob[((8 * g) / POOL + pw) * F] = INFER ? (TS)fmaf(ext, sg, sh) : (TS)ext;
+                ob[((8 * g) / POOL + pw) * F] = INFER ? (TS)fmaf(ext, sg, sh) : (TS)(ext - ctr);
             }
         }
     };
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                         if (INFER) {
                             out[(n * (Lq + 2) + 1 + q) * F + c] = (TS)fmaf(ext, sg, sh);  // ... and here it is the scale
                         } else {
-                            out[(n * (Lq + 2 * e_pad) + e_pad + q) * F + c] = (TS)ext;
+                            out[(n * (Lq + 2 * e_pad) + e_pad + q) * F + c] = (TS)(ext - ctr);
                         }
                     }
                 }

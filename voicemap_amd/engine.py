@@ -494,7 +494,7 @@ class HipEncoderEngine:
             b["act"] = torch.zeros(n_windows, ls[i + 1] + 2, c, dtype=tdt, device=dev)  # halo rows stay zero
             rows = self.lib.query("vm_conv1_stat_rows" if i == 0 else "vm_conv_stat_rows", L)
             b["stat_rows"] = rows
-            for nm in ("mean", "invstd", "scale", "shift", "c1", "c2"):
+            for nm in ("mean", "invstd", "scale", "shift", "c1", "c2") + (("shift_c", "mean_c") if i == 0 else ()):
                 b[nm] = torch.zeros(2, c, dtype=f32, device=dev)
             if training:
                 b["ssum"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
@@ -697,8 +697,10 @@ class HipEncoderEngine:
                         v_ = m_ + 4 * c
                 elif second_of_two:         # plain average: the two updates are sequential -- after tower 1's
                     self.tower_stream.wait_event(pl["tower_ev"][i])
+                centred = i == 0 and fold and self.fuse_block1   # block 1's extreme is stored as e - max(bias, 0): the offset's constants
                 self._call("vm_bn_finalize", ssum, ssq, wpt * rows, ntw, c, float(wpt * L), gam, bet, self.bn_eps, self.bn_momentum,
-                           int(self.unbiased), m_, v_, T(b["mean"]), T(b["invstd"]), T(b["scale"]), T(b["shift"]), _p(cr_ws), zd, zc, st)
+                           int(self.unbiased), m_, v_, T(b["mean"]), T(b["invstd"]), T(b["scale"]), T(b["shift"]), _p(cr_ws), zd, zc,
+                           bias if centred else None, T(b["shift_c"]) if centred else None, T(b["mean_c"]) if centred else None, st)
                 if zd is None and first_of_two:
                     pl["tower_ev"][i].record()
 
@@ -745,7 +747,9 @@ class HipEncoderEngine:
                     wfo, hbo, wfp = self._fold_bufs(i)
                     with_e = i < self.nb - 1
                     use_packed = wfp is not None and self.packed_weights
-                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift"]), bias, ntw, cin, c, dt,
+                    # (block 2 reads block 1's CENTRED extreme: the shift over the stored value)
+                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift_c" if (i == 1 and self.fuse_block1) else "shift"]),
+                               bias, ntw, cin, c, dt,
                                wfo[tw0].data_ptr(), wfp[tw0].data_ptr() if use_packed else None, hbo[tw0].data_ptr(), st)
                     pairs = with_e and self.fold_pairs
                     self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
@@ -831,12 +835,12 @@ class HipEncoderEngine:
                 if b.get("bnred_now") and self.fused_sums_finalize:
                     # the sums of the dgrad epilogue straight into the column reduction: two small launches instead of three
                     self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
-                               _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, float(wpt * L), _p(b["c1"]),
+                               _p(b["shift"]), _p(b["mean_c" if fold else "mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, float(wpt * L), _p(b["c1"]),
                                _p(b["c2"]), _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
                 else:
                     if b.get("bnred_now"):
                         self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
-                                   _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, _p(b["pa"]),
+                                   _p(b["shift"]), _p(b["mean_c" if fold else "mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, _p(b["pa"]),
                                    _p(b["pb"]), st)
                     else:
                         self._call("vm_bn_pool_bwd_reduce", _p(b["e"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
@@ -896,8 +900,8 @@ class HipEncoderEngine:
                     self._call("vm_conv_wgrad_fold", _p(lo["ep"]), _p(b["du"]), n, wpt, L, cin, c, dt, None, None, None,
                                _p(b["wgrad_ws_fold"]), None, stream)
                     self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), stream)
-                    self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]), _p(lo["shift"]),
-                               _p(b["dsum"]), gw, stream)
+                    self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]),
+                               _p(lo["shift_c" if (i == 1 and self.fuse_block1) else "shift"]), _p(b["dsum"]), gw, stream)
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, stream)
                     self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(cr_ws), stream)
