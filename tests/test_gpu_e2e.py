@@ -219,6 +219,14 @@ def test_f16_loss_scale_recovers_inside_a_plain_train_on_batch_loop():
     eng.loss_scale = 1.0
     eng.optimizer_step()
     assert torch.equal(eng.P, pb) and eng.skipped_steps() == n0 + 1
+    # a tiny gradient (scaled norm under scale_norm_low) lifts the scale by 8 per poll, overflow-free
+    eng2 = _engine(arch, p, "uniform_euclidean", "f16")
+    eng2.scale_poll_every, eng2.scale_poll_lag = 2, 1
+    eng2.loss_scale = 4096.0
+    for _ in range(8):
+        eng2.G.fill_(1e-6)                    # what a backward pass would leave: norm 1e-6 * sqrt(n) << 64
+        eng2.optimizer_step()
+    assert eng2.loss_scale >= 4096.0 * 8 ** 2 and eng2.skipped_steps() == 0
 
 
 def test_two_steps_fp32_keep_tracking_oracle():

@@ -246,9 +246,16 @@ class HipEncoderEngine:
         # ``scale_poll_every`` steps the count is copied to pinned memory behind the step; ``scale_poll_lag`` steps later -- a fixed
         # lag, so data-parallel replicas change their scale at the same step -- it is read (the copy is long done: no drain)
         self.scale_poll_every, self.scale_poll_lag = 16, 8
-        self.scale_grow_after, self.scale_max, self.scale_min = 2000, 65536.0, 1.0
+        self.scale_grow_after, self.scale_max, self.scale_min = 2000, 2.0 ** 24, 1.0
+        # ... and the scale follows the gradient's SIZE, not only its overflows: the same poll reads the squared norm of the scaled
+        # gradient buffer the optimizer kernel leaves behind; under ``scale_norm_low`` (a gradient of norm 1e-6 -- a net whose pairs
+        # sit past the contrastive margin -- leaves activation gradients of 1e-10 that 4096 does not lift into half's range: measured
+        # 58 % error on the first layer's gradient, 5 % with a scale of 2^20) the scale is multiplied by 8 per poll.  A scaled norm of
+        # 2^6 keeps every element 2^10 under half's maximum, so the growth itself cannot overflow the parameter gradients.
+        self.scale_norm_low = 64.0
         self._opt_calls, self._clean_steps, self._poll = 0, 0, None
         self._skip_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.loss_scaled else None
+        self._norm_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.loss_scaled else None
 
     def _init_zero_debias(self):
         """Keras 2.2.2 BatchNormalization updates its moving statistics with TF 1.10's assign_moving_average(zero_debias=True)
@@ -394,8 +401,12 @@ class HipEncoderEngine:
             self._poll = None
             ev.synchronize()   # enqueued scale_poll_lag steps ago
             new = self._account_skips(int(self._skip_host[0]))
+            sq = float(self._norm_host[0])   # sum of squares of the scaled gradient buffer at the polled step (inf / nan: a skipped one)
             if new > 0:
                 self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), self.scale_min)
+                self._clean_steps = 0
+            elif math.isfinite(sq) and 0.0 < sq < self.scale_norm_low ** 2 and self.loss_scale < self.scale_max:
+                self.loss_scale = min(self.loss_scale * 8.0, self.scale_max)   # a tiny gradient: lift it (see _init_loss_scale)
                 self._clean_steps = 0
             else:
                 self._clean_steps += self.scale_poll_every
@@ -405,6 +416,7 @@ class HipEncoderEngine:
         if self._poll is None and k % self.scale_poll_every == 0:
             with torch.cuda.stream(torch.cuda.current_stream(self.device)):
                 self._skip_host.copy_(self._skipped, non_blocking=True)
+                self._norm_host.copy_(self._sqnorm, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
             self._poll = (k, ev)
