@@ -47,6 +47,8 @@ BLOCKS = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
 # rocprofv3 kernel names of the GEMM families under the default dispatch (what profiles/r03_rocprofv3_kernel_stats.csv lists)
 KERNEL_SYMBOL = {"vm_conv_fwd": "vm::conv_nt2r_kernel<{T}, 0>", "vm_conv_dgrad": "vm::conv_nt2r_kernel<{T}, 1>",
                  "vm_conv_wgrad": "vm::conv_tn8x_kernel<{T}>"}
+# round 4: with packed weights (the default for 16-bit storage) forward / dgrad run conv_nt3_kernel<T, EPI, K-side channels / 32, true>
+NT3_EPI = {"vm_conv_fwd": 3, "vm_conv_dgrad": 1}
 CTYPE = {"bf16": "__bf16", "f16": "_Float16", "f32": "float", "f32s": "float"}
 
 
@@ -336,18 +338,26 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             key = "%s|%d|%d|%d|%d" % (a.dominant, shape["n_windows"], shape["L"], shape["c_in"], shape["c_out"])
             roof["traffic"] = json.load(f)["kernels"][key]["hbm_bytes"]
+            roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape on another "
+                                      "box (tools/pmc_traffic.py; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- NOT measured in this run")
     except (OSError, KeyError, ValueError):
         pass
     roof["kernel"] = a.dominant
-    def symbol(nm):   # the folded forward (vm_conv_fwd_fold) is epilogue variant 3 of the same kernel
+    def symbol(nm, shp=None):   # the folded forward (vm_conv_fwd_fold) is epilogue variant 3 of the same kernel
         sym = KERNEL_SYMBOL[nm].format(T=CTYPE.get(a.dtype, a.dtype))
-        if nm == "vm_conv_fwd" and any(str(l["shape"]["fused"]).startswith("vm_conv_fwd_fold") for l in fam[nm]["launches"]):
+        folded = nm == "vm_conv_fwd" and any(str(l["shape"]["fused"]).startswith("vm_conv_fwd_fold") for l in fam[nm]["launches"])
+        if folded:
             sym = sym.replace(", 0>", ", 3>")
+        fused = nm == "vm_conv_dgrad" and any(l["shape"]["fused"] == "vm_conv_dgrad_bnred" for l in fam[nm]["launches"])
+        nt3 = nm in NT3_EPI and getattr(eng, "packed_weights", False) and (folded or fused) and "nt3=0" not in a.tune
+        if nt3:   # K-side channel chunks: c_in for the forward, c_out for dgrad (a family: one instantiation per layer)
+            ck = None if shp is None else (shp["c_in"] if nm == "vm_conv_fwd" else shp["c_out"]) // 32
+            sym = "vm::conv_nt3_kernel<%s, %d, %s, true>" % (CTYPE.get(a.dtype, a.dtype), NT3_EPI[nm], "*" if ck is None else str(ck))
         return sym
-    roof["kernel_symbol"] = symbol(a.dominant)
+    roof["kernel_symbol"] = symbol(a.dominant, shape)
     roof["source"] = ("bench.py serial attribution pass of this run: HIP events on the launch stream around every GEMM launch, median per "
-                      "launch shape; committed counterparts: profiles/r03_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
-                      "serial step), profiles/r03_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
+                      "launch shape; committed counterparts: profiles/r04_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
+                      "serial step), profiles/r04_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
     # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense 16-bit peak) and algorithmic GB/s
@@ -409,6 +419,26 @@ def main():
                                          "intra-op thread counts listed in threads_tried on a %d-cpu host: a batch of %d pairs does "
                                          "not scale to every core; %.0f ms/step)"
                                          % (cpu_steps, cpu_pairs, os.cpu_count() or 1, cpu_pairs, sec * 1e3)}
+        # the other two legs BASELINE.md 3 names, on the same host with the thread count the search above chose (bounded: ~10 s):
+        # the inference embedding pass (voicemap/utils.py:141-156) and BASELINE.json config 1, the classifier step at batch 8
+        # (experiments/train_classifier.py:110-127) -- each beside the GPU figure of the same work from this run's extras
+        try:
+            legs = {}
+            n_emb = 16
+            t_e = O.time_cpu_embed_only(arch, n_emb, 3, threads)
+            legs["embed_only"] = {"value": n_emb * 3.0 / t_e, "unit": "audio-s/s", "cores": threads, "kind": "port",
+                                  "sample": "%d windows of 3 s per pass, inference BatchNorm, fp32 (%.0f ms per pass)" % (n_emb, t_e * 1e3),
+                                  "gpu_value_this_run": (out.get("extras") or {}).get("embed_only_audio_s_per_s")}
+            n_cls, classes = 8, 40
+            t_c = O.time_cpu_classifier_steps(arch, n_cls, classes, 3, threads)
+            legs["classifier_step_batch8"] = {"value": n_cls * 3.0 / t_c, "unit": "audio-s/s", "cores": threads, "kind": "port",
+                                              "sample": "BASELINE.json config 1: train_on_batch of the speaker classifier (cfg-A encoder + "
+                                                        "Dense(%d, softmax), categorical CE, Adam(clipnorm 1)), batch %d of 3 s windows, "
+                                                        "fp32 (%.0f ms per step)" % (classes, n_cls, t_c * 1e3),
+                                              "gpu_value_this_run": (out.get("extras") or {}).get("classifier_batch8_audio_s_per_s")}
+            out["cpu_baseline"]["legs"] = legs
+        except Exception as e:   # a side figure never takes the line down
+            out["cpu_baseline"]["legs_error"] = repr(e)
     if rank == 0:
         print(json.dumps(out))
 
@@ -466,8 +496,9 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
                                 "meets_1e-3": bool(m["embedding_rel_err_vs_f32_mode"] < 1e-3),
                                 "reference": "north star: embeddings within 1e-3 rel-tol of the reference arithmetic; measured here against the "
                                              "fp32-storage / fp32-MFMA mode of this library on the timed batch (that mode is 1e-6 from the float64 "
-                                             "CPU oracle at this size: tests/test_gpu_fullsize_oracle.py, profiles/r03_parity_report.csv, "
-                                             "which also holds this mode's figure against the oracle itself)"}
+                                             "CPU oracle at this size); against_oracle: this mode against the CPU oracle itself, from the committed "
+                                             "parity report of the -m gpu tests (not measured in this run)"}
+            out["precision"]["against_oracle"] = oracle_referenced_figures(a.dtype)
         restore(eng, snap)
     except Exception as e:
         ex["modes_error"] = repr(e)
@@ -486,6 +517,21 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         t_embed = timed(embed_only, reps=20)
         ex["embed_only_audio_s_per_s"] = 2 * pairs * 3.0 / t_embed
         ex["embed_only_ms_per_256_windows"] = t_embed * 1e3
+        # BASELINE.json config 1 on the GPU (the CPU leg of cpu_baseline.legs times the same step): the speaker classifier at batch 8
+        ecls = type(eng)(BLOCKS, E, dropout=0.0, head="classifier", num_classes=40, dtype=a.dtype, device=dev, seed=1234)
+        xc, lab = xcat[:8].contiguous(), torch.arange(8, device=dev, dtype=torch.int32) % 40
+        pc = ecls.plan(8, L0, True)
+
+        def cls_step():
+            ecls.preprocess(pc, xc, 4, True, 8)
+            ecls.forward(pc, 8, None)
+            ecls.classifier_head(pc, lab)
+            ecls.backward(pc)
+            ecls.optimizer_step()
+        t_cls = timed(cls_step, reps=20)
+        ex["classifier_batch8_ms_per_step"] = t_cls * 1e3
+        ex["classifier_batch8_audio_s_per_s"] = 8 * 3.0 / t_cls
+        del ecls, pc
         # PCIe-inclusive step: the boundary handed host buffers (pinned int16 PCM of the same windows) -- never `value`
         host16 = (xcat.clamp(-1, 1) * 32767.0).round().to(torch.int16).cpu().pin_memory()
         dev16 = torch.empty_like(host16, device=dev)
@@ -624,6 +670,27 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         ex["accuracy_error"] = repr(e)
     restore(eng, snap)
     return ex
+
+
+def oracle_referenced_figures(dtype):
+    """Embedding error of storage mode ``dtype`` against the CPU ORACLE in three states, read from the parity report the -m gpu tests
+    wrote (profiles/r04_parity_report.csv, committed; the run that produced it is named there): the bench batch at fresh-init weights
+    (tests/test_gpu_fullsize_oracle.py), the same batch at a trained-like BatchNorm / bias state, and the reference's shipped
+    checkpoint on its own 8 LibriSpeech clips in training mode (tests/test_gpu_golden_step.py).  ``meets_1e-3`` per state."""
+    want = {"full_size_oracle[%s]" % dtype: ("emb_rel_err_vs_fp64_oracle", "bench_batch_fresh_init"),
+            "full_size_oracle_trained_state[%s]" % dtype: ("emb_rel_err_vs_fp32_oracle", "bench_batch_trained_like_batchnorm_and_bias_state"),
+            "golden_step_cfgCK_real_clips[%s]" % dtype: ("emb_rel_err", "reference_checkpoint_on_its_8_librispeech_clips_training_mode")}
+    out = {"source": "profiles/r04_parity_report.csv (tests/test_gpu_fullsize_oracle.py, tests/test_gpu_golden_step.py on an MI355X; NOT this run)"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_parity_report.csv")) as f:
+            for line in f:
+                parts = line.strip().split(",")
+                if len(parts) == 3 and parts[0] in want and parts[1] == want[parts[0]][0]:
+                    v = float(parts[2])
+                    out[want[parts[0]][1]] = {"embedding_rel_err": v, "meets_1e-3": bool(v < 1e-3)}
+    except (OSError, ValueError):
+        out["error"] = "parity report not found"
+    return out
 
 
 def accuracy_figures(a, dev):

@@ -811,3 +811,48 @@ def time_cpu_train_steps(arch, batch_pairs: int, steps: int, loss: str = "contra
     torch.set_num_threads(threads)
     sec = run(steps, t_start + budget_s)
     return sec, threads
+
+
+def time_cpu_embed_only(arch, windows: int, reps: int, threads: int, seed: int = 1234, downsampling: int = 4, budget_s: float = 8.0):
+    """bench.py cpu_baseline leg: the inference embedding pass (preprocess + encoder forward with the moving statistics,
+    voicemap/utils.py:141-156 `encoder.predict`) of ``windows`` 3 s windows, fp32, ``threads`` intra-op threads.  Seconds per pass."""
+    import time
+    torch.set_num_threads(threads)
+    x1, _, _ = synthetic_pairs(windows, seed)
+    pre = preprocess_instances(downsampling)
+    p = init_params(arch, seed=seed, dtype=torch.float32)
+    ts, t_start = [], time.perf_counter()
+    with torch.no_grad():
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            a = torch.tensor(pre(x1.astype(np.float64)).astype(np.float32))
+            encoder_forward(arch, p, a, False)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s and len(ts) >= 2:
+                break
+    return float(np.mean(ts[1:])) if len(ts) > 1 else float(ts[0])
+
+
+def time_cpu_classifier_steps(arch, batch: int, num_classes: int, steps: int, threads: int, seed: int = 1234, downsampling: int = 4,
+                              budget_s: float = 8.0):
+    """bench.py cpu_baseline leg: BASELINE.json config 1 -- one train_on_batch of experiments/train_classifier.py:110-127 (encoder +
+    Dense(num_classes, softmax), categorical cross-entropy, Adam(clipnorm 1)) at batch ``batch``, fp32.  Seconds per step."""
+    import time
+    torch.set_num_threads(threads)
+    x, _, _ = synthetic_pairs(batch, seed)
+    pre = preprocess_instances(downsampling)
+    p = init_params(arch, head="classifier", num_classes=num_classes, seed=seed, dtype=torch.float32)
+    st = AdamState()
+    labels = np.arange(batch) % num_classes
+    y = torch.tensor(np.eye(num_classes, dtype=np.float32)[labels])
+    ts, t_start = [], time.perf_counter()
+    for _ in range(steps + 1):
+        t0 = time.perf_counter()
+        a = torch.tensor(pre(x.astype(np.float64)).astype(np.float32))
+        out = classifier_train_step(arch, p, st, a, y)
+        p = out["params"]
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and len(ts) >= 2:
+            break
+    return float(np.mean(ts[1:])) if len(ts) > 1 else float(ts[0])
+

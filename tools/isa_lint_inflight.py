@@ -7,8 +7,8 @@ vector-memory queue: loads and LDS-DMAs retire in order, ``vmcnt(N)`` leaves the
 
   python tools/isa_lint_inflight.py conv_gemm-hip-amdgcn-amd-amdhsa-gfx950.s --kernel conv_nt3_kernel
 
-Exit code 1 and a report on the first violation per kernel.  Branches inside the checked region are reported as well (the replay
-assumes straight-line code between the first tracked load and the last wait)."""
+Exit code 1 and a report on the first violation per kernel.  Forward branches are replayed as straight-line text; a backward branch
+(a loop) with hidden loads in flight is reported."""
 import argparse
 import re
 import sys
@@ -30,6 +30,11 @@ def lint(lines, name):
     queue = []      # outstanding VMEM ops, oldest first: (line_no, set of destination VGPRs or empty)
     lq = []         # outstanding LDS ops (lgkmcnt): the same replay for hand-counted ds_read_* (they return in order)
     problems = []
+    labels = {}
+    for no, raw in lines:
+        m = re.match(r"^(\.?\w+):", raw.strip())
+        if m:
+            labels[m.group(1)] = no
     in_asm = False  # inside a ;;#ASMSTART ... ;;#ASMEND bracket: only THOSE loads are hidden from the compiler's own wait insertion
     for no, raw in lines:
         if "#ASMSTART" in raw:
@@ -85,8 +90,13 @@ def lint(lines, name):
                                 % (name, no, ins, sorted(touched), src[0][0]))
                 break
             if op.startswith("s_cbranch") or op == "s_branch":
-                problems.append("%s: line %d `%s`: branch while asm loads are in flight (replay assumes straight-line code)" % (name, no, ins))
-                break
+                # a FORWARD branch is replayed as straight-line text (both arms are checked for touches, which is conservative; no
+                # register of a load in flight can need a phi copy unless an arm writes it, and that is a touch); a BACKWARD branch
+                # with loads in flight is the loop-carried case that made hipcc copy registers before their data had landed
+                target = ins.split()[-1]
+                if labels.get(target, 1 << 60) <= no:
+                    problems.append("%s: line %d `%s`: backward branch while asm loads are in flight" % (name, no, ins))
+                    break
     return problems
 
 
