@@ -519,7 +519,8 @@ __device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4])
 // instructions per thread; products of bf16 values are exact in fp32, so the sums are those of the stored (rounded) values as
 // before, in a different (fixed) order.  Rows that are not positions of the window (254 / 255 of the input-resident tile, the
 // tail of the last tile) are written to LDS as zeros so that they drop out.
-// The epilogue in two halves, so that different waves can run them (conv_nt4_kernel): n2_tile_write moves a wave's accumulators into
+// The epilogue in two halves (so that different waves COULD run them: conv_nt4_kernel, the persistent compute-wave / drain-wave
+// experiment of round 4 -- bit-identical, 5-16 % slower, removed; profiles/r04_nt4_wave_profile.txt): n2_tile_write moves a wave's accumulators into
 // the 16-bit LDS tile, n2_tile_drain does everything that reads the tile (stores, pool pairs, statistics, the fused BatchNorm-backward
 // sums).  ``bar``: the drain's synchronisation policy -- sync() = a barrier the draining waves NEED between two of its phases
 // (only the fused sums have them), point() = a place where a barrier may be put for balance and nothing depends on it.
@@ -1473,379 +1474,6 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_nt4_kernel (round 4): conv_nt3_kernel's K loop in a PERSISTENT workgroup whose waves have roles.
-//
-// The wave profile of conv_nt3_kernel (profiles/r04_nt3_wave_profile.txt) says where a tile's time goes once the K loop is fast: block-2
-// forward 10.8 k ticks of K loop against 11 k of epilogue and 6 k of start-up; block-4 dgrad 49 k / 12.8 k / 5 k.  Two independent
-// workgroups per CU hide one's epilogue under the other's K loop only when their phases happen to alternate; when both store, the
-// matrix pipes idle.  Here ONE 512-thread workgroup owns the CU for the whole launch:
-//   waves 0-3  compute: the K loop of tile i, then -- straight away -- the first input blocks, weight fragments and start vector of
-//              tile i + 1 are requested, the accumulators go to the LDS tile (n2_tile_write), and the K loop of tile i + 1 begins;
-//   waves 4-7  drain: everything that reads the LDS tile of tile i - 1 (n2_tile_drain: stores, pool pairs, BatchNorm statistics, the
-//              fused BatchNorm-backward sums) while the compute waves run tile i.
-// Every SIMD holds one wave of each kind, so its matrix pipe always has exactly one K loop to run and the store path exactly one
-// drain.  This is also the persistent form that a single-role workgroup cannot be on this ISA: a wave that has stores
-// in flight can no longer count its loads with s_waitcnt vmcnt(N) -- here the waves that count loads never store, and the waves that
-// store wait vmcnt(0).
-// Synchronisation is s_barrier only (gfx950 has no named barriers, so every barrier is all eight waves).  Per tile slot the compute
-// waves execute CHUNKS barriers inside the K loop (the input ring's, as in conv_nt3_kernel), then B1 ("the drain is done with the LDS
-// tile") and B2 ("the tile is written").  The drain waves execute the same count: n2_tile_drain calls its barrier policy at the two
-// places the fused sums need one and at ~10 balance points between its stores; N4DrainSync turns an evenly spaced subset of them into
-// barriers so that a drain segment and a K-loop chunk meet at each one, and pads with bare barriers when it has none left.  A compute
-// wave waits at a chunk barrier only while the drain is behind (store-bound launches), a drain wave only while the K loop is.
-// LDS: input ring 64 KB + tile 68 KB = 132 KB.  Registers: the compute role's ~250.
-// ------------------------------------------------------------------------------------------------
-namespace n4 {
-constexpr int RING = n3::NBLK * n3::A_BLK;             // 64 KB
-constexpr int LDS_BYTES = RING + n2::TM * n2::TP;      // + the 16-bit tile of the drain
-static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-}  // namespace n4
-
-// s_waitcnt vmcnt(N) of iteration kt in conv_nt4_kernel (-1: nothing to wait for).  When a tile's K loop starts, its A(0), A(1), A(2),
-// B(0), B(1) and start vector are all complete (the previous slot ends on vmcnt(0)); iteration i then issues
-//   WAIT   B(i + 2) [4, first eight MFMAs]   A(c + 3) pieces [2, last eight; taps 0, 1]
-constexpr int n4_nwait(int kt, int chunks) {
-    const int nk = 3 * chunks;
-    if (kt < 2) return -1;
-    int after = 0;   // issued after B(kt) (iteration kt - 2's weight loads): its input pieces, then all of iteration kt - 1
-    for (int i = kt - 2; i < kt; ++i) {
-        if (i > kt - 2 && i + 2 < nk) after += 4;
-        const int c = i / 3, tap = i - 3 * c;
-        if (tap < 2 && c + 3 < chunks) after += 2;
-    }
-    return after;
-}
-static_assert(n4_nwait(0, 4) == -1 && n4_nwait(2, 4) == 8 && n4_nwait(3, 4) == 6 && n4_nwait(11, 4) == 0 && n4_nwait(5, 8) == 8,
-              "conv_nt4_kernel wait schedule");
-
-// the drain waves' barrier policy (see the kernel header): ``budget`` barriers per tile slot, ``need`` of them inside the drain's own
-// phases (sync), the others spread evenly (Bresenham) over the ``pts`` balance points the drain will pass
-struct N4DrainSync {
-    int budget, opt_total, pts, done = 0, seen = 0, opt_done = 0;
-    __device__ inline N4DrainSync(int budget_, int need_, int pts_) : budget(budget_), opt_total(budget_ - need_), pts(pts_ > 0 ? pts_ : 1) {}
-    __device__ inline void sync() {
-        __builtin_amdgcn_s_barrier();
-        ++done;
-    }
-    __device__ inline void point() {
-        const int before = (seen * opt_total) / pts, after = ((seen + 1) * opt_total) / pts;
-        ++seen;
-        if (after > before && opt_done < opt_total) {
-            __builtin_amdgcn_s_barrier();
-            ++done;
-            ++opt_done;
-        }
-    }
-    __device__ inline void finish() {   // out of work: meet the compute waves at their remaining chunk barriers
-        while (done < budget) {
-            __builtin_amdgcn_s_barrier();
-            ++done;
-        }
-    }
-};
-
-template <typename T, int EPI, int CHUNKS>
-__global__ __launch_bounds__(512) void conv_nt4_kernel(NtArgs<T> p, int64_t n_groups) {
-    using namespace n2;
-    using V8 = typename Mfma<T>::Frag;
-    constexpr int A_BLK = n3::A_BLK, NK = 3 * CHUNKS;
-    static_assert(CHUNKS >= 4 && CHUNKS % 4 == 0 && CHUNKS <= 16, "the ring slots of a tile's first blocks are free when its last chunk runs");
-    __shared__ __attribute__((aligned(1024))) char lds[n4::LDS_BYTES];
-    char* const tile = lds + n4::RING;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned total = (unsigned)(n_groups * p.tilesN);
-    const unsigned my_tiles = blockIdx.x < total ? (total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
-    const bool xcd_order = (n_groups & 7) == 0;
-    struct Coords {
-        int64_t n;
-        int tl, t0, n0;
-        unsigned tw;
-    };
-    auto coords = [&](unsigned v) {
-        unsigned group;
-        int tn;
-        const unsigned tiles_n = (unsigned)p.tilesN;
-        if (xcd_order) {
-            const unsigned j = v >> 3, q = j / tiles_n;
-            tn = (int)(j - q * tiles_n);
-            group = q * 8 + (v & 7);
-        } else {
-            group = v / tiles_n;
-            tn = (int)(v - group * tiles_n);
-        }
-        const unsigned nw = group / (unsigned)p.tilesL;
-        Coords c;
-        c.n = nw;
-        c.tl = (int)(group - nw * (unsigned)p.tilesL);
-        c.t0 = c.tl * n2r::TROWS;
-        c.n0 = tn * TN;
-        c.tw = EPI == EPI_FWD_FOLD ? nw / (unsigned)p.tower_windows : 0u;
-        return c;
-    };
-
-    if (w >= 4) {
-        // ================= drain waves: tile s - 1 while the compute waves run tile s =================
-        const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
-        constexpr bool FWD = EPI == EPI_FWD || EPI == EPI_FWD_FOLD;
-        const int pts = EPI == EPI_FWD_POOL ? 8
-                        : FWD ? ((p.pool_o != nullptr ? 0 : 2) + (p.pool_e != nullptr ? 8 : 0) + (p.stat_sum != nullptr ? 2 : 0))
-                              : 2 + (red ? 4 : 0);
-        VM_PROF(long long pd_drain = 0, pd_fin = 0, pd_b12 = 0; const long long pd_start = __builtin_amdgcn_s_memtime();)
-        for (unsigned s = 0; s <= my_tiles; ++s) {
-            N4DrainSync bar(CHUNKS, red ? 2 : 0, pts);
-            VM_PROF(const long long t0_ = __builtin_amdgcn_s_memtime();)
-            if (s >= 1) {
-                const Coords c = coords(blockIdx.x + (s - 1) * gridDim.x);   // (the drain reads nothing that differs per tower)
-                n2_tile_drain<T, EPI>(p, tile, c.n, c.tl, c.t0, c.n0, n2r::TROWS, tid - 256, lane, w - 4, bar);
-            }
-            VM_PROF(const long long t1_ = __builtin_amdgcn_s_memtime();)
-            bar.finish();
-            VM_PROF(const long long t2_ = __builtin_amdgcn_s_memtime();)
-            __builtin_amdgcn_s_barrier();   // B1: this tile's reads of the LDS tile are done (every one was consumed above)
-            __builtin_amdgcn_s_barrier();   // B2: the compute waves have written the next tile
-            VM_PROF(const long long t3_ = __builtin_amdgcn_s_memtime(); pd_drain += t1_ - t0_; pd_fin += t2_ - t1_; pd_b12 += t3_ - t2_;)
-        }
-#if defined(VM_EXPERIMENT_PROFILE)
-        if (lane == 0 && blockIdx.x < 4096) {
-            unsigned int* q = g_prof + ((int64_t)blockIdx.x * 8 + w) * 8;
-            q[0] = (unsigned int)(__builtin_amdgcn_s_memtime() - pd_start);  // whole life
-            q[1] = (unsigned int)pd_drain;   // inside n2_tile_drain (its own barrier waits included)
-            q[2] = (unsigned int)pd_fin;     // bare chunk barriers after the drain's work (waiting for the K loop)
-            q[3] = (unsigned int)pd_b12;     // B1 + B2 (waiting for the compute waves' tile write)
-            q[4] = my_tiles;
-        }
-#endif
-        return;
-    }
-
-    // ================= compute waves =================
-    const int wm = w >> 1, wn = w & 1;
-    const int lrow = lane >> 2, lchunk = lane & 3;
-    const uint32_t bvoff = lane * 16;
-    const int r = lane & 31, kh = lane >> 5;
-    int a_addr[3][2];
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-        const int row = wm * 128 + r + tap;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_addr[tap][ks] = row * KB + (((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
-#else
-    const uint32_t lds0 = 0;
-#endif
-    const float* const hb0 = p.fold_hb;
-    const float* const bias0 = p.bias;
-
-    // per-tile state of the tile whose K loop runs (cur) and of the one being prefetched (nxt)
-    const char* a_src[4];
-    const char* a_nxt[4];
-    uint64_t bbase = 0, bbase_nxt = 0;
-    Coords cur = coords(blockIdx.x < total ? blockIdx.x : 0u), nx = cur;
-    u32x4 bs[3][4];   // weight register sets of K tiles kt % 3 (constant indices only)
-    f32x4 bias4[2][4];
-    auto setup = [&](const Coords& c, const char* (&src)[4], uint64_t& bb, const float*& bptr) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (w + 4 * i) * 16 + lrow;
-            int pr = c.t0 + row;
-            pr = pr < p.L + 2 ? pr : p.L + 1;
-            src[i] = reinterpret_cast<const char*>(p.a + c.n * p.a_win_stride + (int64_t)pr * p.a_c) + ((lchunk ^ ((row >> 2) & 3)) << 4);
-        }
-        const uint64_t q = (uint64_t)(uintptr_t)p.bt_packed +
-                           ((uint64_t)c.tw * (unsigned)(p.N >> 6) + (unsigned)((c.n0 >> 6) + wn)) * (uint64_t)(NK * n3::KT_BYTES);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
-        bb = ((uint64_t)hi << 32) | lo;
-        // accumulator start vector: the bias (forward), row 3 of this tower's hb (folded forward), nothing (dgrad)
-        bptr = EPI == EPI_FWD_FOLD ? hb0 + (c.tw * 4 + 3) * p.N : bias0;
-        if (EPI != EPI_DGRAD) bptr += c.n0 + wn * 64 + 4 * kh;
-    };
-    // the prefetch of a tile, first part (the accumulators of the finished tile are still live): B(0), B(1) and the input blocks A(0),
-    // A(1), A(2); second part once the accumulators are in the LDS tile and their registers free: the start vector [8 loads, forward]
-    auto prefetch_start = [&](const float* bptr) {
-        if constexpr (EPI != EPI_DGRAD) {
-            const uint64_t pb = (uint64_t)(uintptr_t)bptr;   // per lane (kh): a VGPR address
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:0" : "=v"(bias4[j][g]) : "v"(pb + (uint64_t)((32 * j + 8 * g) * 4)) : "memory");
-        }
-    };
-    auto prefetch = [&](const char* (&src)[4], uint64_t bb) {
-        VM_GLOAD_FRAG(bs[0][0], bvoff, bb, 0);
-        VM_GLOAD_FRAG(bs[0][1], bvoff, bb, 1024);
-        VM_GLOAD_FRAG(bs[0][2], bvoff, bb, 2048);
-        VM_GLOAD_FRAG(bs[0][3], bvoff, bb, 3072);
-        const uint64_t bb1 = bb + n3::KT_BYTES;
-        VM_GLOAD_FRAG(bs[1][0], bvoff, bb1, 0);
-        VM_GLOAD_FRAG(bs[1][1], bvoff, bb1, 1024);
-        VM_GLOAD_FRAG(bs[1][2], bvoff, bb1, 2048);
-        VM_GLOAD_FRAG(bs[1][3], bvoff, bb1, 3072);
-#pragma unroll
-        for (int blk = 0; blk < 3; ++blk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                glds16(src[i] + blk * KB, lds + blk * A_BLK + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
-    };
-    auto prefetch_wait = [&]() {   // everything of the prefetch (the input blocks were requested a tile write and two barriers ago)
-        if constexpr (EPI != EPI_DGRAD) {
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(bias4[0][0]), "+v"(bias4[0][1]), "+v"(bias4[0][2]), "+v"(bias4[0][3]), "+v"(bias4[1][0]), "+v"(bias4[1][1]),
-                           "+v"(bias4[1][2]), "+v"(bias4[1][3]), "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[0][3]), "+v"(bs[1][0]),
-                           "+v"(bs[1][1]), "+v"(bs[1][2]), "+v"(bs[1][3])
-                         :
-                         : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[0][3]), "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2]),
-                           "+v"(bs[1][3])
-                         :
-                         : "memory");
-        }
-    };
-    auto issue_a1 = [&](int blk, int chunk, int i) {  // piece i of this wave's four, current tile
-        glds16(a_src[i] + chunk * KB, lds + blk * A_BLK + __builtin_amdgcn_readfirstlane((w + 4 * i) * 1024));
-    };
-
-    if (my_tiles > 0) {
-        const float* bptr;
-        setup(cur, a_src, bbase, bptr);
-        prefetch(a_src, bbase);
-        prefetch_start(bptr);
-        prefetch_wait();
-    }
-    const float* bptr_nxt = nullptr;
-    VM_PROF(long long pc_k = 0, pc_pre = 0, pc_b1 = 0, pc_w = 0, pc_b2 = 0; const long long pc_start = __builtin_amdgcn_s_memtime();)
-    for (unsigned it = 0; it <= my_tiles; ++it) {
-        if (it == my_tiles) {   // the slot in which only the drain waves have work: keep the barrier count
-            for (int b = 0; b < CHUNKS + 2; ++b) __builtin_amdgcn_s_barrier();
-            break;
-        }
-        VM_PROF(const long long t0_ = __builtin_amdgcn_s_memtime();)
-        f32x16 acc[4][2];
-        if constexpr (EPI == EPI_DGRAD) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        n2_fill_acc(acc, bias4);
-        u32x4 f0[4], f1[4];
-#define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
-#define VM_FRAG_READ(dst, base, I)                                                              \
-    if constexpr ((I) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(base));          \
-    if constexpr ((I) == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dst) : "v"(base)); \
-    if constexpr ((I) == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(dst) : "v"(base)); \
-    if constexpr ((I) == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(dst) : "v"(base));
-#define VM_P_STEP0(I)                                                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f0[I]));                                                                               \
-    VM_MM(f0[I], bs[cur_][0], I, 0);                                                                                                  \
-    VM_MM(f0[I], bs[cur_][2], I, 1);                                                                                                  \
-    VM_FRAG_READ(f1[I], aa1_, I)                                                                                                      \
-    if constexpr (kt_ + 2 < NK) {                                                                                                     \
-        if constexpr ((I) == 0) VM_GLOAD_FRAG(bs[nxt_][0], bvoff, sb_, 0);                                                            \
-        if constexpr ((I) == 1) VM_GLOAD_FRAG(bs[nxt_][1], bvoff, sb_, 1024);                                                         \
-        if constexpr ((I) == 2) VM_GLOAD_FRAG(bs[nxt_][2], bvoff, sb_, 2048);                                                         \
-        if constexpr ((I) == 3) VM_GLOAD_FRAG(bs[nxt_][3], bvoff, sb_, 3072);                                                         \
-    }                                                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-#define VM_P_STEP1(I)                                                                                                                 \
-    if constexpr (kt_ + 1 < NK) {                                                                                                     \
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[I]));                                                                           \
-    } else {                                                                                                                          \
-        if constexpr ((I) == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[I]));                                                   \
-        if constexpr ((I) == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f1[I]));                                                   \
-        if constexpr ((I) == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f1[I]));                                                   \
-        if constexpr ((I) == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[I]));                                                   \
-    }                                                                                                                                 \
-    VM_MM(f1[I], bs[cur_][1], I, 0);                                                                                                  \
-    VM_MM(f1[I], bs[cur_][3], I, 1);                                                                                                  \
-    if constexpr (kt_ + 1 < NK) { VM_FRAG_READ(f0[I], an0_, I) }                                                                      \
-    if constexpr ((I) < 2 && tap_ < 2 && c_ + 3 < CHUNKS) issue_a1((c_ + 3) % 4, c_ + 3, 2 * tap_ + (I));                             \
-    __builtin_amdgcn_sched_barrier(0);
-#define VM_KTILE_P(KT)                                                                                                                \
-    if constexpr ((KT) < NK) {                                                                                                        \
-        constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, nxt_ = (kt_ + 2) % 3, ablk_ = c_ % 4;             \
-        constexpr int nc_ = (kt_ + 1) / 3, ntap_ = (kt_ + 1) - 3 * nc_;   /* chunk and tap of the next tile */                          \
-        if constexpr (n4_nwait(kt_, CHUNKS) >= 0) n3_wait_b<(n4_nwait(kt_, CHUNKS) >= 0 ? n4_nwait(kt_, CHUNKS) : 0)>(bs[cur_]);      \
-        if constexpr (kt_ == 0) {                                                                                                     \
-            __builtin_amdgcn_s_barrier();                                                                                             \
-            const uint32_t a00_ = lds0 + a_addr[0][0];                                                                                \
-            VM_FRAG_READ(f0[0], a00_, 0) VM_FRAG_READ(f0[1], a00_, 1) VM_FRAG_READ(f0[2], a00_, 2) VM_FRAG_READ(f0[3], a00_, 3)         \
-        }                                                                                                                             \
-        const uint32_t aa1_ = lds0 + ablk_ * A_BLK + a_addr[tap_][1];                                                                  \
-        const uint32_t an0_ = lds0 + (nc_ % 4) * A_BLK + a_addr[ntap_][0];                                                             \
-        const uint64_t sb_ = bbase + (uint64_t)((kt_ + 2) * n3::KT_BYTES);                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        VM_P_STEP0(0) VM_P_STEP0(1) VM_P_STEP0(2) VM_P_STEP0(3)                                                                       \
-        if constexpr (tap_ == 2 && kt_ + 1 < NK) {                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));                                 \
-            __builtin_amdgcn_s_barrier();                                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                                        \
-        }                                                                                                                             \
-        VM_P_STEP1(0) VM_P_STEP1(1) VM_P_STEP1(2) VM_P_STEP1(3)                                                                       \
-    }
-#define VM_CHUNK(C) VM_KTILE_P(3 * (C)) VM_KTILE_P(3 * (C) + 1) VM_KTILE_P(3 * (C) + 2)
-        VM_CHUNK(0) VM_CHUNK(1) VM_CHUNK(2) VM_CHUNK(3) VM_CHUNK(4) VM_CHUNK(5) VM_CHUNK(6) VM_CHUNK(7)
-        VM_CHUNK(8) VM_CHUNK(9) VM_CHUNK(10) VM_CHUNK(11) VM_CHUNK(12) VM_CHUNK(13) VM_CHUNK(14) VM_CHUNK(15)
-#undef VM_CHUNK
-#undef VM_KTILE_P
-#undef VM_P_STEP0
-#undef VM_P_STEP1
-#undef VM_FRAG_READ
-#undef VM_MM
-        VM_PROF(const long long t1_ = __builtin_amdgcn_s_memtime();)
-        // ---- the K loop is done and nothing of it is in flight.  Request the next tile right away (the last slot re-requests its own
-        // tile: harmless bytes into free registers and ring blocks, and the code path has no branch around loads in flight) ----
-        {
-            const unsigned vn = blockIdx.x + (it + 1 < my_tiles ? it + 1 : it) * gridDim.x;
-            nx = coords(vn);
-            setup(nx, a_nxt, bbase_nxt, bptr_nxt);
-            prefetch(a_nxt, bbase_nxt);
-        }
-        // (the lane index goes through an empty asm per tile: otherwise the ~60 lane-only address and mask values of the two calls below
-        // are hoisted out of the tile loop, live across the whole K loop, and spilled to scratch)
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        if constexpr (EPI == EPI_FWD_FOLD) {
-            p.fold_hb = hb0 + cur.tw * 4 * p.N;   // (p is this wave's own copy of the arguments)
-            const int c0 = cur.n0 + wn * 64 + 4 * (lane_t >> 5), rl = p.L - 1 - cur.t0;
-            if (cur.t0 == 0) n2_fold_edge<T>(p, acc, 0, 0, wm, lane_t & 31, c0);
-            if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane_t & 31, c0);
-        }
-        VM_PROF(const long long t2_ = __builtin_amdgcn_s_memtime();)
-        __builtin_amdgcn_s_barrier();   // B1: the drain waves are done with the LDS tile of the previous slot
-        VM_PROF(const long long t3_ = __builtin_amdgcn_s_memtime();)
-        n2_tile_write<T, EPI>(p, tile, acc, cur.t0, n2r::TROWS, lane_t, wm, wn);
-        prefetch_start(bptr_nxt);   // (the accumulators are dead: their registers take the next start vector)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile stores have reached the LDS
-        VM_PROF(const long long t4_ = __builtin_amdgcn_s_memtime();)
-        __builtin_amdgcn_s_barrier();   // B2: the tile is the drain waves'
-        prefetch_wait();
-        VM_PROF(const long long t5_ = __builtin_amdgcn_s_memtime(); pc_k += t1_ - t0_; pc_pre += t2_ - t1_; pc_b1 += t3_ - t2_; pc_w += t4_ - t3_; pc_b2 += t5_ - t4_;)
-        cur = nx;
-        bbase = bbase_nxt;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a_src[i] = a_nxt[i];
-    }
-#if defined(VM_EXPERIMENT_PROFILE)
-    if (lane == 0 && blockIdx.x < 4096) {
-        unsigned int* q = g_prof + ((int64_t)blockIdx.x * 8 + w) * 8;
-        q[0] = (unsigned int)(__builtin_amdgcn_s_memtime() - pc_start);  // whole life
-        q[1] = (unsigned int)pc_k;    // K loops (chunk barrier waits included)
-        q[2] = (unsigned int)pc_pre;  // next tile's coordinates + prefetch issue + edge fix
-        q[3] = (unsigned int)pc_b1;   // waiting at B1 (the drain of the previous tile)
-        q[4] = (unsigned int)pc_w;    // accumulators -> LDS tile
-        q[5] = (unsigned int)pc_b2;   // B2 + the wait for the prefetched registers
-        q[6] = my_tiles;
-    }
-#endif
-}
-
 // (N, 3 * a_c) row-major GEMM-layout weights (vm_prep_conv_weights' wf / wd, vm_fold_bn_weights' wf_folded; `towers` of them back to
 // back) -> the fragment order conv_nt3_kernel streams: one thread per 16-byte piece of the OUTPUT (coalesced writes; the reads are
 // 16-byte gathers out of L2).  out piece index = ((((t * N/64 + b64) * nk + kt) * 2 + j) * 2 + ks) * 64 + lane.
@@ -1903,8 +1531,6 @@ extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 namespace vm {
 int g_nt_n2 = 3;       // conv_nt2r_kernel for 16-bit storage: bit 0 forward, bit 1 dgrad; vm_set_tuning("nt_n2", 0..3)
 int g_nt3 = 3;         // conv_nt3_kernel (weights L2 -> registers) where the caller supplies packed weights: bit 0 forward, bit 1 dgrad
-int g_nt4 = 3;         // conv_nt4_kernel (persistent workgroup, compute / drain waves) instead of conv_nt3_kernel: bit 0 forward, bit 1 dgrad
-int g_nt4_blocks = 256;  // its grid: one workgroup per CU
 int g_nt3_pipe = 3;    // conv_nt3_kernel's interleaved K loop: bit 0 forward, bit 1 dgrad (0: the block-structured loop; A/B only)
 int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0, else register staging; vm_set_tuning("nt_glds", 0 | 1)
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
@@ -1938,19 +1564,6 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
         if constexpr (EPI != EPI_FWD) {  // the entry points that take packed weights (vm_pack_nt_weights)
             if (b.bt_packed != nullptr && (g_nt3 & (EPI == EPI_DGRAD ? 2 : 1)) && nt3_chunks(a.a_c)) {
                 const dim3 grid((unsigned)(n_groups * b.tilesN));
-                if (g_nt4 & (EPI == EPI_DGRAD ? 2 : 1)) {   // the persistent, role-split form: one 512-thread workgroup per CU
-                    const int64_t tiles_total = n_groups * b.tilesN;
-                    const dim3 pgrid((unsigned)(tiles_total < g_nt4_blocks ? tiles_total : g_nt4_blocks));
-#define VM_NT4(CH) hipLaunchKernelGGL((conv_nt4_kernel<T, EPI, CH>), pgrid, dim3(512), 0, stream, b, n_groups)
-                    switch (a.a_c / 32) {
-                        case 4: VM_NT4(4); break;
-                        case 8: VM_NT4(8); break;
-                        case 12: VM_NT4(12); break;
-                        default: VM_NT4(16); break;
-                    }
-#undef VM_NT4
-                    return;
-                }
 #define VM_NT3(CH, PIPE) hipLaunchKernelGGL((conv_nt3_kernel<T, EPI, CH, PIPE>), grid, dim3(256), 0, stream, b, n_groups)
                 const bool pipe = (g_nt3_pipe & (EPI == EPI_DGRAD ? 2 : 1)) != 0;
                 switch (a.a_c / 32) {  // the K loop is written out per channel count: 128, 256, 384, 512 channels on the K side
@@ -2250,7 +1863,7 @@ extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int*
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_pipe", &g_nt3_pipe, 0, 3}, {"nt4", &g_nt4, 0, 3}, {"nt4_blocks", &g_nt4_blocks, 8, 4096}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_pipe", &g_nt3_pipe, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;
