@@ -30,11 +30,14 @@ def lint(lines, name):
     queue = []      # outstanding VMEM ops, oldest first: (line_no, set of destination VGPRs or empty)
     lq = []         # outstanding LDS ops (lgkmcnt): the same replay for hand-counted ds_read_* (they return in order)
     problems = []
-    labels = {}
+    labels, headers, last_label = {}, set(), None
     for no, raw in lines:
         m = re.match(r"^(\.?\w+):", raw.strip())
         if m:
             labels[m.group(1)] = no
+            last_label = (m.group(1), no)
+        if "Loop Header" in raw and last_label is not None and no - last_label[1] <= 1:
+            headers.add(last_label[0])   # hipcc annotates loop header blocks: a branch to one of THEM is a loop back edge
     in_asm = False  # inside a ;;#ASMSTART ... ;;#ASMEND bracket: only THOSE loads are hidden from the compiler's own wait insertion
     for no, raw in lines:
         if "#ASMSTART" in raw:
@@ -91,10 +94,11 @@ def lint(lines, name):
                 break
             if op.startswith("s_cbranch") or op == "s_branch":
                 # a FORWARD branch is replayed as straight-line text (both arms are checked for touches, which is conservative; no
-                # register of a load in flight can need a phi copy unless an arm writes it, and that is a touch); a BACKWARD branch
-                # with loads in flight is the loop-carried case that made hipcc copy registers before their data had landed
+                # register of a load in flight can need a phi copy unless an arm writes it, and that is a touch); a branch BACK to a
+                # loop header with loads in flight is the loop-carried case that made hipcc copy registers before their data had landed
+                # (backward branches to other blocks are the compiler's layout of if / else joins inside one iteration)
                 target = ins.split()[-1]
-                if labels.get(target, 1 << 60) <= no:
+                if labels.get(target, 1 << 60) <= no and (target in headers or not headers):
                     problems.append("%s: line %d `%s`: backward branch while asm loads are in flight" % (name, no, ins))
                     break
     return problems

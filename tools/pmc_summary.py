@@ -8,12 +8,17 @@ import sys
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("conv_nt2r", "conv_tn8x", "conv_nt_glds", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_gmax",
+    for key in ("conv_nt3", "conv_nt2r", "conv_tn8x", "conv_nt_glds", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_gmax",
                 "bn_drop_pool_fwd", "conv1_fused_bwd", "conv1_fused_fwd", "global_maxpool", "slab_stage", "colreduce", "whiten", "dense", "adam",
                 "siamese"):
         if key in name:
             extra = ""
-            if "conv_nt" in name:   # mangled: ...ILi0E / Li1E ...; demangled: <T, 0> / <T, 1>
+            if key == "conv_nt3":   # conv_nt3_kernel<T, EPI, chunks, pipe>: mangled ...Li<EPI>ELi<chunks>ELb1E
+                import re
+                m = re.search(r"Li(\d)ELi(\d+)E", name) or re.search(r", (?:\(int\))?(\d), (?:\(int\))?(\d+),", name)
+                epi, ch = (m.group(1), m.group(2)) if m else ("?", "?")
+                extra = "<%s, K-side %s ch>" % ({"3": "fwd+fold", "1": "dgrad", "2": "fwd+pool"}.get(epi, epi), int(ch) * 32 if ch != "?" else ch)
+            elif "conv_nt" in name:   # mangled: ...ILi0E / Li1E ...; demangled: <T, 0> / <T, 1>
                 extra = ("<fwd>" if ("Li0E" in name or ", 0>" in name or "(int)0>" in name) else
                          "<fwd+fold>" if ("Li3E" in name or ", 3>" in name or "(int)3>" in name) else "<dgrad>")
             if "bn_pool_bwd" in name:

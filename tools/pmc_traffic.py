@@ -61,9 +61,12 @@ def main(fetch_dir, write_dir, out):
     shapes = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
     # (rocprofv3 prints some instantiations demangled, with the epilogue enum elided: "<bool _Accum, int, E, 128, false>")
     # (Li3 = the forward on the pool extremes with the BatchNorm affine folded in, vm_conv_fwd_fold: what a default step launches)
+    # (round 4: with packed weights the same launches are conv_nt3_kernel<T, EPI, chunks, true>: "Li3ELi<chunks>E" mangled)
     for entry, has, order in (("vm_conv_fwd", [("conv_nt2r", "Li0E"), ("conv_nt2r_kernel<", ", 0>"), ("conv_nt2r_kernel<", "(int)0>"),
-                                               ("conv_nt2r", "Li3E"), ("conv_nt2r_kernel<", ", 3>"), ("conv_nt2r_kernel<", "(int)3>")], shapes),
-                              ("vm_conv_dgrad", [("conv_nt2r", "Li1E"), ("conv_nt2r_kernel<", ", 1>"), ("conv_nt2r_kernel<", "(int)1>")],
+                                               ("conv_nt2r", "Li3E"), ("conv_nt2r_kernel<", ", 3>"), ("conv_nt2r_kernel<", "(int)3>"),
+                                               ("conv_nt3", "Li3ELi"), ("conv_nt3_kernel<", ", 3, "), ("conv_nt3_kernel<", "(int)3, ")], shapes),
+                              ("vm_conv_dgrad", [("conv_nt2r", "Li1E"), ("conv_nt2r_kernel<", ", 1>"), ("conv_nt2r_kernel<", "(int)1>"),
+                                                 ("conv_nt3", "Li1ELi"), ("conv_nt3_kernel<", ", 1, "), ("conv_nt3_kernel<", "(int)1, ")],
                                shapes[::-1])):
         fv, wv = per_order(fetch_dir, "FETCH_SIZE", has, 3), per_order(write_dir, "WRITE_SIZE", has, 3)
         for (L, cin, cout), f_, w_ in zip(order, fv, wv):

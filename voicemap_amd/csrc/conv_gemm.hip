@@ -703,10 +703,13 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
 #else
         const uint32_t lds0 = 0;
 #endif
-        // fragment geometry of the transposing read: lane (kh, lg, li) supplies the 8-byte word of row kh * 8 + (li >> 2), channels
-        // 16 lg + 4 (li & 3) .. + 3 and receives channel 16 lg + li, rows kh * 8 .. + 3 (second read: + 4 rows)
+        // fragment geometry of the transposing read: lane (kh, lg, li) supplies the 8-byte word of row 4 (li >> 2) + 2 kh, channels
+        // 16 lg + 4 (li & 3) .. + 3 and receives channel 16 lg + li of the four rows 2 kh + {0, 4, 8, 12} (second read: + 1 row).
+        // WHICH 16 positions a k-step holds does not matter to a sum over positions (both MFMA operands are these registers), and with
+        // the rows of one read 4 apart their four 64-byte segments fall in four different quarters of the bank line (a 272-byte pitch
+        // moves a row by 4 banks: consecutive rows overlapped in 12 of their 16 banks -- the 4-way conflicts of the round-3 counters)
         const int li = lane & 15, lg = (lane >> 4) & 1;
-        const uint32_t xoff = lds0 + (kh * 8 + (li >> 2)) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+        const uint32_t xoff = lds0 + (4 * (li >> 2) + 2 * kh) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
         const V8 ones = ones16<T>();
         const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
         const int cn = lane & 31;             // the channel (of this wave's 32) whose sums this lane extracts
@@ -721,7 +724,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             for (int rs = 0; rs < 8; ++rs) {
                 const uint32_t a = xoff + (h * 128 + rs * 16) * TP;
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[rs]) : "v"(a));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1088" : "=v"(hi[rs]) : "v"(a));  // + 4 rows of 272 bytes
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:272" : "=v"(hi[rs]) : "v"(a));  // + 1 row of 272 bytes
             }
 #pragma unroll
             for (int rs = 0; rs < 8; ++rs) {
@@ -771,8 +774,10 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
 #else
         const uint32_t lds0 = 0;
 #endif
+        // (the row order of the statistics reads above: 4 (li >> 2) + 2 kh, second read + 1 row -- the same for dp and for A, whose
+        // k indices must agree)
         const int li = lane & 15, lg = (lane >> 4) & 1;
-        const uint32_t xoff = lds0 + (kh * 8 + (li >> 2)) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+        const uint32_t xoff = lds0 + (4 * (li >> 2) + 2 * kh) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
         const V8 ones = ones16<T>();
         u32x2 dlo[16], dhi[16];
         f32x16 d1[2], d2[2];
@@ -784,7 +789,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         for (int q = 0; q < 16; ++q) {
             const uint32_t a = xoff + (q * 16) * TP;
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dlo[q]) : "v"(a));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1088" : "=v"(dhi[q]) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:272" : "=v"(dhi[q]) : "v"(a));
             if (q == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]),
                                      "+v"(dlo[3]), "+v"(dhi[3]), "+v"(dlo[4]), "+v"(dhi[4]), "+v"(dlo[5]), "+v"(dhi[5]), "+v"(dlo[6]), "+v"(dhi[6]),
                                      "+v"(dlo[7]), "+v"(dhi[7]));
@@ -793,16 +798,19 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
                      "+v"(dhi[11]), "+v"(dlo[12]), "+v"(dhi[12]), "+v"(dlo[13]), "+v"(dhi[13]), "+v"(dlo[14]), "+v"(dhi[14]), "+v"(dlo[15]),
                      "+v"(dhi[15]));
         bar.sync();  // every wave has its dp fragments and has issued its output stores: the tile memory is free
-        // A tile: 256 rows x 128 channels, 256-byte rows (unpadded: the LDS-DMA destination is lane-linear), 64 pieces of 4 rows
+        // A tile: 256 rows x 128 channels, 256-byte rows (unpadded: the LDS-DMA destination is lane-linear), 64 pieces of 4 rows.  A
+        // row is a whole bank line, so the four rows of a transposing read would sit on the same banks: the 64-byte quarters of row R are
+        // stored XOR-ed with (R >> 2) & 3 (applied to the per-lane SOURCE address here and to the read address below)
         {
             const int arow = lane >> 4, achunk = lane & 15;
-            const T* abase = p.red_a + n * p.red_a_win_stride + (int64_t)(t0 + p.red_a_row0) * p.N + n0 + achunk * 8;
+            const T* abase = p.red_a + n * p.red_a_win_stride + (int64_t)(t0 + p.red_a_row0) * p.N + n0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int pi = w + 4 * k;
                 int R = pi * 4 + arow;
+                const int sw = (achunk ^ ((pi & 3) << 2)) * 8;   // (R >> 2) & 3 == pi & 3
                 R = R < valid ? R : valid - 1;  // rows outside the window: any finite value (their dp rows are zero)
-                glds16(reinterpret_cast<const char*>(abase + (int64_t)R * p.N), lds + __builtin_amdgcn_readfirstlane(pi * 1024));
+                glds16(reinterpret_cast<const char*>(abase + (int64_t)R * p.N + sw), lds + __builtin_amdgcn_readfirstlane(pi * 1024));
                 if ((k & 3) == 3) bar.point();
             }
         }
@@ -813,7 +821,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and loads retire out of order with each other: no counted wait here
         bar.sync();  // the A tile has landed for every wave
-        const uint32_t aoff = lds0 + (kh * 8 + (li >> 2)) * 256 + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
+        const uint32_t aoff = lds0 + (4 * (li >> 2) + 2 * kh) * 256 + (((32 * w + 16 * lg + 4 * (li & 3)) * 2) ^ ((li >> 2) << 6));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x2 alo[8], ahi[8];
@@ -821,7 +829,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             for (int rs = 0; rs < 8; ++rs) {
                 const uint32_t a = aoff + (h * 128 + rs * 16) * 256;
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[rs]) : "v"(a));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(ahi[rs]) : "v"(a));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(ahi[rs]) : "v"(a));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]),
                          "+v"(ahi[3]), "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]));
