@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-r4ab}; mkdir -p $OUT
 python -m pytest tests/test_gpu_fold.py tests/test_gpu_kernels.py -x -q -m gpu -k "fold or bnred or fwd_pool or pack_nt" > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 i=0
-TUNES="${2:-nt3=3,nt3_pipe=3 nt3=3,nt3_pipe=0 nt3=0 nt3=3,nt3_pipe=3 nt3=3,nt3_pipe=0 nt3=0}"
+TUNES="${2:-nt3_lean=3 nt3_lean=0 nt3=0 nt3_lean=3 nt3_lean=0 nt3=0}"
 for t in $TUNES; do
   i=$((i+1)); python bench.py --no-extras --no-cpu-baseline --blocks 3 --tune $t > "$OUT/bench_$i.$t.json" 2>> $OUT/bench.err
 done

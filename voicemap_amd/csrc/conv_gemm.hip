@@ -1182,12 +1182,26 @@ __device__ inline void n3_wait_b(u32x4 (&b)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
 }
 
-// The issue schedule of conv_nt3_kernel, replayed at compile time: the number of vector-memory operations a wave has issued after
-// the last fragment of B(kt) when it reaches the wait of iteration kt -- the N of that iteration's s_waitcnt vmcnt(N).
-//   prologue   A(0) [4]   B(0) [4]   A(1) [4, chunks > 1]   B(1) [4]   A(2) [4, chunks > 2]
-//   iteration i = 3 c + tap:   B(i + 2) [4, i + 2 < nk]   WAIT   (barrier, tap 0)   A(c + 3) pieces [2, tap < 2 and c + 3 < chunks]
-//   PIPE (the interleaved loop): iteration i:   WAIT   B(i + 2) [4, inside the first eight MFMAs]   A pieces [2, inside the last eight]
-constexpr int n3_nwait(int kt, int chunks, bool pipe = false) {
+// The issue schedule of conv_nt3_kernel as constexpr functions: which input (A) pieces iteration i = 3 c + tap issues under its last
+// eight MFMAs, and -- by replaying the whole schedule -- the number of vector-memory operations a wave has issued after the last
+// fragment of B(kt) when it reaches the wait that opens iteration kt: the N of that iteration's s_waitcnt vmcnt(N).
+//   prologue          A(0) [4]   B(0) [4]   B(1) [4]   A(1) [4, chunks > 1]            (LEAN; the first wait needs A(0), B(0) only)
+//                     A(0) [4]   B(0) [4]   A(1) [4]   B(1) [4]   A(2) [4, chunks > 2]  (!LEAN: the first form)
+//   iteration i       WAIT   B(i + 2) [4, i + 2 < nk, under the first eight MFMAs]   A pieces [under the last eight]:
+//                     LEAN: i = 0: all four of A(2); i = 1: all four of A(3); i = 2: none; from chunk 1 on as below
+//                     pieces 2 tap, 2 tap + 1 of A(c + 3) at taps 0, 1 while c + 3 < chunks
+// LEAN issues four LDS-DMA instructions (~250 ticks each under load) fewer before the first MFMA of a tile.
+struct N3Pieces {
+    int count, block, first;
+};
+constexpr N3Pieces n3_pieces(int i, int chunks, bool lean) {
+    const int c = i / 3, tap = i - 3 * c;
+    if (lean && i == 0) return N3Pieces{chunks > 2 ? 4 : 0, 2, 0};
+    if (lean && i == 1) return N3Pieces{chunks > 3 ? 4 : 0, 3, 0};
+    if (lean && c == 0) return N3Pieces{0, 0, 0};
+    return N3Pieces{(tap < 2 && c + 3 < chunks) ? 2 : 0, c + 3, 2 * tap};
+}
+constexpr int n3_nwait(int kt, int chunks, bool lean) {
     const int nk = 3 * chunks;
     int after = -1;  // operations issued since B(kt) completed its issue; -1: B(kt) not issued yet
     auto issue = [&](int count, bool is_bkt) {
@@ -1199,26 +1213,27 @@ constexpr int n3_nwait(int kt, int chunks, bool pipe = false) {
     };
     issue(4, false);                       // A(0)
     issue(4, kt == 0);                     // B(0)
-    if (chunks > 1) issue(4, false);       // A(1)
-    issue(4, kt == 1);                     // B(1)
-    if (chunks > 2) issue(4, false);       // A(2)
-    for (int i = 0; i <= kt; ++i) {
-        if (pipe && i == kt) break;        // PIPE: the wait opens the iteration
+    if (lean) {
+        issue(4, kt == 1);                 // B(1)
+        if (chunks > 1) issue(4, false);   // A(1)
+    } else {
+        if (chunks > 1) issue(4, false);   // A(1)
+        issue(4, kt == 1);                 // B(1)
+        if (chunks > 2) issue(4, false);   // A(2)
+    }
+    for (int i = 0; i < kt; ++i) {         // (the wait of iteration kt opens it)
         if (i + 2 < nk) issue(4, i + 2 == kt);
-        if (i == kt) break;                // the wait of iteration kt
-        const int c = i / 3, tap = i - 3 * c;
-        if (tap < 2 && c + 3 < chunks) issue(2, false);
+        issue(n3_pieces(i, chunks, lean).count, false);
     }
     return after;
 }
-static_assert(n3_nwait(0, 4) == 16 && n3_nwait(1, 4) == 14 && n3_nwait(2, 4) == 12 && n3_nwait(11, 4) == 0 && n3_nwait(10, 4) == 4,
-              "conv_nt3_kernel wait schedule");
+static_assert(n3_nwait(0, 4, false) == 12 && n3_nwait(1, 4, false) == 10 && n3_nwait(2, 4, false) == 8 && n3_nwait(11, 4, false) == 0 &&
+              n3_nwait(5, 8, false) == 8, "conv_nt3_kernel wait schedule");
+static_assert(n3_nwait(0, 4, true) == 8 && n3_nwait(1, 4, true) == 12 && n3_nwait(2, 4, true) == 12 && n3_nwait(3, 4, true) == 8 &&
+              n3_nwait(4, 8, true) == 6 && n3_nwait(11, 4, true) == 0, "conv_nt3_kernel wait schedule (lean prologue)");
 
-static_assert(n3_nwait(0, 4, true) == 12 && n3_nwait(1, 4, true) == 10 && n3_nwait(2, 4, true) == 8 && n3_nwait(11, 4, true) == 0 &&
-              n3_nwait(5, 8, true) == 8, "conv_nt3_kernel wait schedule (interleaved loop)");
-
-// PIPE: the interleaved K loop (below, VM_KTILE_P); false: the block-structured loop of the first version (kept for the A/B)
-template <typename T, int EPI, int CHUNKS, bool PIPE>
+// LEAN: the prologue that leaves A(2), A(3) to the first two K tiles (A/B switch nt3_lean)
+template <typename T, int EPI, int CHUNKS, bool LEAN>
 __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n_groups) {
     VM_PROF(const long long pt_start = __builtin_amdgcn_s_memtime(); long long pt_first = 0, pt_bar = 0;)
     using namespace n2;
@@ -1306,76 +1321,28 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
 #endif
 
     VM_PROF(const long long pt_s2 = __builtin_amdgcn_s_memtime();)
-    // ---- prologue: A(0), B(0), A(1), B(1), A(2) ----
+    // ---- prologue (see n3_nwait) ----
     issue_a(0, 0, 0);
     issue_a(0, 0, 2);
     VM_LOAD_SET(0);
+    if constexpr (LEAN) VM_LOAD_SET(1);
     if constexpr (CHUNKS > 1) {
         issue_a(1, 1, 0);
         issue_a(1, 1, 2);
     }
-    VM_LOAD_SET(1);
-    if constexpr (CHUNKS > 2) {
-        issue_a(2, 2, 0);
-        issue_a(2, 2, 2);
+    if constexpr (!LEAN) {
+        VM_LOAD_SET(1);
+        if constexpr (CHUNKS > 2) {
+            issue_a(2, 2, 0);
+            issue_a(2, 2, 2);
+        }
     }
     VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
     f32x16 acc[4][2];
     n2_fill_acc(acc, bias4);
 #define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
-    // one K tile; KT is a literal: every index, every wait count and every branch below is a compile-time constant, the loop is straight-
-    // line code and no register that a load is still writing ever meets a phi (the rolled form made hipcc copy them)
-#define VM_KTILE(KT)                                                                                                                  \
-    if constexpr ((KT) < NK) {                                                                                                        \
-        constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, ablk_ = c_ % 4;                                  \
-        if constexpr (kt_ + 2 < NK) VM_LOAD_SET(kt_ + 2);                                                                             \
-        n3_wait_b<n3_nwait(kt_, CHUNKS)>(bs[cur_]);                                                                                   \
-        if constexpr (tap_ == 0) __builtin_amdgcn_s_barrier();                                                                        \
-        if constexpr (tap_ < 2 && c_ + 3 < CHUNKS) issue_a((c_ + 3) % 4, c_ + 3, 2 * tap_);                                           \
-        const uint32_t aa0 = lds0 + ablk_ * A_BLK + a_addr[tap_][0], aa1 = lds0 + ablk_ * A_BLK + a_addr[tap_][1];                     \
-        u32x4 f0[4], f1[4];                                                                                                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f0[0]) : "v"(aa0));                                                                 \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f0[1]) : "v"(aa0));                                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f0[2]) : "v"(aa0));                                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f0[3]) : "v"(aa0));                                                     \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f1[0]) : "v"(aa1));                                                                 \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f1[1]) : "v"(aa1));                                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f1[2]) : "v"(aa1));                                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f1[3]) : "v"(aa1));                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f0[0]));                                                                           \
-        VM_MM(f0[0], bs[cur_][0], 0, 0);                                                                                              \
-        VM_MM(f0[0], bs[cur_][2], 0, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f0[1]));                                                                           \
-        VM_MM(f0[1], bs[cur_][0], 1, 0);                                                                                              \
-        VM_MM(f0[1], bs[cur_][2], 1, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f0[2]));                                                                           \
-        VM_MM(f0[2], bs[cur_][0], 2, 0);                                                                                              \
-        VM_MM(f0[2], bs[cur_][2], 2, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f0[3]));                                                                           \
-        VM_MM(f0[3], bs[cur_][0], 3, 0);                                                                                              \
-        VM_MM(f0[3], bs[cur_][2], 3, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f1[0]));                                                                           \
-        VM_MM(f1[0], bs[cur_][1], 0, 0);                                                                                              \
-        VM_MM(f1[0], bs[cur_][3], 0, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f1[1]));                                                                           \
-        VM_MM(f1[1], bs[cur_][1], 1, 0);                                                                                              \
-        VM_MM(f1[1], bs[cur_][3], 1, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f1[2]));                                                                           \
-        VM_MM(f1[2], bs[cur_][1], 2, 0);                                                                                              \
-        VM_MM(f1[2], bs[cur_][3], 2, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[3]));                                                                           \
-        VM_MM(f1[3], bs[cur_][1], 3, 0);                                                                                              \
-        VM_MM(f1[3], bs[cur_][3], 3, 1);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                            \
-    }
+    // KT is a literal in the macros below: every index, every wait count and every branch is a compile-time constant, the loop is
+    // straight-line code and no register that a load is still writing ever meets a phi (the rolled form made hipcc copy them)
     // ---- the interleaved loop.  Every memory operation of a K tile sits INSIDE its MFMA stream, one per pair of MFMAs: the
     // k-step-1 fragments of this tile and the weight fragments of tile kt + 2 under the k-step-0 MFMAs, the k-step-0 fragments of the
     // NEXT tile (their registers are free by then) and the input DMA pieces under the k-step-1 MFMAs.  An LDS read has eight MFMAs
@@ -1413,13 +1380,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     VM_MM(f1[I], bs[cur_][1], I, 0);                                                                                                  \
     VM_MM(f1[I], bs[cur_][3], I, 1);                                                                                                  \
     if constexpr (kt_ + 1 < NK) { VM_FRAG_READ(f0[I], an0_, I) }                                                                      \
-    if constexpr ((I) < 2 && tap_ < 2 && c_ + 3 < CHUNKS) issue_a1((c_ + 3) % 4, c_ + 3, 2 * tap_ + (I));                             \
+    if constexpr ((I) < n3_pieces(kt_, CHUNKS, LEAN).count)                                                                           \
+        issue_a1(n3_pieces(kt_, CHUNKS, LEAN).block % 4, n3_pieces(kt_, CHUNKS, LEAN).block, n3_pieces(kt_, CHUNKS, LEAN).first + (I)); \
     __builtin_amdgcn_sched_barrier(0);
 #define VM_KTILE_P(KT)                                                                                                                \
     if constexpr ((KT) < NK) {                                                                                                        \
         constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, nxt_ = (kt_ + 2) % 3, ablk_ = c_ % 4;             \
         constexpr int nc_ = (kt_ + 1) / 3, ntap_ = (kt_ + 1) - 3 * nc_;   /* chunk and tap of the next tile */                          \
-        n3_wait_b<n3_nwait(kt_, CHUNKS, true)>(bs[cur_]);                                                                             \
+        n3_wait_b<n3_nwait(kt_, CHUNKS, LEAN)>(bs[cur_]);                                                                             \
         if constexpr (kt_ == 0) {                                                                                                     \
             __builtin_amdgcn_s_barrier();                                                                                             \
             VM_PROF(pt_bar = __builtin_amdgcn_s_memtime();)                                                                           \
@@ -1439,17 +1407,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         VM_P_STEP1(0) VM_P_STEP1(1) VM_P_STEP1(2) VM_P_STEP1(3)                                                                       \
         VM_PROF(if (kt_ == 0) pt_first = __builtin_amdgcn_s_memtime();)                                                               \
     }
-#define VM_CHUNK(C)                                                              \
-    if constexpr (PIPE) {                                                        \
-        VM_KTILE_P(3 * (C)) VM_KTILE_P(3 * (C) + 1) VM_KTILE_P(3 * (C) + 2)      \
-    } else {                                                                     \
-        VM_KTILE(3 * (C)) VM_KTILE(3 * (C) + 1) VM_KTILE(3 * (C) + 2)            \
-    }
+#define VM_CHUNK(C) VM_KTILE_P(3 * (C)) VM_KTILE_P(3 * (C) + 1) VM_KTILE_P(3 * (C) + 2)
     VM_CHUNK(0) VM_CHUNK(1) VM_CHUNK(2) VM_CHUNK(3) VM_CHUNK(4) VM_CHUNK(5) VM_CHUNK(6) VM_CHUNK(7)
     VM_CHUNK(8) VM_CHUNK(9) VM_CHUNK(10) VM_CHUNK(11) VM_CHUNK(12) VM_CHUNK(13) VM_CHUNK(14) VM_CHUNK(15)
     static_assert(CHUNKS <= 16, "conv_nt3_kernel: at most 16 channel chunks are written out");
 #undef VM_CHUNK
-#undef VM_KTILE
 #undef VM_KTILE_P
 #undef VM_P_STEP0
 #undef VM_P_STEP1
@@ -1539,7 +1501,7 @@ extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 namespace vm {
 int g_nt_n2 = 3;       // conv_nt2r_kernel for 16-bit storage: bit 0 forward, bit 1 dgrad; vm_set_tuning("nt_n2", 0..3)
 int g_nt3 = 3;         // conv_nt3_kernel (weights L2 -> registers) where the caller supplies packed weights: bit 0 forward, bit 1 dgrad
-int g_nt3_pipe = 3;    // conv_nt3_kernel's interleaved K loop: bit 0 forward, bit 1 dgrad (0: the block-structured loop; A/B only)
+int g_nt3_lean = 3;    // conv_nt3_kernel's lean prologue (A(2), A(3) requested under the first two K tiles): bit 0 forward, bit 1 dgrad
 int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0, else register staging; vm_set_tuning("nt_glds", 0 | 1)
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
 extern int g_tn_x, g_tn_tile;  // conv_wgrad.hip
@@ -1573,7 +1535,7 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
             if (b.bt_packed != nullptr && (g_nt3 & (EPI == EPI_DGRAD ? 2 : 1)) && nt3_chunks(a.a_c)) {
                 const dim3 grid((unsigned)(n_groups * b.tilesN));
 #define VM_NT3(CH, PIPE) hipLaunchKernelGGL((conv_nt3_kernel<T, EPI, CH, PIPE>), grid, dim3(256), 0, stream, b, n_groups)
-                const bool pipe = (g_nt3_pipe & (EPI == EPI_DGRAD ? 2 : 1)) != 0;
+                const bool pipe = (g_nt3_lean & (EPI == EPI_DGRAD ? 2 : 1)) != 0;
                 switch (a.a_c / 32) {  // the K loop is written out per channel count: 128, 256, 384, 512 channels on the K side
                     case 4: if (pipe) VM_NT3(4, true); else VM_NT3(4, false); break;
                     case 8: if (pipe) VM_NT3(8, true); else VM_NT3(8, false); break;
@@ -1871,7 +1833,7 @@ extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int*
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_pipe", &g_nt3_pipe, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;
