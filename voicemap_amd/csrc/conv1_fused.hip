@@ -28,7 +28,22 @@
 
 #include "common.hpp"
 
+// experiment builds (tools/build_variant.sh <name> -DVM_C1_ABL=<bits> conv1_fused.hip; results are wrong by design): 1 no pooled-tensor
+// traffic (forward: no stores; backward: no dp loads), 2 no VALU epilogue, 4 no convolution MFMAs / LDS fragment reads, 8 (backward)
+// no weight-gradient MFMAs / LDS gathers.
+#ifndef VM_C1_ABL
+#define VM_C1_ABL 0
+#endif
+
 namespace vm {
+
+#if defined(VM_EXPERIMENT_PROFILE)  // where a wave of the block-1 kernels spends its clocks (s_memtime); experiment builds only
+constexpr int PROF1_SLOTS = 4096 * 4;
+__device__ unsigned int g_prof1[PROF1_SLOTS * 8];
+#define VM_PROF1(...) __VA_ARGS__
+#else
+#define VM_PROF1(...)
+#endif
 
 constexpr int F1_K = 32;       // taps
 constexpr int F1_CHUNK = 256;  // positions per chunk (8 MFMA row tiles of 32)
@@ -101,12 +116,19 @@ __device__ inline void f1_load_weights(F1Weights& w, const float* __restrict__ w
 }
 
 // u[p][c] for the 32 positions of row tile rt (local p = 32*rt + row) x the wave's 32 channels
+// (Starting the accumulator at the bias -- the C operand of the first MFMA -- instead of adding it in the epilogue was measured in
+// round 4: 8 v_pk_add_f32 fewer per tile, forward 115 -> 120 us, backward 195 -> 219 us (16 more VGPRs, one wave per SIMD fewer).)
 __device__ inline f32x16 f1_conv_tile(const F1Copies& sm, const F1Weights& w, int rt, int lane) {
     const int i = lane & 31, kh = lane >> 5;
     const int s = i & 7;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (VM_C1_ABL & 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = (float)(lane + rt) * 1e-3f * (float)(r - 7) + (float)w.h[0][r & 7];
+        return acc;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int m0 = F1_PAD + 32 * rt + (i & ~7) + 16 * ks + 8 * kh;
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
     // e_pad (training): 1 = the pool extreme is written as a padded activation tensor (n_windows, L / POOL + 2, F), rows 1 .. L / POOL
     __shared__ __attribute__((aligned(16))) F1Copies cp[2];
     __shared__ float red[4][32][2];
+    VM_PROF1(const long long pq_s0 = __builtin_amdgcn_s_memtime();)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n = blockIdx.x / splits;
@@ -205,6 +228,17 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
     // pointer per tile.  ALLMAX (wave-uniform): plain maxima, no min/max selects.
     auto fast_tile = [&](const f32x16& acc, TS* ob, auto allmax) {
         constexpr bool ALLMAX = decltype(allmax)::value;
+        if (VM_C1_ABL & 2) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += acc[r];  // keeps the tile alive: 16 adds instead of the epilogue
+            csum += v;
+            if (!(VM_C1_ABL & 1)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ob[(2 * g) * F] = (TS)acc[4 * g];
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (INFER && ALLMAX) {
@@ -236,24 +270,34 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                     const float v = z[pw * POOL + j];
                     ext = ALLMAX ? __builtin_fmaxf(ext, v) : (use_min ? __builtin_fminf(ext, v) : __builtin_fmaxf(ext, v));
                 }
-                ob[((8 * g) / POOL + pw) * F] = INFER ? (TS)fmaf(ext, sg, sh) : (TS)(ext - ctr);
+                if (VM_C1_ABL & 1) {
+                    csum += ext;  // the pooled value stays live
+                } else {
+                    ob[((8 * g) / POOL + pw) * F] = INFER ? (TS)fmaf(ext, sg, sh) : (TS)(ext - ctr);
+                }
             }
         }
     };
 
+    VM_PROF1(long long pq_bar = 0, pq_conv = 0, pq_epi = 0, pq_stash = 0; const long long pq_s1 = __builtin_amdgcn_s_memtime();)
     F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
     f1_stash(cp[0], nxt, tid);
+    VM_PROF1(const long long pq_s2 = __builtin_amdgcn_s_memtime();)
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int buf = (chunk - ch_lo) & 1;
         // this chunk's copies are visible, and every wave is done reading the other buffer (previous chunk)
+        VM_PROF1(const long long pq_b0 = __builtin_amdgcn_s_memtime();)
         __syncthreads();
+        VM_PROF1(pq_bar += __builtin_amdgcn_s_memtime() - pq_b0;)
         const bool more = chunk + 1 < ch_hi;
         if (more) nxt = f1_fetch(xrow, (int64_t)(chunk + 1) * F1_CHUNK, L + F1_K - 1, tid);  // lands while the tiles run
         const F1Copies& sm = cp[buf];
         const int64_t t0 = (int64_t)chunk * F1_CHUNK;
         for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
-            const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            VM_PROF1(const long long pq_t0 = __builtin_amdgcn_s_memtime();)
+            f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            VM_PROF1(asm volatile("" : "+v"(acc)); const long long pq_t1 = __builtin_amdgcn_s_memtime(); pq_conv += pq_t1 - pq_t0;)
             if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
                 TS* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F
                                 : out + (n * (Lq + 2 * e_pad) + e_pad + (t0 + 32 * rt) / POOL) * F) + lane_off;
@@ -262,6 +306,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 } else {
                     fast_tile(acc, ob, std::false_type{});
                 }
+                VM_PROF1(pq_epi += __builtin_amdgcn_s_memtime() - pq_t1;)
                 continue;
             }
 #pragma unroll
@@ -293,8 +338,11 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
                 }
             }
         }
+        VM_PROF1(const long long pq_h0 = __builtin_amdgcn_s_memtime();)
         if (more) f1_stash(cp[buf ^ 1], nxt, tid);
+        VM_PROF1(pq_stash += __builtin_amdgcn_s_memtime() - pq_h0;)
     }
+    VM_PROF1(const long long pq_s3 = __builtin_amdgcn_s_memtime();)
     if (!INFER) {
         // one statistics row per chunk (vm_conv1_stat_rows): the block's sum goes to its first chunk's row, zeros to the rest
         csum += csum2[0] + csum2[1];
@@ -326,7 +374,25 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
             }
         }
     }
+#if defined(VM_EXPERIMENT_PROFILE)
+    if (!INFER) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long pq_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+            unsigned int* q = g_prof1 + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            q[0] = (unsigned int)(pq_end - pq_s0);   // whole wave
+            q[1] = (unsigned int)(pq_s1 - pq_s0);    // prologue: weights, constants
+            q[2] = (unsigned int)(pq_s2 - pq_s1);    // first fetch + stash
+            q[3] = (unsigned int)pq_bar;             // barriers
+            q[4] = (unsigned int)pq_conv;            // fragment reads + MFMAs until the accumulator is readable
+            q[5] = (unsigned int)pq_epi;             // epilogue VALU + store issue
+            q[6] = (unsigned int)pq_stash;           // stash of the next chunk (waits for its fetch)
+            q[7] = (unsigned int)(pq_end - pq_s3);   // statistics reduction + store drain
+        }
+    }
+#endif
 }
+
 
 // ------------------------------------------------------------------------------------------------------
 // backward.  grid = (n_windows * splits, ceil(F/128)); a block walks `cps` chunks of one window and keeps its
@@ -461,7 +527,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
         const int64_t Fs = fast ? F : 0;
         const TS* dpb = dp + (fast ? (n * Lq + (t0 + 32 * rt) / POOL) * F : 0) + csafe + PW * hi * Fs;
 #pragma unroll
-        for (int k = 0; k < NDP; ++k) dpv[k] = dpb[((8 * (k / PW)) / POOL + k % PW) * Fs];
+        for (int k = 0; k < NDP; ++k) dpv[k] = (VM_C1_ABL & 1) ? (TS)(float)(k + rt) : dpb[((8 * (k / PW)) / POOL + k % PW) * Fs];
     };
 
     F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
@@ -483,7 +549,11 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
             for (int k = 0; k < NDP; ++k) dpv[k] = dpn[k];
             load_dp(dpn, t0, rt + role.RS);
             bf16x2 dub[8];  // du of accumulator registers (2k, 2k+1), already packed as the next MFMA wants them
-            if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
+            if (VM_C1_ABL & 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    dub[k] = __builtin_convertvector(f32x2{acc[2 * k] + (float)dpv[k & (NDP - 1)], acc[2 * k + 1]}, bf16x2);
+            } else if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
                 if (all_max) {
                     fast_tile(acc, dpv, dub, std::true_type{});
                 } else {
@@ -526,6 +596,11 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
             }
             // weight gradient: dW[tap i][c] += sum_rows x_loc[32*rt + row + i] * du[row][c].  K-slot e of half kh in
             // MFMA m <-> accumulator register 8m+e of this lane <-> row 16m + 8(e>>2) + 4kh + (e&3).
+            if (VM_C1_ABL & 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) accw[k] += (float)dub[k][0] + (float)dub[k][1];
+                continue;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 bf16x8 bfrag;
@@ -583,6 +658,14 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
         if (cok && hi == 0) slab[32 * F + c] = bs;
     }
 }
+
+#if defined(VM_EXPERIMENT_PROFILE)
+extern "C" int vm_debug_prof1_read(unsigned int* out, int n_slots) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof1), sizeof(unsigned int) * 8 * (size_t)n_slots);
+    return 0;
+}
+#endif
 
 int g_f1_blocks = 1024;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
 int g_f1_fwd_blocks = 4096;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n))
