@@ -1265,9 +1265,23 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         tw = nw / (unsigned)p.tower_windows;
         p.fold_hb += tw * 4 * p.N;
     }
-    f32x4 bias4[2][4];
     if constexpr (EPI == EPI_FWD_FOLD) p.bias = p.fold_hb + 3 * p.N;  // row 3 of hb: bias + the three per-tap constants (vm_fold_bn_weights)
-    n2_load_bias<T, EPI>(p, bias4, n0 + wn * 64 + 4 * (lane >> 5));
+    // The wave's 64 bias values by SCALAR loads (the address is wave-uniform; a lane wants the 32 of its half kh).  As 8 vector loads
+    // per lane they cost ~3000 ticks of VMEM issue in the setup, and -- hipcc cannot see the counted waits behind the inline-asm loads
+    // -- an s_waitcnt vmcnt(0) in front of the first MFMA, which drained the whole prologue (first K tile 2500 ticks against 760).
+    // They must stay IN FRONT of the first inline-asm statement with a memory clobber: behind one, hipcc no longer proves the bias
+    // unclobbered and falls back to vector loads (16 of them, and the vmcnt(0) again).
+    f32x4 bias_lo[2][4], bias_hi[2][4];
+    if constexpr (EPI != EPI_DGRAD) {
+        const float* bp = p.bias + n0 + wn * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bias_lo[j][g] = *reinterpret_cast<const f32x4*>(bp + 32 * j + 8 * g);
+                bias_hi[j][g] = *reinterpret_cast<const f32x4*>(bp + 32 * j + 8 * g + 4);
+            }
+    }
 
     // ---- input DMA sources (as conv_nt2r_kernel): one instruction = 16 rows x 64 B ----
     const int lrow = lane >> 2, lchunk = lane & 3;
@@ -1339,7 +1353,17 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     }
     VM_PROF(const long long pt_s3 = __builtin_amdgcn_s_memtime();)
     f32x16 acc[4][2];
-    n2_fill_acc(acc, bias4);
+    {
+        f32x4 bias4[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI != EPI_DGRAD) bias4[j][g] = (lane >> 5) ? bias_hi[j][g] : bias_lo[j][g];
+            }
+        n2_fill_acc(acc, bias4);
+    }
 #define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
     // KT is a literal in the macros below: every index, every wait count and every branch is a compile-time constant, the loop is
     // straight-line code and no register that a load is still writing ever meets a phi (the rolled form made hipcc copy them)
