@@ -333,5 +333,7 @@ def test_k_way_accuracy_script_cached_sweep(tmp_path, monkeypatch):
     C.seed_everything(0, 0)              # what setup() did before the script's first draw
     want = [R.n_shot_task_evaluation_cached(loaded, valid, pre, 16, n, k, "siamese", "cosine", cache=cache) for k in (2, 5) for n in (1, 3)]
     assert list(df["n_correct"]) == want
-    df2 = k_way_accuracy.main(args + ["--device-sampler"])
-    assert len(df2) == 4 and ((df2["n_correct"] >= 0) & (df2["n_correct"] <= 16)).all()
+    args2 = ["--siamese", path, "--synthetic", "--k-way", "5", "--n-shot", "1", "--num-tasks", "16", "--distance", "cosine", "--cached",
+             "--device-sampler"]
+    df2 = k_way_accuracy.main(args2)
+    assert len(df2) == 1 and ((df2["n_correct"] >= 0) & (df2["n_correct"] <= 16)).all()
