@@ -612,6 +612,287 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_tn9_kernel (round 4): conv_tn8x_kernel's tile, ring and DMA geometry with a FREE-RUNNING K loop -- no READ / MFMA slots, one
+// barrier per stage (64 positions) instead of four.  A wave's stream is one MFMA, two transposing LDS reads of the NEXT k-step, one
+// MFMA, ...: the fragments of a k-step (16 positions: 3 tap fragments of x, 2 column fragments of dU = 10 ds_read_b64_tr_b16, 20
+// registers) are double-buffered in registers, every read has five to six MFMAs (>= 160 clocks) to return and every wait is a counted
+// lgkmcnt(6); the four DMA instructions of stage g + 3 go one per k-step behind the fourth MFMA.  The phase kernel kept the matrix
+// pipe of a SIMD busy only while the OTHER wave's READ slot was shorter than this wave's MFMA slot (8 MFMAs beside 16 reads + 4 DMA
+// + the vmcnt wait); here the two waves of a SIMD interleave instruction by instruction, as in conv_nt3_kernel.
+//   * RAW: stage g + 2 is waited for (vmcnt(4): the four youngest loads are stage g + 3's) and published by the barrier in k-step 3
+//     of stage g; stage g reads its own rows from k-step 0 on and rows 0, 1 of stage g + 1 (tap overflow) in k-step 3.
+//   * WAR: the DMA of stage g + 3 overwrites the ring slot of stage g - 1.  Its first instruction is issued in k-step 0 of stage g,
+//     i.e. behind the barrier of stage g - 1, which every wave enters with lgkmcnt(0) -- all its reads of that slot returned.
+//   * The loop is ROTATED: its back edge sits right behind that barrier, where no LDS read is in flight (hipcc copies registers at
+//     loop phis; a copy of a register that a read is still writing would move stale bytes -- tools/isa_lint_inflight.py).  The last
+//     two MFMAs of a stage's k-step 3 are issued at the top of the next iteration, behind the ten reads of its k-step 0 (the first
+//     iteration runs them on zero fragments).
+//   * A fragment register is overwritten by a read no earlier than four MFMAs after the last MFMA that read it.
+// ------------------------------------------------------------------------------------------------
+// experiment builds (tools/build_variant.sh <name> -DVM_TN9_ABL=<bits> conv_wgrad.hip; results are wrong by design): 1 no in-loop DMA,
+// 2 no fragment reads, 4 no per-stage barrier, 8 no MFMAs
+#ifndef VM_TN9_ABL
+#define VM_TN9_ABL 0
+#endif
+template <typename T>
+__global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types (bf16 / f16)");
+    using V8 = typename Mfma<T>::Frag;
+    using namespace t8x;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;  // channel block (0..3), output-column half (0..1)
+
+    int64_t b = blockIdx.x;
+    {
+        const int64_t NT = (int64_t)p.tilesI * p.tilesJ;
+        const int64_t full = (int64_t)(p.splits / 8) * 8 * NT;
+        if (p.xcd_remap && b < full) {
+            const int64_t xcd = b & 7, local = b >> 3;
+            b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        }
+    }
+    const int tj = __builtin_amdgcn_readfirstlane((int)(b % p.tilesJ));
+    b /= p.tilesJ;
+    const int ti = __builtin_amdgcn_readfirstlane((int)(b % p.tilesI));
+    const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
+    const int ci0 = ti * 128, j0 = tj * 128;
+
+    int w_begin, w_end;
+    {
+        int64_t wb, we;
+        split_windows(p, split, wb, we);
+        w_begin = (int)wb;
+        w_end = (int)we;
+    }
+    const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
+    const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
+
+    if (G > 0) {
+        // zero the A ring once: tap-overflow reads of never-staged rows must be finite
+        for (int i = tid * 16; i < A_BYTES; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+
+        // ---- DMA geometry (conv_tn8x_kernel): one instruction = 8 position rows x 128 bytes, halves swapped by row bit 1 ----
+        const int drow = w * 8 + (lane >> 3);
+        const int dchunk = ((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8;
+        const char* const x_base = reinterpret_cast<const char*>(p.x);
+        const char* const d_base = reinterpret_cast<const char*>(p.du);
+        auto piece = [&](int slot, int n, int st, int q) {  // q = 0, 1: the A blocks; 2, 3: the B blocks of the stage
+            const int t = st * 64 + drow;
+            const int j = q & 1;
+            if (q < 2) {
+                const int r = t < p.L + 1 ? t : p.L + 1;
+                int c0 = ci0 + j * 64;
+                c0 = c0 < p.c_in ? c0 : 0;
+                glds16(x_base + n * p.x_win_stride * 2 + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, lds + slot * 8192 + w * 1024 + j * ABLK);
+            } else {
+                const int r = (t < p.L ? t : p.L) + 1;
+                int co0 = j0 + j * 64;
+                co0 = co0 < p.c_out ? co0 : 0;
+                glds16(d_base + n * p.du_win_stride * 2 + (unsigned)(r * p.c_out + co0 + dchunk) * 2u,
+                       lds + A_BYTES + slot * BSTAGE + w * 1024 + j * BBLK);
+            }
+        };
+        int nn = w_begin, ss = 0, staged = 0;  // stream cursor of the stage to be staged next
+        auto advance = [&]() {
+            ++staged;
+            if (++ss == spw) {
+                ss = 0;
+                ++nn;
+            }
+        };
+
+        // ---- fragment geometry (conv_tn8x_kernel) ----
+        const int li = lane & 15, lg = (lane >> 4) & 1, kh = lane >> 5;
+        const int rowl = kh * 8 + (li >> 2);
+        const int sub = lg * 32 + (li & 3) * 8;
+        int a_off[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a_off[t] = (rowl + t) * 128 + (((wm & 1) ^ (((rowl + t) >> 1) & 1)) * 64) + sub;
+        const int b_off = rowl * 128 + ((((rowl >> 1) & 1)) * 64) + sub;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#else
+        const uint32_t lds0 = 0;
+#endif
+        const uint32_t ablk = lds0 + (wm >> 1) * ABLK;
+        const uint32_t bblk = lds0 + A_BYTES + wn * BBLK;
+
+        // ---- prologue: stages 0, 1, 2 ----
+        for (int i = 0; i < 3 && staged < G; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) piece(staged & 3, nn, ss, q);
+            advance();
+        }
+        if (G > 2) {
+            wait_vmcnt<4>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+
+        struct Fr {
+            u32x2 lo, hi;
+        };
+        Fr fa[2][3], fb[2][2];  // [register set][tap] / [register set][column half]; constant indices only
+#pragma unroll
+        for (int t = 0; t < 3; ++t) fa[1][t].lo = fa[1][t].hi = u32x2{0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[1][j].lo = fb[1][j].hi = u32x2{0u, 0u};
+
+#define VM_TR(DST, ADDR, OFF) \
+    if constexpr (!(VM_TN9_ABL & 2)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+        // k-step S of the stage whose addresses are in aaddr / a3lo / a3hi / baddr -> register set SET
+#define VM_RDA(SET, TAP, S)                                      \
+    if constexpr ((S) == 0) {                                    \
+        VM_TR(fa[SET][TAP].lo, aaddr[TAP], 0);                   \
+        VM_TR(fa[SET][TAP].hi, aaddr[TAP], 512);                 \
+    } else if constexpr ((S) == 1) {                             \
+        VM_TR(fa[SET][TAP].lo, aaddr[TAP], 2048);                \
+        VM_TR(fa[SET][TAP].hi, aaddr[TAP], 2560);                \
+    } else if constexpr ((S) == 2) {                             \
+        VM_TR(fa[SET][TAP].lo, aaddr[TAP], 4096);                \
+        VM_TR(fa[SET][TAP].hi, aaddr[TAP], 4608);                \
+    } else {                                                     \
+        VM_TR(fa[SET][TAP].lo, a3lo[TAP], 0);                    \
+        VM_TR(fa[SET][TAP].hi, a3hi[TAP], 0);                    \
+    }
+#define VM_RDB(SET, JN, S)                                       \
+    if constexpr ((S) == 0) {                                    \
+        VM_TR(fb[SET][JN].lo, baddr[JN], 0);                     \
+        VM_TR(fb[SET][JN].hi, baddr[JN], 512);                   \
+    } else if constexpr ((S) == 1) {                             \
+        VM_TR(fb[SET][JN].lo, baddr[JN], 2048);                  \
+        VM_TR(fb[SET][JN].hi, baddr[JN], 2560);                  \
+    } else if constexpr ((S) == 2) {                             \
+        VM_TR(fb[SET][JN].lo, baddr[JN], 4096);                  \
+        VM_TR(fb[SET][JN].hi, baddr[JN], 4608);                  \
+    } else {                                                     \
+        VM_TR(fb[SET][JN].lo, baddr[JN], 6144);                  \
+        VM_TR(fb[SET][JN].hi, baddr[JN], 6656);                  \
+    }
+#define VM_LGKM(N, F) \
+    if constexpr (!(VM_TN9_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"((F).lo), "+v"((F).hi))
+#define VM_FRAG(F) __builtin_bit_cast(V8, (u32x4{(F).lo[0], (F).lo[1], (F).hi[0], (F).hi[1]}))
+#define VM_MMA(SET, TAP, JN)                                                                                                   \
+    if constexpr (!(VM_TN9_ABL & 8)) acc[TAP][JN] = Mfma<T>::run(VM_FRAG(fb[SET][JN]), VM_FRAG(fa[SET][TAP]), acc[TAP][JN]);   \
+    else acc[TAP][JN][0] += __builtin_bit_cast(float, fb[SET][JN].lo[0] ^ fa[SET][TAP].hi[1]);                                 \
+    __builtin_amdgcn_sched_barrier(0)
+        // one k-step out of set CUR while k-step SN of the same stage loads into set NXT; Q: the DMA piece of stage g + 3 it carries
+#define VM_KSTEP(CUR, NXT, SN, Q)                     \
+    VM_LGKM(6, fb[CUR][0]);                           \
+    VM_LGKM(6, fa[CUR][0]);                           \
+    VM_MMA(CUR, 0, 0);                                \
+    VM_RDB(NXT, 0, SN);                               \
+    VM_LGKM(6, fa[CUR][1]);                           \
+    VM_MMA(CUR, 1, 0);                                \
+    VM_RDA(NXT, 0, SN);                               \
+    VM_LGKM(6, fa[CUR][2]);                           \
+    VM_MMA(CUR, 2, 0);                                \
+    VM_RDA(NXT, 1, SN);                               \
+    VM_LGKM(6, fb[CUR][1]);                           \
+    VM_MMA(CUR, 0, 1);                                \
+    VM_RDA(NXT, 2, SN);                               \
+    if (more && !(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, Q); \
+    __builtin_amdgcn_sched_barrier(0);                \
+    VM_MMA(CUR, 1, 1);                                \
+    VM_RDB(NXT, 1, SN);                               \
+    VM_MMA(CUR, 2, 1)
+
+        for (int g = 0; g < G; ++g) {
+            const int slot = g & 3;
+            const bool more = staged < G;
+            uint32_t aaddr[3], a3lo[3], a3hi[3], baddr[2];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint32_t u = slot * 8192 + a_off[t];
+                aaddr[t] = ablk + u;
+                a3lo[t] = ablk + ((u + 3 * 2048) & (ABLK - 1));
+                a3hi[t] = ablk + ((u + 3 * 2048 + 512) & (ABLK - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) baddr[j] = bblk + slot * BSTAGE + (b_off ^ (j * 64));
+            // k-step 0 of this stage -> set 0 (last read in k-step 2 of the previous stage)
+            VM_RDB(0, 0, 0);
+            VM_RDA(0, 0, 0);
+            VM_RDA(0, 1, 0);
+            VM_RDA(0, 2, 0);
+            VM_RDB(0, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the last two MFMAs of the previous stage's k-step 3 (set 1; zero fragments in the first iteration)
+            VM_MMA(1, 1, 1);
+            VM_MMA(1, 2, 1);
+            VM_KSTEP(0, 1, 1, 0);
+            VM_KSTEP(1, 0, 2, 1);
+            VM_KSTEP(0, 1, 3, 2);
+            // k-step 3 (set 1), nothing to prefetch: the waits count down
+            VM_LGKM(6, fb[1][0]);
+            VM_LGKM(6, fa[1][0]);
+            VM_MMA(1, 0, 0);
+            VM_LGKM(4, fa[1][1]);
+            VM_MMA(1, 1, 0);
+            VM_LGKM(2, fa[1][2]);
+            VM_MMA(1, 2, 0);
+            VM_LGKM(0, fb[1][1]);
+            VM_MMA(1, 0, 1);
+            if (more) {
+                if (!(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, 3);
+                advance();
+                if (!(VM_TN9_ABL & 1)) wait_vmcnt<4>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            if (!(VM_TN9_ABL & 4)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        VM_MMA(1, 1, 1);
+        VM_MMA(1, 2, 1);
+#undef VM_KSTEP
+#undef VM_MMA
+#undef VM_FRAG
+#undef VM_LGKM
+#undef VM_RDB
+#undef VM_RDA
+#undef VM_TR
+    }
+
+    // ---- the split's slab tile: rows kk = tap * C_in + ci ----
+    float* out = p.ws + (int64_t)split * p.Kk * p.c_out;
+    const int hi = lane >> 5;
+    const int ci = ci0 + wm * 32 + (lane & 31);
+    if (ci0 + wm * 32 < p.c_in) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t row = (int64_t)t * p.c_in + ci;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = j0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+                    if (col < p.c_out) {
+                        const f32x4 v = {acc[t][jn][4 * g4], acc[t][jn][4 * g4 + 1], acc[t][jn][4 * g4 + 2], acc[t][jn][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(out + row * p.c_out + col) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 Keras kernel (3, c_in, c_out) -> wf[co][k*c_in + ci] = W[k][ci][co];  wd[ci][j*c_out + co] = W[2-j][ci][co]
 template <typename T>
 __global__ void prep_weights_kernel(const float* w, int c_in, int c_out, T* wf, T* wd) {
@@ -635,6 +916,7 @@ using namespace vm;
 static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 namespace vm {
+int g_tn9 = 1;        // conv_tn9_kernel (free-running K loop) instead of conv_tn8x_kernel (READ / MFMA slots); vm_set_tuning("tn9", 0 | 1)
 int g_tn_x = 1;       // conv_tn8x_kernel for 16-bit storage with channel counts % 64 == 0; vm_set_tuning("tn_x", 0 | 1)
 int g_tn_tile = 256;  // tile of the register-transposing kernels: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 }  // namespace vm
@@ -722,7 +1004,11 @@ static int launch_wgrad(const void* in, const void* du, int64_t n_windows, int64
             }
         } else {
             if (xres) {
-                hipLaunchKernelGGL((conv_tn8x_kernel<T>), grid, dim3(512), 0, st, a);
+                if (g_tn9) {
+                    hipLaunchKernelGGL((conv_tn9_kernel<T>), grid, dim3(512), 0, st, a);
+                } else {
+                    hipLaunchKernelGGL((conv_tn8x_kernel<T>), grid, dim3(512), 0, st, a);
+                }
             } else if (big) {
                 hipLaunchKernelGGL((conv_tn256_kernel<T, 128>), grid, dim3(512), 0, st, a);
             } else {
