@@ -62,11 +62,14 @@ int vm_check_device(void);
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
 /* Kernel-selection table for the tests that pin a fallback kernel and for A/B measurements (process-global, see the conventions
  * above; not part of the drop-in surface: voicemap_amd never calls it outside bench.py --tune).  Unknown keys / values out of
- * range return VM_ERR_ARG.  Six keys:
+ * range return VM_ERR_ARG.  Keys:
  *   "nt_n2" 0..3      forward / dgrad, 16-bit storage: conv_nt2r_kernel (254 x 128 tiles, two workgroups per CU, input-resident A
  *                     by LDS-DMA; bit 0 forward, bit 1 dgrad; default 3); where it is off or does not serve the shape:
+ *   "nt3" 0..3, "nt3_lean" 0..3   conv_nt3_kernel (weights L2 -> registers from the packed copy) for forward (bit 0) / dgrad (bit 1) where
+ *                     the packed weights are given, and its lean prologue (defaults 3, 3); off: conv_nt2r_kernel
  *   "nt_glds" 0|1     the 128 x 128 LDS-DMA kernel where K * sizeof(T) % 64 == 0 (default 1), else the register-staged 128 x 128 one
- *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA kernel (default 1), else
+ *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA tile (default 1), else
+ *   "tn9" 0|1         ... with the free-running K loop (conv_tn9_kernel, default 1) or the READ / MFMA slots (conv_tn8x_kernel)
  *   "tn_tile" 128|256 the tile of the register-transposing wgrad kernels (default 256 where the layer is wide enough)
  *   "f1_blocks", "f1_fwd_blocks"   target workgroup counts of the fused block-1 kernels (launch geometry; the fp32 partial sums of a
  *                     window are grouped differently, i.e. results change in the last bits). */
