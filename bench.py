@@ -46,7 +46,7 @@ F, E, L0 = 128, 64, 12000
 BLOCKS = [(32, F, 4), (3, 2 * F, 2), (3, 3 * F, 2), (3, 4 * F, 2)]
 # rocprofv3 kernel names of the GEMM families under the default dispatch (what profiles/r03_rocprofv3_kernel_stats.csv lists)
 KERNEL_SYMBOL = {"vm_conv_fwd": "vm::conv_nt2r_kernel<{T}, 0>", "vm_conv_dgrad": "vm::conv_nt2r_kernel<{T}, 1>",
-                 "vm_conv_wgrad": "vm::conv_tn8x_kernel<{T}>"}
+                 "vm_conv_wgrad": "vm::conv_tn9_kernel<{T}>"}
 # round 4: with packed weights (the default for 16-bit storage) forward / dgrad run conv_nt3_kernel<T, EPI, K-side channels / 32, true>
 NT3_EPI = {"vm_conv_fwd": 3, "vm_conv_dgrad": 1}
 CTYPE = {"bf16": "__bf16", "f16": "_Float16", "f32": "float", "f32s": "float"}

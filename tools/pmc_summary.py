@@ -8,7 +8,7 @@ import sys
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("conv_nt3", "conv_nt2r", "conv_tn8x", "conv_nt_glds", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_gmax",
+    for key in ("conv_nt3", "conv_nt2r", "conv_tn9", "conv_tn8x", "conv_nt_glds", "conv_nt_kernel", "conv_tn256", "conv_tn_kernel", "bn_pool_bwd", "bn_drop_pool_gmax",
                 "bn_drop_pool_fwd", "conv1_fused_bwd", "conv1_fused_fwd", "global_maxpool", "slab_stage", "colreduce", "whiten", "dense", "adam",
                 "siamese"):
         if key in name:

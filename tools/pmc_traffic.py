@@ -51,9 +51,9 @@ def main(fetch_dir, write_dir, out):
         grids = []
         for splits in (lib.query("vm_conv_wgrad_splits", n, L, cin, cout),
                        lib.query("vm_conv_wgrad_fold_workspace_bytes", n, n // 2, L, cin, cout) // (3 * cin * cout * 4)):
-            grids.append(splits * (-(-cin // 128)) * (-(-cout // 128)) * 512)  # conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
+            grids.append(splits * (-(-cin // 128)) * (-(-cout // 128)) * 512)  # conv_tn9_kernel / conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
         for (name, g), fv in fetch.items():
-            if "conv_tn8x" in name and g in grids:
+            if ("conv_tn9" in name or "conv_tn8x" in name) and g in grids:
                 wv = write.get((name, g), 0.0)
                 res["kernels"]["vm_conv_wgrad|%d|%d|%d|%d" % (n, L, cin, cout)] = {
                     "fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024, "grid": g}
