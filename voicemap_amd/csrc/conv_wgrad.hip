@@ -635,8 +635,12 @@ __global__ __launch_bounds__(512) void conv_tn8x_kernel(TnArgs<T> p) {
 #ifndef VM_TN9_ABL
 #define VM_TN9_ABL 0
 #endif
-template <typename T>
-__global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
+// PW (producer waves): a 768-thread workgroup whose waves 8..11 (one per SIMD: a workgroup's waves go to the SIMDs cyclically) issue ALL
+// the LDS-DMA -- a DMA instruction holds a wave's in-order issue for 60-250 ticks, and the 152 registers of this kernel leave room for a
+// third wave per SIMD.  Producer iteration g: the 8 instructions of stage g + 3 for the rows of compute waves 2 (w - 8), 2 (w - 8) + 1,
+// vmcnt(8) (stage g + 2 landed), the stage barrier; the compute waves carry no vector-memory instruction at all.
+template <typename T, bool PW>
+__global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
     static_assert(sizeof(T) == 2, "16-bit storage types (bf16 / f16)");
     using V8 = typename Mfma<T>::Frag;
     using namespace t8x;
@@ -680,30 +684,30 @@ __global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
 
     if (G > 0) {
         // zero the A ring once: tap-overflow reads of never-staged rows must be finite
-        for (int i = tid * 16; i < A_BYTES; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+        for (int i = tid * 16; i < A_BYTES; i += (PW ? 768 : 512) * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
         __syncthreads();
 
         // ---- DMA geometry (conv_tn8x_kernel): one instruction = 8 position rows x 128 bytes, halves swapped by row bit 1 ----
-        const int drow = w * 8 + (lane >> 3);
         const int dchunk = ((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8;
         const char* const x_base = reinterpret_cast<const char*>(p.x);
         const char* const d_base = reinterpret_cast<const char*>(p.du);
-        auto piece = [&](int slot, int n, int st, int q) {  // q = 0, 1: the A blocks; 2, 3: the B blocks of the stage
-            const int t = st * 64 + drow;
+        auto piece_of = [&](int wr, int slot, int n, int st, int q) {  // rows 8 wr .. 8 wr + 7; q = 0, 1: the A blocks; 2, 3: the B blocks
+            const int t = st * 64 + wr * 8 + (lane >> 3);
             const int j = q & 1;
             if (q < 2) {
                 const int r = t < p.L + 1 ? t : p.L + 1;
                 int c0 = ci0 + j * 64;
                 c0 = c0 < p.c_in ? c0 : 0;
-                glds16(x_base + n * p.x_win_stride * 2 + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, lds + slot * 8192 + w * 1024 + j * ABLK);
+                glds16(x_base + n * p.x_win_stride * 2 + (unsigned)(r * p.c_in + c0 + dchunk) * 2u, lds + slot * 8192 + wr * 1024 + j * ABLK);
             } else {
                 const int r = (t < p.L ? t : p.L) + 1;
                 int co0 = j0 + j * 64;
                 co0 = co0 < p.c_out ? co0 : 0;
                 glds16(d_base + n * p.du_win_stride * 2 + (unsigned)(r * p.c_out + co0 + dchunk) * 2u,
-                       lds + A_BYTES + slot * BSTAGE + w * 1024 + j * BBLK);
+                       lds + A_BYTES + slot * BSTAGE + wr * 1024 + j * BBLK);
             }
         };
+        auto piece = [&](int slot, int n, int st, int q) { piece_of(w, slot, n, st, q); };
         int nn = w_begin, ss = 0, staged = 0;  // stream cursor of the stage to be staged next
         auto advance = [&]() {
             ++staged;
@@ -730,17 +734,50 @@ __global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
         const uint32_t bblk = lds0 + A_BYTES + wn * BBLK;
 
         // ---- prologue: stages 0, 1, 2 ----
-        for (int i = 0; i < 3 && staged < G; ++i) {
+        if constexpr (PW) {
+            if (w >= 8) {
+                const int w0 = 2 * (w - 8);
+                auto stage_all = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) piece(staged & 3, nn, ss, q);
-            advance();
-        }
-        if (G > 2) {
-            wait_vmcnt<4>();
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) piece_of(w0 + i, staged & 3, nn, ss, q);
+                    advance();
+                };
+                for (int i = 0; i < 3 && staged < G; ++i) stage_all();
+                if (G > 2) {
+                    wait_vmcnt<8>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                for (int g = 0; g < G; ++g) {
+                    if (staged < G) {
+                        stage_all();
+                        wait_vmcnt<8>();
+                    } else {
+                        wait_vmcnt<0>();
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                return;
+            }
+            __builtin_amdgcn_s_barrier();
         } else {
-            wait_vmcnt<0>();
+            for (int i = 0; i < 3 && staged < G; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) piece(staged & 3, nn, ss, q);
+                advance();
+            }
+            if (G > 2) {
+                wait_vmcnt<4>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_s_barrier();
 
         struct Fr {
             u32x2 lo, hi;
@@ -804,7 +841,7 @@ __global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
     VM_LGKM(6, fb[CUR][1]);                           \
     VM_MMA(CUR, 0, 1);                                \
     VM_RDA(NXT, 2, SN);                               \
-    if (more && !(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, Q); \
+    if (!PW && more && !(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, Q); \
     __builtin_amdgcn_sched_barrier(0);                \
     VM_MMA(CUR, 1, 1);                                \
     VM_RDB(NXT, 1, SN);                               \
@@ -846,12 +883,14 @@ __global__ __launch_bounds__(512) void conv_tn9_kernel(TnArgs<T> p) {
             VM_MMA(1, 2, 0);
             VM_LGKM(0, fb[1][1]);
             VM_MMA(1, 0, 1);
-            if (more) {
-                if (!(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, 3);
-                advance();
-                if (!(VM_TN9_ABL & 1)) wait_vmcnt<4>();
-            } else {
-                wait_vmcnt<0>();
+            if constexpr (!PW) {
+                if (more) {
+                    if (!(VM_TN9_ABL & 1)) piece(staged & 3, nn, ss, 3);
+                    advance();
+                    if (!(VM_TN9_ABL & 1)) wait_vmcnt<4>();
+                } else {
+                    wait_vmcnt<0>();
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
@@ -916,7 +955,7 @@ using namespace vm;
 static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 namespace vm {
-int g_tn9 = 1;        // conv_tn9_kernel (free-running K loop) instead of conv_tn8x_kernel (READ / MFMA slots); vm_set_tuning("tn9", 0 | 1)
+int g_tn9 = 1;        // conv_tn9_kernel (free-running K loop; 2 = with producer waves) instead of conv_tn8x_kernel (READ / MFMA slots); vm_set_tuning("tn9", 0 | 1 | 2)
 int g_tn_x = 1;       // conv_tn8x_kernel for 16-bit storage with channel counts % 64 == 0; vm_set_tuning("tn_x", 0 | 1)
 int g_tn_tile = 256;  // tile of the register-transposing kernels: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 }  // namespace vm
@@ -1004,8 +1043,10 @@ static int launch_wgrad(const void* in, const void* du, int64_t n_windows, int64
             }
         } else {
             if (xres) {
-                if (g_tn9) {
-                    hipLaunchKernelGGL((conv_tn9_kernel<T>), grid, dim3(512), 0, st, a);
+                if (g_tn9 == 2) {
+                    hipLaunchKernelGGL((conv_tn9_kernel<T, true>), grid, dim3(768), 0, st, a);
+                } else if (g_tn9) {
+                    hipLaunchKernelGGL((conv_tn9_kernel<T, false>), grid, dim3(512), 0, st, a);
                 } else {
                     hipLaunchKernelGGL((conv_tn8x_kernel<T>), grid, dim3(512), 0, st, a);
                 }
