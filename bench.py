@@ -191,10 +191,12 @@ def main():
         return e
     eng = make_engine(a.dtype)
     ENGINE_SWITCHES = {"overlap_wgrad": bool, "pooled_reduce": bool, "split_towers": bool, "fused_bn_reduce": bool, "wgrad_after_dgrad": bool,
-                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool, "fold_affine": bool, "fold_pairs": bool}
+                       "fused_pool_extreme": bool, "tower_stagger": int, "loss_scale": float, "fused_sums_finalize": bool, "fold_affine": bool, "fold_pairs": bool, "side_priority": int}
     for kv in [t for t in a.tune.split(",") if t]:
         k, v = kv.split("=")
-        if k in ENGINE_SWITCHES:
+        if k == "main_priority":   # experiment: the whole step on a stream of this HIP priority (-1 = above the side stream's 0)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(v)))
+        elif k in ENGINE_SWITCHES:
             setattr(eng, k, ENGINE_SWITCHES[k](float(v)))
         else:
             eng.lib.call("vm_set_tuning", k.encode(), int(v))

@@ -223,6 +223,7 @@ class HipEncoderEngine:
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
+        self._side_priority = 0
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
         self.tower_stream = torch.cuda.Stream(device=self.device)
@@ -420,6 +421,16 @@ class HipEncoderEngine:
                 ev = torch.cuda.Event()
                 ev.record()
             self._poll = (k, ev)
+
+    @property
+    def side_priority(self):
+        return self._side_priority
+
+    @side_priority.setter
+    def side_priority(self, v):
+        """experiment (bench.py --tune side_priority=N): the HIP priority of the side stream the weight-gradient GEMMs run on"""
+        self._side_priority = int(v)
+        self.side_stream = torch.cuda.Stream(device=self.device, priority=int(v))
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
