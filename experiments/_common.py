@@ -40,6 +40,10 @@ def base_parser(description, **defaults):
                    help="with --device-data under torchrun: every rank keeps only 1/world of the speakers resident and draws its "
                         "different-speaker pairs among them (a different negative distribution from the reference's whole-corpus "
                         "sampling: opt-in; the default keeps the whole corpus on every rank)")
+    p.add_argument("--sync-bn", action="store_true",
+                   help="under torchrun: BatchNormalization over the GLOBAL batch (one small all-reduce per BatchNorm and direction; "
+                        "N ranks x B pairs then train exactly like one device with N x B pairs).  Off by default: the reference's "
+                        "BatchNormalization is per process")
     p.add_argument("--training-set", nargs="+", default=["train-clean-100", "train-clean-360"])
     p.add_argument("--validation-set", default="dev-clean")
     return p
@@ -69,6 +73,15 @@ def device_resident(a, train):
     ds = shards.ShardedSpeechDataset(a.device_data, a.n_seconds, stochastic=True, pad=False, speaker_shard=shard)
     ds.to_device("cuda")
     return ds
+
+
+def apply_sync_bn(a, model):
+    """--sync-bn: switch the model's engine to SyncBN (engine.sync_bn; waveform encoders only)."""
+    if getattr(a, "sync_bn", False):
+        eng = model._ensure_engine()
+        if type(eng).__name__ != "HipEncoderEngine":   # the log-mel / 2-D engine has its own BatchNorm passes
+            raise SystemExit("--sync-bn: waveform encoders only (%s)" % type(eng).__name__)
+        eng.sync_bn = True
 
 
 def input_length(a):

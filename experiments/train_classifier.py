@@ -48,6 +48,7 @@ def main(argv=None):
     classifier.add(Dense(train.num_classes(), activation="softmax"))
     classifier.compile(loss="categorical_crossentropy", optimizer=Adam(clipnorm=1.), metrics=["accuracy"])
     classifier.summary()
+    C.apply_sync_bn(a, classifier)
     name = "classifier__filters_{}__embed_{}__drop_{}__pad={}".format(a.filters, a.embedding_dimension, a.dropout, a.pad)
     # twice the siamese step count: a siamese batch carries two windows per sample (reference comment, :126-127)
     return classifier.fit_generator(generator=ShuffledBatches(train, pre, a.batchsize), steps_per_epoch=2 * a.steps_per_epoch,

@@ -30,6 +30,7 @@ def main(argv=None):
     siamese = build_siamese_net(encoder, (C.input_length(a), 1), distance_metric="uniform_euclidean")
     siamese.compile(loss="binary_crossentropy", optimizer=Adam(clipnorm=1.), metrics=["accuracy"])
     siamese.summary()
+    C.apply_sync_bn(a, siamese)
     name = "siamese__filters_{}__embed_{}__drop_{}__pad={}".format(a.filters, a.embedding_dimension, a.dropout, a.pad)
     if a.frontend == "logmel":
         name = "logmel_" + name

@@ -230,6 +230,13 @@ class HipEncoderEngine:
         self.defer_head_reduce = True   # backward() enqueues the head's sums on the side stream (engines that borrow siamese_head: no)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
+        # SyncBN (optional; off by default as in the reference, whose BatchNormalization is per process): under data
+        # parallelism the batch statistics and the two BatchNorm-backward means are taken over the GLOBAL batch -- one small all-reduce
+        # per BatchNorm and direction (8 + 8 per siamese step) -- which makes N ranks x B pairs the same arithmetic as one device with
+        # N x B pairs (tests/test_parallel_cpu.py).  parallel.attach() sets sync_bn_world.
+        self.sync_bn = False
+        self.sync_bn_world = 1
+        self._sync_bufs = {}
         self._plans: Dict[Tuple, dict] = {}
         self.init_params(seed)
 
@@ -284,6 +291,37 @@ class HipEncoderEngine:
     # ------------------------------------------------------------------------------------------------
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _sync_rows(self, key, a_ptr, b_ptr, rows_per_tower, ntw, c, row_stride, cr_ws, st):
+        """SyncBN: two partial-sum tensors of ``rows_per_tower`` rows per tower -> one row per tower (vm_colsum), summed over the ranks
+        (one all-reduce of 2 x ntw x C floats on the current stream).  Returns the pointers of the two reduced (ntw * row_stride, C)
+        tensors: the tower's sums in its first row, zeros in the other row_stride - 1 (the finalize kernels walk row_stride rows per
+        window)."""
+        import torch.distributed as dist
+        buf = self._sync_bufs.get((key, ntw, c, row_stride))
+        if buf is None:
+            buf = self._sync_bufs[(key, ntw, c, row_stride)] = torch.zeros(2, ntw * row_stride, c, dtype=torch.float32, device=self.device)
+        for j, ptr in enumerate((a_ptr, b_ptr)):
+            for t in range(ntw):
+                self._call("vm_colsum", ptr + t * rows_per_tower * c * 4, rows_per_tower, c, buf[j, t * row_stride].data_ptr(), cr_ws, st)
+        if self.sync_bn_world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return buf[0].data_ptr(), buf[1].data_ptr()
+
+    def _bn_bwd_finalize(self, key, pa, pb, n, wpt, c, count, c1, c2, g_gamma, g_beta, cr_ws, st):
+        """vm_bn_bwd_finalize; with SyncBN the two means (c1, c2) are taken over the global batch while the gamma / beta gradients stay
+        this rank's (they are averaged with every other gradient later)."""
+        self._call("vm_bn_bwd_finalize", pa, pb, n, wpt, c, count, c1, c2, g_gamma, g_beta, cr_ws, st)
+        if not self.sync_bn:
+            return
+        prow = self.lib.query("vm_bn_part_rows")
+        ntw = n // wpt
+        ga, gb = self._sync_rows(key, pa, pb, wpt * prow, ntw, c, prow, cr_ws, st)
+        scratch = self._sync_bufs.get(("gscratch", c))
+        if scratch is None:
+            scratch = self._sync_bufs[("gscratch", c)] = torch.empty(2, c, dtype=torch.float32, device=self.device)
+        self._call("vm_bn_bwd_finalize", ga, gb, ntw, 1, c, count * self.sync_bn_world, c1, c2, scratch[0].data_ptr(), scratch[1].data_ptr(),
+                   cr_ws, st)
 
     def _call(self, name, *args):
         """Enqueue one C-ABI entry point; entry points listed in ``self.timed`` are bracketed by HIP events on the
@@ -597,6 +635,8 @@ class HipEncoderEngine:
         if not (self.fold_affine and pl["training"] and self.is16 and self.fuse_block1 and self.fused_bn_reduce
                 and self.fused_sums_finalize and self.nb >= 2 and self.wt):
             return False
+        if self.sync_bn:
+            return False   # SyncBN goes through the two plain finalize funnels (vm_bn_finalize, vm_bn_bwd_finalize): the unfolded path
         if drop_masks is not None and any(m is not None for m in drop_masks):
             return False   # SpatialDropout1D scales per (window, channel): not a per-channel affine
         n, dt = pl["n"], self.dtype
@@ -721,7 +761,11 @@ class HipEncoderEngine:
                 elif second_of_two:         # plain average: the two updates are sequential -- after tower 1's
                     self.tower_stream.wait_event(pl["tower_ev"][i])
                 centred = i == 0 and fold and self.fuse_block1   # block 1's extreme is stored as e - max(bias, 0): the offset's constants
-                self._call("vm_bn_finalize", ssum, ssq, wpt * rows, ntw, c, float(wpt * L), gam, bet, self.bn_eps, self.bn_momentum,
+                s_sum, s_sq, s_rows, s_cnt = ssum, ssq, wpt * rows, float(wpt * L)
+                if self.sync_bn:
+                    s_sum, s_sq = self._sync_rows(("fwd", i, tw0), ssum, ssq, wpt * rows, ntw, c, 1, _p(cr_ws), st)
+                    s_rows, s_cnt = 1, float(wpt * L) * self.sync_bn_world
+                self._call("vm_bn_finalize", s_sum, s_sq, s_rows, ntw, c, s_cnt, gam, bet, self.bn_eps, self.bn_momentum,
                            int(self.unbiased), m_, v_, T(b["mean"]), T(b["invstd"]), T(b["scale"]), T(b["shift"]), _p(cr_ws), zd, zc,
                            bias if centred else None, T(b["shift_c"]) if centred else None, T(b["mean_c"]) if centred else None, st)
                 if zd is None and first_of_two:
@@ -855,7 +899,7 @@ class HipEncoderEngine:
             dm = _p(drop[i]) if drop is not None and drop[i] is not None else None
             if i == 0 and self.fuse_block1:
                 Lq = pl["L"][1]
-                if b.get("bnred_now") and self.fused_sums_finalize:
+                if b.get("bnred_now") and self.fused_sums_finalize and not self.sync_bn:
                     # the sums of the dgrad epilogue straight into the column reduction: two small launches instead of three
                     self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None, _p(b["dp"]), _p(b["scale"]),
                                _p(b["shift"]), _p(b["mean_c" if fold else "mean"]), _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, 0, float(wpt * L), _p(b["c1"]),
@@ -868,8 +912,8 @@ class HipEncoderEngine:
                     else:
                         self._call("vm_bn_pool_bwd_reduce", _p(b["e"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]),
                                    _p(b["invstd"]), dm, n, wpt, Lq, c, 1, dt, _p(b["pa"]), _p(b["pb"]), st)
-                    self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                               _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
+                    self._bn_bwd_finalize(("bwd", 0), _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                                          _p(self.view("bn1.gamma", G)), _p(self.view("bn1.beta", G)), _p(pl["cr_ws"]), st)
                 self._call("vm_conv1_fused_bwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
                            _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
                            c, pool, dt, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
@@ -883,7 +927,7 @@ class HipEncoderEngine:
             fused_fin = False
             if sparse:
                 self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
-            elif b.get("bnred_now") and self.fused_sums_finalize:
+            elif b.get("bnred_now") and self.fused_sums_finalize and not self.sync_bn:
                 self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None if b.get("pairs_now") else _p(b["z"]),
                            _p(b["dp"]), _p(b["scale"]),
                            _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
@@ -902,8 +946,8 @@ class HipEncoderEngine:
             else:
                 self._call("vm_bn_pool_bwd_reduce", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             if not fused_fin:
-                self._call("vm_bn_bwd_finalize", _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
-                           _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
+                self._bn_bwd_finalize(("bwd", i), _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                                      _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             if b.get("pairs_now") and not sparse:
                 self._call("vm_bn_pool_bwd_apply_pairs", _p(b["ep"]), _p(b["o"]), *common[1:], _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, dt,
                            _p(b["du"]), _p(b["pdu"]), st)

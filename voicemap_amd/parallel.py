@@ -144,6 +144,7 @@ class GradAllReduce:
 def attach(engine, world: int, overlap: bool = True):
     engine.grad_sync = GradAllReduce(world, overlap=overlap)
     engine.grad_prescale = 1.0 / world
+    engine.sync_bn_world = world   # used only where engine.sync_bn is set (SyncBN: BatchNorm over the global batch, engine.py)
 
 
 def attach_if_distributed(engine) -> Tuple[int, int]:
