@@ -246,27 +246,26 @@ def test_two_rank_hip_engine_on_one_gpu_over_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
-def test_sync_bn_two_ranks_equal_one_device_with_the_global_batch(tmp_path, dtype):
+def test_sync_bn_two_ranks_equal_one_device_with_the_global_batch(tmp_path):
     """SyncBN (engine.sync_bn): two ranks x 4 pairs == one device x 8 pairs -- loss, gradients and the weights after an Adam
     step -- because the BatchNorm statistics and the two BatchNorm-backward means are all-reduced; without it the replicas normalise
     over their own 4 pairs and the gradients differ visibly (asserted too)."""
     port = 29500 + ((os.getpid() + 13) % 2000)
-    mp.spawn(_sync_bn_worker, args=(2, port, str(tmp_path), dtype), nprocs=2, join=True)
-    res = torch.load(str(tmp_path / "syncbn.pt"))
+    mp.spawn(_sync_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)   # both storage modes in one pair of processes
     from tests.gpu_util import report
-    for k, v in res.items():
-        report("sync_bn_2_ranks_x_4_pairs_vs_1_device_x_8_pairs[%s]" % dtype, k, v)
-    tol = {"f32": 2e-5, "f16": 3e-2}[dtype]
-    assert res["grad_rel_err_sync"] < tol, res
-    assert res["param_rel_err_sync"] < {"f32": 1e-6, "f16": 1e-3}[dtype], res
-    assert abs(res["loss_sync"] - res["loss_single"]) < {"f32": 1e-6, "f16": 2e-3}[dtype], res
-    assert res["moving_rel_err_sync"] < {"f32": 1e-6, "f16": 2e-3}[dtype], res
-    assert res["grad_rel_err_plain"] > 10 * res["grad_rel_err_sync"] and res["grad_rel_err_plain"] > 1e-2, res
-    assert res["collectives_sync"] > res["collectives_plain"] == 2
+    for dtype in ("f32", "f16"):
+        res = torch.load(str(tmp_path / ("syncbn_%s.pt" % dtype)))
+        for k, v in res.items():
+            report("sync_bn_2_ranks_x_4_pairs_vs_1_device_x_8_pairs[%s]" % dtype, k, v)
+        assert res["grad_rel_err_sync"] < {"f32": 2e-5, "f16": 3e-2}[dtype], res
+        assert res["param_rel_err_sync"] < {"f32": 1e-6, "f16": 1e-3}[dtype], res
+        assert abs(res["loss_sync"] - res["loss_single"]) < {"f32": 1e-6, "f16": 2e-3}[dtype], res
+        assert res["moving_rel_err_sync"] < {"f32": 1e-6, "f16": 2e-3}[dtype], res
+        assert res["grad_rel_err_plain"] > 10 * res["grad_rel_err_sync"] and res["grad_rel_err_plain"] > 1e-2, res
+        assert res["collectives_sync"] > res["collectives_plain"] == 2
 
 
-def _sync_bn_worker(rank, world, port, outdir, dtype):
+def _sync_bn_worker(rank, world, port, outdir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     from voicemap_amd.engine import HipEncoderEngine
@@ -288,42 +287,43 @@ def _sync_bn_worker(rank, world, port, outdir, dtype):
             e.view("conv%d.bias" % i).copy_(0.1 * torch.randn(e.view("conv%d.bias" % i).shape, generator=gg))
         e.refresh_weights()
 
-    def run(sync_bn):
-        e = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype=dtype, seed=5)
-        trained_like(e)
-        e.sync_bn = sync_bn
-        parallel.attach(e, world)
-        parallel.broadcast_state(e)
-        c0 = dist_collectives()
-        pl = e.siamese_train_step(x1[lo:hi], x2[lo:hi], y[lo:hi], drop_masks=None, apply_update=True)
-        torch.cuda.synchronize()
-        losses = [torch.zeros(1, device="cuda") for _ in range(world)]
-        dist.all_gather(losses, pl["loss_acc"][:1].float().clone())
-        return e, float(sum(losses).item() / world), dist_collectives() - c0
+    for dtype in ("f32", "f16"):
+        def run(sync_bn):
+            e = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype=dtype, seed=5)
+            trained_like(e)
+            e.sync_bn = sync_bn
+            parallel.attach(e, world)
+            parallel.broadcast_state(e)
+            c0 = dist_collectives()
+            pl = e.siamese_train_step(x1[lo:hi], x2[lo:hi], y[lo:hi], drop_masks=None, apply_update=True)
+            torch.cuda.synchronize()
+            losses = [torch.zeros(1, device="cuda") for _ in range(world)]
+            dist.all_gather(losses, pl["loss_acc"][:1].float().clone())
+            return e, float(sum(losses).item() / world), dist_collectives() - c0
 
-    counter = {"n": 0}
-    real_all_reduce = dist.all_reduce
+        counter = {"n": 0}
+        real_all_reduce = dist.all_reduce
 
-    def counting_all_reduce(*a, **k):
-        counter["n"] += 1
-        return real_all_reduce(*a, **k)
-    dist.all_reduce = counting_all_reduce
-    dist_collectives = lambda: counter["n"]
-    e_sync, loss_sync, n_sync = run(True)
-    e_plain, loss_plain, n_plain = run(False)
-    dist.all_reduce = real_all_reduce
-    if rank == 0:
-        single = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype=dtype, seed=5)
-        trained_like(single)
-        pl = single.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=True)
-        torch.cuda.synchronize()
-        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-        scale = lambda e: e.G / float(e.loss_scale)
-        mov = lambda e: torch.cat([e.view("bn%d.moving_%s" % (i, k)).reshape(-1) for i in range(1, 5) for k in ("mean", "variance")])
-        torch.save({"grad_rel_err_sync": rel(scale(e_sync) * 0.5, scale(single)), "grad_rel_err_plain": rel(scale(e_plain) * 0.5, scale(single)),
-                    "param_rel_err_sync": rel(e_sync.P, single.P), "loss_sync": loss_sync, "loss_plain": loss_plain,
-                    "loss_single": float(pl["loss_acc"][0].item()), "moving_rel_err_sync": rel(mov(e_sync), mov(single)),
-                    "collectives_sync": n_sync, "collectives_plain": n_plain}, os.path.join(outdir, "syncbn.pt"))
+        def counting_all_reduce(*a, **k):
+            counter["n"] += 1
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting_all_reduce
+        dist_collectives = lambda: counter["n"]
+        e_sync, loss_sync, n_sync = run(True)
+        e_plain, loss_plain, n_plain = run(False)
+        dist.all_reduce = real_all_reduce
+        if rank == 0:
+            single = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype=dtype, seed=5)
+            trained_like(single)
+            pl = single.siamese_train_step(x1, x2, y, drop_masks=None, apply_update=True)
+            torch.cuda.synchronize()
+            rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+            scale = lambda e: e.G / float(e.loss_scale)
+            mov = lambda e: torch.cat([e.view("bn%d.moving_%s" % (i, k)).reshape(-1) for i in range(1, 5) for k in ("mean", "variance")])
+            torch.save({"grad_rel_err_sync": rel(scale(e_sync) * 0.5, scale(single)), "grad_rel_err_plain": rel(scale(e_plain) * 0.5, scale(single)),
+                        "param_rel_err_sync": rel(e_sync.P, single.P), "loss_sync": loss_sync, "loss_plain": loss_plain,
+                        "loss_single": float(pl["loss_acc"][0].item()), "moving_rel_err_sync": rel(mov(e_sync), mov(single)),
+                        "collectives_sync": n_sync, "collectives_plain": n_plain}, os.path.join(outdir, "syncbn_%s.pt" % dtype))
     dist.barrier()
     dist.destroy_process_group()
 
