@@ -1,0 +1,52 @@
+"""Training in the large, mode against mode: the same 1 200 Adam steps (same synthetic speakers, same pair draws, same initial weights) of
+the cfg-A siamese net in f32s (fp32 storage, the parity-grade mode), f16 (the benchmarked mode) and bf16 storage -- training loss per 100
+steps and 5-way 1-shot accuracy on held-out speakers.  PYTHONPATH=$PWD python tools/probe/convergence_modes.py > profiles/..."""
+import os, sys, tempfile, time
+import numpy as np, torch
+from voicemap_amd import models as VM, retrieval as R, shards as VS, utils as VU
+from voicemap_amd.keras_like import Adam
+from voicemap_amd.librispeech import SyntheticSpeechDataset
+F, E, steps, bs = 128, 64, int(os.environ.get("STEPS", "1200")), 64
+dev = torch.device("cuda", 0)
+bp = VU.BatchPreProcessor("siamese", VU.preprocess_instances(4))
+rows = {}
+with tempfile.TemporaryDirectory() as td:
+    VS.write_shards(SyntheticSpeechDataset(num_speakers=64, files_per_speaker=8, seconds=3, seed=0), os.path.join(td, "train"))
+    VS.write_shards(SyntheticSpeechDataset(num_speakers=40, files_per_speaker=6, seconds=3, seed=1, subset="heldout"), os.path.join(td, "valid"))
+    valid = VS.ShardedSpeechDataset(os.path.join(td, "valid"), 3, stochastic=False)
+    valid.to_device("cuda")
+    sampler = R.DeviceTaskSampler(valid, dev, seed=3)
+    q0, s0 = sampler.draw(5000, 5, 1)
+    for dtype in sys.argv[1:] or ["f32s", "f16", "bf16"]:
+        train = VS.ShardedSpeechDataset(os.path.join(td, "train"), 3, stochastic=True)
+        train.to_device("cuda")
+        torch.manual_seed(1)
+        np.random.seed(1)
+        enc = VM.get_baseline_convolutional_encoder(F, E, dropout=0.0, dtype=dtype)
+        net = VM.build_siamese_net(enc, (train.fragment_length // 4, 1))
+        net.compile(loss="binary_crossentropy", optimizer=Adam(clipnorm=1.0), metrics=["accuracy"])
+        acc0 = R.evaluate_tasks(R.embed_corpus(net, valid, bp), q0, s0, 5, 1, "euclidean") / 5000.0
+        gen = (bp(b) for b in train.yield_verification_batches_device(bs))
+        losses, accs, cur, t0 = [], [], [], time.perf_counter()
+        for i in range(steps):
+            x, yb = next(gen)
+            out = net.train_on_batch(x, yb)
+            cur.append([float(out[0]), float(out[1])])
+            if (i + 1) % 100 == 0:
+                m = np.mean(cur, 0)
+                losses.append(m[0]); accs.append(m[1]); cur = []
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng = net._ensure_engine() if hasattr(net, "_ensure_engine") else None
+        acc1 = R.evaluate_tasks(R.embed_corpus(net, valid, bp), q0, s0, 5, 1, "euclidean") / 5000.0
+        rows[dtype] = (losses, accs, acc0, acc1, dt / steps * 1e3, eng.skipped_steps() if eng is not None and hasattr(eng, "skipped_steps") else 0,
+                       float(getattr(eng, "loss_scale", 1.0)) if eng is not None else 1.0)
+print("%d Adam steps of %d pairs, BCE, cfg-A (filters 128, embedding 64), 64 synthetic speakers resident on the device; held-out: 5000 5-way "
+      "1-shot tasks on 40 other speakers (chance 0.2)" % (steps, bs))
+print("mean training loss / pair accuracy per 100 steps:")
+print("  steps   " + "".join("%22s" % d for d in rows))
+for k in range(len(next(iter(rows.values()))[0])):
+    print("  %5d   " % ((k + 1) * 100) + "".join("      %.4f / %.3f  " % (rows[d][0][k], rows[d][1][k]) for d in rows))
+for d, r in rows.items():
+    print("%-5s 5-way 1-shot held-out accuracy %.4f -> %.4f   %.2f ms per step incl. the host's pair draws   skipped steps %d   final loss scale %g"
+          % (d, r[2], r[3], r[4], r[5], r[6]))
