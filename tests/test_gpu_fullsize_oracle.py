@@ -54,7 +54,7 @@ def _trained_like(p, seed=77):
 def oracle_full_size():
     """float64 forward (no autograd) + fp32 autograd step of the oracle on the bench batch; ~1 min on 16+ host cores."""
     threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("VOICEMAP_TEST_ORACLE_THREADS", "32")))))
     try:
         arch = O.EncoderArch.baseline(F, E, dropout=0.0)
         p = O.init_params(arch, head="uniform_euclidean", seed=1234)

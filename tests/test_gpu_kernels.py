@@ -713,9 +713,9 @@ def _window_slices(n):
     return sorted({0, n // 2, n - 1})   # first / last window and the first window of the second tower
 
 
-# (fp32 storage on the first shape only -- its kernels do not depend on the channel counts beyond % 128; wall-clock budget of the suite)
+# (fp32 storage -- f32, f32s -- on the first shape only: its kernels do not depend on the channel counts beyond % 128; wall-clock budget)
 @pytest.mark.parametrize("dt,l,cin,cout", [(dt,) + g for g in CFG_A_GEMMS for dt in ("f32", "f32s", "bf16", "f16")
-                                           if dt != "f32" or g == CFG_A_GEMMS[0]])
+                                           if dt in ("bf16", "f16") or g == CFG_A_GEMMS[0]])
 def test_conv_cfgA_full_batch_sampled_windows(dt, l, cin, cout):
     """The bench launch itself (256 windows = 128 pairs): forward + statistics and dgrad are per-window independent, so the
     oracle is run on a handful of sampled windows of the very same launch; wgrad sums over windows, so it is checked (a)
