@@ -48,7 +48,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"nt_n2": 3, "nt_glds": 1, "tn_x": 1, "tn_tile": 256}   # the library's defaults (conv_gemm.hip / conv_wgrad.hip)
+GEMM_DEFAULTS = {"nt_n2": 3, "nt_glds": 1, "tn_x": 1, "tn_tile": 256, "tn9": 1}   # the library's defaults (conv_gemm.hip / conv_wgrad.hip)
 
 
 @pytest.fixture
@@ -87,12 +87,22 @@ def test_conv_fwd_dgrad_wgrad_fallback_kernels(dt, n, l, cin, cout, gemm_kernels
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n,l,cin,cout", [(2, 700, 128, 256), (3, 760, 256, 256), (2, 650, 64, 512), (1, 129, 32, 128), (2, 5, 128, 128),
-                                          (4, 3000, 128, 256), (4, 1500, 256, 384), (4, 750, 384, 512)])
+                                          (3, 131, 192, 320), (1, 62, 64, 64), (4, 3000, 128, 256), (4, 1500, 256, 384), (4, 750, 384, 512)])
 def test_conv_input_resident_kernel_shapes(dt, n, l, cin, cout):
     """conv_nt2r_kernel / conv_tn8x_kernel under the default dispatch on the shapes that exercise their tiling: 254-position tiles
     with ragged last tiles (700, 760, 650), windows whose second statistics row of the last tile does not exist (129, 650: the
     forward falls back to the 128 x 128 kernel there, dgrad does not), a window shorter than one tile (5), cfg-A's own geometries."""
     _conv_fwd_dgrad_wgrad(dt, n, l, cin, cout)
+
+
+@pytest.mark.parametrize("gemm_kernels", [{"tn9": 0}, {"tn9": 2}], indirect=True, ids=["tn8x-slots", "tn9-producer-waves"])
+@pytest.mark.parametrize("n,l,cin,cout", [(2, 700, 128, 256), (2, 650, 64, 512), (2, 5, 128, 128), (3, 131, 192, 320), (1, 62, 64, 64),
+                                          (4, 750, 384, 512)])
+def test_conv_wgrad_kernel_variants(n, l, cin, cout, gemm_kernels):
+    """The two other forms of the input-resident wgrad tile (the default is conv_tn9_kernel): conv_tn8x_kernel (READ / MFMA slots) and
+    conv_tn9_kernel with producer waves, on ragged stages (700, 650, 131), a window shorter than a stage (5, 62), half-filled tiles
+    (64, 192, 320 channels) and cfg-A's block 4."""
+    _conv_fwd_dgrad_wgrad("f16", n, l, cin, cout)
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (3, 131, 96, 32),
