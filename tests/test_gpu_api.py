@@ -314,18 +314,18 @@ def test_k_way_accuracy_script_cached_sweep(tmp_path, monkeypatch):
     os.makedirs(os.path.join(str(tmp_path), "logs"), exist_ok=True)
     torch.manual_seed(2)
     enc = VM.get_baseline_convolutional_encoder(16, 16, dropout=0.0, dtype="f32")
-    net = VM.build_siamese_net(enc, (12000, 1))
+    net = VM.build_siamese_net(enc, (4000, 1))   # 1 s windows: the sweep, not the window length, is under test
     net.compile(loss="binary_crossentropy", optimizer="adam")
     path = os.path.join(str(tmp_path), "siamese.hdf5")
     net.save(path)
-    args = ["--siamese", path, "--synthetic", "--k-way", "2", "5", "--n-shot", "1", "3", "--num-tasks", "16", "--distance", "cosine", "--cached"]
+    args = ["--siamese", path, "--synthetic", "--k-way", "2", "5", "--n-shot", "1", "3", "--num-tasks", "16", "--distance", "cosine", "--cached", "--n-seconds", "1"]
     df = k_way_accuracy.main(args)       # (the script seeds np.random itself: experiments/_common.setup)
     assert list(df.columns) == ["method", "n_correct", "n_tasks", "n", "k"] and len(df) == 4
     assert ((df["n_correct"] >= 0) & (df["n_correct"] <= 16)).all()
     rows = open(os.path.join(str(tmp_path), "logs", "k-way_n-shot_accuracy_dev-clean_cosine.csv")).read().strip().splitlines()
     assert rows[0] == "method,n_correct,n_tasks,n_shot,k_way" and len(rows) == 5
     # the same cells by hand, same seed
-    valid = SyntheticSpeechDataset(num_speakers=40, files_per_speaker=12, seconds=3, stochastic=False, seed=1)
+    valid = SyntheticSpeechDataset(num_speakers=40, files_per_speaker=12, seconds=1, stochastic=False, seed=1)
     pre = VU.BatchPreProcessor("siamese", VU.preprocess_instances(4))
     loaded = VM.load_model(path)
     cache = R.embed_corpus(loaded, valid, pre)
@@ -334,6 +334,6 @@ def test_k_way_accuracy_script_cached_sweep(tmp_path, monkeypatch):
     want = [R.n_shot_task_evaluation_cached(loaded, valid, pre, 16, n, k, "siamese", "cosine", cache=cache) for k in (2, 5) for n in (1, 3)]
     assert list(df["n_correct"]) == want
     args2 = ["--siamese", path, "--synthetic", "--k-way", "5", "--n-shot", "1", "--num-tasks", "16", "--distance", "cosine", "--cached",
-             "--device-sampler"]
+             "--device-sampler", "--n-seconds", "1"]
     df2 = k_way_accuracy.main(args2)
     assert len(df2) == 1 and ((df2["n_correct"] >= 0) & (df2["n_correct"] <= 16)).all()

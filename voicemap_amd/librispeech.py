@@ -14,6 +14,7 @@ run and benchmarks (no LibriSpeech on the GPU box).
 from __future__ import annotations
 
 import os
+import functools
 import wave
 
 import numpy as np
@@ -326,6 +327,21 @@ class LibriSpeechDataset(Sequence):
         return audio_files
 
 
+@functools.lru_cache(maxsize=512)
+def _synthetic_recording(sid, fno, length, f0, harm, noise):
+    """One generated recording: a deterministic function of its arguments, so the ~5 ms of numpy per call are spent once per process
+    (the evaluation paths walk a corpus several times).  Read-only; _load hands out copies."""
+    rng = np.random.default_rng(sid * 1000 + fno)
+    t = np.arange(length) / LIBRISPEECH_SAMPLING_RATE
+    vib = 1.0 + 0.01 * np.sin(2 * np.pi * rng.uniform(3, 7) * t + rng.uniform(0, 6.28))
+    phase = 2 * np.pi * f0 * np.cumsum(vib) / LIBRISPEECH_SAMPLING_RATE
+    x = sum(h * np.sin((i + 1) * phase + rng.uniform(0, 6.28)) for i, h in enumerate(harm))
+    env = 0.5 + 0.5 * np.sin(2 * np.pi * rng.uniform(1.5, 4.0) * t + rng.uniform(0, 6.28)) ** 2
+    out = 0.05 * env * x / np.sqrt(len(harm)) + noise * rng.standard_normal(length)
+    out.setflags(write=False)
+    return out
+
+
 class SyntheticSpeechDataset(LibriSpeechDataset):
     """Same API over generated "speakers" (no audio files): every speaker has a fundamental frequency, a few harmonic
     weights and a noise colour; every file is a deterministic function of (speaker, file number).  Used by the tests
@@ -358,10 +374,4 @@ class SyntheticSpeechDataset(LibriSpeechDataset):
         fno = int(path.rsplit('/', 1)[1])
         length = int(self.df.loc[index, 'length'])
         f0, harm, noise = self._voice[sid]
-        rng = np.random.default_rng(sid * 1000 + fno)
-        t = np.arange(length) / LIBRISPEECH_SAMPLING_RATE
-        vib = 1.0 + 0.01 * np.sin(2 * np.pi * rng.uniform(3, 7) * t + rng.uniform(0, 6.28))
-        phase = 2 * np.pi * f0 * np.cumsum(vib) / LIBRISPEECH_SAMPLING_RATE
-        x = sum(h * np.sin((i + 1) * phase + rng.uniform(0, 6.28)) for i, h in enumerate(harm))
-        env = 0.5 + 0.5 * np.sin(2 * np.pi * rng.uniform(1.5, 4.0) * t + rng.uniform(0, 6.28)) ** 2
-        return 0.05 * env * x / np.sqrt(len(harm)) + noise * rng.standard_normal(length)
+        return _synthetic_recording(sid, fno, length, f0, tuple(float(h) for h in harm), noise).copy()   # (the cached array is read-only)
