@@ -55,6 +55,39 @@ def test_fit_generator_like_train_siamese(tmp_path):
     assert e.shape == (4, 32) and np.isfinite(e).all()
 
 
+def test_fit_generator_deferred_batch_logs_equal_the_per_batch_ones():
+    """fit_generator reads the per-batch (loss, acc) in blocks when no callback has an on_batch_end (the host keeps enqueueing instead of
+    waiting for every step): the epoch logs and the weights are those of the per-batch loop, bit for bit; a callback with an on_batch_end
+    gets every batch's numbers as before."""
+    train = SyntheticSpeechDataset(num_speakers=12, files_per_speaker=3, seconds=0.5, pad=True, seed=1)
+    bp = utils.BatchPreProcessor("siamese", utils.preprocess_instances(4))
+    np.random.seed(5)
+    batches = [bp(train.build_verification_batch(8)) for _ in range(6)]
+
+    class Seen(K.Callback):
+        def __init__(self):
+            super().__init__()
+            self.losses = []
+
+        def on_batch_end(self, batch, logs=None):
+            self.losses.append(logs["loss"])
+
+    def run(defer, cbs):
+        torch.manual_seed(3)
+        enc = models.get_baseline_convolutional_encoder(16, 24, dropout=0.0, dtype="f16")
+        net = models.build_siamese_net(enc, (2000, 1), distance_metric="uniform_euclidean")
+        net.compile(loss="binary_crossentropy", optimizer=K.Adam(clipnorm=1.), metrics=["accuracy"])
+        net.defer_batch_logs = defer
+        h = net.fit_generator(generator=iter(batches), steps_per_epoch=3, epochs=2, workers=0, verbose=0, callbacks=cbs)
+        return h.history, net.engine.P.clone()
+    h1, p1 = run(True, [])
+    h0, p0 = run(False, [])
+    seen = Seen()
+    h2, p2 = run(True, [seen])
+    assert h1["loss"] == h0["loss"] == h2["loss"] and h1["acc"] == h0["acc"] and torch.equal(p1, p0) and torch.equal(p1, p2)
+    assert len(seen.losses) == 6 and np.isclose(np.mean(seen.losses[:3]), h2["loss"][0])
+
+
 @pytest.mark.parametrize("ext", ["hdf5", "npz"])
 def test_checkpoint_resume_is_bit_identical(tmp_path, ext):
     """model.save -> load_model restores weights, moving statistics, Adam slots and the iteration counter exactly: the next

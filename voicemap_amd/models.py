@@ -41,6 +41,7 @@ class _TrainableModel:
         self._pending_weights = None
         self._pending_adam = None
         self.history = None
+        self.defer_batch_logs = True   # fit_generator: read the per-batch loss / acc in blocks when no callback has an on_batch_end
 
     # ---- engine lifecycle -------------------------------------------------------------------------------
     def _engine_args(self):
@@ -267,17 +268,32 @@ class _TrainableModel:
         if validation_data is not None and not isinstance(validation_data, tuple):
             valid = K.BatchFeeder(validation_data, workers, max_queue_size)
         self.stop_training = False
+        import torch
+        deferred = self.defer_batch_logs and hasattr(self, "_train_step") and \
+            all(type(cb).on_batch_end is K.Callback.on_batch_end for cb in cbs)
         K.run_callbacks(cbs, "on_train_begin")
         try:
             for epoch in range(initial_epoch, epochs):
                 K.run_callbacks(cbs, "on_epoch_begin", epoch)
                 t0 = time.time()
                 tot, wl, wa = 0, 0.0, 0.0
+                pending = []   # (loss_acc on the device, batch size) of steps whose numbers nobody has asked for yet
                 for step in range(steps_per_epoch):
                     x, y = train.get()[:2]
-                    loss, acc = self.train_on_batch(x, y)
                     n = self._batch_size(x)
                     tot += n
+                    if deferred:
+                        # no callback looks at a batch's loss: the host keeps enqueueing (it needs ~1.2 ms per step) instead of waiting
+                        # for every step's two numbers -- at the scripts' 64 pairs that wait is a quarter of the epoch
+                        pending.append((self._train_step(x, y)["loss_acc"].clone(), n))
+                        if len(pending) == 256 or step + 1 == steps_per_epoch:
+                            vals = torch.stack([t for t, _ in pending]).cpu().numpy()
+                            for (l_, a_), (_, n_) in zip(vals[:, :2], pending):
+                                wl += float(l_) * n_
+                                wa += float(a_) * n_
+                            pending = []
+                        continue
+                    loss, acc = self.train_on_batch(x, y)
                     wl += loss * n
                     wa += acc * n
                     K.run_callbacks(cbs, "on_batch_end", step, {"loss": loss, "acc": acc, "size": n})
@@ -445,7 +461,8 @@ class ConvolutionalEncoder(_TrainableModel):
             return y.argmax(axis=1).astype(np.int32)
         return y.reshape(-1).astype(np.int32)
 
-    def train_on_batch(self, x, y):
+    def _train_step(self, x, y):
+        """One optimizer step enqueued; returns the engine's plan (``loss_acc`` on the device: reading it is the only host sync)."""
         if not self.classifier_units:
             raise RuntimeError("the bare encoder has no loss; add Dense(num_classes, activation='softmax') or wrap it in "
                                "build_siamese_net")
@@ -453,11 +470,12 @@ class ConvolutionalEncoder(_TrainableModel):
             raise NotImplementedError("classifier loss %r" % (self.loss,))
         eng = self._ensure_engine()
         if _is_lazy(x):
-            pl = eng.classifier_train_step(x.raw, self._labels(y), preprocessed=False, downsampling=x.downsampling,
-                                           whitening=x.whitening)
-        else:
-            pl = eng.classifier_train_step(np.asarray(x, dtype=np.float32), self._labels(y))
-        la = pl["loss_acc"].cpu().numpy()
+            return eng.classifier_train_step(x.raw, self._labels(y), preprocessed=False, downsampling=x.downsampling,
+                                             whitening=x.whitening)
+        return eng.classifier_train_step(np.asarray(x, dtype=np.float32), self._labels(y))
+
+    def train_on_batch(self, x, y):
+        la = self._train_step(x, y)["loss_acc"].cpu().numpy()
         return float(la[0]), float(la[1])
 
     def test_on_batch(self, x, y):
@@ -617,7 +635,8 @@ class SiameseNet(_TrainableModel):
             return fn(r1, r2, preprocessed=False, downsampling=x1.downsampling, whitening=x1.whitening, **kw)
         return fn(np.asarray(x1, dtype=np.float32), np.asarray(x2, dtype=np.float32), **kw)
 
-    def train_on_batch(self, x, y):
+    def _train_step(self, x, y):
+        """One optimizer step enqueued; returns the engine's plan (``loss_acc`` on the device: reading it is the only host sync)."""
         eng = self._ensure_engine()
         x1, x2 = self._pair(x)
         loss = self._loss_name()
@@ -625,13 +644,13 @@ class SiameseNet(_TrainableModel):
                 and x1.raw.audio is x2.raw.audio:
             # device data path: the crop happens inside the preprocessing kernel (vm_crop_decimate_whiten)
             assert (x1.downsampling, x1.whitening) == (x2.downsampling, x2.whitening)
-            pl = eng.siamese_train_step_from_offsets(x1.raw.audio, x1.raw.offsets, x2.raw.offsets,
-                                                     np.asarray(y, dtype=np.float32), x1.raw.length, loss=loss,
-                                                     downsampling=x1.downsampling, whitening=x1.whitening)
-            la = pl["loss_acc"].cpu().numpy()
-            return float(la[0]), float(la[1])
-        pl = self._run(lambda a, b, **kw: eng.siamese_train_step(a, b, np.asarray(y, dtype=np.float32), loss=loss, **kw), x1, x2)
-        la = pl["loss_acc"].cpu().numpy()
+            return eng.siamese_train_step_from_offsets(x1.raw.audio, x1.raw.offsets, x2.raw.offsets,
+                                                       np.asarray(y, dtype=np.float32), x1.raw.length, loss=loss,
+                                                       downsampling=x1.downsampling, whitening=x1.whitening)
+        return self._run(lambda a, b, **kw: eng.siamese_train_step(a, b, np.asarray(y, dtype=np.float32), loss=loss, **kw), x1, x2)
+
+    def train_on_batch(self, x, y):
+        la = self._train_step(x, y)["loss_acc"].cpu().numpy()
         return float(la[0]), float(la[1])
 
     def test_on_batch(self, x, y):
