@@ -285,6 +285,50 @@ def test_classifier_train_step_matches_oracle():
     _check_params_after_adam(eng.get_params(), ref["params"], ref["grads"], 1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_config1_classifier_batch8_at_full_size_against_the_oracle(dtype):
+    """BASELINE.json configs[0] as the reference runs it (experiments/train_classifier.py:110-127): cfg-A encoder (filters 128, embedding
+    64, SpatialDropout1D 0.05 with given keep masks) + Dense(40, softmax), categorical CE, batch 8 of 3 s windows at L = 12 000 -- the
+    full size, not a reduced one -- against the float64 CPU oracle: probabilities, loss, every gradient, the weights after the Adam step."""
+    nc, n, l0, rate = 40, 8, 12000, 0.05
+    arch = O.EncoderArch.baseline(128, 64, dropout=rate)
+    p = O.init_params(arch, head="classifier", num_classes=nc, seed=2)
+    r = np.random.default_rng(2)
+    x = O.whiten(r.normal(0, 0.05, (n, l0, 1))).astype(np.float32).astype(np.float64)
+    labels = r.integers(0, nc, n)
+    masks = [torch.tensor((r.random((n, 1, c)) >= rate).astype(np.float64)) for (_, c, _) in arch.blocks]
+    eng = _engine(arch, p, "classifier", dtype, num_classes=nc)
+    dm = [(m[:, 0, :] / (1.0 - rate)).to("cuda", torch.float32).contiguous() for m in masks]
+    pl = eng.classifier_train_step(x, labels, drop_masks=dm)
+    oh = torch.nn.functional.one_hot(torch.tensor(labels), nc).double()
+    ref = O.classifier_train_step(arch, p, O.AdamState(), torch.tensor(x), oh, drop_masks=masks)
+    tag = "config1_classifier_batch8_full_size[%s]" % dtype
+    e_prob = rel_err(pl["prob"].cpu().numpy(), ref["prob"].numpy())
+    e_emb = rel_err(pl["emb"].cpu().numpy(), ref["e"].numpy()) if "e" in ref else float("nan")
+    report(tag, "prob_rel_err_vs_fp64", e_prob)
+    report(tag, "emb_rel_err_vs_fp64", e_emb)
+    report(tag, "loss_abs_err", abs(pl["loss_acc"][0].item() - ref["loss"].item()))
+    grads = eng.get_grads()
+    g_all = np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in ref["grads"]])
+    r_all = np.concatenate([g.numpy().ravel() for g in ref["grads"].values()])
+    report(tag, "grad_rel_err", rel_err(g_all, r_all))
+    report(tag, "grad_cosine", cosine(g_all, r_all))
+    if dtype == "f32":
+        assert e_prob < 1e-4 and abs(pl["loss_acc"][0].item() - ref["loss"].item()) < 1e-4
+        for k, g in ref["grads"].items():
+            assert grad_close(grads[k], g.numpy(), 2e-3), k
+        # the first Adam step moves every weight by ~lr * g / (|g| + eps): where the clipped gradient is within a few eps of zero a 3e-4
+        # relative gradient error is a visible fraction of lr, so (as in test_gpu_golden_step.py) the bulk and the worst case are bounded
+        newp = eng.get_params()
+        d = np.concatenate([np.abs(np.asarray(newp[k], dtype=np.float64) - v.numpy()).ravel() for k, v in ref["params"].items() if k in ref["grads"]])
+        report(tag, "params_after_adam_abs_err_q999", float(np.quantile(d, 0.999)))
+        report(tag, "params_after_adam_abs_err_max", float(d.max()))
+        assert np.quantile(d, 0.999) < 2e-5 and d.max() < 1.01e-3
+    else:
+        assert e_prob < 5e-3 and abs(pl["loss_acc"][0].item() - ref["loss"].item()) < 5e-3
+        assert cosine(g_all, r_all) > 0.99
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_known_answer_task_on_shipped_checkpoint(dtype, golden_dir):
     """notebooks/Human_Evaluation.ipynb cell 8 ("The correct answer was 5") with the reference's only checkpoint:
