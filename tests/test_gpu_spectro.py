@@ -271,7 +271,7 @@ def _clips(n, raw_len, seed):
 
 
 SMALL = (4, 400 + 160 * 63, 8, 8)     # 64 frames x 64 mels -> 4 x 4 before the global max
-CONFIG4 = (2, 48000, 32, 64)          # BASELINE.json config 4 at its own size: 3 s clips -> 298 x 64 log-mel, filters 32, embedding 64
+CONFIG4 = (8, 48000, 32, 64)          # BASELINE.json config 4 at its own size: 8 pairs of 3 s clips -> 298 x 64 log-mel, filters 32, embedding 64
 
 
 @pytest.mark.parametrize("dt,drop,size", [("f32", 0.0, SMALL), ("f32", 0.25, SMALL), ("bf16", 0.0, SMALL), ("f16", 0.0, SMALL),
@@ -331,7 +331,9 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
         if dt == "f32":
             assert grad_close(grads[k], gr, 2e-3, 1e-7), (k, rel_err(grads[k], gr))
         assert err <= rel_b * float(np.linalg.norm(gr)) + floor_b * total, (k, rel_err(grads[k], gr), share)
-        if rel_err(grads[k], gr) > worst:
+        # the worst LIVE tensor (one that carries more than ``floor`` of the whole gradient; for the others -- e.g. bn4.beta, whose
+        # gradient is zero up to rounding in front of the global max -- a relative error is a ratio of two noises)
+        if share > floor_b and rel_err(grads[k], gr) > worst:
             worst, worst_k = rel_err(grads[k], gr), k
     report(tag, "worst_grad_rel_err", worst)
     report(tag, "worst_grad_rel_err_tensor[%s]" % worst_k, worst)
