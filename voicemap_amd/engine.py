@@ -112,6 +112,13 @@ _TIMED_AS = {"vm_conv_dgrad_bnred": ("vm_conv_dgrad", ()), "vm_conv_fwd_e": ("vm
              "vm_bn_pool_bwd_apply_pairs": ("vm_bn_pool_bwd_apply", (1,))}
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:   # older torch: the documented way
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 class HipEncoderEngine:
     """The voicemap encoder (voicemap/models.py:6-41) + optional head on one MI355X.
 
@@ -141,6 +148,8 @@ class HipEncoderEngine:
         self.dtype = _DT[dtype]
         self.tdt = _TORCH_DT[self.dtype]
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._views = {}
         self.bn_eps, self.bn_momentum = float(bn_eps), float(bn_momentum)
         self.unbiased = bool(unbiased_moving_variance)
         self.nb = len(self.blocks)
@@ -290,7 +299,8 @@ class HipEncoderEngine:
 
     # ------------------------------------------------------------------------------------------------
     def stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        # the raw HIP stream of torch's current stream (asked ~25 times per step; torch.cuda.current_stream() costs 8 us a call)
+        return _raw_stream(self._dev_index)
 
     def _sync_rows(self, key, a_ptr, b_ptr, rows_per_tower, ntw, c, row_stride, cr_ws, st):
         """SyncBN: two partial-sum tensors of ``rows_per_tower`` rows per tower -> one row per tower (vm_colsum), summed over the ranks
@@ -338,11 +348,21 @@ class HipEncoderEngine:
         rec.append((e0, e1, tuple(a for k, a in enumerate(args) if k not in drop) + ((name,) if as_name != name else ())))
 
     def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if name in self.nt_off:
+        # (memoised per (name, buffer): a training step asks ~70 times, and at small batches the step is bound by the host)
+        nt = name in self.nt_off
+        base = self.NT if nt else (self.P if buf is None else buf)
+        key = (name, None if (nt or buf is None) else id(buf))
+        v = self._views.get(key)
+        if v is not None and v[0] is base:
+            return v[1]
+        if nt:
             o, n = self.nt_off[name]
-            return self.NT[o:o + n]
-        o, n, shape = self.offsets[name]
-        return (self.P if buf is None else buf)[o:o + n].view(shape)
+            out = self.NT[o:o + n]
+        else:
+            o, n, shape = self.offsets[name]
+            out = base[o:o + n].view(shape)
+        self._views[key] = (base, out)
+        return out
 
     def init_params(self, seed: Optional[int] = None):
         """Keras default initialisers (glorot_uniform kernels, zero biases, gamma 1, beta 0, moving 0 / 1)."""
