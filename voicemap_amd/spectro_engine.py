@@ -51,6 +51,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.dtype = _DT[dtype]
         self.tdt = _TORCH_DT[self.dtype]
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._views = {}
         self.bn_eps, self.bn_momentum = float(bn_eps), float(bn_momentum)
         self.unbiased = bool(unbiased_moving_variance)
         self.n_mels, self.win_length, self.hop, self.log_floor = int(n_mels), int(win_length), int(hop), float(log_floor)
