@@ -9,6 +9,11 @@ Outputs (committed, data only -- no reference source text):
   counter) of the one Keras HDF5 checkpoint the reference ships
   (models/n_seconds/siamese__nseconds_3.0__filters_32__embed_64__drop_0.05__r_0.hdf5),
   keyed ``<layer>/<name>``.
+* ``ckpt_cfgCK_adam_slots.npz`` -- the optimizer state of the same file (``optimizer_weights/training/Adam/Variable*``):
+  the 20 first-moment (``m/<layer>/<name>``) and 20 second-moment (``v/<layer>/<name>``) accumulators after its 11 000
+  iterations, keyed like the weights (Keras ``trainable_weights`` order), plus ``vhat_max`` (the 20 amsgrad
+  placeholders are all zero).  These and the BatchNorm moving statistics are the only numbers in the reference tree that
+  its own forward / backward pass computed; tests/test_oracle_reference_pin.py holds the oracle to them.
 * ``ckpt_cfgCK_meta.json``    -- layer geometry read from its ``model_config``
   attribute (kernel sizes, pool sizes, BN eps/momentum, head type) and the
   optimizer config from ``training_config``.
@@ -80,6 +85,26 @@ def main():
         weights["dense_2/%s" % name.split(":")[0]] = np.asarray(head[name])
     weights["adam_iterations"] = np.asarray(f["optimizer_weights/Adam/iterations:0"])
     np.savez_compressed(os.path.join(OUT, "ckpt_cfgCK_weights.npz"), **weights)
+
+    # Adam slots: Keras 2.2.2 Adam.get_updates stores self.weights = [iterations] + ms + vs + vhats, each list in
+    # model.trainable_weights order = the order of model_weights' weight_names with the moving statistics dropped.
+    order = []
+    for grp in ("model_weights/sequential_1", "model_weights/dense_2"):
+        for n in f[grp].attrs["weight_names"]:
+            n = n.decode() if isinstance(n, bytes) else str(n)
+            if "moving_" not in n:
+                order.append((grp, n))
+    assert len(order) == 20, order
+    adam = f["optimizer_weights/training/Adam"]
+    slot = lambda i: np.asarray(adam["Variable:0" if i == 0 else "Variable_%d:0" % i])
+    slots = {}
+    for i, (grp, n) in enumerate(order):
+        key = "/".join(n.split(":")[0].split("/")[-2:])          # "conv1d_1/kernel", ..., "dense_2/bias": the keys of the weights file
+        assert slot(i).shape == f[grp][n].shape == slot(20 + i).shape, (key, slot(i).shape)
+        slots["m/" + key], slots["v/" + key] = slot(i), slot(20 + i)
+    slots["vhat_max"] = np.array([float(np.abs(slot(40 + i)).max()) for i in range(20)])
+    slots["order"] = np.array([k[2:] for k in slots if k.startswith("m/")])
+    np.savez_compressed(os.path.join(OUT, "ckpt_cfgCK_adam_slots.npz"), **slots)
 
     mc = json.loads(f.attrs["model_config"])
     tc = json.loads(f.attrs["training_config"])
