@@ -225,7 +225,7 @@ def main():
 
         def step():
             e.preprocess(p_, xcat, 4, True, pairs)
-            e.forward(p_, pairs, None)
+            e.forward(p_, pairs, None, defer_tail=True)
             e.siamese_head(p_, y, loss)
             e.backward(p_, sync_tail=sync_tail)   # N > 1: the large gradient all-reduce starts before block 1's backward
             e.optimizer_step()
@@ -460,7 +460,7 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         def grads_of(e):
             s_, p_ = make_step(e, sync_tail=False)
             e.preprocess(p_, xcat, 4, True, pairs)
-            e.forward(p_, pairs, None)
+            e.forward(p_, pairs, None, defer_tail=True)
             e.siamese_head(p_, y, a.loss)
             e.backward(p_)
             torch.cuda.synchronize()
@@ -541,7 +541,7 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         def step_h2d():
             dev16.copy_(host16, non_blocking=True)
             eng.preprocess(pl, dev16, 4, True, pairs)
-            eng.forward(pl, pairs, None)
+            eng.forward(pl, pairs, None, defer_tail=True)
             eng.siamese_head(pl, y, a.loss)
             eng.backward(pl)
             eng.optimizer_step()
@@ -553,7 +553,7 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
 
         def step_offsets():
             eng.preprocess(pl, corpus, 4, True, pairs, offsets=offs, raw_len=48000)
-            eng.forward(pl, pairs, None)
+            eng.forward(pl, pairs, None, defer_tail=True)
             eng.siamese_head(pl, y, a.loss)
             eng.backward(pl)
             eng.optimizer_step()
@@ -563,6 +563,46 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
     except Exception as e:
         ex["variants_error"] = repr(e)
         restore(eng, snap)
+
+    # ---- cfg-B: the reference's CONTRASTIVE-LOSS script as it runs it (experiments/siamese_contrastive_loss.py:19-23,67-70): filters 32,
+    # embedding 128, SpatialDropout1D 0.05 (masks drawn on the device), 32 pairs, contrastive loss.  SURVEY 8(d): 0.516 GFLOP and
+    # 11.04 MB of algorithmic traffic per window in training -> 64 windows are 33 GFLOP / 0.71 GB: 13 us of MFMA, 88 us of HBM; the step is
+    # bounded by its launch chain (dropout masks are per (window, channel), so the BatchNorm fold is off and the unfolded kernel sequence
+    # runs), not by any tile shape.  Same engine at the headline's 128 pairs beside it. ----
+    try:
+        cb_blocks = [(32, 32, 4), (3, 64, 2), (3, 96, 2), (3, 128, 2)]
+        cfgb = {}
+        for pr in (32, pairs):
+            eb = type(eng)(cb_blocks, 128, dropout=0.05, head="uniform_euclidean", dtype=a.dtype, device=dev, seed=1234)
+            pb = eb.plan(2 * pr, L0, True)
+            xb = torch.cat([xcat[:pr], xcat[pairs:pairs + pr]], 0).contiguous()
+            yb = torch.cat([torch.zeros(pr // 2, device=dev), torch.ones(pr - pr // 2, device=dev)]).contiguous()
+
+            def cfgb_step():
+                eb.preprocess(pb, xb, 4, True, pr)
+                eb.forward(pb, pr, eb.make_drop_masks(2 * pr), defer_tail=True)
+                eb.siamese_head(pb, yb, "contrastive")
+                eb.backward(pb)
+                eb.optimizer_step()
+            t_b = timed(cfgb_step, reps=20)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                cfgb_step()
+            t_host = (time.perf_counter() - t0) / 50
+            torch.cuda.synchronize()
+            key = "pairs_%d" % pr
+            cfgb[key] = {"ms_per_step": t_b * 1e3, "audio_s_per_s": 2 * pr * 3.0 / t_b, "host_enqueue_ms_per_step": t_host * 1e3,
+                         "step_hbm_frac": 11.04e6 * 2 * pr / t_b / 8e12, "step_mfma_frac": 0.516e9 * 2 * pr / t_b / 2.5e15}
+            del eb, pb
+        cfgb["config"] = ("filters 32 (channels 32-64-96-128), embedding 128, dropout 0.05 with device-drawn masks, contrastive loss, "
+                          "%s storage; pairs_32 is the reference script's own batch" % a.dtype)
+        cfgb["kernels"] = ("block 1 conv1_fused; blocks 2-3 forward and all dgrads on the 128-wide tiles (conv_nt_glds_kernel: N-side "
+                           "channels 32 / 64 / 96 are not multiples of the 256 x 128 tile's 128), block 4 forward conv_nt2r_kernel; wgrad "
+                           "conv_tn_kernel family; unfolded BatchNorm / dropout / pool passes (bn_drop_pool_fwd, bn_pool_bwd_*)")
+        ex["cfgB"] = cfgb
+        torch.cuda.empty_cache()
+    except Exception as e:
+        ex["cfgB_error"] = repr(e)
 
     # ---- BASELINE.json config 4: the log-mel + 2-D CNN variant (not in the reference): one siamese training step
     # of 128 pairs of RAW 3 s clips -- vm_stft_logmel + four Conv2D 3x3 blocks (filters 32) + loss + backward + Adam ----

@@ -47,7 +47,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 6.  History: 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -355,6 +355,12 @@ int64_t vm_bn_drop_pool_gmax_workspace_bytes(int64_t n_windows, int C);
 int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_windows,
                              int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* gmax, int32_t* gidx,
                              void* ws, void* stream);
+/* The first launch of vm_bn_drop_pool_gmax_fwd alone: part_v / part_i receive the vm_bn_part_rows() partial (value, position) rows
+ * of every window ((n_windows * rows, C) each; two arrays so that the two towers' launches can fill the halves of one pair of
+ * arrays); vm_tail_fwd_bwd (below) finishes them inside its own launch. */
+int vm_bn_drop_pool_gmax_partials(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_windows,
+                                  int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_v, int32_t* part_i,
+                                  void* stream);
 
 /* ---- a1 tail: GlobalMaxPool1D + Dense(E)  (voicemap/models.py:37-39) ------------------------------------
  * act: padded (n_windows, L+2, C) `dtype`; gmax (n_windows, C) fp32; gidx (n_windows, C) int32 = first argmax. */
@@ -389,6 +395,28 @@ int vm_siamese_head_loss(const float* emb, const float* head_w, const float* hea
                          float* grad_hw, float* grad_hb, float* ws, void* stream);
 int vm_siamese_head_reduce(const float* emb, const float* ws, int64_t pairs, int E, int head_kind, float* loss_acc, float* grad_hw,
                            float* grad_hb, void* stream);
+
+/* ---- the whole tail of a siamese training step, forward and backward (SURVEY 8(b) `vm_tail_fwd_bwd`) -------------------------
+ * GlobalMaxPool1D -> Dense(E) (voicemap/models.py:37-39) -> twin distance -> Dense(1, sigmoid) (models.py:55-69) -> loss
+ * (voicemap/utils.py:77-85 / 'binary_crossentropy' experiments/train_siamese.py:57) -> d loss / d emb -> d loss / d gmax.
+ * All of it is local to a pair: ONE launch, one workgroup per pair (windows b and pairs + b), replaces gmax_segments + vm_dense_fwd +
+ * the per-pair pass of vm_siamese_head_loss + the input half of vm_dense_bwd.  What crosses pairs and is nobody's input before the
+ * optimizer -- loss_acc, the head's and the dense layer's parameter gradients -- is vm_tail_param_grads, a second launch the
+ * caller may put on another stream (it replaces vm_siamese_head_reduce + the parameter half of vm_dense_bwd).  Bit-identical to the
+ * six launches they replace (same summation orders).
+ *   gmax_part_v / gmax_part_i: the partial rows of vm_bn_drop_pool_gmax_partials ((2*pairs * seg_rows, C), seg_rows =
+ *               vm_bn_part_rows()), or both NULL when gmax / gidx (2*pairs, C) are already final (vm_global_maxpool_fwd); with
+ *               parts, gmax and gidx are WRITTEN here.
+ *   dense_w (C, E), dense_b (E) or NULL; head_w / head_b / y / head_kind / loss_kind / grad_scale as in vm_siamese_head_loss.
+ *   outputs: emb (2*pairs, E), pred (pairs), demb (2*pairs, E), dgmax (2*pairs, C), ws (4*pairs: the per-pair terms).
+ * vm_tail_fwd_bwd_supported: C <= 1024 and E <= 256 (the pair's rows live in LDS). */
+int vm_tail_fwd_bwd_supported(int C, int E);
+int vm_tail_fwd_bwd(const float* gmax_part_v, const int32_t* gmax_part_i, int seg_rows, float* gmax, int32_t* gidx, const float* dense_w, const float* dense_b,
+                    const float* head_w, const float* head_b, const float* y, int64_t pairs, int C, int E, int head_kind,
+                    int loss_kind, float grad_scale, float* emb, float* pred, float* demb, float* dgmax, float* ws, void* stream);
+int vm_tail_param_grads(const float* gmax, const float* demb, const float* emb, const float* ws, int64_t pairs, int C, int E,
+                        int head_kind, float* loss_acc, float* grad_dense_w, float* grad_dense_b, float* grad_hw, float* grad_hb,
+                        void* stream);
 
 /* ---- a9: classifier head Dense(num_classes, softmax) + categorical CE  (experiments/train_classifier.py:112,115)
  * logits (rows, n_classes) fp32 -> prob; labels int32 (rows); loss_acc[0] = mean CE (Keras clip 1e-7), [1] = accuracy;

@@ -1028,6 +1028,21 @@ extern "C" int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const
     return check_launch("vm_bn_drop_pool_gmax_fwd");
 }
 
+// the first launch of vm_bn_drop_pool_gmax_fwd alone: the BN_SEG partial (value, position) rows per window, into two caller-given
+// arrays (so that two launches -- the two towers on their streams -- can fill the halves of one pair); vm_tail_fwd_bwd finishes them
+extern "C" int vm_bn_drop_pool_gmax_partials(const void* z, const float* scale, const float* shift, const float* drop,
+                                             int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype,
+                                             float* part_v, int32_t* part_i, void* stream) {
+    VM_REQUIRE(z && scale && shift && part_v && part_i, "vm_bn_drop_pool_gmax_partials: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= pool && C % 8 == 0, "vm_bn_drop_pool_gmax_partials: bad sizes");
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i);
+    }));
+    return check_launch("vm_bn_drop_pool_gmax_partials");
+}
+
 extern "C" int vm_bn_part_rows(void) { return BN_SEG; }
 
 extern "C" int vm_bn_pool_bwd_reduce(const void* z, const void* dp, const float* scale, const float* shift, const float* mean,

@@ -313,6 +313,202 @@ __global__ __launch_bounds__(256) void siamese_head_reduce_kernel(const float* _
     }
 }
 
+// ---- the whole tail of a siamese training step in two launches (vm_tail_fwd_bwd) ----------------------------------------
+// GlobalMaxPool1D (finish of the segment partials) -> Dense(E) -> twin distance -> Dense(1, sigmoid) -> loss -> d loss / d emb
+// -> d loss / d gmax is PAIR-LOCAL: nothing of it crosses pairs, so one workgroup runs it for the two windows of a pair out of LDS
+// (tail_pair_kernel).  What crosses pairs -- loss, accuracy, the head's and the dense layer's parameter gradients -- is nobody's
+// input before the optimizer: tail_reduce_kernel, which the caller may put on another stream.  Six launches of 4-9 us (gmax_segments,
+// dense_fwd, siamese_head_pair, siamese_head_reduce, dense_bwd_w, dense_bwd_in) become two, one of them on the critical path.
+// Every sum keeps the order of the kernel it replaces (the device functions are shared or restated term by term), so the fused
+// path is bit-identical to the six-launch path.
+constexpr int TAIL_MAX_C = 1024, TAIL_MAX_E = 256;
+
+__global__ __launch_bounds__(64 * DENSE_KS) void tail_pair_kernel(const float* __restrict__ part_v, const int32_t* __restrict__ part_i,
+                                                                  int seg_rows, float* __restrict__ gmax, int32_t* __restrict__ gidx,
+                                                                  const float* __restrict__ dw, const float* __restrict__ db,
+                                                                  const float* __restrict__ hw, const float* __restrict__ hb,
+                                                                  const float* __restrict__ y, int64_t pairs, int C, int E, int head_kind,
+                                                                  int loss_kind, float grad_scale, float* __restrict__ emb,
+                                                                  float* __restrict__ pred, float* __restrict__ demb,
+                                                                  float* __restrict__ dgmax, float* __restrict__ pair_ws) {
+    __shared__ float g[2][TAIL_MAX_C];
+    __shared__ float ev[2][TAIL_MAX_E];
+    __shared__ float de[2][TAIL_MAX_E];
+    __shared__ float red[DENSE_KS][64];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t win[2] = {b, pairs + b};
+    // 1. GlobalMaxPool1D: the segment partials of vm_bn_drop_pool_gmax_partials (first maximum wins: gmax_segments_kernel's rule)
+    for (int idx = tid; idx < 2 * C; idx += 64 * DENSE_KS) {
+        const int w = idx >= C ? 1 : 0, c = idx - w * C;
+        const int64_t n = win[w];
+        float bv;
+        if (part_v != nullptr) {
+            bv = -INFINITY;
+            int k = 0x7fffffff;
+            for (int s = 0; s < seg_rows; ++s) {
+                const float yv = part_v[(n * seg_rows + s) * C + c];
+                const int kk = part_i[(n * seg_rows + s) * C + c];
+                if (kk != 0x7fffffff && (k == 0x7fffffff || yv > bv || (yv == bv && kk < k))) {
+                    bv = yv;
+                    k = kk;
+                }
+            }
+            gmax[n * C + c] = bv;
+            gidx[n * C + c] = k;
+        } else {
+            bv = gmax[n * C + c];
+        }
+        g[w][c] = bv;
+    }
+    __syncthreads();
+    // 2. Dense(E), linear (voicemap/models.py:39): dense_fwd_kernel's slices and order, the input row in LDS
+    {
+        const int ol = tid & 63, kq = tid >> 6;
+        const int per = (C + DENSE_KS - 1) / DENSE_KS;
+        const int i0 = kq * per, i1 = min(C, i0 + per);
+        for (int w = 0; w < 2; ++w) {
+            for (int ob = 0; ob * 64 < E; ++ob) {
+                const int o = ob * 64 + ol;
+                const float* ir = g[w];
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                if (o < E) {
+                    int i = i0;
+                    for (; i + 8 <= i1; i += 8) {
+                        float x[8], yv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            x[u] = ir[i + u];
+                            yv[u] = dw[(int64_t)(i + u) * E + o];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a[u & 3] = fmaf(x[u], yv[u], a[u & 3]);
+                    }
+                    for (; i < i1; ++i) a[0] = fmaf(ir[i], dw[(int64_t)i * E + o], a[0]);
+                }
+                red[kq][ol] = (a[0] + a[1]) + (a[2] + a[3]);
+                __syncthreads();
+                if (kq == 0 && o < E) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < DENSE_KS; q += 4) t += (red[q][ol] + red[q + 1][ol]) + (red[q + 2][ol] + red[q + 3][ol]);
+                    const float v = (db ? db[o] : 0.f) + t;
+                    emb[win[w] * E + o] = v;
+                    ev[w][o] = v;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // 3. distance -> Dense(1, sigmoid) -> loss terms -> d loss / d emb: siamese_head_pair_kernel's wave, on the LDS copy
+    if (tid < 64) {
+        const int lane = tid;
+        const float* e1 = ev[0];
+        const float* e2 = ev[1];
+        float acc = 0.f;
+        for (int j = lane; j < E; j += 64) {
+            const float df = e1[j] - e2[j];
+            acc += head_kind == VM_HEAD_UNIFORM_EUCLIDEAN ? df * df : hw[j] * fabsf(df);
+        }
+        acc = wave_sum(acc);
+        float d = 0.f, a;
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+            d = sqrtf(acc);
+            a = fmaf(hw[0], d, hb[0]);
+        } else {
+            a = acc + hb[0];
+        }
+        const float p = 1.0f / (1.0f + expf(-a));
+        if (lane == 0) pred[b] = p;
+        const float yy = y[b];
+        const float dlda = grad_scale * (dloss_dpred(p, yy, loss_kind) * p * (1.0f - p) / (float)pairs);
+        if (lane == 0) {
+            pair_ws[b * 4 + 0] = loss_value(p, yy, loss_kind);
+            pair_ws[b * 4 + 1] = (rintf(p) == yy) ? 1.f : 0.f;
+            pair_ws[b * 4 + 2] = dlda;
+            pair_ws[b * 4 + 3] = dlda * d;
+        }
+        const float k = head_kind == VM_HEAD_UNIFORM_EUCLIDEAN ? dlda * hw[0] / d : 0.f;
+        for (int j = lane; j < E; j += 64) {
+            const float df = e1[j] - e2[j];
+            float gv;
+            if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) {
+                gv = k * df;
+            } else {
+                gv = dlda * hw[j] * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+            }
+            demb[b * E + j] = gv;
+            demb[(pairs + b) * E + j] = -gv;
+            de[0][j] = gv;
+            de[1][j] = -gv;
+        }
+    }
+    __syncthreads();
+    // 4. d loss / d gmax = demb W^T (dense_bwd_in_body's two-accumulator order)
+    for (int idx = tid; idx < 2 * C; idx += 64 * DENSE_KS) {
+        const int w = idx >= C ? 1 : 0, i = idx - w * C;
+        const float* wr = dw + (int64_t)i * E;
+        const float* dr = de[w];
+        float a0 = 0.f, a1 = 0.f;
+        int o = 0;
+        for (; o + 2 <= E; o += 2) {
+            a0 = fmaf(dr[o], wr[o], a0);
+            a1 = fmaf(dr[o + 1], wr[o + 1], a1);
+        }
+        for (; o < E; ++o) a0 = fmaf(dr[o], wr[o], a0);
+        dgmax[win[w] * C + i] = a0 + a1;
+    }
+}
+
+// blockIdx.y <= n_in: dense_bwd_w_kernel (row n_in: the bias gradient); blockIdx.y == n_in + 1 (blockIdx.x == 0): the fixed-order
+// sums of siamese_head_reduce_kernel, taken by the first four waves
+__global__ __launch_bounds__(64 * DENSE_KS) void tail_reduce_kernel(const float* __restrict__ gmax, const float* __restrict__ demb,
+                                                                    const float* __restrict__ emb, const float* __restrict__ pair_ws,
+                                                                    int64_t pairs, int C, int E, int head_kind, float* __restrict__ loss_acc,
+                                                                    float* __restrict__ grad_dw, float* __restrict__ grad_db,
+                                                                    float* __restrict__ grad_hw, float* __restrict__ grad_hb) {
+    __shared__ float red[DENSE_KS][64];
+    if ((int)blockIdx.y <= C) {
+        dense_bwd_w_body(gmax, demb, 2 * pairs, C, E, grad_dw, grad_db, blockIdx.x, blockIdx.y, red);
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    const int tid = threadIdx.x;
+    float l = 0.f, h = 0.f, gb = 0.f, gw = 0.f;
+    if (tid < 256) {
+        for (int64_t b = tid; b < pairs; b += 256) {
+            l += pair_ws[b * 4 + 0];
+            h += pair_ws[b * 4 + 1];
+            gb += pair_ws[b * 4 + 2];
+            gw += pair_ws[b * 4 + 3];
+        }
+    }
+    l = wave_sum(l);
+    h = wave_sum(h);
+    gb = wave_sum(gb);
+    gw = wave_sum(gw);
+    if (tid < 256 && (tid & 63) == 0) {
+        red[0][tid >> 6] = l;
+        red[1][tid >> 6] = h;
+        red[2][tid >> 6] = gb;
+        red[3][tid >> 6] = gw;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        loss_acc[0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)pairs;
+        loss_acc[1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)pairs;
+        grad_hb[0] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (head_kind == VM_HEAD_UNIFORM_EUCLIDEAN) grad_hw[0] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+    }
+    if (head_kind == VM_HEAD_WEIGHTED_L1 && tid < 256) {
+        for (int j = tid; j < E; j += 256) {
+            float acc = 0.f;
+            for (int64_t b = 0; b < pairs; ++b) acc = fmaf(pair_ws[b * 4 + 2], fabsf(emb[b * E + j] - emb[(pairs + b) * E + j]), acc);
+            grad_hw[j] = acc;
+        }
+    }
+}
+
 // ---- softmax + categorical cross-entropy ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                           int64_t rows, int n_classes, float* __restrict__ prob,
@@ -500,4 +696,35 @@ extern "C" int vm_softmax_cce(const float* logits, const int32_t* labels, int64_
     hipLaunchKernelGGL(mean2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (const float*)(ws + rows),
                        rows, loss_acc);
     return check_launch("vm_softmax_cce(mean)");
+}
+
+extern "C" int vm_tail_fwd_bwd_supported(int C, int E) { return C > 0 && E > 0 && C <= TAIL_MAX_C && E <= TAIL_MAX_E; }
+
+extern "C" int vm_tail_fwd_bwd(const float* gmax_part_v, const int32_t* gmax_part_i, int seg_rows, float* gmax, int32_t* gidx, const float* dense_w, const float* dense_b,
+                               const float* head_w, const float* head_b, const float* y, int64_t pairs, int C, int E, int head_kind,
+                               int loss_kind, float grad_scale, float* emb, float* pred, float* demb, float* dgmax, float* ws, void* stream) {
+    VM_REQUIRE(gmax && gidx && dense_w && head_w && head_b && y && emb && pred && demb && dgmax && ws, "vm_tail_fwd_bwd: null pointer");
+    VM_REQUIRE(pairs > 0 && vm_tail_fwd_bwd_supported(C, E), "vm_tail_fwd_bwd: needs pairs > 0, 0 < C <= %d, 0 < E <= %d (got %d, %d)",
+               TAIL_MAX_C, TAIL_MAX_E, C, E);
+    VM_REQUIRE((gmax_part_v == nullptr) == (gmax_part_i == nullptr) && (gmax_part_v == nullptr || seg_rows > 0),
+               "vm_tail_fwd_bwd: gmax_part_v / gmax_part_i go together, with seg_rows > 0");
+    VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1,
+               "vm_tail_fwd_bwd: head_kind %d not implemented (the reference raises NotImplementedError too)", head_kind);
+    VM_REQUIRE(loss_kind == VM_LOSS_CONTRASTIVE || loss_kind == VM_LOSS_BCE, "vm_tail_fwd_bwd: unknown loss %d", loss_kind);
+    const float* part_v = gmax_part_v;
+    const int32_t* part_i = gmax_part_i;
+    hipLaunchKernelGGL(tail_pair_kernel, dim3((unsigned)pairs), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, part_v, part_i, seg_rows, gmax,
+                       gidx, dense_w, dense_b, head_w, head_b, y, pairs, C, E, head_kind, loss_kind, grad_scale, emb, pred, demb, dgmax, ws);
+    return check_launch("vm_tail_fwd_bwd");
+}
+
+extern "C" int vm_tail_param_grads(const float* gmax, const float* demb, const float* emb, const float* ws, int64_t pairs, int C, int E,
+                                   int head_kind, float* loss_acc, float* grad_dense_w, float* grad_dense_b, float* grad_hw, float* grad_hb,
+                                   void* stream) {
+    VM_REQUIRE(gmax && demb && emb && ws && loss_acc && grad_dense_w && grad_dense_b && grad_hw && grad_hb, "vm_tail_param_grads: null pointer");
+    VM_REQUIRE(pairs > 0 && C > 0 && E > 0 && C < 65534, "vm_tail_param_grads: bad sizes");
+    VM_REQUIRE(head_kind == VM_HEAD_UNIFORM_EUCLIDEAN || head_kind == VM_HEAD_WEIGHTED_L1, "vm_tail_param_grads: head_kind %d", head_kind);
+    hipLaunchKernelGGL(tail_reduce_kernel, dim3((E + 63) / 64, C + 2), dim3(64 * DENSE_KS), 0, (hipStream_t)stream, gmax, demb, emb, ws, pairs,
+                       C, E, head_kind, loss_acc, grad_dense_w, grad_dense_b, grad_hw, grad_hb);
+    return check_launch("vm_tail_param_grads");
 }

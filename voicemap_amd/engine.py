@@ -236,6 +236,10 @@ class HipEncoderEngine:
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
         self.tower_stream = torch.cuda.Stream(device=self.device)
+        # round 5: GlobalMaxPool1D finish -> Dense(E) -> head -> loss -> their backward as ONE launch per step (vm_tail_fwd_bwd) + one launch of
+        # parameter gradients on the side stream (vm_tail_param_grads) instead of six; bit-identical (tests/test_gpu_kernels.py)
+        self.fused_tail = True
+        self._seg_rows = self.lib.query("vm_bn_part_rows")
         self.defer_head_reduce = True   # backward() enqueues the head's sums on the side stream (engines that borrow siamese_head: no)
         self.grad_sync = None       # callable(flat_grad_tensor) for data parallelism (parallel.py)
         self.grad_prescale = 1.0
@@ -270,6 +274,7 @@ class HipEncoderEngine:
         # 58 % error on the first layer's gradient, 5 % with a scale of 2^20) the scale is multiplied by 8 per poll.  A scaled norm of
         # 2^6 keeps every element 2^10 under half's maximum, so the growth itself cannot overflow the parameter gradients.
         self.scale_norm_low = 64.0
+        self.scale_norm_hold_polls, self._norm_growth_hold = 8, 0   # polls without a norm-driven lift after a skipped step
         self._opt_calls, self._clean_steps, self._poll = 0, 0, None
         self._skip_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.loss_scaled else None
         self._norm_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.loss_scaled else None
@@ -424,7 +429,10 @@ class HipEncoderEngine:
     def _account_skips(self, total: int) -> int:
         """``total`` skipped steps so far: the new ones are taken off ``iterations`` again (a skipped step is not an Adam step: its
         bias correction and lr decay must not advance) and reported once."""
-        new, self._skip_seen = total - self._skip_seen, total
+        # two readers feed this (the lagged pinned copy of _poll_loss_scale and the live counter of adjust_loss_scale /
+        # skipped_steps): a stale total must neither move the watermark backwards nor count a step twice (ADVICE r4)
+        new = max(0, total - self._skip_seen)
+        self._skip_seen = max(self._skip_seen, total)
         if new > 0:
             self.iterations = max(0, self.iterations - new)
             import warnings
@@ -440,9 +448,11 @@ class HipEncoderEngine:
         if not self.loss_scaled:
             return 1.0
         new = self._account_skips(self.skipped_steps())
+        self._poll = None   # a copy in flight predates this read: consumed here, not a second time 8 steps later
         if new > 0:
             self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), self.scale_min)
             self._clean_checks = self._clean_steps = 0
+            self._norm_growth_hold = self.scale_norm_hold_polls
         else:
             self._clean_checks += 1
             if self._clean_checks >= grow_after:
@@ -461,13 +471,18 @@ class HipEncoderEngine:
             ev.synchronize()   # enqueued scale_poll_lag steps ago
             new = self._account_skips(int(self._skip_host[0]))
             sq = float(self._norm_host[0])   # sum of squares of the scaled gradient buffer at the polled step (inf / nan: a skipped one)
+            # G holds the SUM over data-parallel ranks; grad_prescale (1 / world) is applied in the clip: compare what Adam sees
+            sq *= float(getattr(self, "grad_prescale", 1.0)) ** 2
             if new > 0:
                 self.loss_scale = max(self.loss_scale / float(2 ** min(new, 4)), self.scale_min)
                 self._clean_steps = 0
-            elif math.isfinite(sq) and 0.0 < sq < self.scale_norm_low ** 2 and self.loss_scale < self.scale_max:
+                self._norm_growth_hold = self.scale_norm_hold_polls   # no x8 lifts right after an overflow (limit cycle)
+            elif (math.isfinite(sq) and 0.0 < sq < self.scale_norm_low ** 2 and self.loss_scale < self.scale_max
+                  and self._norm_growth_hold == 0):
                 self.loss_scale = min(self.loss_scale * 8.0, self.scale_max)   # a tiny gradient: lift it (see _init_loss_scale)
                 self._clean_steps = 0
             else:
+                self._norm_growth_hold = max(0, self._norm_growth_hold - 1)
                 self._clean_steps += self.scale_poll_every
                 if self._clean_steps >= self.scale_grow_after:
                     self.loss_scale = min(self.loss_scale * 2.0, self.scale_max)
@@ -698,11 +713,16 @@ class HipEncoderEngine:
             pl[i]["wgrad_ws_fold"] = torch.empty(ws // 4 + 16, dtype=torch.float32, device=self.device)
         pl["fold_ready"] = wpt
 
-    def forward(self, pl: dict, windows_per_tower: int, drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
+    def forward(self, pl: dict, windows_per_tower: int, drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                defer_tail: bool = False):
         """x0 -> embeddings (pl['emb']).  Training plans use batch statistics per tower and update the moving
         statistics; inference plans use the moving statistics (Keras learning phase 0).
 
         ``split_towers`` (training, two towers): the two encoder calls of the siamese model (voicemap/models.py:52-53) are
+        ``defer_tail`` (the siamese training steps): the caller goes on to ``siamese_head(pl, y)`` and ``backward(pl)``; the finish of the
+        global max, the dense layer, the head, the loss and their backward then run as one launch there (vm_tail_fwd_bwd) and
+        pl['gmax'] / pl['emb'] are not valid before it.
+
         independent until the head, so tower 2's kernel sequence is enqueued on a second stream over the second half of the
         same buffers: a GEMM of one tower then runs next to a streaming BatchNorm pass of the other (8.6 % off the forward at
         cfg-A forward alone, 1.5 % off the step, tools/tower_pipeline_probe.py).  Every launch computes what its half of the
@@ -718,6 +738,11 @@ class HipEncoderEngine:
         split = training and n_towers == 2 and self.split_towers
         fold = training and self._fold_ok(pl, wpt, drop_masks)
         pl["fold_now"] = fold
+        cl = self.blocks[-1][1]
+        tail = bool(defer_tail and training and n_towers == 2 and self.fused_tail and self.head in HEADS
+                    and self.lib.query("vm_tail_fwd_bwd_supported", cl, self.E))
+        pl["tail_pending"] = tail
+        pl["tail_parts"] = tail   # the last block leaves segment partials (cleared by _forward_range where it runs vm_global_maxpool_fwd)
         if fold:
             if pl.get("fold_ready", wpt) != wpt:   # the slab split depends on the tower size
                 del pl["fold_ready"]
@@ -743,9 +768,9 @@ class HipEncoderEngine:
             cur.wait_stream(self.tower_stream)
         else:
             self._forward_range(pl, 0, n, 0, n_towers, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], fold=fold)
-        cl = self.blocks[-1][1]
-        self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
-                   _p(pl["emb"]), self.stream())
+        if not tail:
+            self._call("vm_dense_fwd", _p(pl["gmax"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")), n, cl, self.E,
+                       _p(pl["emb"]), self.stream())
         return pl["emb"]
 
     def _forward_range(self, pl: dict, w0: int, nw: int, tw0: int, ntw: int, wpt: int, drop_masks, cr_ws, gmax_ws,
@@ -869,12 +894,20 @@ class HipEncoderEngine:
             if i == self.nb - 1:
                 # last block: BN apply + dropout + max-pool + GlobalMaxPool1D in one pass; its pooled tensor has no other
                 # consumer and is never written
-                self._call("vm_bn_drop_pool_gmax_fwd", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt, W(pl["gmax"]), W(pl["gidx"]),
-                           _p(gmax_ws), st)
+                if pl.get("tail_parts"):
+                    # the fused tail finishes the segment partials inside its own launch: every range (tower) writes the rows of its
+                    # windows into the one pair of arrays (value rows, then position rows)
+                    parts, seg = pl["gmax_ws"], self._seg_rows
+                    self._call("vm_bn_drop_pool_gmax_partials", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt,
+                               parts.data_ptr() + w0 * seg * c * 4, parts.data_ptr() + (pl["n"] + w0) * seg * c * 4, st)
+                else:
+                    self._call("vm_bn_drop_pool_gmax_fwd", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt, W(pl["gmax"]), W(pl["gidx"]),
+                               _p(gmax_ws), st)
                 fused_tail = True
                 continue
             self._call("vm_bn_drop_pool_fwd", W(b["z"]), sc, sh, dm, nw, wpt, L, c, pool, dt, W(b["act"]), st)
         if not fused_tail:
+            pl["tail_parts"] = False   # (both ranges of a split forward take this branch or neither)
             cl, Ll = self.blocks[-1][1], pl["L"][-1]
             self._call("vm_global_maxpool_fwd", W(pl[self.nb - 1]["act"]), nw, Ll, cl, dt, W(pl["gmax"]), W(pl["gidx"]), st)
 
@@ -891,7 +924,24 @@ class HipEncoderEngine:
         cl, Ll = self.blocks[-1][1], pl["L"][-1]
         G = self.G
         dense = (_p(pl["gmax"]), _p(self.view("dense.kernel")), _p(pl["demb"]), n, cl, self.E)
-        if self.overlap_wgrad:
+        assert not pl.get("tail_pending"), "forward(defer_tail=True): call siamese_head(pl, y) before backward"
+        if pl.get("tail_grads_pending"):
+            # vm_tail_fwd_bwd has left dgmax; what only the optimizer reads (loss, accuracy, the head's and the dense layer's parameter
+            # gradients) is one launch, on the side stream where there is one
+            pl["tail_grads_pending"] = False
+            tail_args = (_p(pl["gmax"]), _p(pl["demb"]), _p(pl["emb"]), _p(pl["head_ws"]), n // 2, cl, self.E, HEADS[self.head],
+                         _p(pl["loss_acc"]), _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)),
+                         _p(self.view("head.kernel", G)), _p(self.view("head.bias", G)))
+            if self.overlap_wgrad:
+                if "head_ev" not in pl:
+                    pl["head_ev"] = torch.cuda.Event()
+                pl["head_ev"].record()
+                with torch.cuda.stream(self.side_stream):
+                    self.side_stream.wait_event(pl["head_ev"])
+                    self._call("vm_tail_param_grads", *tail_args, self.stream())
+            else:
+                self._call("vm_tail_param_grads", *tail_args, st)
+        elif self.overlap_wgrad:
             # what only the optimizer reads -- the head's sums, the dense layer's parameter gradients -- goes to the side stream: the
             # main stream's chain to the first BatchNorm backward is four small launches shorter
             if "head_ev" not in pl:
@@ -1062,6 +1112,16 @@ class HipEncoderEngine:
         train = y is not None
         # training with the side stream on: only the per-pair pass here; the fixed-order sums (loss, accuracy, head gradients --
         # nobody's input before the optimizer) are enqueued on the side stream by backward()
+        if pl.get("tail_pending"):
+            assert train, "forward(defer_tail=True) must be followed by siamese_head with labels"
+            cl, parts, seg = self.blocks[-1][1], pl["gmax_ws"], self._seg_rows
+            pv = parts.data_ptr() if pl["tail_parts"] else None
+            pi = parts.data_ptr() + pl["n"] * seg * cl * 4 if pl["tail_parts"] else None
+            self._call("vm_tail_fwd_bwd", pv, pi, seg, _p(pl["gmax"]), _p(pl["gidx"]), _p(self.view("dense.kernel")), _p(self.view("dense.bias")),
+                       _p(self.view("head.kernel")), _p(self.view("head.bias")), _p(y), pairs, cl, self.E, HEADS[self.head], LOSSES[loss],
+                       float(self.loss_scale), _p(pl["emb"]), _p(pl["pred"]), _p(pl["demb"]), _p(pl["dgmax"]), _p(pl["head_ws"]), self.stream())
+            pl["tail_pending"], pl["tail_grads_pending"], pl["head_pending"] = False, True, False
+            return pl["pred"][:pairs]
         defer = train and self.overlap_wgrad and pl["training"] and getattr(self, "defer_head_reduce", False)
         self._call("vm_siamese_head_loss", _p(pl["emb"]), _p(self.view("head.kernel")), _p(self.view("head.bias")),
                       _p(y), pairs, self.E, HEADS[self.head], LOSSES[loss], float(self.loss_scale), _p(pl["pred"]),
@@ -1136,7 +1196,7 @@ class HipEncoderEngine:
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(2 * pairs)
         yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
-        self.forward(pl, pairs, drop_masks)
+        self.forward(pl, pairs, drop_masks, defer_tail=True)
         self.siamese_head(pl, yd, loss)
         self.backward(pl, sync_tail=apply_update)
         if apply_update:
@@ -1156,7 +1216,7 @@ class HipEncoderEngine:
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(2 * pairs)
         yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
-        self.forward(pl, pairs, drop_masks)
+        self.forward(pl, pairs, drop_masks, defer_tail=True)
         self.siamese_head(pl, yd, loss)
         self.backward(pl, sync_tail=apply_update)
         if apply_update:
