@@ -224,10 +224,16 @@ def main():
         p_ = e.plan(2 * pairs, L0, True)
 
         def step():
+            if sync_tail or e.grad_sync is None:
+                # the product's step (what siamese_train_step runs behind its host-to-device copies): preprocess -> forward -> head ->
+                # backward (N > 1: the large gradient all-reduce starts before block 1's backward) -> Adam; on one GPU its enqueue
+                # sequence is recorded once and replayed (engine._Program) -- same launches, same arguments
+                e.train_step_resident(p_, pairs, y, loss, raw=xcat, drop_masks=None)
+                return
             e.preprocess(p_, xcat, 4, True, pairs)
             e.forward(p_, pairs, None, defer_tail=True)
             e.siamese_head(p_, y, loss)
-            e.backward(p_, sync_tail=sync_tail)   # N > 1: the large gradient all-reduce starts before block 1's backward
+            e.backward(p_, sync_tail=False)
             e.optimizer_step()
         return step, p_
 
@@ -525,11 +531,7 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         pc = ecls.plan(8, L0, True)
 
         def cls_step():
-            ecls.preprocess(pc, xc, 4, True, 8)
-            ecls.forward(pc, 8, None)
-            ecls.classifier_head(pc, lab)
-            ecls.backward(pc)
-            ecls.optimizer_step()
+            ecls.train_step_resident(pc, 8, lab, None, raw=xc)
         t_cls = timed(cls_step, reps=20)
         ex["classifier_batch8_ms_per_step"] = t_cls * 1e3
         ex["classifier_batch8_audio_s_per_s"] = 8 * 3.0 / t_cls
@@ -579,11 +581,7 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
             yb = torch.cat([torch.zeros(pr // 2, device=dev), torch.ones(pr - pr // 2, device=dev)]).contiguous()
 
             def cfgb_step():
-                eb.preprocess(pb, xb, 4, True, pr)
-                eb.forward(pb, pr, eb.make_drop_masks(2 * pr), defer_tail=True)
-                eb.siamese_head(pb, yb, "contrastive")
-                eb.backward(pb)
-                eb.optimizer_step()
+                eb.train_step_resident(pb, pr, yb, "contrastive", raw=xb)     # (masks drawn on the device, every step)
             t_b = timed(cfgb_step, reps=20)
             t0 = time.perf_counter()
             for _ in range(50):

@@ -12,7 +12,9 @@
  *   - `dtype` selects the storage type of activations / GEMM operands: VM_F32, VM_F32S, VM_BF16 or VM_F16 (the enum below).
  *     Accumulation, batch statistics, the tail (global max -> dense -> head -> loss) and the optimizer are always fp32.
  *   - enqueue-only on `stream` (a hipStream_t passed as void*); no host sync, no allocation; re-entrant per
- *     stream.  The ONE piece of process-global mutable state is the kernel-selection table behind vm_set_tuning
+ *     stream.  Process-global mutable state: (a) the kernel-selection table behind vm_set_tuning, (b) a pool of zero-initialised
+ *     ticket words in device memory that the fused two-stage reductions draw from (round robin per launch; every launch leaves its
+ *     words zero again) -- it makes those entry points, like the table, not thread-safe across host threads.  The table
  *     (below): every selectable kernel computes the same result (each is parity-tested against the oracle), so
  *     the table changes speed, never values; it is read at launch time and is not thread-safe -- set it before
  *     work is enqueued from other threads, or leave the defaults (what the drop-in surface does).
@@ -47,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -60,6 +62,15 @@ int vm_abi_version(void);
 int vm_check_device(void);
 
 int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
+/* Stream-ordering primitives (hipEventCreateWithFlags(DisableTiming) / hipEventRecord / hipStreamWaitEvent) for a host that REPLAYS a
+ * recorded sequence of the calls below with the ordering between its streams (voicemap_amd/engine.py records one training step per
+ * configuration -- the reference's train_on_batch, experiments/train_siamese.py:65-94 runs it 500 times per epoch with identical
+ * shapes -- and replays it without re-deriving pointers and dispatch decisions: at the reference's batch sizes the step is bound by
+ * the host).  event_out receives an opaque handle. */
+int vm_event_create(void** event_out);
+int vm_event_destroy(void* event);
+int vm_event_record(void* event, void* stream);
+int vm_stream_wait_event(void* stream, void* event);
 /* Kernel-selection table for the tests that pin a fallback kernel and for A/B measurements (process-global, see the conventions
  * above; not part of the drop-in surface: voicemap_amd never calls it outside bench.py --tune).  Unknown keys / values out of
  * range return VM_ERR_ARG.  Keys:
@@ -71,6 +82,9 @@ int vm_fill_zero(void* ptr, int64_t bytes, void* stream);
  *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA tile (default 1), else
  *   "tn9" 0|1         ... with the free-running K loop (conv_tn9_kernel, default 1) or the READ / MFMA slots (conv_tn8x_kernel)
  *   "tn_tile" 128|256 the tile of the register-transposing wgrad kernels (default 256 where the layer is wide enough)
+ *   "fuse_finalize" 0|1   the two-stage column reductions (vm_bn_finalize, vm_bn_bwd_finalize, vm_bn_bwd_from_sums_finalize, vm_colsum*,
+ *                     vm_du_tower_sums) as ONE launch whose last-arriving workgroup per channel block runs the finalize (default 1) or as
+ *                     the stage-1 launch + the finalize launch (0); bit-identical
  *   "f1_blocks", "f1_fwd_blocks"   target workgroup counts of the fused block-1 kernels (launch geometry; the fp32 partial sums of a
  *                     window are grouped differently, i.e. results change in the last bits). */
 int vm_set_tuning(const char* key, int value);

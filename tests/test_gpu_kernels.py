@@ -614,7 +614,10 @@ def _conv1_fused_block(dt, n, wpt, l, f, pool, use_drop, neg):
              p(mean2), p(invstd2), p(scale2), p(shift2), p(crws), None, 0.0, p(bd), p(sh_adj), p(mean_adj), stream())
     ctr = torch.clamp(bd, min=0.0)[None, :]
     assert torch.equal(mean2, mean) and torch.equal(scale2, scale) and torch.equal(shift2, shift)
-    assert torch.allclose(sh_adj, shift + scale * ctr, rtol=1e-6, atol=1e-7) and torch.allclose(mean_adj, mean - ctr, rtol=1e-6, atol=1e-7)
+    # (the kernel forms shift_adj with ONE rounding, fma(scale, ctr, shift); torch rounds the product and the sum: where the two terms
+    # cancel the difference is an ulp of the LARGER term)
+    assert ((sh_adj - (shift + scale * ctr)).abs() <= 2.4e-7 * (shift.abs() + (scale * ctr).abs()) + 1e-7).all()
+    assert torch.allclose(mean_adj, mean - ctr, rtol=1e-6, atol=1e-7)
     # mode 2: the extreme as a padded tensor, stored CENTRED (e - max(bias, 0)) in the storage type; same statistics; halo rows untouched
     ep = torch.zeros(n, lq + 2, f, dtype=tdt, device="cuda")
     ss2, sq2 = torch.zeros_like(ss), torch.zeros_like(sq)
@@ -1152,10 +1155,12 @@ def test_tail_fwd_bwd_equals_the_six_launches_and_the_oracle(head, loss, pairs, 
     pi[:, 1, :][tie] = pi[:, 0, :][tie] + 7
     best = pv.max(axis=1)
     want_idx = np.where(pv == best[:, None, :], pi, 0x7fffffff).min(axis=1)
-    dw = r.normal(0, 0.1, (c, e)).astype(np.float32)
+    dw = (r.normal(0, 0.4, (c, e)) / np.sqrt(c)).astype(np.float32)       # embeddings ~N(0, 0.4): the sigmoid stays off its clip
     db = r.normal(0, 0.1, (e,)).astype(np.float32)
     hw = r.normal(0.5, 0.3, (1, 1) if head == "uniform_euclidean" else (e, 1)).astype(np.float32)
     hb = r.normal(-0.5, 0.1, (1,)).astype(np.float32)
+    if head == "weighted_l1":
+        hw /= np.sqrt(e / 16.0)
     y = (r.random(pairs) > 0.5).astype(np.float32)
     d_dw, d_db, d_hw, d_hb, d_y = dev(dw), dev(db), dev(hw), dev(hb), dev(y)
     f = lambda *shape: torch.empty(*shape, device="cuda")

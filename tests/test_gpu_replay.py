@@ -1,0 +1,165 @@
+"""-m gpu: a REPLAYED training step is the eager step.  engine._train_step records the enqueue sequence of a configuration the
+second time it sees it (C-ABI calls with their arguments, event records and waits between the main, tower and side streams) and
+replays that list from the third step on, patching only the per-step values (input / label / mask pointers, the BatchNorm
+zero-debias factor, the loss scale, Adam's lr_t).  The reference's train_on_batch (experiments/train_siamese.py:65-94,
+siamese_contrastive_loss.py:70-99, train_classifier.py:117-127) is the same computation every step, so two engines fed the same
+batches -- one with replay off -- must hold bit-identical weights, optimizer slots, moving statistics and losses after every step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BLOCKS = [(32, 16, 4), (3, 32, 2), (3, 48, 2), (3, 64, 2)]
+
+
+def _engines(head, dtype, dropout, **kw):
+    from voicemap_amd.engine import HipEncoderEngine
+    a = HipEncoderEngine(BLOCKS, 32, dropout=dropout, head=head, dtype=dtype, seed=5, **kw)
+    b = HipEncoderEngine(BLOCKS, 32, dropout=dropout, head=head, dtype=dtype, seed=5, **kw)
+    b.replay = False
+    return a, b
+
+
+def _same_state(a, b, what):
+    for nm in ("P", "M", "V", "NT", "ZD", "G"):
+        u, v = getattr(a, nm), getattr(b, nm)
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32)), (what, nm)      # bit patterns: an overflowed f16 step leaves NaNs in G
+    assert a.iterations == b.iterations and a.bn_steps == b.bn_steps and a.loss_scale == b.loss_scale, what
+
+
+def _programs(eng):
+    from voicemap_amd.engine import _Program
+    return [p for p in eng._programs.values() if isinstance(p, _Program)]
+
+
+@pytest.mark.parametrize("dtype,dropout,loss", [("f16", 0.0, "contrastive"), ("f16", 0.05, "bce"), ("bf16", 0.0, "bce"), ("f32", 0.05, "contrastive")])
+def test_replayed_siamese_steps_are_the_eager_steps(dtype, dropout, loss):
+    a, b = _engines("uniform_euclidean", dtype, dropout)
+    r = np.random.default_rng(3)
+    pairs, raw_len = 6, 4800
+    for step in range(7):
+        x1 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        x2 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        y = (r.random((pairs, 1)) > 0.5).astype(np.float32)
+        out = []
+        for eng in (a, b):
+            pl = eng.siamese_train_step(x1, x2, y, loss=loss, preprocessed=False, downsampling=4)     # masks: the engine's own generator
+            torch.cuda.synchronize()
+            out.append((pl["loss_acc"].clone(), pl["emb"].clone(), pl["pred"].clone()))
+        for u, v in zip(*out):
+            assert torch.equal(u, v), step
+        _same_state(a, b, step)
+    progs = _programs(a)
+    assert len(progs) == 1 and not _programs(b)
+    # what a program holds: the step's C-ABI calls and its stream ordering, and only a handful of patched slots
+    kinds = [c[0] for c in progs[0].cmds]
+    assert kinds.count(0) > 30 and kinds.count(1) >= 3 and kinds.count(2) >= 3
+    assert {k if not isinstance(k, tuple) else k[0] for _, _, k in progs[0].patches} <= {"raw", "y", "loss_scale", "zc", "lr_t", "gpre", "drop", "dropb"}
+
+
+def test_replay_follows_the_configuration():
+    """A different loss, batch size, an injected mask set, apply_update=False or a flipped engine switch is a different program (or
+    the eager path), never a stale replay."""
+    a, b = _engines("weighted_l1", "f16", 0.0)
+    r = np.random.default_rng(4)
+
+    def batch(pairs):
+        return (r.normal(0, 0.05, (pairs, 4800, 1)).astype(np.float32), r.normal(0, 0.05, (pairs, 4800, 1)).astype(np.float32),
+                (r.random((pairs, 1)) > 0.5).astype(np.float32))
+    seq = [(4, "bce", True)] * 4 + [(4, "contrastive", True)] * 3 + [(6, "bce", True)] * 3 + [(4, "bce", False)] * 3 + [(4, "bce", True)] * 2
+    for k, (pairs, loss, upd) in enumerate(seq):
+        x1, x2, y = batch(pairs)
+        if k == 14:
+            a.overlap_wgrad = b.overlap_wgrad = False       # a switch that changes the stream structure
+        for eng in (a, b):
+            eng.siamese_train_step(x1, x2, y, loss=loss, preprocessed=False, apply_update=upd)
+        torch.cuda.synchronize()
+        _same_state(a, b, k)
+    assert len(_programs(a)) == 4
+
+
+def test_replayed_steps_from_a_resident_corpus_and_the_classifier():
+    from voicemap_amd.engine import HipEncoderEngine
+    a, b = _engines("uniform_euclidean", "f16", 0.05)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    audio = (torch.randn(400000, device="cuda", generator=g) * 0.05 * 32767).clamp(-32767, 32767).to(torch.int16)
+    r = np.random.default_rng(6)
+    for step in range(6):
+        o1, o2 = torch.as_tensor(r.integers(0, 390000, 5)), torch.as_tensor(r.integers(0, 390000, 5))
+        y = (r.random(5) > 0.5).astype(np.float32)
+        for eng in (a, b):
+            eng.siamese_train_step_from_offsets(audio, o1, o2, y, raw_len=4800, loss="bce")
+        torch.cuda.synchronize()
+        _same_state(a, b, step)
+    assert len(_programs(a)) == 1
+    c = HipEncoderEngine(BLOCKS, 32, dropout=0.05, head="classifier", num_classes=10, dtype="f16", seed=2)
+    d = HipEncoderEngine(BLOCKS, 32, dropout=0.05, head="classifier", num_classes=10, dtype="f16", seed=2)
+    d.replay = False
+    for step in range(6):
+        x = r.normal(0, 0.05, (8, 4800, 1)).astype(np.float32)
+        lab = r.integers(0, 10, 8)
+        outs = []
+        for eng in (c, d):
+            pl = eng.classifier_train_step(x, lab, preprocessed=False)
+            torch.cuda.synchronize()
+            outs.append(pl["loss_acc"].clone())
+        assert torch.equal(*outs), step
+        _same_state(c, d, step)
+    assert len(_programs(c)) == 1
+
+
+def test_a_replayed_f16_run_keeps_its_loss_scale_logic():
+    """The loss scale is patched into every replay: force a skip (a scale that overflows) and watch both engines halve it at the
+    same step and end with the same weights."""
+    a, b = _engines("uniform_euclidean", "f16", 0.0)
+    for eng in (a, b):
+        eng.scale_poll_every, eng.scale_poll_lag = 2, 1
+    r = np.random.default_rng(8)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for step in range(12):
+            if step == 5:
+                a.loss_scale = b.loss_scale = 2.0 ** 40
+            x1 = r.normal(0, 0.05, (4, 4800, 1)).astype(np.float32)
+            x2 = r.normal(0, 0.05, (4, 4800, 1)).astype(np.float32)
+            y = (r.random((4, 1)) > 0.5).astype(np.float32)
+            for eng in (a, b):
+                eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False)
+            torch.cuda.synchronize()
+            _same_state(a, b, step)
+    assert a.skipped_steps() == b.skipped_steps() >= 1 and a.loss_scale < 2.0 ** 40
+
+
+@pytest.mark.parametrize("dtype,dropout,filters", [("f16", 0.0, 128), ("f16", 0.05, 32), ("bf16", 0.0, 64), ("f32", 0.05, 16)])
+def test_last_arriver_finalize_equals_the_two_launch_form(dtype, dropout, filters):
+    """vm_set_tuning("fuse_finalize", 1): the two-stage column reductions (BatchNorm statistics, BatchNorm-backward sums, bias-gradient
+    column sums, the folded weight gradient's tap sums) finish in the stage-1 launch -- the last workgroup of a channel block to arrive
+    runs the finalize body.  Same partials, same butterfly: training with it on and off must agree bit for bit (folded path at
+    filters 128 / 64 with dropout 0, the unfolded passes with dropout)."""
+    from voicemap_amd import _lib
+    from voicemap_amd.engine import HipEncoderEngine
+    blocks = [(32, filters, 4), (3, 2 * filters, 2), (3, 3 * filters, 2), (3, 4 * filters, 2)]
+    lib = _lib.lib()
+    r = np.random.default_rng(12)
+    pairs, raw_len = 4, 9600
+    batches = [(r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32), r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32),
+                (r.random((pairs, 1)) > 0.5).astype(np.float32)) for _ in range(5)]
+    states = []
+    try:
+        for fuse in (0, 1):
+            lib.call("vm_set_tuning", b"fuse_finalize", fuse)
+            eng = HipEncoderEngine(blocks, 32, dropout=dropout, head="uniform_euclidean", dtype=dtype, seed=9)
+            outs = []
+            for x1, x2, y in batches:
+                pl = eng.siamese_train_step(x1, x2, y, loss="bce", preprocessed=False)
+                torch.cuda.synchronize()
+                outs.append(pl["loss_acc"].clone())
+            states.append((eng, outs))
+    finally:
+        lib.call("vm_set_tuning", b"fuse_finalize", 1)
+    (a, oa), (b, ob) = states
+    for u, v in zip(oa, ob):
+        assert torch.equal(u, v)
+    _same_state(a, b, "fuse_finalize")

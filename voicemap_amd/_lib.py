@@ -32,6 +32,10 @@ SIGNATURES = {
     "vm_abi_version": (I, []),
     "vm_check_device": (I, []),
     "vm_fill_zero": (I, [P, L, P]),
+    "vm_event_create": (I, [ctypes.POINTER(c_void_p)]),
+    "vm_event_destroy": (I, [P]),
+    "vm_event_record": (I, [P, P]),
+    "vm_stream_wait_event": (I, [P, P]),
     "vm_set_tuning": (I, [c_char_p, I]),
     "vm_decimate_whiten_workspace_bytes": (L, [L]),
     "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
@@ -149,6 +153,7 @@ class _Lib:
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        self.tuning_epoch = 0   # bumped by every vm_set_tuning through call(): recorded launch sequences (engine.py) are keyed on it
         self.abi = self.cdll.vm_abi_version()
         if self.abi != ABI_VERSION:  # a stale prebuilt library: its entry points take different arguments
             raise VoicemapHipError("%s reports ABI %d, this package binds ABI %d -- rebuild it (python -m voicemap_amd.build --force)"
@@ -156,6 +161,8 @@ class _Lib:
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise with vm_last_error() on failure."""
+        if name == "vm_set_tuning":
+            self.tuning_epoch += 1
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             msg = self.cdll.vm_last_error()

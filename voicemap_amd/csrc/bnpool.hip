@@ -63,11 +63,76 @@ __device__ inline void ones(float (&v)[VEC]) {
 //   stage 2: the consumer kernel adds the CR_CHUNKS doubles per (segment, channel) in a fixed (butterfly) order.
 constexpr int CR_CHUNKS = 32;
 
+// ---- stage 1 + stage 2 in ONE launch (round 5).  Every two-stage reduction below used to be a stage-1 launch and a 5 us "finalize"
+// launch of a few workgroups -- 15-20 launches of a training step, each a dependent link of the step's chain (at the reference's batch
+// sizes the step IS that chain: 62 kernels, 40 of them at the ~5 us floor of a dependent launch).  Now the stage-1 workgroups of a channel block take a
+// ticket when their partial row is written; the LAST one to arrive runs the finalize body for the block's channels.  Visibility across
+// the eight XCDs' L2s WITHOUT a device-scope fence (a release fence writes back the whole L2 -- measured: with __threadfence() in
+// every stage-1 workgroup the cfg-A step went from 2.59 to 4.38 ms): the partials are stored with agent-scope (write-through, sc1)
+// stores, every wave waits for its stores' acknowledgements (workgroup-scope release = s_waitcnt vmcnt(0)) before the workgroup's
+// barrier, one relaxed agent-scope atomic takes the ticket, and the last arriver reads the partials with agent-scope loads.
+// Same partials, same stage-2 butterfly: bit-identical to the two-launch form.
+// Tickets: a library-owned pool of zero-initialised words; a launch takes a fresh range (round robin -- far more words than launches
+// in flight), the last arriver puts its word back to zero.  The only mutable device state of the library.
+int g_fuse_finalize = 1;   // vm_set_tuning("fuse_finalize", 0 | 1): 0 = the two-launch form (the tests compare the two bit for bit)
+constexpr int TICKET_WORDS = 16384;
+__device__ unsigned g_tickets[TICKET_WORDS];
+static unsigned* ticket_range(int n) {
+    static unsigned next = 0;   // (host calls into the library are not thread-safe per stream anyway: see the header)
+    static unsigned* base = nullptr;
+    if (base == nullptr) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+        base = (unsigned*)p;
+    }
+    if (next + (unsigned)n > (unsigned)TICKET_WORDS) next = 0;
+    unsigned* r = base + next;
+    next += (unsigned)n;
+    return r;
+}
+
+// true in exactly one workgroup of the ``total`` that call it with this ticket: the last to arrive
+__device__ inline bool last_arriver(unsigned* ticket, unsigned total) {
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's store_agent()s are acknowledged (written through)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == total - 1) ? 1 : 0;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+__device__ inline void store_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double load_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+// the finalize body ``fin`` over the CL channels of channel block ``cb`` by the 1024 threads of the last workgroup: 32 groups of 32
+// lanes, one channel per group and pass (the stage-2 butterflies stay inside a 32-lane group)
+template <int CL, typename Fin>
+__device__ inline void run_finalize(const Fin& fin, const double* ws, int cb, int C) {
+#pragma unroll 1
+    for (int cc = threadIdx.x >> 5; cc < CL; cc += 32) {
+        const int c = cb * CL + cc;
+        if (c < C) fin(ws, c, threadIdx.x & 31);
+    }
+}
+struct FinNone {
+    static constexpr bool kOn = false;
+    __device__ inline void operator()(const double*, int, int) const {}
+};
+
 // CL channels x (1024 / CL) row lanes per workgroup: 64 x 16 for the wide layers, 32 x 32 where 64 lanes would be half empty
 // (C = 32, 96: the 2-D variant, whose 131 K partial rows made this kernel 0.4 ms of its step)
-template <int CL>
+template <int CL, typename Fin = FinNone>
 __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                                 int64_t rows_per_seg, int C, double* __restrict__ ws, int row_step) {
+                                                                 int64_t rows_per_seg, int C, double* ws, int row_step, Fin fin = Fin(),
+                                                                 unsigned* tickets = nullptr) {
     // row_step > 1 (vm_colsum_strided): only every row_step-th row of the matrix is read (the others are known to be zero)
     constexpr int RG = 1024 / CL;
     __shared__ double red[2][RG][CL];
@@ -116,28 +181,60 @@ __global__ __launch_bounds__(1024) void colreduce_stage1_kernel(const float* __r
             ss += red[0][i][cl];
             qq += red[1][i][cl];
         }
-        ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
-        ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+        if constexpr (Fin::kOn) {
+            store_agent(ws + ((int64_t)blockIdx.y * 2 + 0) * C + c, ss);
+            store_agent(ws + ((int64_t)blockIdx.y * 2 + 1) * C + c, qq);
+        } else {
+            ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
+            ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+        }
+    }
+    if constexpr (Fin::kOn) {
+        if (last_arriver(tickets + blockIdx.x, gridDim.y)) run_finalize<CL>(fin, ws, blockIdx.x, C);
     }
 }
 
 static void launch_colreduce(const float* a, const float* b, int64_t rows_per_seg, int C, int segs, double* ws, hipStream_t st,
                              int row_step = 1) {
     if (C % 64 == 0 || C > 128) {
-        hipLaunchKernelGGL(colreduce_stage1_kernel<64>, dim3((C + 63) / 64, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
-                           row_step);
+        hipLaunchKernelGGL((colreduce_stage1_kernel<64, FinNone>), dim3((C + 63) / 64, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg,
+                           C, ws, row_step, FinNone(), (unsigned*)nullptr);
     } else {
-        hipLaunchKernelGGL(colreduce_stage1_kernel<32>, dim3((C + 31) / 32, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
-                           row_step);
+        hipLaunchKernelGGL((colreduce_stage1_kernel<32, FinNone>), dim3((C + 31) / 32, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg,
+                           C, ws, row_step, FinNone(), (unsigned*)nullptr);
     }
+}
+// ... with the finalize body run by the last workgroup of every channel block (one launch instead of two)
+template <typename Fin>
+static bool launch_colreduce_fin(const float* a, const float* b, int64_t rows_per_seg, int C, int segs, double* ws, hipStream_t st,
+                                 const Fin& fin, int row_step = 1) {
+    const bool wide = C % 64 == 0 || C > 128;
+    const int blocks = wide ? (C + 63) / 64 : (C + 31) / 32;
+    unsigned* t = ticket_range(blocks);
+    if (t == nullptr) return false;
+    if (wide) {
+        hipLaunchKernelGGL((colreduce_stage1_kernel<64, Fin>), dim3(blocks, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
+                           row_step, fin, t);
+    } else {
+        hipLaunchKernelGGL((colreduce_stage1_kernel<32, Fin>), dim3(blocks, segs * CR_CHUNKS), dim3(1024), 0, st, a, b, rows_per_seg, C, ws,
+                           row_step, fin, t);
+    }
+    return true;
 }
 
 // Stage 2 spread over 32 lanes (one partial each) + a fixed-order butterfly: the finalize kernels are latency-bound chains
 // of dependent loads otherwise (8 us for 512 channels).  Thread layout of the callers: 8 channels x 32 lanes per workgroup.
-__device__ inline void colreduce_stage2_par(const double* __restrict__ ws, int seg, int C, int c, int k, double& s, double& q) {
+template <bool SYNC = false>
+__device__ inline void colreduce_stage2_par(const double* ws, int seg, int C, int c, int k, double& s, double& q) {
     static_assert(CR_CHUNKS == 32, "one lane per partial");
-    s = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c];
-    q = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c];
+    // SYNC: the partials were written by OTHER workgroups of this launch (last-arriver finalize): agent-scope loads
+    if (SYNC) {
+        s = load_agent(ws + ((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c);
+        q = load_agent(ws + ((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c);
+    } else {
+        s = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 0) * C + c];
+        q = ws[((int64_t)(seg * CR_CHUNKS + k) * 2 + 1) * C + c];
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
         s += __shfl_xor(s, o, 64);
@@ -145,14 +242,58 @@ __device__ inline void colreduce_stage2_par(const double* __restrict__ ws, int s
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, int n_towers, int C, double count,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float momentum, int unbiased, float* moving_mean,
-                                                           float* moving_var, float* mean, float* invstd, float* scale,
-                                                           float* shift, float* zd_biased, float zd_correction,
-                                                           const float* __restrict__ center_bias, float* shift_adj, float* mean_adj) {
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    if (c >= C) return;
+template <bool SYNC>
+struct FinBnBwd {
+    static constexpr bool kOn = true;
+    int n_towers, C;
+    double count;
+    float* c1;
+    float* c2;
+    float* grad_gamma;
+    float* grad_beta;
+    __device__ inline void operator()(const double* ws, int c, int k) const {
+    double gg = 0.0, gb = 0.0;
+    for (int tw = 0; tw < n_towers; ++tw) {
+        double ss, qq;
+        colreduce_stage2_par<SYNC>(ws, tw, C, c, k, ss, qq);
+        if (k == 0) {
+            c1[tw * C + c] = (float)(ss / count);
+            c2[tw * C + c] = (float)(qq / count);
+        }
+        gb += ss;
+        gg += qq;
+    }
+    if (k == 0) {
+        grad_gamma[c] = (float)gg;
+        grad_beta[c] = (float)gb;
+    }
+    }
+};
+
+
+// the finalize body as a functor: run by bn_finalize_kernel (its own launch: 8 channels x 32 lanes per workgroup) or, SYNC, by the last
+// stage-1 workgroup of a channel block (launch_colreduce_fin)
+template <bool SYNC>
+struct FinBn {
+    static constexpr bool kOn = true;
+    int n_towers, C;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    int unbiased;
+    float* moving_mean;
+    float* moving_var;
+    float* mean;
+    float* invstd;
+    float* scale;
+    float* shift;
+    float* zd_biased;
+    float zd_correction;
+    const float* center_bias;
+    float* shift_adj;
+    float* mean_adj;
+    __device__ inline void operator()(const double* ws, int c, int k) const {
     float mm = 0.f, mv = 0.f;
     if (moving_mean != nullptr) {
         mm = moving_mean[c];
@@ -160,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
     for (int tw = 0; tw < n_towers; ++tw) {
         double ss, qq;
-        colreduce_stage2_par(ws, tw, C, c, k, ss, qq);
+        colreduce_stage2_par<SYNC>(ws, tw, C, c, k, ss, qq);
         if (k != 0) continue;
         const double m = ss / count;
         double var = qq / count - m * m;
@@ -205,6 +346,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
         moving_mean[c] = mm;
         moving_var[c] = mv;
     }
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, FinBn<false> f) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    if (c >= f.C) return;
+    f(ws, c, k);
 }
 
 __global__ void bn_infer_affine_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
@@ -777,7 +925,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_stage1_kernel(const float* _
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ drop, int64_t wpt, int64_t L, int C, int pool,
-                                                                  int a_is_act, double* __restrict__ ws) {
+                                                                  int a_is_act, double* ws, FinBnBwd<true> fin, unsigned* tickets) {
     __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -831,9 +979,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_stage1_kernel(const float* _
             ss += red[0][i][cl];
             qq += red[1][i][cl];
         }
-        ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ss;
-        ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = qq;
+        store_agent(ws + ((int64_t)blockIdx.y * 2 + 0) * C + c, ss);
+        store_agent(ws + ((int64_t)blockIdx.y * 2 + 1) * C + c, qq);
     }
+    // (tickets NULL: the two-launch form, vm_set_tuning("fuse_finalize", 0))
+    if (tickets != nullptr && last_arriver(tickets + blockIdx.x, gridDim.y)) run_finalize<64>(fin, ws, blockIdx.x, C);
 }
 
 // Reduce pass when dp is the sparse GlobalMaxPool1D-backward form: dy is non-zero at ONE pool group per (window, channel),
@@ -876,48 +1026,47 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_gmax_kernel(const T* _
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int n_towers, int C, double count,
-                                                               float* c1, float* c2, float* grad_gamma, float* grad_beta) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, FinBnBwd<false> f) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    if (c >= C) return;
-    double gg = 0.0, gb = 0.0;
-    for (int tw = 0; tw < n_towers; ++tw) {
-        double ss, qq;
-        colreduce_stage2_par(ws, tw, C, c, k, ss, qq);
-        if (k == 0) {
-            c1[tw * C + c] = (float)(ss / count);
-            c2[tw * C + c] = (float)(qq / count);
-        }
-        gb += ss;
-        gg += qq;
-    }
-    if (k == 0) {
-        grad_gamma[c] = (float)gg;
-        grad_beta[c] = (float)gb;
-    }
+    if (c >= f.C) return;
+    f(ws, c, k);
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ ws, int C, float* out) {
+template <bool SYNC>
+struct FinColsum {
+    static constexpr bool kOn = true;
+    int C;
+    float* out;
+    __device__ inline void operator()(const double* ws, int c, int k) const {
+        double ss, qq;
+        colreduce_stage2_par<SYNC>(ws, 0, C, c, k, ss, qq);
+        if (k == 0) out[c] = (float)ss;
+    }
+};
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ ws, FinColsum<false> f) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    if (c >= C) return;
-    double ss, qq;
-    colreduce_stage2_par(ws, 0, C, c, k, ss, qq);
-    if (k == 0) out[c] = (float)ss;
+    if (c >= f.C) return;
+    f(ws, c, k);
 }
 
 // vm_du_tower_sums: per tower t the column sums of du (from the apply pass's partial rows, via colreduce_stage1_kernel with one segment
 // per tower) and the three tap sums D_t[k][c] a folded weight gradient needs: the sum over the positions whose tap k lies inside the
 // window -- all of them for k = 1, all but position 0 for k = 0, all but position L - 1 for k = 2 (du: padded (n_windows, L + 2, C)).
-template <typename T>
-__global__ __launch_bounds__(256) void du_tower_sums_kernel(const double* __restrict__ ws, const T* __restrict__ du, int towers,
-                                                             int64_t wpt, int64_t L, int C, float* __restrict__ grad_b,
-                                                             float* __restrict__ dsum) {
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    if (c >= C) return;
+template <typename T, bool SYNC>
+struct FinDuTower {
+    static constexpr bool kOn = true;
+    const T* du;
+    int towers;
+    int64_t wpt, L;
+    int C;
+    float* grad_b;
+    float* dsum;
+    __device__ inline void operator()(const double* ws, int c, int k) const {
     double gb = 0.0;
     for (int t = 0; t < towers; ++t) {
         double ss, qq;
-        colreduce_stage2_par(ws, t, C, c, k, ss, qq);
+        colreduce_stage2_par<SYNC>(ws, t, C, c, k, ss, qq);
         double e0 = 0.0, e1 = 0.0;
         for (int64_t w = k; w < wpt; w += 32) {
             const T* row = du + ((int64_t)(t * wpt + w) * (L + 2)) * C + c;
@@ -937,6 +1086,14 @@ __global__ __launch_bounds__(256) void du_tower_sums_kernel(const double* __rest
         gb += ss;
     }
     if (k == 0 && grad_b != nullptr) grad_b[c] = (float)gb;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void du_tower_sums_kernel(const double* __restrict__ ws, FinDuTower<T, false> f) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    if (c >= f.C) return;
+    f(ws, c, k);
 }
 
 static int lanes_for(int cv) {
@@ -963,10 +1120,15 @@ extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
     VM_REQUIRE(zd_biased == nullptr || (moving_mean != nullptr && zd_correction >= 1.0f), "vm_bn_finalize: zero-debias needs the moving statistics and a correction >= 1");
-    launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
-                       n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                       mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj);
+    // stage 1 of the column sums, the statistics by the last workgroup of every channel block: one launch
+    const FinBn<true> fin{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
+                          mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj};
+    if (!g_fuse_finalize || !launch_colreduce_fin(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
+        launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
+        const FinBn<false> f2{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
+                              mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj};
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, f2);
+    }
     return check_launch("vm_bn_finalize");
 }
 
@@ -1115,9 +1277,13 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0,
                "vm_bn_bwd_finalize: n_windows must be a multiple of windows_per_tower");
     const int n_towers = (int)(n_windows / windows_per_tower);
-    launch_colreduce(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
-                       n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta);
+    const FinBnBwd<true> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
+    if (!g_fuse_finalize ||
+        !launch_colreduce_fin(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
+        launch_colreduce(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream);
+        const FinBnBwd<false> f2{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, f2);
+    }
     return check_launch("vm_bn_bwd_finalize");
 }
 
@@ -1133,13 +1299,17 @@ extern "C" int vm_bn_bwd_from_sums_finalize(const float* s0, const float* sa, in
                    C > 0,
                "vm_bn_bwd_from_sums_finalize: bad sizes");
     const int n_towers = (int)(n_windows / windows_per_tower);
+    unsigned* tickets = g_fuse_finalize ? ticket_range((C + 63) / 64) : nullptr;
+    const FinBnBwd<true> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
     VM_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((bn_bwd_sums_stage1_kernel<T>), dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, s0,
                            sa, (int)rows_per_window, (const T*)z, (const T*)dp, scale, shift, mean, invstd, drop, windows_per_tower, L, C, pool,
-                           a_is_act, (double*)ws);
+                           a_is_act, (double*)ws, fin, tickets);
     });
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, n_towers, C,
-                       count_per_tower, c1, c2, grad_gamma, grad_beta);
+    if (tickets == nullptr) {
+        const FinBnBwd<false> f2{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, f2);
+    }
     return check_launch("vm_bn_bwd_from_sums_finalize");
 }
 
@@ -1205,10 +1375,14 @@ extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && L > 0 && C > 0,
                "vm_du_tower_sums: n_windows must be a positive multiple of windows_per_tower");
     const int towers = (int)(n_windows / windows_per_tower);
-    launch_colreduce(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream);
     VM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((du_tower_sums_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
-                           (const T*)du, towers, windows_per_tower, L, C, grad_b, dsum);
+        const FinDuTower<T, true> fin{(const T*)du, towers, windows_per_tower, L, C, grad_b, dsum};
+        if (!g_fuse_finalize ||
+            !launch_colreduce_fin(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream, fin)) {
+            launch_colreduce(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream);
+            const FinDuTower<T, false> f2{(const T*)du, towers, windows_per_tower, L, C, grad_b, dsum};
+            hipLaunchKernelGGL((du_tower_sums_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, f2);
+        }
     });
     return check_launch("vm_du_tower_sums");
 }
@@ -1220,16 +1394,18 @@ extern "C" int vm_bn_part_rows_used(int64_t L, int C, int pool, int dtype) {
 
 extern "C" int vm_colsum_strided(const float* part, int64_t rows, int row_step, int C, float* out, void* ws, void* stream) {
     VM_REQUIRE(part && out && ws && rows > 0 && row_step >= 1 && C > 0, "vm_colsum_strided: bad argument");
-    launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, row_step);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
-                       out);
+    if (!g_fuse_finalize || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out}, row_step)) {
+        launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, row_step);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, FinColsum<false>{C, out});
+    }
     return check_launch("vm_colsum_strided");
 }
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {
     VM_REQUIRE(part && out && ws && rows > 0 && C > 0, "vm_colsum: bad argument");
-    launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, C,
-                       out);
+    if (!g_fuse_finalize || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out})) {
+        launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, FinColsum<false>{C, out});
+    }
     return check_launch("vm_colsum");
 }

@@ -59,3 +59,48 @@ extern "C" int vm_fill_zero(void* ptr, int64_t bytes, void* stream) {
     }
     return VM_OK;
 }
+
+// ---- stream-ordering primitives for a caller that replays a recorded launch sequence (voicemap_amd/engine.py: the training step's
+// C-ABI calls, event records and waits are recorded once per configuration and replayed without the host logic that produced them).
+// Events are created without timing: ordering only. ----
+extern "C" int vm_event_create(void** event_out) {
+    VM_REQUIRE(event_out, "vm_event_create: null pointer");
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        vm::set_error("vm_event_create: %s", hipGetErrorString(e));
+        return VM_ERR_LAUNCH;
+    }
+    *event_out = (void*)ev;
+    return VM_OK;
+}
+
+extern "C" int vm_event_destroy(void* event) {
+    if (event == nullptr) return VM_OK;
+    hipError_t e = hipEventDestroy((hipEvent_t)event);
+    if (e != hipSuccess) {
+        vm::set_error("vm_event_destroy: %s", hipGetErrorString(e));
+        return VM_ERR_LAUNCH;
+    }
+    return VM_OK;
+}
+
+extern "C" int vm_event_record(void* event, void* stream) {
+    VM_REQUIRE(event, "vm_event_record: null event");
+    hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        vm::set_error("vm_event_record: %s", hipGetErrorString(e));
+        return VM_ERR_LAUNCH;
+    }
+    return VM_OK;
+}
+
+extern "C" int vm_stream_wait_event(void* stream, void* event) {
+    VM_REQUIRE(event, "vm_stream_wait_event: null event");
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    if (e != hipSuccess) {
+        vm::set_error("vm_stream_wait_event: %s", hipGetErrorString(e));
+        return VM_ERR_LAUNCH;
+    }
+    return VM_OK;
+}
