@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -189,11 +189,20 @@ int vm_conv_fwd_e(const void* in, const void* wf, const float* bias, const float
  * and the backward takes the pair form (vm_bn_pool_bwd_apply_pairs).
  * vm_conv_wgrad_fold is the matching weight gradient, vm_conv_dgrad[_bnred] is unchanged (it takes the un-folded wd). */
 int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, const float* bias, int towers, int c_in, int c_out,
-                       int dtype, void* wf_folded, void* wf_packed, float* hb, void* stream);
+                       int dtype, void* wf_folded, void* wf_packed, float* hb, float* ctr_out, void* stream);
+/* ctr_out (towers, c_out) or NULL (round 5): the centre of each output channel's tile for vm_conv_fwd_fold's `e_center` --
+ * ctr = max(row 3 of hb, 0) rounded to the storage type (the pedestal the accumulators start from: conv bias + the contribution of
+ * the input's BatchNorm shifts); row 3 of hb is then written with ctr already taken off. */
 int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in, int c_out, int dtype, int with_e);
 int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                      int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z, float* stat_sum,
-                     float* stat_sq, void* e, void* o, const void* wf_packed, void* stream);
+                     float* stat_sq, void* e, void* o, const void* wf_packed, const float* e_center, void* stream);
+/* e_center (towers, c_out) or NULL (round 5; VM_F16 with the (e, o) output only): vm_fold_bn_weights' ctr_out.  The tile is computed
+ * and rounded CENTRED: t = relu(z) - ctr, one rounding of a value whose size is the distance from the channel's pedestal instead of
+ * the pedestal (a half spends its 11 bits on the latter otherwise: 1.06e-3 -> 0.66e-3 on the embeddings of the trained-like state of
+ * tests/test_gpu_fullsize_oracle.py).  e receives the centred extreme, o the other element UN-centred (so that its sign bit stays
+ * free for the position flag), stat_sum / stat_sq the sums of t and t^2: vm_bn_finalize's tile_center, vm_bn_pool_bwd_apply_pairs'
+ * e_center and the *_adj constants take it from there. */
 /* The k = 3 GEMM weights in the order the matrix cores consume them (round 4).  bt: `towers` matrices (n_rows, 3 * a_c) `dtype` back
  * to back -- wf (n_rows = c_out, a_c = c_in), wd (n_rows = c_in, a_c = c_out) of vm_prep_conv_weights, wf_folded of
  * vm_fold_bn_weights; packed: the same elements as [tower][n_rows / 64][K tile = (channel chunk of 32, tap)][32-row half][16-channel
@@ -272,7 +281,11 @@ int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t rows_per
                    double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                    int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
                    float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, const float* center_bias,
-                   float* shift_adj, float* mean_adj, void* stream);
+                   float* shift_adj, float* mean_adj, const float* tile_center, void* stream);
+/* tile_center (n_towers, C) or NULL, exclusive with center_bias (round 5): the layer ran as vm_conv_fwd_fold with `e_center` -- its
+ * statistics partials are sums over t = z - ctr and its pool extreme is stored as e - ctr, ctr = tile_center[tower][c].  The sums are
+ * taken back to z here (sum z = sum t + n ctr, sum z^2 = sum t^2 + 2 ctr sum t + n ctr^2, fp64) and shift_adj / mean_adj carry the
+ * offset for the consumers of the stored extreme exactly as with center_bias. */
 /* center_bias (C) or NULL, with shift_adj / mean_adj (n_towers, C): block 1's pool extreme is stored CENTRED in the folded training
  * path (vm_conv1_fused_fwd mode 2 writes e - ctr, ctr = max(conv bias, 0): the whitened waveform makes conv-1 outputs small next to a
  * bias, and a 16-bit value would spend its significand on that pedestal).  Its consumers are linear in e, so the offset moves into
@@ -347,7 +360,10 @@ int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gid
  * (n_windows, L/2, C) with the position flag in its sign bit.  Same arithmetic and outputs.  16-bit storage, L even. */
 int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const void* dp, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* drop, const float* c1, const float* c2, int64_t n_windows,
-                               int64_t windows_per_tower, int64_t L, int C, int dtype, void* du, float* part_du, void* stream);
+                               int64_t windows_per_tower, int64_t L, int C, int dtype, void* du, float* part_du, const float* e_center,
+                               void* stream);
+/* e_center (towers, C) or NULL: e was stored centred (vm_conv_fwd_fold e_center); the kernel adds ctr back (fp32) before it applies
+ * ReLU's mask and the BatchNorm-backward constants, which stay those of z (mean, not mean_adj). */
 /* out[c] = sum_r part[r][c] in fixed order (bias gradients). */
 int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream);
 /* The part_* tensors have vm_bn_part_rows() rows per window; a pass over short windows (the 2-D variant) fills only the first

@@ -30,7 +30,7 @@ def _fold_weights(w, s, h, dtype, bias=None, packed=False):
     wf = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda")
     wfp = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda") if packed else None
     hb = torch.empty(towers, 4, cout, dtype=torch.float32, device="cuda")
-    L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), p(dev(bias)), towers, cin, cout, vm, p(wf), p(wfp), p(hb), stream())
+    L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), p(dev(bias)), towers, cin, cout, vm, p(wf), p(wfp), p(hb), None, stream())
     torch.cuda.synchronize()
     return (wf, hb, wfp) if packed else (wf, hb)
 
@@ -105,7 +105,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
     ssq = torch.empty_like(ssum)
     eo = torch.full((n, Lw // 2 + 2, cout), 7.0, dtype=tdt, device="cuda") if with_e else None
     L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
-             vm, p(z), p(ssum), p(ssq), p(eo), None, None, stream())
+             vm, p(z), p(ssum), p(ssq), p(eo), None, None, None, stream())
     torch.cuda.synchronize()
     if L().query("vm_pack_nt_weights_supported", cout, cin, vm):
         # round 4: the same launch with the weights in fragment order (conv_nt3_kernel where the channel count has a written-out K
@@ -116,7 +116,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
         z3, ssum3, ssq3 = torch.empty_like(z), torch.empty_like(ssum), torch.empty_like(ssq)
         eo3 = torch.full_like(eo, 7.0) if with_e else None
         L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)) if with_e else None, n, wpt, Lw, cin, cout,
-                 vm, p(z3), p(ssum3), p(ssq3), p(eo3), None, p(wfp), stream())
+                 vm, p(z3), p(ssum3), p(ssq3), p(eo3), None, p(wfp), None, stream())
         torch.cuda.synchronize()
         assert torch.equal(z3, z) and torch.equal(ssum3, ssum) and torch.equal(ssq3, ssq) and (not with_e or torch.equal(eo3, eo))
     # the definition, with the weights the kernel multiplies by (W * scale rounded to the storage type) and exact shift terms
@@ -145,7 +145,7 @@ def test_conv_fwd_fold_matches_definition(dtype, n, Lw, cin, cout, with_e):
         e2, o2 = torch.zeros_like(eo), torch.empty(n, Lw // 2, cout, dtype=tdt, device="cuda")
         ssum2, ssq2 = torch.empty_like(ssum), torch.empty_like(ssq)
         L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)), n, wpt, Lw, cin, cout, vm, None,
-                 p(ssum2), p(ssq2), p(e2), p(o2), None, stream())
+                 p(ssum2), p(ssq2), p(e2), p(o2), None, None, stream())
         torch.cuda.synchronize()
         assert torch.equal(e2[:, 1:-1], eo[:, 1:-1]) and torch.equal(ssum2, ssum) and torch.equal(ssq2, ssq)
         ob = o2.view(torch.int16).cpu().numpy().view(np.uint16)
@@ -188,7 +188,7 @@ def test_bn_pool_bwd_apply_pairs_equals_apply_on_z(dtype):
         pdu = torch.empty(n * prow, c, dtype=torch.float32, device="cuda")
         common = (p(dev(dp, tdt)), p(dev(scale)), p(dev(shift)), p(dev(mean)), p(dev(invstd)), None, p(dev(c1)), p(dev(c2)), n, wpt, Lw, c)
         if pairs:
-            L().call("vm_bn_pool_bwd_apply_pairs", p(ep), p(o), *common, vm, p(du), p(pdu), stream())
+            L().call("vm_bn_pool_bwd_apply_pairs", p(ep), p(o), *common, vm, p(du), p(pdu), None, stream())
         else:
             L().call("vm_bn_pool_bwd_apply", p(zt.contiguous()), *common, 2, vm, p(du), p(pdu), stream())
         torch.cuda.synchronize()
@@ -261,12 +261,14 @@ def _fold_arch_case(seed, pairs, l0, f=128, e=64):
     return arch, p_, x1, x2, y
 
 
-def _run(arch, p_, x1, x2, y, dtype, fold, split=True, loss="contrastive", pairs=True):
+def _run(arch, p_, x1, x2, y, dtype, fold, split=True, loss="contrastive", pairs=True, center=True):
     from voicemap_amd.engine import HipEncoderEngine
     eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=0.0, head="uniform_euclidean", dtype=dtype)
     eng.set_params({k: v.numpy() for k, v in p_.items()})
     eng.fold_affine = fold
     eng.fold_pairs = pairs
+    if not center:
+        eng.center_blocks = ()
     eng.split_towers = split
     pl = eng.siamese_train_step(x1, x2, y, loss=loss, drop_masks=None)
     torch.cuda.synchronize()
@@ -309,10 +311,18 @@ def test_folded_train_step_matches_oracle_and_unfolded_path(dtype, split):
         if "moving" in k:
             assert rel_err(pf[k], v.numpy()) < (3e-3 if dtype == "f16" else 2e-2), k
     assert eng_f.skipped_steps() == 0
-    # (extreme, other element) instead of (z, extreme) is a re-encoding of the same values: the whole step is bit-identical
+    # (extreme, other element) instead of (z, extreme) is a re-encoding of the same values: the whole step is bit-identical -- with
+    # the centred tile of f16 storage (round 5, pairs form only) switched off; with it the embeddings move by the storage rounding
+    # it removes and stay as close to the oracle
     eng_z, pl_z = _run(arch, p_, x1, x2, y, dtype, True, split, pairs=False)
-    assert pl_f[1]["pairs_now"] and not pl_z[1]["pairs_now"]
-    assert torch.equal(pl_z["emb"], pl_f["emb"]) and torch.equal(eng_z.G, eng_f.G)
+    eng_p, pl_p = _run(arch, p_, x1, x2, y, dtype, True, split, pairs=True, center=False)
+    assert pl_p[1]["pairs_now"] and not pl_z[1]["pairs_now"] and not pl_p[1]["ctr_now"]
+    assert torch.equal(pl_z["emb"], pl_p["emb"]) and torch.equal(eng_z.G, eng_p.G)
+    assert bool(pl_f[1]["ctr_now"]) == (dtype == "f16")
+    if dtype == "f16":
+        err_p = rel_err(pl_p["emb"].cpu().numpy(), e_ref)
+        report(tag, "emb_rel_err_vs_fp64_folded_uncentred", err_p)
+        assert err_f < 1.15 * err_p
 
 
 def test_folded_path_falls_back_with_dropout_masks_and_is_deterministic():
@@ -358,3 +368,102 @@ def test_folded_classifier_step_one_tower():
     for k, g in ref["grads"].items():
         report("fold_classifier[f16]", "grad_rel_err_vs_fp64[%s]" % k, rel_err(grads[k], g.numpy()))
         assert grad_close(grads[k], g.numpy(), 0.3, atol=1e-5), k
+
+
+@pytest.mark.parametrize("n,Lw,cin,cout", [(4, 508, 128, 256), (2, 1016, 64, 128)])
+def test_conv_fwd_fold_centred_tile(n, Lw, cin, cout):
+    """Round 5, f16 storage: vm_fold_bn_weights(ctr_out) -> vm_conv_fwd_fold(e_center) computes and rounds the tile CENTRED on the
+    per-channel pedestal ctr = f16(max(start, 0)).  Against the un-centred launch on the same operands and the float64 definition:
+    e_c + ctr is z's extreme to half an ulp of the CENTRED value (closer to the definition wherever the pedestal dominates), o is the
+    un-centred other element with the same position flags, the statistics finalize (tile_center) to the same mean / variance, the
+    *_adj constants carry the offset, and the BatchNorm-backward apply pass (e_center) sees the same z."""
+    dtype, (vm, tdt) = "f16", DTYPES["f16"]
+    if not L().query("vm_conv_fwd_fold_supported", n, Lw, cin, cout, vm, 1):
+        pytest.skip("shape not served")
+    r = np.random.default_rng(cin + 7)
+    e, w, bias, s, h, gamma = _fold_case(r, n, Lw, cin, cout, dtype)
+    bias = (bias + np.where(r.random(cout) < 0.5, r.uniform(1.0, 4.0, cout), 0.0)).astype(np.float32)   # half the channels on a pedestal
+    towers, wpt = 2, n // 2
+    s = np.stack([s, (s * r.normal(1.0, 0.2, cin)).astype(np.float32)])
+    h = np.stack([h * 0.1, (h * 0.1 + r.normal(0.0, 0.05, cin)).astype(np.float32)])
+    wt = np.ascontiguousarray(np.transpose(w, (2, 0, 1)).reshape(cout, 3 * cin))
+    rows = L().query("vm_conv_stat_rows", Lw)
+
+    def launch(centre):
+        wf = torch.empty(towers, cout, 3 * cin, dtype=tdt, device="cuda")
+        hb = torch.empty(towers, 4, cout, dtype=torch.float32, device="cuda")
+        ctr = torch.zeros(towers, cout, dtype=torch.float32, device="cuda")
+        L().call("vm_fold_bn_weights", p(dev(wt)), p(dev(s)), p(dev(h)), p(dev(bias)), towers, cin, cout, vm, p(wf), None, p(hb),
+                 p(ctr) if centre else None, stream())
+        eo = torch.zeros(n, Lw // 2 + 2, cout, dtype=tdt, device="cuda")
+        oo = torch.empty(n, Lw // 2, cout, dtype=tdt, device="cuda")
+        ssum = torch.empty(n * rows, cout, dtype=torch.float32, device="cuda")
+        ssq = torch.empty_like(ssum)
+        L().call("vm_conv_fwd_fold", p(padded(e, tdt)), p(wf), p(dev(bias)), p(hb), p(dev(gamma)), n, wpt, Lw, cin, cout, vm, None,
+                 p(ssum), p(ssq), p(eo), p(oo), None, p(ctr) if centre else None, stream())
+        torch.cuda.synchronize()
+        return hb, ctr, eo, oo, ssum, ssq
+    hb0, _, e0, o0, ss0, sq0 = launch(False)
+    hb1, ctr, e1, o1, ss1, sq1 = launch(True)
+    start = hb0[:, 3].cpu().numpy()
+    c = ctr.cpu().numpy()
+    assert np.array_equal(c, np.maximum(start, 0).astype(np.float16).astype(np.float32)) and (c > 1.0).sum() > cout // 2
+    assert np.allclose(hb1[:, 3].cpu().numpy(), start - c, rtol=0, atol=1e-6) and torch.equal(hb1[:, :3], hb0[:, :3])
+    cw = np.repeat(c, wpt, axis=0)[:, None, :]                                   # per window
+    g_e0, g_e1 = e0[:, 1:-1].double().cpu().numpy(), e1[:, 1:-1].double().cpu().numpy() + cw
+    # the float64 definition of z's pool extreme
+    zr = np.empty((n, Lw, cout))
+    for t in range(towers):
+        wq = quant((w * s[t][None, :, None]).astype(np.float32), dtype).numpy()
+        zr[t * wpt:(t + 1) * wpt] = np.maximum(_conv_same(e[t * wpt:(t + 1) * wpt], wq)
+                                               + _conv_same(np.ones((wpt, Lw, cin)) * h[t][None, None, :].astype(np.float64), w.astype(np.float64)) + bias, 0.0)
+    pr = zr.reshape(n, Lw // 2, 2, cout)
+    want = np.where(gamma[None, None, :] >= 0, pr.max(2), pr.min(2))
+    ped = np.broadcast_to(cw > 1.0, want.shape)
+    err0, err1 = np.abs(g_e0 - want), np.abs(g_e1 - want)
+    report("conv_fwd_fold_centred", "extreme_rms_err_pedestal_channels_uncentred[%d->%d]" % (cin, cout), float(np.sqrt((err0[ped] ** 2).mean())))
+    report("conv_fwd_fold_centred", "extreme_rms_err_pedestal_channels_centred[%d->%d]" % (cin, cout), float(np.sqrt((err1[ped] ** 2).mean())))
+    assert np.sqrt((err1[ped] ** 2).mean()) < 0.6 * np.sqrt((err0[ped] ** 2).mean())       # the point of it (measured: ~0.3)
+    assert np.sqrt((err1[~ped] ** 2).mean()) < 1.1 * np.sqrt((err0[~ped] ** 2).mean()) + 1e-7
+    assert np.abs(g_e1 - g_e0).max() <= 2.0 ** -10 * max(1.0, np.abs(g_e0).max())          # and the same value to f16's spacing
+    # relu's clip: an extreme that is exactly 0 un-centred is exactly -ctr centred
+    assert np.array_equal(g_e1[g_e0 == 0.0], np.zeros((g_e0 == 0.0).sum()))
+    # o: the un-centred other element (one more rounding: <= 1 ulp apart), flags equal wherever the pair is not a near-tie
+    b0, b1 = o0.view(torch.int16).cpu().numpy().view(np.uint16), o1.view(torch.int16).cpu().numpy().view(np.uint16)
+    v0 = torch.from_numpy((b0 & 0x7fff).view(np.int16)).view(tdt).double().numpy()
+    v1 = torch.from_numpy((b1 & 0x7fff).view(np.int16)).view(tdt).double().numpy()
+    assert np.abs(v1 - v0).max() <= 2.0 ** -10 * max(1.0, np.abs(v0).max())
+    neartie = np.abs(pr[:, :, 0] - pr[:, :, 1]) < 2.0 ** -9 * np.maximum(np.abs(pr[:, :, 0]), 1.0)
+    assert np.array_equal((b0 >> 15)[~neartie], (b1 >> 15)[~neartie])
+    assert np.array_equal(v1 == 0.0, v0 == 0.0)
+    # statistics -> vm_bn_finalize(tile_center): the same mean / variance; shift_adj / mean_adj carry ctr
+    f32 = dict(dtype=torch.float32, device="cuda")
+    gd, btd = dev(gamma), dev(r.normal(0, 0.2, cout).astype(np.float32))
+    crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, cout) // 8, dtype=torch.float64, device="cuda")
+    out = []
+    for ss, sq, tc in ((ss0, sq0, None), (ss1, sq1, ctr)):
+        mean, invstd, scale, shift, sha, mea = (torch.zeros(towers, cout, **f32) for _ in range(6))
+        L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, cout, float(wpt * Lw), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
+                 p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, None, p(sha) if tc is not None else None,
+                 p(mea) if tc is not None else None, p(tc), stream())
+        torch.cuda.synchronize()
+        out.append((mean, invstd, scale, shift, sha, mea))
+    (m0, i0, s0, h0, _, _), (m1, i1, s1, h1, sha, mea) = out
+    std = (1.0 / i0).cpu().numpy()
+    assert (np.abs((m1 - m0).cpu().numpy()) < 2e-4 * std + 1e-6).all() and rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 2e-4
+    assert ((sha - (h1 + s1 * ctr)).abs() <= 2.4e-7 * (h1.abs() + (s1 * ctr).abs()) + 1e-7).all()
+    assert torch.allclose(mea, m1 - ctr, rtol=1e-6, atol=1e-6)
+    # apply pass: (e_c, o, e_center) == (e, o) of the un-centred launch up to the storage spacing of du
+    dp = quant(r.normal(0, 1, (n, Lw // 2, cout)), dtype).to("cuda", tdt)
+    c1, c2 = dev(r.normal(0, 0.01, (towers, cout)).astype(np.float32)), dev(r.normal(0, 0.01, (towers, cout)).astype(np.float32))
+    prow = L().query("vm_bn_part_rows")
+    dus = []
+    for ee, oo, tc in ((e0, o0, None), (e1, o1, ctr)):
+        du = torch.zeros(n, Lw + 2, cout, dtype=tdt, device="cuda")
+        pdu = torch.empty(n * prow, cout, **f32)
+        L().call("vm_bn_pool_bwd_apply_pairs", p(ee), p(oo), p(dp), p(s0), p(h0), p(m0), p(i0), None, p(c1), p(c2), n, wpt, Lw, cout, vm,
+                 p(du), p(pdu), p(tc), stream())
+        torch.cuda.synchronize()
+        dus.append(du.double().cpu().numpy())
+    assert rel_err(dus[1], dus[0]) < 1e-3
+    assert np.array_equal(dus[1] == 0.0, dus[0] == 0.0) or ((dus[1] == 0.0) != (dus[0] == 0.0)).mean() < 1e-4

@@ -32,7 +32,10 @@ GRAD_COS = {"f32": 0.9999, "f32s": 0.9999, "f16": 0.99, "bf16": 0.9}
 # figures go to the parity report and bench.py's precision object quotes them), the fp32-storage modes to the same 1e-4
 # (measured: f16 1.06e-3, bf16 8.4e-3 -- with block 1's pool extreme stored centred, round 4; 1.3e-2 / 8.9e-2 before: the whitened
 # waveform makes conv-1 outputs ~0.03, a bias of N(0, 0.2) is a pedestal seven times that)
-EMB_TOL_TRAINED = {"f32": 1e-4, "f32s": 1e-4, "f16": 1.5e-3, "bf16": 1.5e-2}
+# round 5: f16 holds the north star's 1e-3 here too -- block 2's tile is computed and stored centred on its per-channel pedestal
+# (vm_conv_fwd_fold e_center; this state has channels whose pedestal is 10 x their spread: measured 1.06e-3 before, 0.66e-3 in the
+# CPU emulation of the centred storage)
+EMB_TOL_TRAINED = {"f32": 1e-4, "f32s": 1e-4, "f16": 1e-3, "bf16": 1.5e-2}
 GRAD_COS_TRAINED = {"f32": 0.9999, "f32s": 0.9999, "f16": 0.99, "bf16": 0.95}
 
 

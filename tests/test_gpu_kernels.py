@@ -214,7 +214,7 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
     mv = torch.ones(c, **f32)
     crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, c) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
-             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, None, None, None, stream())
+             p(mm), p(mv), p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, None, None, None, None, stream())
     zr = z.clone().requires_grad_(True)
     gr = gamma.clone().requires_grad_(True)
     br = beta.clone().requires_grad_(True)
@@ -236,7 +236,7 @@ def test_bn_drop_pool_fwd_bwd(dt, n, wpt, l, c, pool, use_drop):
     newp = {"bn1.moving_mean": torch.zeros(c, dtype=torch.float64), "bn1.moving_variance": torch.ones(c, dtype=torch.float64)}
     for step in (1, 2):
         L().call("vm_bn_finalize", p(ssum), p(ssq), wpt, towers, c, float(wpt * l), p(dev(gamma)), p(dev(beta)), 1e-3, 0.99, 1,
-                 p(mm2), p(mv2), p(mean), p(invstd), p(scale), p(shift), p(crws), p(zdb), 1.0 / (1.0 - 0.99 ** step), None, None, None, stream())
+                 p(mm2), p(mv2), p(mean), p(invstd), p(scale), p(shift), p(crws), p(zdb), 1.0 / (1.0 - 0.99 ** step), None, None, None, None, stream())
         collects = [{"bn_mean": [m_.detach()], "bn_var": [v_.detach()], "bn_count": [wpt * l]} for (m_, v_) in stats]
         state = O.apply_moving_updates(newp, collects, 1, 1e-3, 0.99, True, state)
         assert rel_err(mm2.cpu().numpy(), newp["bn1.moving_mean"].numpy()) < 1e-5
@@ -606,12 +606,12 @@ def _conv1_fused_block(dt, n, wpt, l, f, pool, use_drop, neg):
     mean, invstd, scale, shift = (torch.empty(towers, f, **f32) for _ in range(4))
     crws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, f) // 8, dtype=torch.float64, device="cuda")
     L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, f, float(wpt * l), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
-             p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, None, None, None, stream())
+             p(mean), p(invstd), p(scale), p(shift), p(crws), None, 0.0, None, None, None, None, stream())
     # the centred form (vm_conv1_fused_fwd mode 2 stores e - max(bias, 0)): shift_adj / mean_adj carry the offset
     sh_adj, mean_adj = torch.empty_like(shift), torch.empty_like(mean)
     mean2, invstd2, scale2, shift2 = (torch.empty(towers, f, **f32) for _ in range(4))
     L().call("vm_bn_finalize", p(ss), p(sq), wpt * rows, towers, f, float(wpt * l), p(gd), p(btd), 1e-3, 0.99, 1, None, None,
-             p(mean2), p(invstd2), p(scale2), p(shift2), p(crws), None, 0.0, p(bd), p(sh_adj), p(mean_adj), stream())
+             p(mean2), p(invstd2), p(scale2), p(shift2), p(crws), None, 0.0, p(bd), p(sh_adj), p(mean_adj), None, stream())
     ctr = torch.clamp(bd, min=0.0)[None, :]
     assert torch.equal(mean2, mean) and torch.equal(scale2, scale) and torch.equal(shift2, shift)
     # (the kernel forms shift_adj with ONE rounding, fma(scale, ctr, shift); torch rounds the product and the sum: where the two terms

@@ -54,9 +54,9 @@ SIGNATURES = {
     "vm_conv_fwd_flat": (I, [P, P, P, L, L, I, I, I, P, P, P, P]),
     "vm_conv_fwd_e_supported": (I, [L, L, I, I, I]),
     "vm_conv_fwd_e": (I, [P, P, P, P, L, L, I, I, I, P, P, P, P, P]),
-    "vm_fold_bn_weights": (I, [P, P, P, P, I, I, I, I, P, P, P, P]),
+    "vm_fold_bn_weights": (I, [P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "vm_conv_fwd_fold_supported": (I, [L, L, I, I, I, I]),
-    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P, P]),
+    "vm_conv_fwd_fold": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, P, P, P, P, P, P]),
     "vm_pack_nt_weights_supported": (I, [I, I, I]),
     "vm_pack_nt_weights": (I, [P, I, I, I, I, P, P]),
     "vm_pack_nt_weights_batch": (I, [I, P, P, P, P, I, P, P]),
@@ -74,7 +74,7 @@ SIGNATURES = {
     "vm_conv_wgrad_fold_finish": (I, [P, L, L, L, I, I, P, P, P, P, P]),
     "vm_prep_conv_weights": (I, [P, I, I, I, P, P, P]),
     "vm_colreduce_workspace_bytes": (L, [I, I]),
-    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P, P, P, P]),
+    "vm_bn_finalize": (I, [P, P, L, I, I, D, P, P, F, F, I, P, P, P, P, P, P, P, P, F, P, P, P, P, P]),
     "vm_bn_infer_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "vm_bn_drop_pool_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P]),
     "vm_bn_part_rows": (I, []),
@@ -86,7 +86,7 @@ SIGNATURES = {
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
-    "vm_bn_pool_bwd_apply_pairs": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P]),
+    "vm_bn_pool_bwd_apply_pairs": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),
     "vm_bn_part_rows_used": (I, [L, I, I, I]),
     "vm_colsum_strided": (I, [P, L, I, I, P, P, P]),

@@ -293,6 +293,7 @@ struct FinBn {
     const float* center_bias;
     float* shift_adj;
     float* mean_adj;
+    const float* tile_center;   // (n_towers, C): the statistics AND the stored extreme are centred by it (vm_conv_fwd_fold e_center)
     __device__ inline void operator()(const double* ws, int c, int k) const {
     float mm = 0.f, mv = 0.f;
     if (moving_mean != nullptr) {
@@ -303,6 +304,13 @@ struct FinBn {
         double ss, qq;
         colreduce_stage2_par<SYNC>(ws, tw, C, c, k, ss, qq);
         if (k != 0) continue;
+        if (tile_center != nullptr) {
+            // the partial sums are over t = z - ctr (rows outside the window are zeros in both): sum z = sum t + n ctr,
+            // sum z^2 = sum t^2 + 2 ctr sum t + n ctr^2
+            const double cc = (double)tile_center[tw * C + c];
+            qq += 2.0 * cc * ss + count * cc * cc;
+            ss += count * cc;
+        }
         const double m = ss / count;
         double var = qq / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -316,6 +324,10 @@ struct FinBn {
             // the block's pool extreme is stored as e - ctr, ctr = max(conv bias, 0) (vm_conv1_fused_fwd mode 2): the affine over the
             // STORED value is scale * e' + (shift + scale * ctr), and sum dp * e = sum dp * e' + ctr * sum dp puts ctr into the mean
             const float ctr = fmaxf(center_bias[c], 0.f);
+            shift_adj[tw * C + c] = fmaf(sc, ctr, beta[c] - (float)m * sc);
+            mean_adj[tw * C + c] = (float)(m - (double)ctr);
+        } else if (tile_center != nullptr) {
+            const float ctr = tile_center[tw * C + c];
             shift_adj[tw * C + c] = fmaf(sc, ctr, beta[c] - (float)m * sc);
             mean_adj[tw * C + c] = (float)(m - (double)ctr);
         }
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ c1, const float* __restrict__ c2,
                                                                 int64_t wpt, int64_t L, int C, int P, T* __restrict__ du,
                                                                 float* __restrict__ part_a, const float* __restrict__ sp_dg,
-                                                                const int32_t* __restrict__ sp_idx) {
+                                                                const int32_t* __restrict__ sp_idx, const float* __restrict__ e_center = nullptr) {
     constexpr int VEC = Elem<T>::kVec;
     __shared__ __attribute__((aligned(16))) float red[256][VEC];
     const int tid = threadIdx.x;
@@ -564,13 +576,16 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
         const int cv = cvb + pl;
         const bool cok = cv < CV;
         const int c0 = cv * VEC;
-        float ka[VEC], kb[VEC], kc[VEC], acc[VEC], sgn[VEC];
+        float ka[VEC], kb[VEC], kc[VEC], acc[VEC], sgn[VEC], ectr[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             acc[i] = 0.f;
             ka[i] = kb[i] = kc[i] = 0.f;
             sgn[i] = 1.f;
+            ectr[i] = 0.f;
         }
+        // PAIRS with a centred extreme (vm_conv_fwd_fold e_center): e holds z - ctr, the other element z itself
+        if (PAIRS && e_center != nullptr && cok) loadv<VEC>(e_center + tw * C + c0, ectr);
         if (cok) {
             float sc[VEC], mu[VEC], is[VEC], dr[VEC], k1[VEC], k2[VEC];
             loadv<VEC>(scale + tw * C + c0, sc);
@@ -613,10 +628,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 Vec16<T> zv[POOL];
                 int nrows = POOL;
                 if (!FULL && q * POOL + POOL > L) nrows = (int)(L - q * POOL);
+                typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 second = (u16x8)0;   // PAIRS: 1 where the extreme is the pair's second element
                 if constexpr (PAIRS && sizeof(T) == 2 && POOL == 2) {
-                    typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
                     const Vec16<T> ev = load16<T>(z + (n * (Lq + 2) + 1 + q) * C + c0), ow = load16<T>(zo + (n * Lq + q) * C + c0);
                     const u16x8 eb = __builtin_bit_cast(u16x8, ev.v), ob = __builtin_bit_cast(u16x8, ow.v);
+                    second = ob >> 15;
                     const u16x8 m = (u16x8)0 - (ob >> 15), oa = ob & (uint16_t)0x7fff;  // m: 0xffff where the extreme is element 1
                     zv[0].v = __builtin_bit_cast(decltype(zv[0].v), (u16x8)((eb & ~m) | (oa & m)));
                     zv[1].v = __builtin_bit_cast(decltype(zv[1].v), (u16x8)((oa & ~m) | (eb & m)));
@@ -635,6 +652,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                     float zj[POOL];
 #pragma unroll
                     for (int j = 0; j < POOL; ++j) zj[j] = (FULL || j < nrows) ? zv[j].get(i) : 0.f;
+                    if constexpr (PAIRS && POOL == 2) {   // the stored extreme back to z (exact where relu clipped: -ctr + ctr)
+                        const bool s2 = second[i] != 0;
+                        zj[0] += s2 ? 0.f : ectr[i];
+                        zj[1] += s2 ? ectr[i] : 0.f;
+                    }
                     float ext = sgn[i] * zj[0];
                     int arg = 0;
 #pragma unroll
@@ -1114,19 +1136,20 @@ extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64
                               double count_per_tower, const float* gamma, const float* beta, float eps, float momentum,
                               int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
                               float* scale, float* shift, void* ws, float* zd_biased, float zd_correction, const float* center_bias,
-                              float* shift_adj, float* mean_adj, void* stream) {
+                              float* shift_adj, float* mean_adj, const float* tile_center, void* stream) {
     VM_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && invstd && scale && shift && ws, "vm_bn_finalize: null pointer");
-    VM_REQUIRE(center_bias == nullptr || (shift_adj && mean_adj), "vm_bn_finalize: center_bias needs shift_adj and mean_adj");
+    VM_REQUIRE((center_bias == nullptr && tile_center == nullptr) || (shift_adj && mean_adj), "vm_bn_finalize: center_bias / tile_center need shift_adj and mean_adj");
+    VM_REQUIRE(center_bias == nullptr || tile_center == nullptr, "vm_bn_finalize: center_bias and tile_center are exclusive");
     VM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "vm_bn_finalize: moving stats must both be set or NULL");
     VM_REQUIRE(rows_per_tower > 0 && n_towers > 0 && C > 0 && count_per_tower > 1.0, "vm_bn_finalize: bad sizes");
     VM_REQUIRE(zd_biased == nullptr || (moving_mean != nullptr && zd_correction >= 1.0f), "vm_bn_finalize: zero-debias needs the moving statistics and a correction >= 1");
     // stage 1 of the column sums, the statistics by the last workgroup of every channel block: one launch
     const FinBn<true> fin{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                          mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj};
+                          mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj, tile_center};
     if (!g_fuse_finalize || !launch_colreduce_fin(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
         launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
         const FinBn<false> f2{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                              mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj};
+                              mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj, tile_center};
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, f2);
     }
     return check_launch("vm_bn_finalize");
@@ -1347,7 +1370,7 @@ extern "C" int vm_bn_pool_bwd_apply(const void* z, const void* dp, const float* 
 extern "C" int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const void* dp, const float* scale, const float* shift,
                                           const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
                                           int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int dtype, void* du,
-                                          float* part_du, void* stream) {
+                                          float* part_du, const float* e_center, void* stream) {
     VM_REQUIRE(e && o && dp && scale && shift && mean && invstd && c1 && c2 && du && part_du, "vm_bn_pool_bwd_apply_pairs: null pointer");
     VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= 2 && !(L & 1) && C % 8 == 0, "vm_bn_pool_bwd_apply_pairs: L must be even, C % 8 == 0");
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool_bwd_apply_pairs: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
@@ -1355,7 +1378,7 @@ extern "C" int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const vo
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / 2, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)e, (const T*)o, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
-                           L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr);
+                           L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr, e_center);
     });
     return check_launch("vm_bn_pool_bwd_apply_pairs");
 }

@@ -202,6 +202,10 @@ struct NtArgs {
     // at; position 0 of a window has no tap 0 and position L - 1 no tap 2 (the SAME padding pads the BatchNorm OUTPUT with zeros), so
     // hb[0] / hb[2] come off there.
     const float* fold_hb = nullptr;
+    // ... and (f16 storage, (pool_e, pool_o) output) fold_ctr (towers, N): the tile is computed and stored CENTRED, t = relu(z) - ctr[co]
+    // with ctr >= 0 exactly representable in the storage type (row 3 of fold_hb then already has ctr taken off): what a 16-bit
+    // value spends its significand on is the distance from the pedestal, not the pedestal (vm_fold_bn_weights `ctr_out`)
+    const float* fold_ctr = nullptr;
     // ... per tower (BatchNorm statistics are per encoder call): windows [t * tower_windows, (t + 1) * tower_windows) use the weights at
     // bt + t * bt_tower_stride and the constants at fold_hb + t * 4 * N
     int64_t tower_windows = 0, bt_tower_stride = 0;

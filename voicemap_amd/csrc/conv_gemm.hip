@@ -530,12 +530,26 @@ struct N2DrainSync {   // the drain run by the four waves of a 256-thread workgr
 };
 
 template <typename T, int EPI>
-__device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int t0, int trows, int lane, int wm, int wn) {
+__device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int t0, int n0, int trows, int lane, int wm, int wn) {
     using namespace n2;
     const int r = lane & 31, kh = lane >> 5;
     constexpr bool FWD = EPI == EPI_FWD || EPI == EPI_FWD_FOLD;
     const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
+    // centred tile (fold_ctr): the accumulators hold z_pre - ctr (the start vector had ctr taken off), so ReLU is max(., -ctr) in fp32
+    // before the ONE rounding to the storage type
+    constexpr bool CAN_CENTRE = EPI == EPI_FWD_FOLD && std::is_same<T, f16>::value;
+    const bool ctrd = CAN_CENTRE && p.fold_ctr != nullptr;
+    f32x4 negc[2][4];
+    if (CAN_CENTRE && ctrd) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + wn * 64 + j * 32 + 8 * g + 4 * kh);
+                negc[j][g] = f32x4{-c[0], -c[1], -c[2], -c[3]};
+            }
+    }
     // ---- registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with it) and
     // ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0 included;
     // rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
@@ -549,10 +563,15 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
             for (int g = 0; g < 4; ++g) {
                 const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
                 T o[4];
+                if (CAN_CENTRE && ctrd) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
+                    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(fmaxf(acc[i][j][4 * g + e], negc[j][g][e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
+                }
                 u32x2 pk = *reinterpret_cast<const u32x2*>(o);
-                if (EPI != EPI_DGRAD) {
+                if (EPI != EPI_DGRAD && !(CAN_CENTRE && ctrd)) {
                     uint32_t lo = pk[0], hi = pk[1];
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
                     asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
@@ -659,6 +678,19 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             neg[2] = (g1[0] < 0.f ? 0xFFFFu : 0u) | (g1[1] < 0.f ? 0xFFFF0000u : 0u);
             neg[3] = (g1[2] < 0.f ? 0xFFFFu : 0u) | (g1[3] < 0.f ? 0xFFFF0000u : 0u);
         }
+        // centred tile (f16, fold_ctr): values may be negative -- the extreme by PACKED HALF max / min, and the pair is taken back to
+        // z = t + ctr (one packed add: exact where relu clipped, t = -ctr) for the "other" element, whose flag bit needs z >= 0
+        constexpr bool CAN_CENTRE = EPI == EPI_FWD_FOLD && std::is_same<T, f16>::value;
+        const bool ctrd = CAN_CENTRE && p.fold_ctr != nullptr;
+        u32x4 c16 = {0u, 0u, 0u, 0u};
+        if (CAN_CENTRE && ctrd) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + c8 * 8), q1 = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + c8 * 8 + 4);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            c16[0] = __builtin_bit_cast(uint32_t, h2{(_Float16)q0[0], (_Float16)q0[1]});
+            c16[1] = __builtin_bit_cast(uint32_t, h2{(_Float16)q0[2], (_Float16)q0[3]});
+            c16[2] = __builtin_bit_cast(uint32_t, h2{(_Float16)q1[0], (_Float16)q1[1]});
+            c16[3] = __builtin_bit_cast(uint32_t, h2{(_Float16)q1[2], (_Float16)q1[3]});
+        }
         const int vq = valid >> 1;
         T* ebase = p.pool_e + (n * (int64_t)(p.L / 2 + 2 * p.pool_e_pad) + p.pool_e_pad + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
         T* obase2 = p.pool_o + (n * (int64_t)(p.L / 2) + (t0 >> 1)) * (int64_t)p.N + n0 + c8 * 8;
@@ -675,19 +707,27 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             u32x4 o, oth;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const uint32_t a = r0[jj][d], b = r1[jj][d];
+                uint32_t a = r0[jj][d], b = r1[jj][d];
                 uint32_t mx, mn;
+                const uint32_t m = neg[d];
+                if (CAN_CENTRE && ctrd) {
+                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+                    asm("v_pk_min_f16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+                    o[d] = (mx & ~m) | (mn & m);                      // the CENTRED extreme: what block i + 1 reads
+                    asm("v_pk_add_f16 %0, %1, %2" : "=v"(a) : "v"(a), "v"(c16[d]));
+                    asm("v_pk_add_f16 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c16[d]));
+                }
                 asm("v_pk_max_i16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
                 asm("v_pk_min_i16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
-                const uint32_t m = neg[d];
-                o[d] = (mx & ~m) | (mn & m);
+                const uint32_t eu = (mx & ~m) | (mn & m);
+                if (!(CAN_CENTRE && ctrd)) o[d] = eu;
                 if (p.pool_o != nullptr) {
                     // the other element, flagged (bit 15) where the extreme is the pair's SECOND element: b > a where a maximum is
                     // taken, b < a for a minimum -- the sign of the 16-bit difference of two non-negative values; ties: the first
                     uint32_t d1, d2;
                     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d1) : "v"(a), "v"(b));
                     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d2) : "v"(b), "v"(a));
-                    oth[d] = (mx ^ mn ^ o[d]) | (((d1 & ~m) | (d2 & m)) & 0x80008000u);
+                    oth[d] = (mx ^ mn ^ eu) | (((d1 & ~m) | (d2 & m)) & 0x80008000u);
                 }
             }
             if (q < vq) {
@@ -860,7 +900,7 @@ template <typename T, int EPI>
 __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int64_t n, int tl, int t0, int n0, int trows,
                                    int tid, int lane, int w, int wm, int wn) {
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
-    n2_tile_write<T, EPI>(p, lds, acc, t0, trows, lane, wm, wn);
+    n2_tile_write<T, EPI>(p, lds, acc, t0, n0, trows, lane, wm, wn);
     __syncthreads();
     N2DrainSync bar;
     n2_tile_drain<T, EPI>(p, lds, n, tl, t0, n0, trows, tid, lane, w, bar);
@@ -954,6 +994,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
         const unsigned tw = nw / (unsigned)p.tower_windows;
         p.bt += tw * p.bt_tower_stride;
         p.fold_hb += tw * 4 * p.N;
+        if (p.fold_ctr != nullptr) p.fold_ctr += tw * p.N;
     }
     // forward: the bias loads go out first and are consumed (accumulator init) only after the prologue DMA has been issued
     f32x4 bias4[2][4];
@@ -1264,6 +1305,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     if constexpr (EPI == EPI_FWD_FOLD) {  // this window's tower: its folded weights and constants
         tw = nw / (unsigned)p.tower_windows;
         p.fold_hb += tw * 4 * p.N;
+        if (p.fold_ctr != nullptr) p.fold_ctr += tw * p.N;
     }
     if constexpr (EPI == EPI_FWD_FOLD) p.bias = p.fold_hb + 3 * p.N;  // row 3 of hb: bias + the three per-tap constants (vm_fold_bn_weights)
     // The wave's 64 bias values by SCALAR loads (the address is wave-uniform; a lane wants the 32 of its half kh).  As 8 vector loads
@@ -1722,8 +1764,11 @@ extern "C" int vm_conv_fwd_fold_supported(int64_t n_windows, int64_t L, int c_in
 
 extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const float* bias, const float* hb, const float* gamma,
                                 int64_t n_windows, int64_t windows_per_tower, int64_t L, int c_in, int c_out, int dtype, void* z,
-                                float* stat_sum, float* stat_sq, void* e, void* o, const void* wf_packed, void* stream) {
+                                float* stat_sum, float* stat_sq, void* e, void* o, const void* wf_packed, const float* e_center,
+                                void* stream) {
     VM_REQUIRE(in_e && wf_folded && bias && hb && stat_sum && stat_sq, "vm_conv_fwd_fold: null pointer");
+    VM_REQUIRE(e_center == nullptr || (dtype == VM_F16 && e != nullptr && o != nullptr),
+               "vm_conv_fwd_fold: a centred tile (e_center) needs VM_F16 storage and the (e, o) pair output");
     VM_REQUIRE(e == nullptr || gamma != nullptr, "vm_conv_fwd_fold: the pool extreme needs gamma (its sign picks max / min)");
     VM_REQUIRE(o == nullptr || e != nullptr, "vm_conv_fwd_fold: o (the other element of each pair) goes with e");
     VM_REQUIRE(z != nullptr || o != nullptr, "vm_conv_fwd_fold: z may only be NULL when (e, o) carry the output");
@@ -1744,6 +1789,7 @@ extern "C" int vm_conv_fwd_fold(const void* in_e, const void* wf_folded, const f
         a.pool_o = (T*)o;
         a.pool_e_pad = 1;
         a.bt_packed = (const T*)wf_packed;
+        a.fold_ctr = e_center;
         launch_n2r<T, EPI_FWD_FOLD>(a, n_windows, (hipStream_t)stream);
     });
     return check_launch("vm_conv_fwd_fold");

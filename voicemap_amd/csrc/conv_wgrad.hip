@@ -1147,7 +1147,8 @@ extern "C" int vm_conv_wgrad_fold(const void* in_e, const void* du, int64_t n_wi
 template <typename T>
 __global__ __launch_bounds__(256) void fold_bn_weights_kernel(const float* __restrict__ wt, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ bias, int c_in,
-                                                              int c_out, T* __restrict__ wf, T* __restrict__ wfp, float* __restrict__ hb) {
+                                                              int c_out, T* __restrict__ wf, T* __restrict__ wfp, float* __restrict__ hb,
+                                                              float* __restrict__ ctr_out) {
     const int lane = threadIdx.x & 63, co = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t = blockIdx.y;
     if (co >= c_out) return;
@@ -1195,12 +1196,21 @@ __global__ __launch_bounds__(256) void fold_bn_weights_kernel(const float* __res
         h[0] = f0;
         h[c_out] = f1;
         h[2 * c_out] = f2;
-        h[3 * c_out] = bias[co] + ((f0 + f1) + f2);   // the sum conv_nt2r_kernel used to form per lane
+        const float start = bias[co] + ((f0 + f1) + f2);   // the sum conv_nt2r_kernel used to form per lane
+        if (ctr_out != nullptr) {
+            // the centre of this channel's tile (vm_conv_fwd_fold `e_center`): the pedestal the accumulators start from, where it is
+            // positive, rounded to the storage type so that relu's clip value -ctr and z = t + ctr are exact
+            const float ctr = (float)(T)fmaxf(start, 0.f);
+            ctr_out[(int64_t)t * c_out + co] = ctr;
+            h[3 * c_out] = start - ctr;
+        } else {
+            h[3 * c_out] = start;
+        }
     }
 }
 
 extern "C" int vm_fold_bn_weights(const float* wt, const float* scale, const float* shift, const float* bias, int towers, int c_in,
-                                  int c_out, int dtype, void* wf_folded, void* wf_packed, float* hb, void* stream) {
+                                  int c_out, int dtype, void* wf_folded, void* wf_packed, float* hb, float* ctr_out, void* stream) {
     VM_REQUIRE(wt && scale && shift && bias && hb && (wf_folded || wf_packed), "vm_fold_bn_weights: null pointer");
     VM_REQUIRE(c_in > 0 && c_out > 0 && towers > 0 && towers < 65536, "vm_fold_bn_weights: bad sizes");
     VM_REQUIRE(c_in % 8 == 0, "vm_fold_bn_weights: c_in must be a multiple of 8 (got %d)", c_in);
@@ -1209,7 +1219,7 @@ extern "C" int vm_fold_bn_weights(const float* wt, const float* scale, const flo
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_fold_bn_weights: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     VM_DISPATCH_16(dtype, {
         hipLaunchKernelGGL((fold_bn_weights_kernel<T>), dim3((unsigned)cdiv(c_out, 4), (unsigned)towers), dim3(256), 0,
-                           (hipStream_t)stream, wt, scale, shift, bias, c_in, c_out, (T*)wf_folded, (T*)wf_packed, hb);
+                           (hipStream_t)stream, wt, scale, shift, bias, c_in, c_out, (T*)wf_folded, (T*)wf_packed, hb, ctr_out);
     });
     return check_launch("vm_fold_bn_weights");
 }

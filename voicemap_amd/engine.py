@@ -260,6 +260,10 @@ class HipEncoderEngine:
         # ... and the folded convs leave (extreme, other element + position flag) instead of (z, extreme): same bytes as a plain
         # forward epilogue, the BatchNorm-backward apply pass reads the pair form (vm_bn_pool_bwd_apply_pairs)
         self.fold_pairs = True
+        # f16 storage, round 5: the folded blocks listed here (0-based) compute and store their tile CENTRED on the per-channel pedestal
+        # max(start, 0) their accumulators start from (vm_fold_bn_weights ctr_out -> vm_conv_fwd_fold e_center).  Block 2 (index 1): its
+        # input is block 1's output, whose variance can sit under BatchNorm's epsilon, so a channel can be pedestal 10 x spread
+        self.center_blocks = (1,)
         self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
@@ -713,7 +717,7 @@ class HipEncoderEngine:
             b["act"] = torch.zeros(n_windows, ls[i + 1] + 2, c, dtype=tdt, device=dev)  # halo rows stay zero
             rows = self.lib.query("vm_conv1_stat_rows" if i == 0 else "vm_conv_stat_rows", L)
             b["stat_rows"] = rows
-            for nm in ("mean", "invstd", "scale", "shift", "c1", "c2") + (("shift_c", "mean_c") if i == 0 else ()):
+            for nm in ("mean", "invstd", "scale", "shift", "c1", "c2") + (("shift_c", "mean_c", "ctr") if i < self.nb - 1 else ()):
                 b[nm] = torch.zeros(2, c, dtype=f32, device=dev)
             if training:
                 b["ssum"] = torch.empty(n_windows * rows, c, dtype=f32, device=dev)
@@ -934,9 +938,12 @@ class HipEncoderEngine:
                 if self.sync_bn:
                     s_sum, s_sq = self._sync_rows(("fwd", i, tw0), ssum, ssq, wpt * rows, ntw, c, 1, _p(cr_ws), st)
                     s_rows, s_cnt = 1, float(wpt * L) * self.sync_bn_world
+                tile_ctr = bool(b.get("ctr_now")) and i > 0   # this block's tile (statistics and stored extreme) is centred: vm_conv_fwd_fold e_center
+                adj = centred or tile_ctr
                 self._call("vm_bn_finalize", s_sum, s_sq, s_rows, ntw, c, s_cnt, gam, bet, self.bn_eps, self.bn_momentum,
                            int(self.unbiased), m_, v_, T(b["mean"]), T(b["invstd"]), T(b["scale"]), T(b["shift"]), _p(cr_ws), zd, zc,
-                           bias if centred else None, T(b["shift_c"]) if centred else None, T(b["mean_c"]) if centred else None, st)
+                           bias if centred else None, T(b["shift_c"]) if adj else None, T(b["mean_c"]) if adj else None,
+                           T(b["ctr"]) if tile_ctr else None, st)
                 if zd is None and first_of_two:
                     self._record(pl["tower_ev"][i])
 
@@ -975,7 +982,7 @@ class HipEncoderEngine:
                     self._call("vm_conv_fwd_pool", W(pl[i - 1]["act"]), _p(self.wf[i]), bias, _p(b["scale"]), _p(b["shift"]), nw, L, cin,
                                c, dt, W(b["act"]), _p(self.wfp.get(i)) if self.packed_weights else None, st)
                     continue
-                b["e_now"] = b["pairs_now"] = False
+                b["e_now"] = b["pairs_now"] = b["ctr_now"] = False
                 if fold:
                     # the BatchNorm affine of the block below (this tower's) goes into this block's weights, the conv reads that
                     # block's pool extreme and leaves its own; no pass in between
@@ -983,15 +990,19 @@ class HipEncoderEngine:
                     wfo, hbo, wfp = self._fold_bufs(i)
                     with_e = i < self.nb - 1
                     use_packed = wfp is not None and self.packed_weights
-                    # (block 2 reads block 1's CENTRED extreme: the shift over the stored value)
-                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift_c" if (i == 1 and self.fuse_block1) else "shift"]),
-                               bias, ntw, cin, c, dt,
-                               wfo[tw0].data_ptr(), wfp[tw0].data_ptr() if use_packed else None, hbo[tw0].data_ptr(), st)
+                    # (a block whose input extreme is stored CENTRED -- block 1's always, a centred tile's below -- folds the shift over
+                    # the stored value)
+                    lo_c = (i == 1 and self.fuse_block1) or bool(lo.get("ctr_now"))
                     pairs = with_e and self.fold_pairs
+                    # f16: this block's own tile centred on the pedestal its accumulators start from (round 5)
+                    ctr = T(b["ctr"]) if (pairs and dt == VM_F16 and i in self.center_blocks) else None
+                    self._call("vm_fold_bn_weights", _p(self.wt[i]), T(lo["scale"]), T(lo["shift_c" if lo_c else "shift"]),
+                               bias, ntw, cin, c, dt,
+                               wfo[tw0].data_ptr(), wfp[tw0].data_ptr() if use_packed else None, hbo[tw0].data_ptr(), ctr, st)
                     self._call("vm_conv_fwd_fold", W(lo["ep"]), wfo[tw0].data_ptr(), bias, hbo[tw0].data_ptr(), gam if with_e else None,
                                nw, wpt, L, cin, c, dt, None if pairs else W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None,
-                               W(b["o"]) if pairs else None, wfp[tw0].data_ptr() if use_packed else None, st)
-                    b["e_now"], b["pairs_now"] = with_e, pairs
+                               W(b["o"]) if pairs else None, wfp[tw0].data_ptr() if use_packed else None, ctr, st)
+                    b["e_now"], b["pairs_now"], b["ctr_now"] = with_e, pairs, ctr is not None
                     if with_e:
                         finalize()
                         continue
@@ -1124,13 +1135,13 @@ class HipEncoderEngine:
             elif b.get("bnred_now") and self.fused_sums_finalize and not self.sync_bn:
                 self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None if b.get("pairs_now") else _p(b["z"]),
                            _p(b["dp"]), _p(b["scale"]),
-                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
+                           _p(b["shift"]), _p(b["mean_c" if b.get("ctr_now") else "mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
                            float(wpt * L), _p(b["c1"]), _p(b["c2"]), _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)),
                            _p(pl["cr_ws"]), st)
                 fused_fin = True
             elif b.get("bnred_now"):
                 self._call("vm_bn_bwd_from_sums", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], _p(b["z"]), _p(b["dp"]), _p(b["scale"]),
-                           _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
+                           _p(b["shift"]), _p(b["mean_c" if b.get("ctr_now") else "mean"]), _p(b["invstd"]), dm, n, wpt, L, c, pool, dt, 0 if b.get("e_now") else 1,
                            _p(b["pa"]), _p(b["pb"]), st)
             elif self.pooled_reduce and L % pool == 0:
                 # throughput mode: the pool-window extreme comes from this block's pooled output (= the next block's input),
@@ -1144,7 +1155,7 @@ class HipEncoderEngine:
                                       _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
             if b.get("pairs_now") and not sparse:
                 self._call("vm_bn_pool_bwd_apply_pairs", _p(b["ep"]), _p(b["o"]), *common[1:], _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, dt,
-                           _p(b["du"]), _p(b["pdu"]), st)
+                           _p(b["du"]), _p(b["pdu"]), _p(b["ctr"]) if b.get("ctr_now") else None, st)
             else:
                 self._call("vm_bn_pool_bwd_apply_gmax" if sparse else "vm_bn_pool_bwd_apply", *common, _p(b["c1"]), _p(b["c2"]), n,
                            wpt, L, c, pool, dt, _p(b["du"]), _p(b["pdu"]), st)
@@ -1162,7 +1173,7 @@ class HipEncoderEngine:
                                _p(b["wgrad_ws_fold"]), None, stream)
                     self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), stream)
                     self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]),
-                               _p(lo["shift_c" if (i == 1 and self.fuse_block1) else "shift"]), _p(b["dsum"]), gw, stream)
+                               _p(lo["shift_c" if ((i == 1 and self.fuse_block1) or lo.get("ctr_now")) else "shift"]), _p(b["dsum"]), gw, stream)
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, stream)
                     self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(cr_ws), stream)
@@ -1336,7 +1347,7 @@ class HipEncoderEngine:
                 self.overlap_wgrad, self.wgrad_after_dgrad, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
-                self.grad_prescale, self.fused_infer_pool, self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
+                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
 
     def _train_step(self, pl: dict, wpt: int, target: torch.Tensor, loss: Optional[str], drop_masks, apply_update: bool, pre):
         """preprocess (``pre`` = None | ("raw", tensor, downsampling, whitening) | ("offsets", audio, offsets, raw_len, downsampling,

@@ -361,7 +361,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 zd, zc = self._zd(i)
                 self._call("vm_bn_finalize", ssum, ssq, stat_rows_per_tower, n_towers, c, float(wpt * L), gam, bet, self.bn_eps,
                            self.bn_momentum, int(self.unbiased), mm, mv, _p(b["mean"]), _p(b["invstd"]), _p(b["scale"]), _p(b["shift"]),
-                           _p(pl["cr_ws"]), zd, zc, None, None, None, st)
+                           _p(pl["cr_ws"]), zd, zc, None, None, None, None, st)
             else:
                 self._call("vm_bn_infer_affine", gam, bet, mm, mv, self.bn_eps, c, _p(b["scale"]), _p(b["shift"]), st)
             dm = None
