@@ -714,15 +714,15 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
 
 def oracle_referenced_figures(dtype):
     """Embedding error of storage mode ``dtype`` against the CPU ORACLE in three states, read from the parity report the -m gpu tests
-    wrote (profiles/r04_parity_report.csv, committed; the run that produced it is named there): the bench batch at fresh-init weights
+    wrote (profiles/r05_parity_report.csv, committed; the run that produced it is named there): the bench batch at fresh-init weights
     (tests/test_gpu_fullsize_oracle.py), the same batch at a trained-like BatchNorm / bias state, and the reference's shipped
     checkpoint on its own 8 LibriSpeech clips in training mode (tests/test_gpu_golden_step.py).  ``meets_1e-3`` per state."""
     want = {"full_size_oracle[%s]" % dtype: ("emb_rel_err_vs_fp64_oracle", "bench_batch_fresh_init"),
             "full_size_oracle_trained_state[%s]" % dtype: ("emb_rel_err_vs_fp32_oracle", "bench_batch_trained_like_batchnorm_and_bias_state"),
             "golden_step_cfgCK_real_clips[%s]" % dtype: ("emb_rel_err", "reference_checkpoint_on_its_8_librispeech_clips_training_mode")}
-    out = {"source": "profiles/r04_parity_report.csv (tests/test_gpu_fullsize_oracle.py, tests/test_gpu_golden_step.py on an MI355X; NOT this run)"}
+    out = {"source": "profiles/r05_parity_report.csv (tests/test_gpu_fullsize_oracle.py, tests/test_gpu_golden_step.py on an MI355X; NOT this run)"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_parity_report.csv")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_parity_report.csv")) as f:
             for line in f:
                 parts = line.strip().split(",")
                 if len(parts) == 3 and parts[0] in want and parts[1] == want[parts[0]][0]:

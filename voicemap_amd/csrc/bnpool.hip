@@ -13,6 +13,10 @@
 
 #include "common.hpp"
 
+#ifndef VM_APPLY_TWO_GROUPS
+#define VM_APPLY_TWO_GROUPS 1   // experiment builds: tools/build_variant.sh <name> -DVM_APPLY_TWO_GROUPS=0 bnpool.hip
+#endif
+
 namespace vm {
 
 constexpr int BN_SEG = 8;  // partial-sum rows per window (the layout of every part_* tensor)
@@ -622,8 +626,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
             }
         }
         if (cok) {
-            // FULL: a whole pool group with its dp row (every group when L % POOL == 0) -- no row-count predicates
-            auto body = [&](int64_t q, auto full_c) {
+            // FULL: a whole pool group with its dp row (every group when L % POOL == 0) -- no row-count predicates.
+            // ``pre``: the group's (e, o, dp) vectors were loaded by the caller (the pair form keeps two groups in flight)
+            auto body = [&](int64_t q, auto full_c, const Vec16<T>* pre) {
                 constexpr bool FULL = decltype(full_c)::value;
                 Vec16<T> zv[POOL];
                 int nrows = POOL;
@@ -631,7 +636,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
                 u16x8 second = (u16x8)0;   // PAIRS: 1 where the extreme is the pair's second element
                 if constexpr (PAIRS && sizeof(T) == 2 && POOL == 2) {
-                    const Vec16<T> ev = load16<T>(z + (n * (Lq + 2) + 1 + q) * C + c0), ow = load16<T>(zo + (n * Lq + q) * C + c0);
+                    const Vec16<T> ev = pre ? pre[0] : load16<T>(z + (n * (Lq + 2) + 1 + q) * C + c0);
+                    const Vec16<T> ow = pre ? pre[1] : load16<T>(zo + (n * Lq + q) * C + c0);
                     const u16x8 eb = __builtin_bit_cast(u16x8, ev.v), ob = __builtin_bit_cast(u16x8, ow.v);
                     second = ob >> 15;
                     const u16x8 m = (u16x8)0 - (ob >> 15), oa = ob & (uint16_t)0x7fff;  // m: 0xffff where the extreme is element 1
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 }
                 const bool has_dp = FULL || q < Lq;
                 Vec16<T> dv;
-                if (!SP && has_dp) dv = load16<T>(dp + (n * Lq + q) * C + c0);
+                if (!SP && has_dp) dv = pre ? pre[2] : load16<T>(dp + (n * Lq + q) * C + c0);
                 Vec16<T> ov[POOL];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -684,8 +690,25 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                     if (FULL || j < nrows) store16<T>(op + j * C, ov[j]);
             };
             int64_t q = seg + (int64_t)rl * gridDim.y;
-            for (; q < Lq; q += (int64_t)RP * gridDim.y) body(q, std::true_type{});
-            if (q < Q) body(q, std::false_type{});  // the remainder rows of a floor pool (q == Lq)
+            const int64_t qs = (int64_t)RP * gridDim.y;
+            if constexpr (VM_APPLY_TWO_GROUPS && PAIRS && !SP && sizeof(T) == 2 && POOL == 2) {
+                // NG pool groups in flight per thread: 3 NG 16-byte loads before the first is consumed (the pass is a pure stream:
+                // 4.5 TB/s with three).  Same groups in the same order: bit-identical
+                constexpr int NG = VM_APPLY_TWO_GROUPS == 1 ? 2 : VM_APPLY_TWO_GROUPS;
+                for (; q + (NG - 1) * qs < Lq; q += NG * qs) {
+                    Vec16<T> a[NG][3];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        a[g][0] = load16<T>(z + (n * (Lq + 2) + 1 + q + g * qs) * C + c0);
+                        a[g][1] = load16<T>(zo + (n * Lq + q + g * qs) * C + c0);
+                        a[g][2] = load16<T>(dp + (n * Lq + q + g * qs) * C + c0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) body(q + g * qs, std::true_type{}, a[g]);
+                }
+            }
+            for (; q < Lq; q += qs) body(q, std::true_type{}, nullptr);
+            if (q < Q) body(q, std::false_type{}, nullptr);  // the remainder rows of a floor pool (q == Lq)
         }
         // reduce over the RP row lanes
 #pragma unroll

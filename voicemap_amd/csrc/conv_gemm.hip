@@ -530,7 +530,8 @@ struct N2DrainSync {   // the drain run by the four waves of a 256-thread workgr
 };
 
 template <typename T, int EPI>
-__device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int t0, int n0, int trows, int lane, int wm, int wn) {
+__device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int t0, int n0, int trows, int lane, int wm, int wn,
+                                     const f32x4 (&negc)[2][4]) {
     using namespace n2;
     const int r = lane & 31, kh = lane >> 5;
     constexpr bool FWD = EPI == EPI_FWD || EPI == EPI_FWD_FOLD;
@@ -538,18 +539,9 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
     // centred tile (fold_ctr): the accumulators hold z_pre - ctr (the start vector had ctr taken off), so ReLU is max(., -ctr) in fp32
     // before the ONE rounding to the storage type
+    // (negc = -ctr of this lane's 32 channels, loaded by n2_epilogue in front of its first barrier)
     constexpr bool CAN_CENTRE = EPI == EPI_FWD_FOLD && std::is_same<T, f16>::value;
     const bool ctrd = CAN_CENTRE && p.fold_ctr != nullptr;
-    f32x4 negc[2][4];
-    if (CAN_CENTRE && ctrd) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + wn * 64 + j * 32 + 8 * g + 4 * kh);
-                negc[j][g] = f32x4{-c[0], -c[1], -c[2], -c[3]};
-            }
-    }
     // ---- registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with it) and
     // ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0 included;
     // rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
@@ -899,8 +891,20 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
 template <typename T, int EPI>
 __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int64_t n, int tl, int t0, int n0, int trows,
                                    int tid, int lane, int w, int wm, int wn) {
+    f32x4 negc[2][4];
+    if constexpr (EPI == EPI_FWD_FOLD && std::is_same<T, f16>::value) {
+        if (p.fold_ctr != nullptr) {   // issued here: the barrier below hides their latency
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+                    negc[j][g] = f32x4{-c[0], -c[1], -c[2], -c[3]};
+                }
+        }
+    }
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
-    n2_tile_write<T, EPI>(p, lds, acc, t0, n0, trows, lane, wm, wn);
+    n2_tile_write<T, EPI>(p, lds, acc, t0, n0, trows, lane, wm, wn, negc);
     __syncthreads();
     N2DrainSync bar;
     n2_tile_drain<T, EPI>(p, lds, n, tl, t0, n0, trows, tid, lane, w, bar);
