@@ -82,9 +82,11 @@ int vm_stream_wait_event(void* stream, void* event);
  *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA tile (default 1), else
  *   "tn9" 0|1         ... with the free-running K loop (conv_tn9_kernel, default 1) or the READ / MFMA slots (conv_tn8x_kernel)
  *   "tn_tile" 128|256 the tile of the register-transposing wgrad kernels (default 256 where the layer is wide enough)
- *   "fuse_finalize" 0|1   the two-stage column reductions (vm_bn_finalize, vm_bn_bwd_finalize, vm_bn_bwd_from_sums_finalize, vm_colsum*,
- *                     vm_du_tower_sums) as ONE launch whose last-arriving workgroup per channel block runs the finalize (default 1) or as
- *                     the stage-1 launch + the finalize launch (0); bit-identical
+ *   "fuse_finalize" mask 0..31   which two-stage column reductions finish inside their stage-1 launch (the last-arriving workgroup of
+ *                     a channel block runs the finalize; bit-identical to the two launches): bit 0 vm_bn_finalize, bit 1
+ *                     vm_bn_bwd_finalize / vm_bn_bwd_from_sums_finalize, bit 2 vm_colsum*, bit 3 vm_du_tower_sums, bit 4 = only where
+ *                     the reduction is narrow and short (C <= 128, <= 4096 rows per tower).  Default 17: the statistics of small
+ *                     layers -- a saved launch pays only there (measurements in bnpool.hip)
  *   "f1_blocks", "f1_fwd_blocks"   target workgroup counts of the fused block-1 kernels (launch geometry; the fp32 partial sums of a
  *                     window are grouped differently, i.e. results change in the last bits). */
 int vm_set_tuning(const char* key, int value);

@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 BLOCKS = [(32, 16, 4), (3, 32, 2), (3, 48, 2), (3, 64, 2)]
+DEFAULT_FUSE = 17  # the library's default vm_set_tuning("fuse_finalize") mask
 
 
 def _engines(head, dtype, dropout, **kw):
@@ -148,7 +149,7 @@ def test_last_arriver_finalize_equals_the_two_launch_form(dtype, dropout, filter
                 (r.random((pairs, 1)) > 0.5).astype(np.float32)) for _ in range(5)]
     states = []
     try:
-        for fuse in (0, 1):
+        for fuse in (0, 15):
             lib.call("vm_set_tuning", b"fuse_finalize", fuse)
             eng = HipEncoderEngine(blocks, 32, dropout=dropout, head="uniform_euclidean", dtype=dtype, seed=9)
             outs = []
@@ -158,7 +159,7 @@ def test_last_arriver_finalize_equals_the_two_launch_form(dtype, dropout, filter
                 outs.append(pl["loss_acc"].clone())
             states.append((eng, outs))
     finally:
-        lib.call("vm_set_tuning", b"fuse_finalize", 1)
+        lib.call("vm_set_tuning", b"fuse_finalize", DEFAULT_FUSE)
     (a, oa), (b, ob) = states
     for u, v in zip(oa, ob):
         assert torch.equal(u, v)

@@ -293,8 +293,10 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
         # this untrained net maps the four clips to nearly the same point: the whole gradient has norm 1.5e-6 and the activation
         # gradients are 1e-10 -- the default scale (4096) leaves them under half's range (first-layer gradient 58 % off; 11 % at 2^16,
         # 5.5 % from 2^20 on: tools/probe/f16_loss_scale_probe.py).  A training loop gets there by itself (the engine multiplies the
-        # scale by 8 per poll while the scaled gradient norm is under 64, tests/test_gpu_e2e.py); this is ONE step, so it is set.
-        eng.loss_scale = 2.0 ** 20
+        # scale by 8 per poll while the scaled gradient norm is under 64, tests/test_gpu_e2e.py); this is ONE step from a cold start,
+        # so the same search is run synchronously first (no hand-set scale)
+        eng.calibrate_loss_scale(lambda: eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None, apply_update=False))
+        assert eng.loss_scale >= 2.0 ** 18
     masks = None
     m1 = m2 = None
     if drop > 0:

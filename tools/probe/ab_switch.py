@@ -23,6 +23,13 @@ y = torch.cat([torch.zeros(pairs // 2), torch.ones(pairs - pairs // 2)]).cuda()
 pl = eng.plan(2 * pairs, 12000, True)
 
 
+def set_value(v):
+    if attr.startswith("tune:"):       # a kernel-selection knob of the library (vm_set_tuning) instead of an engine attribute
+        eng.lib.call("vm_set_tuning", attr[5:].encode(), int(v))
+    else:
+        setattr(eng, attr, v)
+
+
 def block(k=40):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -34,11 +41,11 @@ def block(k=40):
 
 res = {0: [], 1: []}
 for i, v in enumerate((va, vb)):
-    setattr(eng, attr, v)
+    set_value(v)
     block(10)
 for rep in range(7):
     for i, v in enumerate((va, vb)):
-        setattr(eng, attr, v)
+        set_value(v)
         res[i].append(block())
 print("%s %d pairs  %s=%r: %.3f ms   %s=%r: %.3f ms   (all: %s | %s)" % (name, pairs, attr, va, float(np.median(res[0])), attr, vb, float(np.median(res[1])),
       " ".join("%.3f" % t for t in res[0]), " ".join("%.3f" % t for t in res[1])))

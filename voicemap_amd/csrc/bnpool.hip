@@ -78,7 +78,15 @@ constexpr int CR_CHUNKS = 32;
 // Same partials, same stage-2 butterfly: bit-identical to the two-launch form.
 // Tickets: a library-owned pool of zero-initialised words; a launch takes a fresh range (round robin -- far more words than launches
 // in flight), the last arriver puts its word back to zero.  The only mutable device state of the library.
-int g_fuse_finalize = 1;   // vm_set_tuning("fuse_finalize", 0 | 1): 0 = the two-launch form (the tests compare the two bit for bit)
+// vm_set_tuning("fuse_finalize", mask): which two-stage reductions finish in their stage-1 launch -- bit 0 the BatchNorm statistics
+// (vm_bn_finalize), bit 1 the BatchNorm-backward sums (vm_bn_bwd_finalize, vm_bn_bwd_from_sums_finalize), bit 2 plain column sums
+// (vm_colsum*), bit 3 vm_du_tower_sums, bit 4: only where the reduction is small (C <= 128 and <= 4096 rows per tower); 0 = the
+// two-launch form everywhere (the tests compare 0 with 15 bit for bit).  Measured (interleaved on one box, ms per step; cfg-A 128 pairs
+// / cfg-B 32 pairs): bit 0 2.645 -> 2.667 / 0.503 -> 0.496; bit 1 2.650 -> 2.656 / 0.503 -> 0.506; bit 2 no change; bit 3 2.644 ->
+// 2.669 / (not on its path): the last workgroup finalises 64 channels in two dependent passes of write-through loads where the
+// finalize launch spreads them over C / 8 workgroups reading from L2 -- a launch saved (~5 us) only pays where the layer is narrow.
+// Default: the statistics of narrow, short reductions (the reference's cfg-B at its own batch), nothing else.
+int g_fuse_finalize = 17;
 constexpr int TICKET_WORDS = 16384;
 __device__ unsigned g_tickets[TICKET_WORDS];
 static unsigned* ticket_range(int n) {
@@ -1169,7 +1177,8 @@ extern "C" int vm_bn_finalize(const float* stat_sum, const float* stat_sq, int64
     // stage 1 of the column sums, the statistics by the last workgroup of every channel block: one launch
     const FinBn<true> fin{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
                           mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj, tile_center};
-    if (!g_fuse_finalize || !launch_colreduce_fin(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
+    const bool small = C <= 128 && rows_per_tower <= 4096;
+    if (!(g_fuse_finalize & 1) || ((g_fuse_finalize & 16) && !small) || !launch_colreduce_fin(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
         launch_colreduce(stat_sum, stat_sq, rows_per_tower, C, n_towers, (double*)ws, (hipStream_t)stream);
         const FinBn<false> f2{n_towers, C, count_per_tower, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
                               mean, invstd, scale, shift, zd_biased, zd_correction, center_bias, shift_adj, mean_adj, tile_center};
@@ -1324,7 +1333,7 @@ extern "C" int vm_bn_bwd_finalize(const float* part_dy, const float* part_dyz, i
                "vm_bn_bwd_finalize: n_windows must be a multiple of windows_per_tower");
     const int n_towers = (int)(n_windows / windows_per_tower);
     const FinBnBwd<true> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
-    if (!g_fuse_finalize ||
+    if (!(g_fuse_finalize & 2) ||
         !launch_colreduce_fin(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream, fin)) {
         launch_colreduce(part_dy, part_dyz, windows_per_tower * BN_SEG, C, n_towers, (double*)ws, (hipStream_t)stream);
         const FinBnBwd<false> f2{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
@@ -1345,7 +1354,7 @@ extern "C" int vm_bn_bwd_from_sums_finalize(const float* s0, const float* sa, in
                    C > 0,
                "vm_bn_bwd_from_sums_finalize: bad sizes");
     const int n_towers = (int)(n_windows / windows_per_tower);
-    unsigned* tickets = g_fuse_finalize ? ticket_range((C + 63) / 64) : nullptr;
+    unsigned* tickets = (g_fuse_finalize & 2) ? ticket_range((C + 63) / 64) : nullptr;
     const FinBnBwd<true> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
     VM_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((bn_bwd_sums_stage1_kernel<T>), dim3((C + 63) / 64, n_towers * CR_CHUNKS), dim3(1024), 0, (hipStream_t)stream, s0,
@@ -1423,7 +1432,7 @@ extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_
     const int towers = (int)(n_windows / windows_per_tower);
     VM_DISPATCH_DTYPE(dtype, {
         const FinDuTower<T, true> fin{(const T*)du, towers, windows_per_tower, L, C, grad_b, dsum};
-        if (!g_fuse_finalize ||
+        if (!(g_fuse_finalize & 8) ||
             !launch_colreduce_fin(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream, fin)) {
             launch_colreduce(part_du, nullptr, windows_per_tower * (int64_t)BN_SEG, C, towers, (double*)ws, (hipStream_t)stream);
             const FinDuTower<T, false> f2{(const T*)du, towers, windows_per_tower, L, C, grad_b, dsum};
@@ -1440,7 +1449,7 @@ extern "C" int vm_bn_part_rows_used(int64_t L, int C, int pool, int dtype) {
 
 extern "C" int vm_colsum_strided(const float* part, int64_t rows, int row_step, int C, float* out, void* ws, void* stream) {
     VM_REQUIRE(part && out && ws && rows > 0 && row_step >= 1 && C > 0, "vm_colsum_strided: bad argument");
-    if (!g_fuse_finalize || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out}, row_step)) {
+    if (!(g_fuse_finalize & 4) || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out}, row_step)) {
         launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, row_step);
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, FinColsum<false>{C, out});
     }
@@ -1449,7 +1458,7 @@ extern "C" int vm_colsum_strided(const float* part, int64_t rows, int row_step, 
 
 extern "C" int vm_colsum(const float* part, int64_t rows, int C, float* out, void* ws, void* stream) {
     VM_REQUIRE(part && out && ws && rows > 0 && C > 0, "vm_colsum: bad argument");
-    if (!g_fuse_finalize || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out})) {
+    if (!(g_fuse_finalize & 4) || !launch_colreduce_fin(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream, FinColsum<true>{C, out})) {
         launch_colreduce(part, nullptr, rows, C, 1, (double*)ws, (hipStream_t)stream);
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const double*)ws, FinColsum<false>{C, out});
     }

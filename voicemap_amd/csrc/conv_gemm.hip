@@ -1908,7 +1908,7 @@ extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int*
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"fuse_finalize", &g_fuse_finalize, 0, 1}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"fuse_finalize", &g_fuse_finalize, 0, 31}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;

@@ -587,6 +587,24 @@ class HipEncoderEngine:
                 self._clean_checks = 0
         return self.loss_scale
 
+    def calibrate_loss_scale(self, run_backward, max_rounds: int = 8) -> float:
+        """The norm-driven part of the loss-scale search, synchronously: ``run_backward()`` runs one forward + backward (no update)
+        and leaves the scaled gradient in G; while its norm (as Adam will see it after grad_prescale) is under ``scale_norm_low`` the
+        scale is multiplied by 8 -- what ``_poll_loss_scale`` does every ``scale_poll_every`` steps of a training loop -- and halved
+        on an overflow.  For callers that take ONE step from a cold start (tests, a first evaluation of gradients)."""
+        if not self.loss_scaled:
+            return 1.0
+        for _ in range(max_rounds):
+            run_backward()
+            g = float(self.G.double().norm().item()) * float(self.grad_prescale)
+            if not math.isfinite(g):
+                self.loss_scale = max(self.loss_scale / 2.0, self.scale_min)
+            elif 0.0 < g < self.scale_norm_low and self.loss_scale < self.scale_max:
+                self.loss_scale = min(self.loss_scale * 8.0, self.scale_max)
+            else:
+                break
+        return self.loss_scale
+
     def _poll_loss_scale(self):
         """Called once per optimizer step (f16 storage).  Step k with k % scale_poll_every == 0 enqueues a copy of the device's skip
         count to pinned memory; step k + scale_poll_lag consumes it."""
