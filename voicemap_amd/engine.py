@@ -159,6 +159,7 @@ class HipEncoderEngine:
     _stream_stack = ()
     replay = False
     fused_tail = False
+    _packed_weights = False
 
     def __init__(self, blocks: Sequence[Tuple[int, int, int]], embedding_dimension: int, dropout: float = 0.05,
                  head: Optional[str] = None, num_classes: int = 0, dtype: str = DEFAULT_DTYPE, device="cuda",
@@ -639,6 +640,23 @@ class HipEncoderEngine:
                 ev = torch.cuda.Event()
                 ev.record()
             self._poll = (k, ev)
+
+    @property
+    def packed_weights(self):
+        return self._packed_weights
+
+    @packed_weights.setter
+    def packed_weights(self, v):
+        """conv_nt3_kernel's fragment-order weight copies on / off.  Turning them on later (bench.py --tune, a test) re-derives every
+        copy and drops what cached the decision (the folded-weight buffers, the pack argument tables): no stale or uninitialised
+        packed operand can reach a kernel."""
+        changed = bool(v) != getattr(self, "_packed_weights", None)
+        self._packed_weights = bool(v)
+        if changed and hasattr(self, "_plans"):   # (during __init__ the copies are made by init_params -> refresh_weights)
+            self._fold = {}
+            self._pack_args = None
+            self._wfp_stale = True
+            self.refresh_weights()
 
     @property
     def side_priority(self):

@@ -269,8 +269,15 @@ class _TrainableModel:
             valid = K.BatchFeeder(validation_data, workers, max_queue_size)
         self.stop_training = False
         import torch
+        # Deferred batch logs (``defer_batch_logs``, default on): when NO callback looks at a batch -- neither a class-level override of
+        # on_batch_begin / on_batch_end nor a hook assigned on the instance (LambdaCallback style) -- the loop does not read every step's
+        # (loss, acc) back; it collects up to 256 steps' device values and reads them in one go.  The host then runs up to 256 steps ahead
+        # of the GPU, so a ``stop_training`` set from another hook is honoured at the next epoch boundary, as in Keras.
+        def _plain(cb, hook):
+            h = getattr(cb, hook, None)
+            return h is None or getattr(h, "__func__", None) is getattr(K.Callback, hook)
         deferred = self.defer_batch_logs and hasattr(self, "_train_step") and \
-            all(type(cb).on_batch_end is K.Callback.on_batch_end for cb in cbs)
+            all(_plain(cb, "on_batch_end") and _plain(cb, "on_batch_begin") for cb in cbs)
         K.run_callbacks(cbs, "on_train_begin")
         try:
             for epoch in range(initial_epoch, epochs):
