@@ -364,8 +364,8 @@ def main():
         return sym
     roof["kernel_symbol"] = symbol(a.dominant, shape)
     roof["source"] = ("bench.py serial attribution pass of this run: HIP events on the launch stream around every GEMM launch, median per "
-                      "launch shape; committed counterparts: profiles/r04_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
-                      "serial step), profiles/r04_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
+                      "launch shape; committed counterparts: profiles/r05_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
+                      "serial step), profiles/r05_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
     # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense 16-bit peak) and algorithmic GB/s
