@@ -20,8 +20,8 @@ with tempfile.TemporaryDirectory() as td:
     for dtype in sys.argv[1:] or ["f32s", "f16", "bf16"]:
         train = VS.ShardedSpeechDataset(os.path.join(td, "train"), 3, stochastic=True)
         train.to_device("cuda")
-        torch.manual_seed(1)
-        np.random.seed(1)
+        torch.manual_seed(int(os.environ.get("SEED", "1")))
+        np.random.seed(int(os.environ.get("SEED", "1")))
         enc = VM.get_baseline_convolutional_encoder(F, E, dropout=0.0, dtype=dtype)
         net = VM.build_siamese_net(enc, (train.fragment_length // 4, 1))
         net.compile(loss="binary_crossentropy", optimizer=Adam(clipnorm=1.0), metrics=["accuracy"])

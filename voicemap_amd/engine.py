@@ -265,6 +265,9 @@ class HipEncoderEngine:
         # max(start, 0) their accumulators start from (vm_fold_bn_weights ctr_out -> vm_conv_fwd_fold e_center).  Block 2 (index 1): its
         # input is block 1's output, whose variance can sit under BatchNorm's epsilon, so a channel can be pedestal 10 x spread
         self.center_blocks = (1,)
+        import os as _os
+        if _os.environ.get("VOICEMAP_CENTER_BLOCKS") is not None:   # experiments (tools/probe/convergence_modes.py): "" = off, "1,2"
+            self.center_blocks = tuple(int(v) for v in _os.environ["VOICEMAP_CENTER_BLOCKS"].split(",") if v.strip())
         self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
