@@ -465,6 +465,17 @@ class HipEncoderEngine:
         self._ev_record, self._ev_wait = self.lib.cdll.vm_event_record, self.lib.cdll.vm_stream_wait_event
         return prog
 
+    def __del__(self):
+        # the recorded programs' events are the only library-side objects an engine owns
+        try:
+            for prog in getattr(self, "_programs", {}).values():
+                if isinstance(prog, _Program):
+                    for h in prog.events.values():
+                        self.lib.cdll.vm_event_destroy(h)
+                    prog.events = {}
+        except Exception:   # interpreter shutdown: the library may be gone already
+            pass
+
     def _run_program(self, prog: _Program, dyn: dict):
         cmds = prog.cmds
         for ci, ai, key in prog.patches:
