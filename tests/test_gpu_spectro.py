@@ -322,7 +322,10 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
     # to the rest of the gradient (a 16-bit path cannot resolve them) -- and ONLY those: a tensor that carries more than ``floor`` of
     # the whole gradient must itself be right to ``rel``.
     total = float(np.sqrt(sum(float((g.numpy().astype(np.float64) ** 2).sum()) for g in ref["grads"].values())))
-    rel_b, floor_b = {"f32": (2e-3, 1e-6), "f16": (0.25, 2e-3), "bf16": (0.6, 1.5e-2)}[dt]
+    # (bf16 at config 4's size: measured worst live tensor conv1.bias at 0.41 -- four 2 x 2 max-pools deep, every pool window whose two
+    # largest elements are within bf16's 2^-8 of each other may route its gradient to the other position, and the first layer's bias
+    # gradient is the plain sum of everything that arrives; f16: 0.14 on conv1.kernel.  Bounds = measured x 1.2 / x 1.8)
+    rel_b, floor_b = {"f32": (2e-3, 1e-6), "f16": (0.25, 2e-3), "bf16": (0.5, 1.5e-2)}[dt]
     worst, worst_k = 0.0, ""
     for k, gref in ref["grads"].items():
         gr = gref.numpy().astype(np.float64)
