@@ -1,7 +1,8 @@
 """Where a wave of conv_nt3_kernel spends its clocks (the hot entry points of a cfg-A step: vm_conv_fwd_fold with the pair epilogue,
 vm_conv_dgrad_bnred), against a -DVM_EXPERIMENT_PROFILE build:
   bash tools/build_profile_lib.sh && VOICEMAP_HIP_LIB=voicemap_amd/lib/libvoicemap_hip_prof.so python tools/probe/nt3_prof.py"""
-import ctypes, sys
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from voicemap_amd import _lib
 L = _lib.lib()
@@ -26,7 +27,7 @@ for (l, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
             rows = L.query("vm_conv_stat_rows", l)
             ss = torch.empty(n * rows, cout, device="cuda"); sq = torch.empty_like(ss)
             e = torch.zeros(n, l // 2 + 2, cout, dtype=tdt, device="cuda"); o = torch.empty(n, l // 2, cout, dtype=tdt, device="cuda")
-            run = lambda: L.call("vm_conv_fwd_fold", p(a), p(w), p(bias), p(hb), p(gam), n, n // 2, l, cin, cout, vm, None, p(ss), p(sq), p(e), p(o), p(wp), st())
+            run = lambda: L.call("vm_conv_fwd_fold", p(a), p(w), p(bias), p(hb), p(gam), n, n // 2, l, cin, cout, vm, None, p(ss), p(sq), p(e), p(o), p(wp), None, st())
         else:
             a = torch.zeros(n, l + 2, cout, dtype=tdt, device="cuda"); a[:, 1:l + 1] = torch.randn(n, l, cout, device="cuda", generator=g).to(tdt)
             w = (torch.randn(cin * 3 * cout, device="cuda", generator=g) * 0.05).to(tdt)
