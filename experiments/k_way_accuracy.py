@@ -1,5 +1,6 @@
 """k-way n-shot accuracy sweep of trained models -- counterpart of the reference's experiments/k_way_accuracy.py
-(k = 2..20, n in {1, 5}, 1000 tasks each, distance 'dot_product'); results are appended to a CSV as they arrive.
+(k = 2..20, n in {1, 5}, 1000 tasks each, distance 'dot_product'); results are appended to a CSV as they arrive and the finished table replaces
+them at the end, as in the reference (:46-72).
     python -m experiments.k_way_accuracy --siamese models/x.hdf5 [--classifier models/y.hdf5] [--synthetic]"""
 import argparse
 
@@ -60,11 +61,16 @@ def main(argv=None):
                                                                       cache=caches[method], sampler=sampler or "reference")
                 else:
                     correct = n_shot_task_evaluation(net, valid, pre, a.num_tasks, n, k, network_type=kind, distance=a.distance)
-                rows.append({"method": method, "n_correct": correct, "n_tasks": a.num_tasks, "n": n, "k": k})
+                # (the reference's table calls the classifier's rows 'bottleneck', its intermediate lines 'classifier': k_way_accuracy.py:64-69)
+                rows.append({"method": "bottleneck" if method == "classifier" else method, "n_correct": correct, "n_tasks": a.num_tasks,
+                             "n": n, "k": k})
                 if rank == 0:
                     with open(out, "a") as f:
                         f.write("{},{},{},{},{}\n".format(method, correct, a.num_tasks, n, k))
-    return pd.DataFrame(rows)
+    results = pd.DataFrame(rows)
+    if rank == 0:
+        results.to_csv(out, index=False)     # like the reference (:71-72): the finished table replaces the intermediate lines
+    return results
 
 
 if __name__ == "__main__":
