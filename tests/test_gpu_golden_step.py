@@ -120,3 +120,43 @@ def test_tiny_training_step_against_golden_vectors(dt, loss, head):
     # rounded twice) and so few channels average little: half storage measures 4.1e-3 here against 4e-4..1e-3 at the real widths
     _check("golden_step_tiny[%s-%s]" % (dt, loss), dt, eng, step, g, loss + "/", names,
            tol=dict(emb=8e-3, loss=2e-2, cos=0.97) if dt == "f16" else None)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_hip_batch_statistics_match_the_reference_checkpoints_moving_statistics(dt):
+    """The PRODUCT against numbers the reference itself computed, with no oracle in between (cf. tests/test_oracle_reference_pin.py,
+    which holds the oracle to the same figures): the HIP encoder in training mode over the 8 LibriSpeech clips of the reference's
+    notebooks (raw int16 -> decimate x4 + whiten on the GPU, one encoder call of 8 windows) -- its four BatchNorm layers' batch
+    means / variances against the moving means / variances in the reference's shipped checkpoint: per-layer correlation >= 0.9
+    (means, log variances), median ratios within 1.25.  Oracle rules measured 0.92-0.99 / 0.92-1.04; the current models.py pool
+    geometry (first pool 4) 0.54-0.73."""
+    from voicemap_amd.engine import HipEncoderEngine
+    w = np.load(os.path.join(GOLDEN, "ckpt_cfgCK_weights.npz"))
+    arch, p = O.params_from_checkpoint(w)
+    h, v = np.load(os.path.join(GOLDEN, "clips_human_eval.npz")), np.load(os.path.join(GOLDEN, "clips_embedding_vis.npz"))
+    clips = np.concatenate([h["query"][None], h["support"], v["clips"]]).astype(np.int16)          # (8, 48000)
+    rows = []
+    for blocks in (arch.blocks, [(32, 32, 4)] + list(arch.blocks[1:])):
+        eng = HipEncoderEngine(blocks, arch.embedding_dimension, dropout=0.0, head=None, dtype=dt)
+        eng.set_params({k: t.numpy() for k, t in p.items() if not k.startswith("head.")})
+        pl = eng.plan(8, 12000, True)
+        eng.preprocess(pl, torch.as_tensor(clips).to("cuda"), 4, True, 8)
+        eng.forward(pl, 8, None)
+        torch.cuda.synchronize()
+        agree = []
+        for i in range(4):
+            mean = pl[i]["mean"][0].cpu().numpy().astype(np.float64)
+            var = np.maximum(1.0 / pl[i]["invstd"][0].cpu().numpy().astype(np.float64) ** 2 - arch.bn_eps, 1e-30)
+            mm = w[f"batch_normalization_{i+1}/moving_mean"].astype(np.float64)
+            mv = w[f"batch_normalization_{i+1}/moving_variance"].astype(np.float64)
+            agree.append((np.corrcoef(mean, mm)[0, 1], np.corrcoef(np.log(var), np.log(mv))[0, 1], np.median(mean / mm), np.median(var / mv)))
+        rows.append(np.array(agree))
+        del eng, pl
+    good, pool4 = rows
+    tag = "hip_vs_checkpoint_moving_statistics[%s]" % dt
+    for i in range(4):
+        report(tag, "bn%d_mean_correlation" % (i + 1), good[i, 0])
+        report(tag, "bn%d_logvar_correlation" % (i + 1), good[i, 1])
+        report(tag, "bn%d_median_var_ratio" % (i + 1), good[i, 3])
+    assert (good[:, :2] >= 0.9).all() and (np.abs(np.log(good[:, 2:])) <= np.log(1.25)).all(), good
+    assert pool4[1:, :2].min() < 0.8, pool4           # the wrong geometry does NOT match: the check discriminates
