@@ -160,3 +160,40 @@ def test_hip_batch_statistics_match_the_reference_checkpoints_moving_statistics(
         report(tag, "bn%d_median_var_ratio" % (i + 1), good[i, 3])
     assert (good[:, :2] >= 0.9).all() and (np.abs(np.log(good[:, 2:])) <= np.log(1.25)).all(), good
     assert pool4[1:, :2].min() < 0.8, pool4           # the wrong geometry does NOT match: the check discriminates
+
+
+def test_hip_gradient_profile_matches_the_reference_checkpoints_adam_slots():
+    """... and the backward pass: the HIP path's clipped BCE gradient on 4 pairs of the reference's clips, SpatialDropout1D(0.05) masks
+    drawn per tower (mean square over 8 draws), against mean(v) of the 20 Adam second-moment accumulators in the reference's
+    checkpoint (2e-7 ... 5e-3, 4.4 decades): every tensor within 10^0.45 (the oracle: 10^0.37), dense_1/bias -- a structural zero of
+    the weighted-L1 head -- at rounding noise.  Same clips, masks and bounds as tests/test_oracle_reference_pin.py."""
+    from voicemap_amd.engine import HipEncoderEngine
+    w = np.load(os.path.join(GOLDEN, "ckpt_cfgCK_weights.npz"))
+    s = np.load(os.path.join(GOLDEN, "ckpt_cfgCK_adam_slots.npz"))
+    arch, p = O.params_from_checkpoint(w)
+    names = O.param_names(arch, head="weighted_l1")
+    v = {n: s["v/" + k].astype(np.float64) for n, k in zip(names, s["order"])}
+    h, e = np.load(os.path.join(GOLDEN, "clips_human_eval.npz")), np.load(os.path.join(GOLDEN, "clips_embedding_vis.npz"))
+    clips = np.concatenate([h["query"][None], h["support"], e["clips"]]).astype(np.float32) / 32768.0
+    left, right = clips[[0, 1, 2, 6]][:, :, None], clips[[5, 3, 4, 7]][:, :, None]
+    y = np.array([[0.0], [1.0], [1.0], [1.0]], dtype=np.float32)
+    eng = HipEncoderEngine(arch.blocks, arch.embedding_dimension, dropout=arch.dropout, head="weighted_l1", dtype="f32")
+    eng.set_params({k: t.numpy() for k, t in p.items()})
+    acc = {n: 0.0 for n in names}
+    for seed in range(8):
+        r = np.random.default_rng(seed)       # the draws of tests/test_oracle_reference_pin.py::_step
+        m1 = [(r.random((4, 1, c)) >= arch.dropout) for (_, c, _) in arch.blocks]
+        m2 = [(r.random((4, 1, c)) >= arch.dropout) for (_, c, _) in arch.blocks]
+        dm = [torch.as_tensor(np.concatenate([a[:, 0, :], b[:, 0, :]], 0).astype(np.float32) / (1.0 - arch.dropout)).to("cuda") for a, b in zip(m1, m2)]
+        eng.siamese_train_step(left, right, y, loss="bce", preprocessed=False, downsampling=4, drop_masks=dm, apply_update=False)
+        torch.cuda.synchronize()
+        g = eng.get_grads()
+        norm = np.sqrt(sum(float((np.asarray(g[n], dtype=np.float64) ** 2).sum()) for n in names))
+        assert norm > 3.0                     # the clip is active, as it was on almost every batch of the reference's run (sum v = 0.9985)
+        for n in names:
+            acc[n] += float(((np.asarray(g[n], dtype=np.float64) / norm) ** 2).mean()) / 8
+    lp = np.array([np.log10(max(acc[n], 1e-300) / v[n].mean()) for n in names if n != "dense.bias"])
+    report("hip_vs_checkpoint_adam_slots[f32]", "max_abs_log10_ratio", float(np.abs(lp).max()))
+    report("hip_vs_checkpoint_adam_slots[f32]", "rms_log10_ratio", float(np.sqrt((lp ** 2).mean())))
+    assert len(lp) == 19 and np.abs(lp).max() < 0.45 and np.sqrt((lp ** 2).mean()) < 0.18, lp
+    assert acc["dense.bias"] < 1e-12 * acc["dense.kernel"]
