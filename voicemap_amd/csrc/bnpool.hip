@@ -479,10 +479,7 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                 ones<VEC>(dr);
             }
             const T* zrow = z + n * L * C + c0;
-            for (int64_t q = seg + (int64_t)rl * gridDim.y; q < Lq; q += (int64_t)RP * gridDim.y) {
-                Vec16<T> v[POOL];
-#pragma unroll
-                for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
+            auto group = [&](int64_t q, const Vec16<T> (&v)[POOL]) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float y = fmaf(v[0].get(i), sc[i], sh[i]) * dr[i];
@@ -497,6 +494,24 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                         bi[i] = (int)q;
                     }
                 }
+            };
+            const int64_t qs = (int64_t)RP * gridDim.y;
+            int64_t q = seg + (int64_t)rl * gridDim.y;
+            // two pool groups in flight per thread (as the apply pass: a pure stream over z), same groups in the same order
+            for (; q + qs < Lq; q += 2 * qs) {
+                Vec16<T> v0[POOL], v1[POOL];
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) v0[j] = load16<T>(zrow + (q * POOL + j) * C);
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) v1[j] = load16<T>(zrow + ((q + qs) * POOL + j) * C);
+                group(q, v0);
+                group(q + qs, v1);
+            }
+            for (; q < Lq; q += qs) {
+                Vec16<T> v[POOL];
+#pragma unroll
+                for (int j = 0; j < POOL; ++j) v[j] = load16<T>(zrow + (q * POOL + j) * C);
+                group(q, v);
             }
         }
 #pragma unroll
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                     const T* zp = z + (n * L + q * POOL) * C + c0;
 #pragma unroll
                     for (int j = 0; j < POOL; ++j)
-                        if (FULL || j < nrows) zv[j] = load16<T>(zp + j * C);
+                        if (FULL || j < nrows) zv[j] = pre ? pre[j] : load16<T>(zp + j * C);
                 }
                 const bool has_dp = FULL || q < Lq;
                 Vec16<T> dv;
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
             };
             int64_t q = seg + (int64_t)rl * gridDim.y;
             const int64_t qs = (int64_t)RP * gridDim.y;
-            if constexpr (VM_APPLY_TWO_GROUPS && PAIRS && !SP && sizeof(T) == 2 && POOL == 2) {
+            if constexpr (VM_APPLY_TWO_GROUPS && POOL == 2 && !(PAIRS && (SP || sizeof(T) != 2))) {
                 // NG pool groups in flight per thread: 3 NG 16-byte loads before the first is consumed (the pass is a pure stream:
                 // 4.5 TB/s with three).  Same groups in the same order: bit-identical
                 constexpr int NG = VM_APPLY_TWO_GROUPS == 1 ? 2 : VM_APPLY_TWO_GROUPS;
@@ -707,9 +722,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                     Vec16<T> a[NG][3];
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        a[g][0] = load16<T>(z + (n * (Lq + 2) + 1 + q + g * qs) * C + c0);
-                        a[g][1] = load16<T>(zo + (n * Lq + q + g * qs) * C + c0);
-                        a[g][2] = load16<T>(dp + (n * Lq + q + g * qs) * C + c0);
+                        if constexpr (PAIRS) {
+                            a[g][0] = load16<T>(z + (n * (Lq + 2) + 1 + q + g * qs) * C + c0);
+                            a[g][1] = load16<T>(zo + (n * Lq + q + g * qs) * C + c0);
+                        } else {   // the dense / sparse-dp forms: the group's two z rows
+                            a[g][0] = load16<T>(z + (n * L + (q + g * qs) * 2) * C + c0);
+                            a[g][1] = load16<T>(z + (n * L + (q + g * qs) * 2 + 1) * C + c0);
+                        }
+                        if constexpr (!SP) a[g][2] = load16<T>(dp + (n * Lq + q + g * qs) * C + c0);
                     }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) body(q + g * qs, std::true_type{}, a[g]);
