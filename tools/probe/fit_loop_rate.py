@@ -22,4 +22,15 @@ with tempfile.TemporaryDirectory() as td:
             torch.cuda.synchronize(); t0 = time.perf_counter()
             h = net.fit_generator(generator=gen, steps_per_epoch=300, epochs=1, workers=0, verbose=0)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            print("batch %3d pairs  deferred logs %-5s  %.3f ms per step   epoch loss %.4f" % (bs, defer, dt / 300 * 1e3, h.history["loss"][0]))
+            # the same net's bare device step on the last batch's shape (no generator, no wrappers): what the GPU needs
+            eng = net._ensure_engine()
+            (x1, x2), yb = next(gen)
+            o1, o2 = x1.raw.offsets, x2.raw.offsets
+            yd = torch.as_tensor(np.asarray(yb, dtype=np.float32).reshape(-1)).to("cuda")
+            for _ in range(10):
+                eng.siamese_train_step_from_offsets(x1.raw.audio, o1, o2, yd, x1.raw.length, loss="bce")
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(200):
+                eng.siamese_train_step_from_offsets(x1.raw.audio, o1, o2, yd, x1.raw.length, loss="bce")
+            torch.cuda.synchronize(); bare = (time.perf_counter() - t1) / 200 * 1e3
+            print("batch %3d pairs  deferred logs %-5s  %.3f ms per step   epoch loss %.4f   bare device step %.3f ms" % (bs, defer, dt / 300 * 1e3, h.history["loss"][0], bare))

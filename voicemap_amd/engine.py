@@ -1504,20 +1504,52 @@ class HipEncoderEngine:
         self._train_step(pl, pairs, yd, loss, drop_masks, apply_update, None if preprocessed else ("raw", x, downsampling, whitening))
         return pl
 
-    def siamese_train_step_from_offsets(self, audio: torch.Tensor, offsets_1: torch.Tensor, offsets_2: torch.Tensor, y,
+    def siamese_train_step_from_offsets(self, audio: torch.Tensor, offsets_1, offsets_2, y,
                                         raw_len: int, loss: str = "contrastive", downsampling: int = 4, whitening: bool = True,
                                         drop_masks="auto", apply_update: bool = True):
         """``siamese_train_step`` fed from a device-resident recording buffer: ``audio`` 1-D int16/fp32 on the device,
         ``offsets_k`` (pairs,) int64 start samples of the windows of tower k (shards.ShardedSpeechDataset chooses them the way
-        LibriSpeechDataset.__getitem__ / build_verification_batch do)."""
-        pairs = int(offsets_1.numel())
-        offs = torch.cat([offsets_1.reshape(-1), offsets_2.reshape(-1)]).to(self.device, torch.int64).contiguous()
+        LibriSpeechDataset.__getitem__ / build_verification_batch do).  Host numpy offsets with host labels (what fit_generator
+        hands over) go up in one asynchronous copy (_stage_offsets_and_labels); tensors are taken as they are."""
+        host = isinstance(offsets_1, np.ndarray) and isinstance(offsets_2, np.ndarray)
+        pairs = int(offsets_1.size) if host else int(offsets_1.numel())
         pl = self.plan(2 * pairs, (raw_len + downsampling - 1) // downsampling, True)
+        if host and not torch.is_tensor(y):
+            offs, yd = self._stage_offsets_and_labels(pl, offsets_1, offsets_2, y, pairs)
+        else:
+            offs = torch.cat([torch.as_tensor(offsets_1).reshape(-1), torch.as_tensor(offsets_2).reshape(-1)]).to(self.device, torch.int64).contiguous()
+            yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(2 * pairs)
-        yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
         self._train_step(pl, pairs, yd, loss, drop_masks, apply_update, ("offsets", audio, offs, raw_len, downsampling, whitening))
         return pl
+
+    def _stage_offsets_and_labels(self, pl: dict, o1: "np.ndarray", o2: "np.ndarray", y, pairs: int):
+        """Host arrays -> the plan's persistent device buffers (2 * pairs int64 offsets, pairs fp32 labels) in ONE asynchronous copy
+        from a ring of pinned staging buffers.  torch's ``.to(device)`` of a pageable array is a blocking copy that is ordered behind
+        everything already enqueued on the stream: three of them per step made the host wait for the GPU to drain, then left the GPU
+        idle while the host prepared the next step (fit_generator at 64 pairs: 1.67 ms per step against 1.45 ms of GPU work).  A slot
+        is reused after 32 steps; its copy's event is waited for first (long done)."""
+        st = pl.get("h2d")
+        if st is None:
+            nbytes = 2 * pairs * 8 + pairs * 4
+            st = pl["h2d"] = {"dev": torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                              "pin": [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(32)],
+                              "ev": [None] * 32, "k": 0}
+            st["offs"] = st["dev"][:2 * pairs * 8].view(torch.int64)
+            st["y"] = st["dev"][2 * pairs * 8:].view(torch.float32)
+        k = st["k"] % 32
+        st["k"] += 1
+        if st["ev"][k] is not None:
+            st["ev"][k].synchronize()
+        buf = st["pin"][k].numpy()
+        buf[:pairs * 8] = np.ascontiguousarray(o1, dtype=np.int64).reshape(-1).view(np.uint8)
+        buf[pairs * 8:2 * pairs * 8] = np.ascontiguousarray(o2, dtype=np.int64).reshape(-1).view(np.uint8)
+        buf[2 * pairs * 8:] = np.ascontiguousarray(np.asarray(y, dtype=np.float32).reshape(pairs)).view(np.uint8)
+        st["dev"].copy_(st["pin"][k], non_blocking=True)
+        ev = st["ev"][k] = st["ev"][k] or torch.cuda.Event()
+        ev.record()
+        return st["offs"], st["y"]
 
     def classifier_train_step(self, x, labels, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True,
                               drop_masks="auto", apply_update: bool = True):

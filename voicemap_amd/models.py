@@ -651,7 +651,7 @@ class SiameseNet(_TrainableModel):
                 and x1.raw.audio is x2.raw.audio:
             # device data path: the crop happens inside the preprocessing kernel (vm_crop_decimate_whiten)
             assert (x1.downsampling, x1.whitening) == (x2.downsampling, x2.whitening)
-            return eng.siamese_train_step_from_offsets(x1.raw.audio, x1.raw.offsets, x2.raw.offsets,
+            return eng.siamese_train_step_from_offsets(x1.raw.audio, x1.raw.offsets_host, x2.raw.offsets_host,
                                                        np.asarray(y, dtype=np.float32), x1.raw.length, loss=loss,
                                                        downsampling=x1.downsampling, whitening=x1.whitening)
         return self._run(lambda a, b, **kw: eng.siamese_train_step(a, b, np.asarray(y, dtype=np.float32), loss=loss, **kw), x1, x2)

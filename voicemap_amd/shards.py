@@ -69,19 +69,30 @@ class DeviceWindows:
     the GPU (``vm_crop_decimate_whiten``); ``np.asarray`` materialises the float windows on the host (tests, oracle)."""
 
     def __init__(self, audio, offsets, length: int):
-        import torch
         self.audio = audio
-        self.offsets = torch.as_tensor(np.asarray(offsets, dtype=np.int64)).to(audio.device)
+        # the offsets stay on the HOST until somebody needs them on the device: the training step uploads both towers' offsets and
+        # the labels in ONE asynchronous copy from pinned memory (engine.siamese_train_step_from_offsets); a torch ``.to(device)`` of
+        # a pageable array here would block the host until the device has drained its queue -- once per tower per step
+        self.offsets_host = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64).reshape(-1))
+        self._offsets_dev = None
         self.length = int(length)
 
     ndim = 3
 
     @property
+    def offsets(self):
+        """The start offsets as an int64 tensor on the audio's device (uploaded on first use)."""
+        if self._offsets_dev is None:
+            import torch
+            self._offsets_dev = torch.as_tensor(self.offsets_host).to(self.audio.device)
+        return self._offsets_dev
+
+    @property
     def shape(self):
-        return (int(self.offsets.numel()), self.length, 1)
+        return (int(self.offsets_host.size), self.length, 1)
 
     def __len__(self):
-        return int(self.offsets.numel())
+        return int(self.offsets_host.size)
 
     def gather(self):
         """(n, T) windows on the device, in the buffer's dtype."""
