@@ -47,6 +47,18 @@ for (l, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
             run()
         e1.record(); torch.cuda.synchronize()
         L.cdll.vm_debug_prof_read(buf.ctypes.data, NS)
+        if os.environ.get("EPI"):     # -DVM_EXPERIMENT_PROFILE_EPI build: raw stamps start, [K loop end], sync, tile write, sync, pool pairs / stores, statistics, drained
+            tilesN = (cout if kind == "fwd" else cin) // 128
+            nwg = min(8192, n * ((l + 253) // 254) * tilesN)
+            raw = buf[:nwg * 4].astype(np.int64)
+            dd = np.diff(raw, axis=1) % (1 << 32)
+            m = dd.mean(0)
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            print("%-5s L%-4d %3d->%3d: %6.1f us/launch | start -> end of K loop %6.0f | wait at barrier 1 %5.0f | tile write %5.0f | wait at barrier 2 %5.0f | "
+                  "%s %5.0f | %s %5.0f | store drain (vmcnt 0) %5.0f | total %6.0f" % (
+                      kind, l, cin, cout, us, m[0], m[1], m[2], m[3], "pool pairs + stores" if kind == "fwd" else "tile stores", m[4],
+                      "statistics" if kind == "fwd" else "(none)", m[5], m[6], dd.sum(1).mean()))
+            continue
         tilesN = (cout if kind == "fwd" else cin) // 128
         nwg = min(8192, n * ((l + 253) // 254) * tilesN)
         d = buf[:nwg * 4].astype(np.float64)

@@ -524,6 +524,16 @@ __device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4])
 // the 16-bit LDS tile, n2_tile_drain does everything that reads the tile (stores, pool pairs, statistics, the fused BatchNorm-backward
 // sums).  ``bar``: the drain's synchronisation policy -- sync() = a barrier the draining waves NEED between two of its phases
 // (only the fused sums have them), point() = a place where a barrier may be put for balance and nothing depends on it.
+#if defined(VM_EXPERIMENT_PROFILE_EPI)  // experiment builds only: raw s_memtime stamps of the epilogue's phases (tools/probe/nt3_prof.py epi)
+extern __device__ unsigned int g_prof[];
+__device__ inline void vm_epi_mark(int k) {
+    const long long t = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) g_prof[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] = (unsigned int)t;
+}
+#define VM_EPI_MARK(k) vm_epi_mark(k)
+#else
+#define VM_EPI_MARK(k)
+#endif
 struct N2DrainSync {   // the drain run by the four waves of a 256-thread workgroup that also computed the tile
     __device__ inline void sync() { __syncthreads(); }
     __device__ inline void point() {}
@@ -545,35 +555,48 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
     // ---- registers -> bf16 tile in LDS.  Forward: the bias is already in the accumulators (they were initialised with it) and
     // ReLU is applied to the PACKED bf16 pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16, -0.0 included;
     // rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
+    // (the run-time switch is hoisted into two straight-line copies: left inside, hipcc branched on it once per 4 values -- 64
+    // branches per wave-tile, 4.8 k clocks of tile write against the dgrad form's 2.0 k; profiles/r05_nt3_epilogue_phases.txt)
+    auto body = [&](auto ctrd_c) {
+        constexpr bool CTRD = decltype(ctrd_c)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = wm * 128 + i * 32 + r;
-        const bool partial = wm * 128 + i * 32 + 32 > valid;  // wave-uniform: this 32-row block has rows outside the window
+        for (int i = 0; i < 4; ++i) {
+            const int m = wm * 128 + i * 32 + r;
+            const bool partial = wm * 128 + i * 32 + 32 > valid;  // wave-uniform: this 32-row block has rows outside the window
+            const bool zero = (FWD || red) && partial && m >= valid;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
-                T o[4];
-                if (CAN_CENTRE && ctrd) {
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
+                    T o[4];
+                    if constexpr (CTRD) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(fmaxf(acc[i][j][4 * g + e], negc[j][g][e]));
-                } else {
+                        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(fmaxf(acc[i][j][4 * g + e], negc[j][g][e]));
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
+                        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
+                    }
+                    u32x2 pk = *reinterpret_cast<const u32x2*>(o);
+                    if constexpr (EPI != EPI_DGRAD && !CTRD) {
+                        uint32_t lo = pk[0], hi = pk[1];
+                        asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
+                        asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
+                        pk[0] = lo;
+                        pk[1] = hi;
+                    }
+                    pk[0] = zero ? 0u : pk[0];
+                    pk[1] = zero ? 0u : pk[1];
+                    *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
                 }
-                u32x2 pk = *reinterpret_cast<const u32x2*>(o);
-                if (EPI != EPI_DGRAD && !(CAN_CENTRE && ctrd)) {
-                    uint32_t lo = pk[0], hi = pk[1];
-                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
-                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
-                    pk[0] = lo;
-                    pk[1] = hi;
-                }
-                if ((FWD || red) && partial && m >= valid) pk[0] = pk[1] = 0u;
-                *reinterpret_cast<u32x2*>(lds + m * TP + nl * 2) = pk;
             }
         }
+    };
+    if constexpr (CAN_CENTRE) {
+        if (ctrd) body(std::true_type{});
+        else body(std::false_type{});
+    } else {
+        body(std::false_type{});
     }
 }
 
@@ -693,42 +716,65 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             r0[jj] = *reinterpret_cast<const u32x4*>(lds + (2 * q) * TP + c8 * 16);
             r1[jj] = *reinterpret_cast<const u32x4*>(lds + (2 * q + 1) * TP + c8 * 16);
         }
+        // (the two run-time switches select one of four straight-line copies: inside the loops hipcc branched on them per 32-bit word)
+        auto pairs = [&](auto ctrd_c, auto other_c) {
+            constexpr bool CTRD = decltype(ctrd_c)::value, OTHER = decltype(other_c)::value;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int q = rg + 16 * jj;
-            u32x4 o, oth;
+            for (int jj = 0; jj < 8; ++jj) {
+                const int q = rg + 16 * jj;
+                u32x4 o, oth;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                uint32_t a = r0[jj][d], b = r1[jj][d];
-                uint32_t mx, mn;
-                const uint32_t m = neg[d];
-                if (CAN_CENTRE && ctrd) {
-                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
-                    asm("v_pk_min_f16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
-                    o[d] = (mx & ~m) | (mn & m);                      // the CENTRED extreme: what block i + 1 reads
-                    asm("v_pk_add_f16 %0, %1, %2" : "=v"(a) : "v"(a), "v"(c16[d]));
-                    asm("v_pk_add_f16 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c16[d]));
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t a = r0[jj][d], b = r1[jj][d];
+                    const uint32_t m = neg[d];
+                    if constexpr (CTRD) {
+                        uint32_t mx, mn;
+                        asm("v_pk_max_f16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+                        asm("v_pk_min_f16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+                        o[d] = (mx & ~m) | (mn & m);                      // the CENTRED extreme: what block i + 1 reads
+                        if constexpr (OTHER) {
+                            asm("v_pk_add_f16 %0, %1, %2" : "=v"(a) : "v"(a), "v"(c16[d]));
+                            asm("v_pk_add_f16 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c16[d]));
+                        }
+                    }
+                    if constexpr (!CTRD || OTHER) {
+                        // a, b >= 0 here (ReLU, or un-centred above), so they order as 15-bit integers; XOR with 0x7FFF reverses that
+                        // order: in the flipped domain of a gamma < 0 channel the wanted minimum is a maximum too, and one packed
+                        // max / min / subtract serve both kinds of channel (8 VALU operations per word instead of 11)
+                        const uint32_t fl = m & 0x7FFF7FFFu;
+                        const uint32_t af = a ^ fl, bf = b ^ fl;
+                        uint32_t mx, mn;
+                        asm("v_pk_max_i16 %0, %1, %2" : "=v"(mx) : "v"(af), "v"(bf));
+                        if constexpr (!CTRD) o[d] = mx ^ fl;
+                        if constexpr (OTHER) {
+                            // the other element, flagged (bit 15) where the extreme is the pair's SECOND element: bf > af -- the sign of
+                            // the 16-bit difference of two non-negative values; ties: the first
+                            uint32_t df;
+                            asm("v_pk_min_i16 %0, %1, %2" : "=v"(mn) : "v"(af), "v"(bf));
+                            asm("v_pk_sub_i16 %0, %1, %2" : "=v"(df) : "v"(af), "v"(bf));
+                            oth[d] = (mn ^ fl) | (df & 0x80008000u);
+                        }
+                    }
                 }
-                asm("v_pk_max_i16 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
-                asm("v_pk_min_i16 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
-                const uint32_t eu = (mx & ~m) | (mn & m);
-                if (!(CAN_CENTRE && ctrd)) o[d] = eu;
-                if (p.pool_o != nullptr) {
-                    // the other element, flagged (bit 15) where the extreme is the pair's SECOND element: b > a where a maximum is
-                    // taken, b < a for a minimum -- the sign of the 16-bit difference of two non-negative values; ties: the first
-                    uint32_t d1, d2;
-                    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d1) : "v"(a), "v"(b));
-                    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d2) : "v"(b), "v"(a));
-                    oth[d] = (mx ^ mn ^ eu) | (((d1 & ~m) | (d2 & m)) & 0x80008000u);
+                if (q < vq) {
+                    *reinterpret_cast<u32x4*>(ebase + (int64_t)q * p.N) = o;
+                    if constexpr (OTHER) *reinterpret_cast<u32x4*>(obase2 + (int64_t)q * p.N) = oth;
                 }
+                bar.point();
             }
-            if (q < vq) {
-                *reinterpret_cast<u32x4*>(ebase + (int64_t)q * p.N) = o;
-                if (p.pool_o != nullptr) *reinterpret_cast<u32x4*>(obase2 + (int64_t)q * p.N) = oth;
-            }
-            bar.point();
+        };
+        const bool other = p.pool_o != nullptr;
+        if constexpr (CAN_CENTRE) {
+            if (ctrd && other) pairs(std::true_type{}, std::true_type{});
+            else if (ctrd) pairs(std::true_type{}, std::false_type{});
+            else if (other) pairs(std::false_type{}, std::true_type{});
+            else pairs(std::false_type{}, std::false_type{});
+        } else {
+            if (other) pairs(std::false_type{}, std::true_type{});
+            else pairs(std::false_type{}, std::false_type{});
         }
     }
+    VM_EPI_MARK(5);
     if (stats) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
@@ -796,6 +842,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
             bar.point();
         }
     }
+    VM_EPI_MARK(6);
     if (red) {
         // ---- BatchNorm-backward partial sums of the layer below, from the tile that is in LDS anyway (vm_conv_dgrad_bnred):
         //   S0[c] = sum_r dp[r][c] = (1^T DP)[c],   S1[c] = sum_r dp[r][c] * A[r][c] = diag(DP^T A)[c]
@@ -903,9 +950,13 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
                 }
         }
     }
+    VM_EPI_MARK(1);
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
+    VM_EPI_MARK(2);
     n2_tile_write<T, EPI>(p, lds, acc, t0, n0, trows, lane, wm, wn, negc);
+    VM_EPI_MARK(3);
     __syncthreads();
+    VM_EPI_MARK(4);
     N2DrainSync bar;
     n2_tile_drain<T, EPI>(p, lds, n, tl, t0, n0, trows, tid, lane, w, bar);
 }
@@ -1499,6 +1550,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const long long pt_end = __builtin_amdgcn_s_memtime();
+#if defined(VM_EXPERIMENT_PROFILE_EPI)
+        if (lane == 0 && blockIdx.x < 8192) {   // raw stamps: slots 1..6 were written by the epilogue (VM_EPI_MARK)
+            unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
+            q[0] = (unsigned int)pt_start;
+            q[7] = (unsigned int)pt_end;
+        }
+        (void)pt_first; (void)pt_bar; (void)pt_s2; (void)pt_s3; (void)pt_loop;
+#else
         if (lane == 0 && blockIdx.x < 8192) {
             unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
             q[0] = (unsigned int)(pt_end - pt_start);    // the whole wave-tile (incl. the drain of its stores)
@@ -1510,6 +1569,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
             q[6] = (unsigned int)(pt_bar - pt_s3);       // accumulator init, first data wait, first barrier
             q[7] = (unsigned int)(pt_first - pt_bar);    // fragment reads + 16 MFMAs of the first K tile
         }
+#endif
     }
 #endif
 }
