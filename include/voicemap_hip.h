@@ -81,6 +81,9 @@ int vm_stream_wait_event(void* stream, void* event);
  *   "nt_glds" 0|1     the 128 x 128 LDS-DMA kernel where K * sizeof(T) % 64 == 0 (default 1), else the register-staged 128 x 128 one
  *   "tn_x" 0|1        wgrad, 16-bit storage: the input-resident (3 taps x 128 ci) x 128 co LDS-DMA tile (default 1), else
  *   "tn9" 0|1         ... with the free-running K loop (conv_tn9_kernel, default 1) or the READ / MFMA slots (conv_tn8x_kernel)
+ *   "tn9_stages" 0|1  conv_tn9_kernel's split-K ranges are 64-position stages of a tower's window stream (default 1: the launch is
+ *                     balanced to one stage) or whole windows.  Changes vm_conv_wgrad_splits / vm_conv_wgrad_workspace_bytes: set it
+ *                     before plans are sized
  *   "tn_tile" 128|256 the tile of the register-transposing wgrad kernels (default 256 where the layer is wide enough)
  *   "fuse_finalize" mask 0..31   which two-stage column reductions finish inside their stage-1 launch (the last-arriving workgroup of
  *                     a channel block runs the finalize; bit-identical to the two launches): bit 0 vm_bn_finalize, bit 1

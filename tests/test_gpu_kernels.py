@@ -48,7 +48,7 @@ def _conv_ref(x, w, b):
     return O.conv1d_same_relu(x, w, b)
 
 
-GEMM_DEFAULTS = {"nt_n2": 3, "nt_glds": 1, "tn_x": 1, "tn_tile": 256, "tn9": 1}   # the library's defaults (conv_gemm.hip / conv_wgrad.hip)
+GEMM_DEFAULTS = {"nt_n2": 3, "nt_glds": 1, "tn_x": 1, "tn_tile": 256, "tn9": 1, "tn9_stages": 1}   # the library's defaults (conv_gemm.hip / conv_wgrad.hip)
 
 
 @pytest.fixture
@@ -103,6 +103,38 @@ def test_conv_wgrad_kernel_variants(n, l, cin, cout, gemm_kernels):
     conv_tn9_kernel with producer waves, on ragged stages (700, 650, 131), a window shorter than a stage (5, 62), half-filled tiles
     (64, 192, 320 channels) and cfg-A's block 4."""
     _conv_fwd_dgrad_wgrad("f16", n, l, cin, cout)
+
+
+@pytest.mark.parametrize("gemm_kernels", [{"tn9_stages": 1}, {"tn9_stages": 0}, {"tn9": 2, "tn9_stages": 1}], indirect=True,
+                         ids=["stage-splits", "window-splits", "stage-splits+producer-waves"])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("n,wpt,l,cin,cout", [(6, 3, 190, 64, 64), (10, 5, 64, 128, 128), (3, 3, 62, 64, 128), (14, 7, 1000, 128, 128),
+                                              (2, 1, 3000, 128, 256), (9, 9, 129, 192, 64), (22, 11, 318, 64, 64)])
+def test_conv_wgrad_split_granularity(dt, n, wpt, l, cin, cout, gemm_kernels):
+    """conv_tn9_kernel's split-K ranges: 64-position stages of a tower's window stream (default; a split may begin and end inside a
+    window, and one that ends inside stages one stage more than it computes, for taps 1 and 2 of its last two positions) against whole
+    windows.  Both the plain entry point (one tower) and vm_conv_wgrad_fold's slabs per tower (identity affine, zero shift: the
+    folded gradient IS the plain one) must match the float64 definition; windows of 1, 2, 3, 5, 16 and 47 stages, stage counts that
+    do and do not divide the split length, towers of 1 .. 11 windows."""
+    vm, tdt = DTYPES[dt]
+    r = rng(n * l + cin)
+    x = quant(r.normal(0, 1.0, (n, l, cin)), dt).numpy()
+    du = quant(r.normal(0, 1.0, (n, l, cout)), dt).numpy()
+    xp_ = np.zeros((n, l + 2, cin))
+    xp_[:, 1:l + 1] = x
+    want = np.stack([np.einsum("nli,nlo->io", xp_[:, k:k + l], du) for k in range(3)])
+    xp, dup = padded(x, tdt), padded(du, tdt)
+    ws = torch.empty(L().query("vm_conv_wgrad_workspace_bytes", n, l, cin, cout) // 4 + 16, device="cuda")
+    gw = torch.empty(3, cin, cout, device="cuda")
+    L().call("vm_conv_wgrad", p(xp), p(dup), n, l, cin, cout, vm, p(ws), p(gw), stream())
+    assert rel_err(gw.cpu().numpy(), want) < 2e-5
+    towers = n // wpt
+    one, zero = torch.ones(towers, cin, device="cuda"), torch.zeros(towers, cin, device="cuda")
+    dsum = torch.zeros(towers, 3, cout, device="cuda")
+    wsf = torch.empty(L().query("vm_conv_wgrad_fold_workspace_bytes", n, wpt, l, cin, cout) // 4 + 16, dtype=torch.float32, device="cuda")
+    gwf = torch.empty(3, cin, cout, device="cuda")
+    L().call("vm_conv_wgrad_fold", p(xp), p(dup), n, wpt, l, cin, cout, vm, p(one), p(zero), p(dsum), p(wsf), p(gwf), stream())
+    assert rel_err(gwf.cpu().numpy(), want) < 2e-5
 
 
 @pytest.mark.parametrize("n,l,cin,cout", [(3, 200, 16, 24), (2, 300, 128, 256), (1, 129, 8, 136), (2, 5, 24, 8), (3, 131, 96, 32),

@@ -54,6 +54,12 @@ for (l, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
             dd = np.diff(raw, axis=1) % (1 << 32)
             m = dd.mean(0)
             us = e0.elapsed_time(e1) * 1e3 / reps
+            if os.environ["EPI"] == "2":
+                if kind == "dgrad":
+                    print("dgrad L%-4d %3d->%3d: %6.1f us/launch | start -> tile stores issued %6.0f | dp transposing reads %5.0f | barrier %5.0f | 16 LDS-DMA issued %5.0f | "
+                          "16 MFMAs + vmcnt(0): second operand landed AND output stores acknowledged %5.0f | barrier %5.0f | 32 reads + 16 MFMAs + sums stored + drained %5.0f | total %6.0f"
+                          % (l, cin, cout, us, m[0], m[1], m[2], m[3], m[4], m[5], m[6], dd.sum(1).mean()))
+                continue
             print("%-5s L%-4d %3d->%3d: %6.1f us/launch | start -> end of K loop %6.0f | wait at barrier 1 %5.0f | tile write %5.0f | wait at barrier 2 %5.0f | "
                   "%s %5.0f | %s %5.0f | store drain (vmcnt 0) %5.0f | total %6.0f" % (
                       kind, l, cin, cout, us, m[0], m[1], m[2], m[3], "pool pairs + stores" if kind == "fwd" else "tile stores", m[4],

@@ -530,9 +530,16 @@ __device__ inline void vm_epi_mark(int k) {
     const long long t = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) g_prof[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] = (unsigned int)t;
 }
+#if VM_EXPERIMENT_PROFILE_EPI + 0 == 2   // =2: the stamps go to the dgrad's fused BatchNorm-backward sums instead (EPI=2 nt3_prof.py)
+#define VM_EPI_MARK(k)
+#define VM_RED_MARK(k) vm_epi_mark(k)
+#else
 #define VM_EPI_MARK(k) vm_epi_mark(k)
+#define VM_RED_MARK(k)
+#endif
 #else
 #define VM_EPI_MARK(k)
+#define VM_RED_MARK(k)
 #endif
 struct N2DrainSync {   // the drain run by the four waves of a 256-thread workgroup that also computed the tile
     __device__ inline void sync() { __syncthreads(); }
@@ -843,6 +850,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         }
     }
     VM_EPI_MARK(6);
+    VM_RED_MARK(1);
     if (red) {
         // ---- BatchNorm-backward partial sums of the layer below, from the tile that is in LDS anyway (vm_conv_dgrad_bnred):
         //   S0[c] = sum_r dp[r][c] = (1^T DP)[c],   S1[c] = sum_r dp[r][c] * A[r][c] = diag(DP^T A)[c]
@@ -876,7 +884,9 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[8]), "+v"(dhi[8]), "+v"(dlo[9]), "+v"(dhi[9]), "+v"(dlo[10]), "+v"(dhi[10]), "+v"(dlo[11]),
                      "+v"(dhi[11]), "+v"(dlo[12]), "+v"(dhi[12]), "+v"(dlo[13]), "+v"(dhi[13]), "+v"(dlo[14]), "+v"(dhi[14]), "+v"(dlo[15]),
                      "+v"(dhi[15]));
+        VM_RED_MARK(2);
         bar.sync();  // every wave has its dp fragments and has issued its output stores: the tile memory is free
+        VM_RED_MARK(3);
         // A tile: 256 rows x 128 channels, 256-byte rows (unpadded: the LDS-DMA destination is lane-linear), 64 pieces of 4 rows.  A
         // row is a whole bank line, so the four rows of a transposing read would sit on the same banks: the 64-byte quarters of row R are
         // stored XOR-ed with (R >> 2) & 3 (applied to the per-lane SOURCE address here and to the read address below)
@@ -893,13 +903,16 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
                 if ((k & 3) == 3) bar.point();
             }
         }
+        VM_RED_MARK(4);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const u32x4 xv = {dlo[q][0], dlo[q][1], dhi[q][0], dhi[q][1]};
             d1[q >> 3] = Mfma<T>::run(ones, __builtin_bit_cast(V8, xv), d1[q >> 3]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and loads retire out of order with each other: no counted wait here
+        VM_RED_MARK(5);
         bar.sync();  // the A tile has landed for every wave
+        VM_RED_MARK(6);
         const uint32_t aoff = lds0 + (4 * (li >> 2) + 2 * kh) * 256 + (((32 * w + 16 * lg + 4 * (li & 3)) * 2) ^ ((li >> 2) << 6));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1634,7 +1647,7 @@ int g_nt3 = 3;         // conv_nt3_kernel (weights L2 -> registers) where the ca
 int g_nt3_lean = 3;    // conv_nt3_kernel's lean prologue (A(2), A(3) requested under the first two K tiles): bit 0 forward, bit 1 dgrad
 int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0, else register staging; vm_set_tuning("nt_glds", 0 | 1)
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
-extern int g_tn_x, g_tn_tile, g_tn9;  // conv_wgrad.hip
+extern int g_tn_x, g_tn_tile, g_tn9, g_tn9_stages;  // conv_wgrad.hip
 extern int g_fuse_finalize;          // bnpool.hip
 }  // namespace vm
 
@@ -1968,7 +1981,7 @@ extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int*
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"fuse_finalize", &g_fuse_finalize, 0, 31}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"tn9_stages", &g_tn9_stages, 0, 1}, {"fuse_finalize", &g_fuse_finalize, 0, 31}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;

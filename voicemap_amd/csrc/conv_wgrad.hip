@@ -35,6 +35,9 @@ struct TnArgs {
     // s / splits_per_tower); the plain entry point has one "tower" of all windows
     int64_t tower_windows = 0;
     int splits_per_tower = 0;
+    // conv_tn9_kernel only: a split is a range of 64-position STAGES of its tower's stream (window after window), not of whole
+    // windows -- 128 windows over 21 splits are 6.1 windows each, not 7 (0 = whole windows, win_per_split)
+    int64_t stages_per_split = 0;
 };
 
 // windows [w_begin, w_end) of split ``split``
@@ -664,15 +667,32 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
     const int split = __builtin_amdgcn_readfirstlane((int)(b / p.tilesI));
     const int ci0 = ti * 128, j0 = tj * 128;
 
-    int w_begin, w_end;
-    {
+    const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
+    // G stages are computed, Gs >= G are staged; the stream starts at stage ss0 of window nn0
+    int nn0, ss0 = 0, G, Gs;
+    if (p.stages_per_split > 0) {
+        // stages [g0, g1) of the tower's stream.  A split that ends INSIDE a window stages one stage more than it computes: taps 1, 2 of
+        // its last two positions read the first two input rows of the next stage (at a window's end those positions are halo rows
+        // whose gradient rows are zero, and nothing more is needed)
+        const int tw = split / p.splits_per_tower, j = split - tw * p.splits_per_tower;
+        const int64_t t0 = (int64_t)tw * p.tower_windows;
+        int64_t t1 = t0 + p.tower_windows;
+        if (t1 > p.n_windows) t1 = p.n_windows;
+        const int64_t S = (t1 - t0) * spw;
+        int64_t g0 = (int64_t)j * p.stages_per_split, g1 = g0 + p.stages_per_split;
+        g0 = g0 < S ? g0 : S;
+        g1 = g1 < S ? g1 : S;
+        G = __builtin_amdgcn_readfirstlane((int)(g1 - g0));
+        nn0 = __builtin_amdgcn_readfirstlane((int)(t0 + g0 / spw));
+        ss0 = __builtin_amdgcn_readfirstlane((int)(g0 % spw));
+        Gs = G + ((G > 0 && g1 % spw != 0) ? 1 : 0);
+    } else {
         int64_t wb, we;
         split_windows(p, split, wb, we);
-        w_begin = (int)wb;
-        w_end = (int)we;
+        nn0 = (int)wb;
+        G = we > wb ? (int)(we - wb) * spw : 0;
+        Gs = G;
     }
-    const int spw = (p.L + 2 + 63) / 64;  // stages per window (the last one holds the halo row L + 1)
-    const int G = w_end > w_begin ? (w_end - w_begin) * spw : 0;
 
     f32x16 acc[3][2];
 #pragma unroll
@@ -708,7 +728,7 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
             }
         };
         auto piece = [&](int slot, int n, int st, int q) { piece_of(w, slot, n, st, q); };
-        int nn = w_begin, ss = 0, staged = 0;  // stream cursor of the stage to be staged next
+        int nn = nn0, ss = ss0, staged = 0;  // stream cursor of the stage to be staged next
         auto advance = [&]() {
             ++staged;
             if (++ss == spw) {
@@ -744,15 +764,15 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
                         for (int q = 0; q < 4; ++q) piece_of(w0 + i, staged & 3, nn, ss, q);
                     advance();
                 };
-                for (int i = 0; i < 3 && staged < G; ++i) stage_all();
-                if (G > 2) {
+                for (int i = 0; i < 3 && staged < Gs; ++i) stage_all();
+                if (Gs > 2) {
                     wait_vmcnt<8>();
                 } else {
                     wait_vmcnt<0>();
                 }
                 __builtin_amdgcn_s_barrier();
                 for (int g = 0; g < G; ++g) {
-                    if (staged < G) {
+                    if (staged < Gs) {
                         stage_all();
                         wait_vmcnt<8>();
                     } else {
@@ -766,12 +786,12 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
             }
             __builtin_amdgcn_s_barrier();
         } else {
-            for (int i = 0; i < 3 && staged < G; ++i) {
+            for (int i = 0; i < 3 && staged < Gs; ++i) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) piece(staged & 3, nn, ss, q);
                 advance();
             }
-            if (G > 2) {
+            if (Gs > 2) {
                 wait_vmcnt<4>();
             } else {
                 wait_vmcnt<0>();
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
 
         for (int g = 0; g < G; ++g) {
             const int slot = g & 3;
-            const bool more = staged < G;
+            const bool more = staged < Gs;
             uint32_t aaddr[3], a3lo[3], a3hi[3], baddr[2];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -956,12 +976,15 @@ static int tiles(int64_t x, int t) { return (int)((x + t - 1) / t); }
 
 namespace vm {
 int g_tn9 = 1;        // conv_tn9_kernel (free-running K loop; 2 = with producer waves) instead of conv_tn8x_kernel (READ / MFMA slots); vm_set_tuning("tn9", 0 | 1 | 2)
+int g_tn9_stages = 1;  // conv_tn9_kernel's splits are ranges of 64-position stages, not of whole windows; vm_set_tuning("tn9_stages", 0 | 1)
 int g_tn_x = 1;       // conv_tn8x_kernel for 16-bit storage with channel counts % 64 == 0; vm_set_tuning("tn_x", 0 | 1)
 int g_tn_tile = 256;  // tile of the register-transposing kernels: 256 (8 waves, one workgroup per CU) or 128; vm_set_tuning("tn_tile", ..)
 }  // namespace vm
 
 static bool tn_x_shape(int c_in, int c_out) { return g_tn_x && c_in % 64 == 0 && c_out % 64 == 0; }
 static bool tn_use_256(int c_in, int c_out) { return g_tn_tile == 256 && 3 * c_in >= 192 && c_out >= 192; }
+static bool tn_stage_splits(int c_in, int c_out) { return tn_x_shape(c_in, c_out) && g_tn9 != 0 && g_tn9_stages != 0; }
+static int64_t tn9_stages_per_window(int64_t L) { return (L + 2 + 63) / 64; }
 
 // Split of the position reduction over windows.  All workgroups of a launch do the same amount of work
 // (windows_per_split windows) and a fixed number of them is resident at a time (2 per CU for the 128-tile kernel, 1 per
@@ -979,6 +1002,27 @@ static int wgrad_splits_per_tower(int64_t n_windows, int64_t tower_windows, int6
     const double t_window = xres ? 2.0 * 384 * 128 * (double)L / 5.0e12 : 2.0 * tile * tile * (double)L / (big ? 4.0e12 : 1.0e12);
     const double t_slab = 8.0 * 3.0 * c_in * c_out / 3.0e12;
     const int64_t towers = (n_windows + tower_windows - 1) / tower_windows;
+    if (tn_stage_splits(c_in, c_out)) {
+        // conv_tn9_kernel: a split is a range of stages (64 positions) of its tower's stream, so the work of a launch is balanced to one
+        // stage, not to one window: cfg-A block 3 (128 windows per tower, 6 output tiles) runs 2 x 21 splits of 147 stages (252 of 256
+        // workgroup slots, 6.1 windows each) where whole windows gave 2 x 19 of 168.  A split that ends inside a window stages one
+        // stage more than it computes (the + 1).  (The fp32 kernels run whole windows under the same split count: ceil(128 / 21) = 7
+        // windows fill 19 splits, the last two write zero slabs.)
+        const int64_t spw = tn9_stages_per_window(L), S = tower_windows * spw;
+        const double t_stage = t_window / (double)spw;
+        int64_t best_spt = 1;
+        double best = -1.0;
+        for (int64_t spt = 1; spt <= S && spt <= 4096; ++spt) {
+            const int64_t splits = towers * spt, sps = (S + spt - 1) / spt;
+            const int64_t rounds = (t * splits + slots - 1) / slots;
+            const double cost = (double)(rounds * (sps + 1)) * t_stage + (double)splits * t_slab;
+            if (best < 0.0 || cost < best) {
+                best = cost;
+                best_spt = spt;
+            }
+        }
+        return (int)best_spt;
+    }
     int64_t best_wps = 1;
     double best_cost = -1.0;
     for (int64_t wps = 1; wps <= tower_windows; ++wps) {
@@ -1029,6 +1073,7 @@ static int launch_wgrad(const void* in, const void* du, int64_t n_windows, int64
         a.tower_windows = tower_windows;
         a.splits_per_tower = spt;
         a.win_per_split = (tower_windows + spt - 1) / spt;
+        if (xres && tn_stage_splits(c_in, c_out)) a.stages_per_split = (tower_windows * tn9_stages_per_window(L) + spt - 1) / spt;
         a.split = dtype == VM_F32S;
         const dim3 grid((unsigned)((int64_t)splits * a.tilesI * a.tilesJ));
         if constexpr (sizeof(T) == 4) {
