@@ -52,11 +52,16 @@ def main(fetch_dir, write_dir, out):
         for splits in (lib.query("vm_conv_wgrad_splits", n, L, cin, cout),
                        lib.query("vm_conv_wgrad_fold_workspace_bytes", n, n // 2, L, cin, cout) // (3 * cin * cout * 4)):
             grids.append(splits * (-(-cin // 128)) * (-(-cout // 128)) * 512)  # conv_tn9_kernel / conv_tn8x_kernel: (3 taps x 128 ci) x 128 co tiles
-        for (name, g), fv in fetch.items():
-            if ("conv_tn9" in name or "conv_tn8x" in name) and g in grids:
-                wv = write.get((name, g), 0.0)
+        # the folded entry point's grid first (the default step); the plain one only where no launch has that grid -- with the
+        # stage-granular splits one shape's plain grid can equal another shape's folded grid (21 x 12 tiles = 42 x 6)
+        for want in (grids[1], grids[0]):
+            hit = [(name, g) for (name, g) in fetch if ("conv_tn9" in name or "conv_tn8x" in name) and g == want]
+            if hit:
+                name, g = hit[0]
+                fv, wv = fetch[(name, g)], write.get((name, g), 0.0)
                 res["kernels"]["vm_conv_wgrad|%d|%d|%d|%d" % (n, L, cin, cout)] = {
                     "fetch_kb": fv, "write_kb": wv, "hbm_bytes": 2 * fv * 1024 + wv * 1024, "grid": g}
+                break
     # forward / dgrad launches share one grid size: told apart by dispatch order (forward: blocks 2,3,4; dgrad: 4,3,2)
     shapes = [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]
     # (rocprofv3 prints some instantiations demangled, with the epilogue enum elided: "<bool _Accum, int, E, 128, false>")

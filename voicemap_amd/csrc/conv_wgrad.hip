@@ -659,6 +659,13 @@ __global__ __launch_bounds__(PW ? 768 : 512) void conv_tn9_kernel(TnArgs<T> p) {
         if (p.xcd_remap && b < full) {
             const int64_t xcd = b & 7, local = b >> 3;
             b = ((local / NT) * 8 + xcd) * NT + local % NT;
+        } else if (p.xcd_remap) {
+            // the splits % 8 splits behind the whole groups of 8: left in launch order their co-tiles went round the eight XCDs and every
+            // L2 fetched the split's operands for itself (cfg-A block 4: 4 of 20 splits, 3.5 x their bytes -- most of the kernel's
+            // counted excess over its algorithmic traffic).  Each XCD takes a contiguous run of (split, tile) pairs instead: a split's
+            // 12 tiles sit on two XCDs
+            const int64_t rest = (int64_t)p.splits * NT - full, per = rest / 8, bb = b - full;
+            if (bb < per * 8) b = full + (bb & 7) * per + (bb >> 3);
         }
     }
     const int tj = __builtin_amdgcn_readfirstlane((int)(b % p.tilesJ));
