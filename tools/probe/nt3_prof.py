@@ -27,7 +27,9 @@ for (l, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
             rows = L.query("vm_conv_stat_rows", l)
             ss = torch.empty(n * rows, cout, device="cuda"); sq = torch.empty_like(ss)
             e = torch.zeros(n, l // 2 + 2, cout, dtype=tdt, device="cuda"); o = torch.empty(n, l // 2, cout, dtype=tdt, device="cuda")
-            run = lambda: L.call("vm_conv_fwd_fold", p(a), p(w), p(bias), p(hb), p(gam), n, n // 2, l, cin, cout, vm, None, p(ss), p(sq), p(e), p(o), p(wp), None, st())
+            ctr = torch.zeros(2 * cout, device="cuda") if os.environ.get("CTR") else None   # CTR=1: the centred-tile form (block 2's default)
+            run = lambda: L.call("vm_conv_fwd_fold", p(a), p(w), p(bias), p(hb), p(gam), n, n // 2, l, cin, cout, vm, None, p(ss), p(sq), p(e), p(o), p(wp),
+                                 p(ctr) if ctr is not None else None, st())
         else:
             a = torch.zeros(n, l + 2, cout, dtype=tdt, device="cuda"); a[:, 1:l + 1] = torch.randn(n, l, cout, device="cuda", generator=g).to(tdt)
             w = (torch.randn(cin * 3 * cout, device="cuda", generator=g) * 0.05).to(tdt)
@@ -54,6 +56,16 @@ for (l, cin, cout) in [(3000, 128, 256), (1500, 256, 384), (750, 384, 512)]:
             dd = np.diff(raw, axis=1) % (1 << 32)
             m = dd.mean(0)
             us = e0.elapsed_time(e1) * 1e3 / reps
+            if os.environ.get("PER_WAVE"):   # which of the four waves arrives late at the epilogue's first barrier
+                pw = dd[:, 1].reshape(-1, 4)
+                k0 = dd[:, 0].reshape(-1, 4)
+                print("%-5s L%-4d per-wave (w = 2 wm + wn) mean clocks start -> end of K loop %s | wait at barrier 1 %s | share of tiles where wave w waits least %s" % (
+                    kind, l, np.round(k0.mean(0)).astype(int), np.round(pw.mean(0)).astype(int), np.round(np.bincount(pw.argmin(1), minlength=4) / len(pw), 2)))
+            if os.environ.get("PER_WAVE"):
+                spread = k0.max(1) - k0.min(1)
+                print("      per-tile spread of the four waves' arrival (max - min of start -> end of K loop): quantiles 10/50/90/99 %% = %s; wait quantiles %s; "
+                      "tiles whose slowest wave is > 1000 clocks behind the fastest: %.2f" % (
+                          np.percentile(spread, [10, 50, 90, 99]).astype(int), np.percentile(pw, [10, 50, 90, 99]).astype(int), (spread > 1000).mean()))
             if os.environ["EPI"] == "2":
                 if kind == "dgrad":
                     print("dgrad L%-4d %3d->%3d: %6.1f us/launch | start -> tile stores issued %6.0f | dp transposing reads %5.0f | barrier %5.0f | 16 LDS-DMA issued %5.0f | "
