@@ -554,8 +554,8 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
     constexpr bool FWD = EPI == EPI_FWD || EPI == EPI_FWD_FOLD;
     const bool red = EPI == EPI_DGRAD && p.red_a != nullptr;
     const int valid = (p.L - t0) < trows ? (p.L - t0) : trows;  // MFMA-tile rows that are positions of the window
-    // centred tile (fold_ctr): the accumulators hold z_pre - ctr (the start vector had ctr taken off), so ReLU is max(., -ctr) in fp32
-    // before the ONE rounding to the storage type
+    // centred tile (fold_ctr): the accumulators hold z_pre - ctr (the start vector had ctr taken off), so ReLU is max(., -ctr), with
+    // ONE rounding to the storage type
     // (negc = -ctr of this lane's 32 channels, loaded by n2_epilogue in front of its first barrier)
     constexpr bool CAN_CENTRE = EPI == EPI_FWD_FOLD && std::is_same<T, f16>::value;
     const bool ctrd = CAN_CENTRE && p.fold_ctr != nullptr;
@@ -564,8 +564,24 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
     // rounding is monotone, so relu(round(x)) == round(relu(x))): 1 VALU instruction per element instead of 2.5 ----
     // (the run-time switch is hoisted into two straight-line copies: left inside, hipcc branched on it once per 4 values -- 64
     // branches per wave-tile, 4.8 k clocks of tile write against the dgrad form's 2.0 k; profiles/r05_nt3_epilogue_phases.txt)
+    // The centred form takes its maximum with -ctr AFTER the conversion, as a packed half maximum: rounding is monotone and -ctr is a
+    // half, so max(rn(x), -ctr) == rn(max(x, -ctr)) -- still one rounding, 2 operations per 4 values instead of 4 fp32 maxima (a VALU
+    // operation costs 12-20 clocks here, beside a wave that issues MFMAs back to back: centred tile write 3.0 k -> 2.0 k clocks, the
+    // un-centred form's).  (Zeroing the rows outside the window only in the 32-row blocks that have any -- a wave-uniform branch per
+    // block instead of two selects per group -- was measured too: no faster, and the four copies of the loop cost the dgrad 1 %.)
     auto body = [&](auto ctrd_c) {
         constexpr bool CTRD = decltype(ctrd_c)::value;
+        uint32_t nc16[2][4][2];   // -ctr of the lane's channels as packed halves (exact: ctr is a half)
+        if constexpr (CTRD) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    nc16[j][g][0] = __builtin_bit_cast(uint32_t, h2{(_Float16)negc[j][g][0], (_Float16)negc[j][g][1]});
+                    nc16[j][g][1] = __builtin_bit_cast(uint32_t, h2{(_Float16)negc[j][g][2], (_Float16)negc[j][g][3]});
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = wm * 128 + i * 32 + r;
@@ -577,15 +593,16 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
                 for (int g = 0; g < 4; ++g) {
                     const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
                     T o[4];
-                    if constexpr (CTRD) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(fmaxf(acc[i][j][4 * g + e], negc[j][g][e]));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
                     u32x2 pk = *reinterpret_cast<const u32x2*>(o);
-                    if constexpr (EPI != EPI_DGRAD && !CTRD) {
+                    if constexpr (CTRD) {
+                        uint32_t lo = pk[0], hi = pk[1];
+                        asm("v_pk_max_f16 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(nc16[j][g][0]));
+                        asm("v_pk_max_f16 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(nc16[j][g][1]));
+                        pk[0] = lo;
+                        pk[1] = hi;
+                    } else if constexpr (EPI != EPI_DGRAD) {
                         uint32_t lo = pk[0], hi = pk[1];
                         asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
                         asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
