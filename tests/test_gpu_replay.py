@@ -164,3 +164,50 @@ def test_last_arriver_finalize_equals_the_two_launch_form(dtype, dropout, filter
     for u, v in zip(oa, ob):
         assert torch.equal(u, v)
     _same_state(a, b, "fuse_finalize")
+
+
+def test_inference_between_replayed_steps_sees_the_current_weights():
+    """a replayed optimizer step must mark the packed inference weights stale like the eager one does -- the ordinary
+    train / evaluate / train / evaluate loop of experiments/train_siamese.py:65-94 (validation and the n-shot callback per epoch)."""
+    a, b = _engines("uniform_euclidean", "f16", 0.0)
+    assert a.packed_weights
+    r = np.random.default_rng(11)
+    pairs, raw_len = 6, 4800
+    probe = r.normal(0, 0.05, (5, raw_len // 4)).astype(np.float32)
+    seen = []
+    for step in range(12):
+        x1 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        x2 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        y = (r.random((pairs, 1)) > 0.5).astype(np.float32)
+        for eng in (a, b):
+            eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4)
+        if step in (3, 6, 7, 11):      # the first embed clears the stale flag; the later ones follow REPLAYED steps
+            ea, eb = a.embed(probe).clone(), b.embed(probe).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(ea, eb), step
+            seen.append(ea)
+    assert len(_programs(a)) == 1
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[2], seen[3])   # the weights did move in between
+
+
+def test_recorded_steps_are_dropped_when_their_buffers_go():
+    """programs hold raw device pointers; toggling packed_weights (bench.py --tune, tests) re-makes the fold buffers and a
+    plan used with another tower size re-makes its fold plan -- neither may leave a recorded step behind."""
+    a, b = _engines("uniform_euclidean", "f16", 0.0)
+    r = np.random.default_rng(12)
+
+    def steps(pairs, k):
+        for _ in range(k):
+            x1 = r.normal(0, 0.05, (pairs, 4800, 1)).astype(np.float32)
+            x2 = r.normal(0, 0.05, (pairs, 4800, 1)).astype(np.float32)
+            y = (r.random((pairs, 1)) > 0.5).astype(np.float32)
+            for eng in (a, b):
+                eng.siamese_train_step(x1, x2, y, loss="bce", preprocessed=False)
+        torch.cuda.synchronize()
+    steps(4, 4)
+    assert len(_programs(a)) == 1
+    for v in (False, True):
+        a.packed_weights = b.packed_weights = v
+        assert not a._programs
+        steps(4, 4)
+        _same_state(a, b, v)

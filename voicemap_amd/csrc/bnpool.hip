@@ -9,6 +9,7 @@
 //   du          = dz * [z > 0]                                           (ReLU fused into the conv)
 //   dgamma      = sum(dy*zhat), dbeta = sum(dy)   (both towers added)
 // pass 1 (reduce) builds the two sums, pass 2 (apply) writes du into a halo-padded tensor for dgrad/wgrad.
+#include <mutex>
 #include <type_traits>
 
 #include "common.hpp"
@@ -89,24 +90,37 @@ constexpr int CR_CHUNKS = 32;
 int g_fuse_finalize = 17;
 constexpr int TICKET_WORDS = 16384;
 __device__ unsigned g_tickets[TICKET_WORDS];
+//  the symbol is resolved per device -- a process that drives several GPUs has one g_tickets per device -- and the cursor
+// is advanced under a lock, so two host threads can never be handed overlapping words.
 static unsigned* ticket_range(int n) {
-    static unsigned next = 0;   // (host calls into the library are not thread-safe per stream anyway: see the header)
-    static unsigned* base = nullptr;
-    if (base == nullptr) {
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static unsigned next[MAX_DEV] = {};
+    static unsigned* base[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV || n > TICKET_WORDS) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (base[dev] == nullptr) {
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
-        base = (unsigned*)p;
+        base[dev] = (unsigned*)p;
     }
-    if (next + (unsigned)n > (unsigned)TICKET_WORDS) next = 0;
-    unsigned* r = base + next;
-    next += (unsigned)n;
+    if (next[dev] + (unsigned)n > (unsigned)TICKET_WORDS) next[dev] = 0;
+    unsigned* r = base[dev] + next[dev];
+    next[dev] += (unsigned)n;
     return r;
 }
 
 // true in exactly one workgroup of the ``total`` that call it with this ticket: the last to arrive
 __device__ inline bool last_arriver(unsigned* ticket, unsigned total) {
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's store_agent()s are acknowledged (written through)
+    // Every wave waits until its write-through (sc1) partial stores are ACKNOWLEDGED before the barrier that precedes the ticket.
+    // A workgroup-scope release fence does not do that on gfx950 (the compiled code had the stores, s_barrier and the
+    // ticket atomic back to back with no vmcnt wait, so the last arriver -- possibly on another XCD -- could read stale partials);
+    // the explicit wait does, and it is all that is needed: the stores bypass this XCD's L2 write-back state (sc1), and a wait
+    // for their acknowledgement costs no cache operation.  tests/test_isa_lint.py checks the instruction is in the code object.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -465,14 +465,28 @@ class HipEncoderEngine:
         self._ev_record, self._ev_wait = self.lib.cdll.vm_event_record, self.lib.cdll.vm_stream_wait_event
         return prog
 
+    def _destroy_program(self, prog):
+        if isinstance(prog, _Program):
+            for h in prog.events.values():
+                self.lib.cdll.vm_event_destroy(h)
+            prog.events = {}
+
+    def _drop_programs(self):
+        """Forget every recorded step.  Programs hold raw device pointers: whoever frees or reallocates a buffer a program may
+        reference (the fold buffers, a plan's lazily sized buffers, a stream) calls this."""
+        progs = getattr(self, "_programs", None)
+        if progs:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(self.device)   # a replayed step may still be in flight on the events about to go
+            for prog in progs.values():
+                self._destroy_program(prog)
+            progs.clear()
+
     def __del__(self):
         # the recorded programs' events are the only library-side objects an engine owns
         try:
             for prog in getattr(self, "_programs", {}).values():
-                if isinstance(prog, _Program):
-                    for h in prog.events.values():
-                        self.lib.cdll.vm_event_destroy(h)
-                    prog.events = {}
+                self._destroy_program(prog)
         except Exception:   # interpreter shutdown: the library may be gone already
             pass
 
@@ -667,6 +681,7 @@ class HipEncoderEngine:
         changed = bool(v) != getattr(self, "_packed_weights", None)
         self._packed_weights = bool(v)
         if changed and hasattr(self, "_plans"):   # (during __init__ the copies are made by init_params -> refresh_weights)
+            self._drop_programs()   # recorded steps point into the fold buffers dropped below
             self._fold = {}
             self._pack_args = None
             self._wfp_stale = True
@@ -680,6 +695,7 @@ class HipEncoderEngine:
     def side_priority(self, v):
         """experiment (bench.py --tune side_priority=N): the HIP priority of the side stream the weight-gradient GEMMs run on"""
         self._side_priority = int(v)
+        self._drop_programs()
         self.side_stream = torch.cuda.Stream(device=self.device, priority=int(v))
 
     def refresh_weights(self):
@@ -923,6 +939,7 @@ class HipEncoderEngine:
         if fold:
             if pl.get("fold_ready", wpt) != wpt:   # the slab split depends on the tower size
                 del pl["fold_ready"]
+                self._drop_programs()              # steps recorded for the other tower size point at the buffers re-made below
             self._fold_plan(pl)
         if training:
             self.bn_steps += 1
@@ -1407,16 +1424,24 @@ class HipEncoderEngine:
         usable = self.replay and self.grad_sync is None and not self.timed and not self.sync_bn
         prog = key = None
         if usable:
-            sig = None if pre is None else (pre[0], pre[1].dtype, tuple(pre[1].shape)) + tuple(pre[-2:]) + ((pre[3],) if pre[0] == "offsets" else ())
+            # (the offsets path never reads the audio buffer's length: its shape is not part of what a program depends on)
+            sig = None if pre is None else ((pre[0], pre[1].dtype, tuple(pre[1].shape)) + tuple(pre[-2:]) if pre[0] == "raw"
+                                            else (pre[0], pre[1].dtype, pre[3]) + tuple(pre[-2:]))
             masks = None if drop_masks is None else tuple(m is not None for m in drop_masks)
             key = (id(pl), wpt, loss, apply_update, self.stream(), sig, masks, self._step_flags())
             prog = self._programs.get(key)
             if isinstance(prog, _Program):
+                self._programs[key] = self._programs.pop(key)   # most recently used last
                 self._replay_step(prog, pl, wpt, target, drop_masks, apply_update, pre)
                 return
             if prog is None:
                 self._programs[key] = 1            # first sighting: run it (lazy buffers get allocated), record the next one
-            elif len(self._programs) < 64:
+                while len(self._programs) > 64:    # bounded: the least recently used configuration goes (with its events)
+                    old = next(iter(self._programs))
+                    if isinstance(self._programs[old], _Program):
+                        torch.cuda.synchronize(self.device)
+                    self._destroy_program(self._programs.pop(old))
+            else:
                 self._rec = _Program()
         try:
             if pre is not None:
@@ -1481,6 +1506,7 @@ class HipEncoderEngine:
             dyn["lr_t"], dyn["gpre"] = float(lr_t), float(self.grad_prescale) / float(self.loss_scale)
         self._run_program(prog, dyn)
         if apply_update:
+            self._wfp_stale = True   # what refresh_weights() / _pack_weights() note on the eager path: the inference copies are old
             self.iterations = t
             if self.loss_scaled:
                 self._poll_loss_scale()
