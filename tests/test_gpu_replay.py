@@ -211,3 +211,53 @@ def test_recorded_steps_are_dropped_when_their_buffers_go():
         assert not a._programs
         steps(4, 4)
         _same_state(a, b, v)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_preprocessing_beside_the_previous_steps_tail_is_the_same_step(dtype):
+    """Round 6 (engine.pre_overlap): with input_ready the decimate / whiten pass of step k + 1 runs on the tower stream as soon as
+    step k's block-1 backward has read x0 (voicemap/utils.py:22-34, 88-101 is the same function of the batch wherever it runs).  A
+    different batch every step: a preprocessing that overwrote x0 too early, or a forward that started too early, changes the weights.
+    Eager, recorded and replayed steps follow one another on one plan."""
+    a, b = _engines("uniform_euclidean", dtype, 0.0)
+    b.replay = True
+    b.pre_overlap = False
+    r = np.random.default_rng(21)
+    pairs, raw_len = 16, 12000
+    raws = [torch.from_numpy(r.normal(0, 0.05, (2 * pairs, raw_len)).astype(np.float32)).cuda() for _ in range(4)]
+    y = torch.from_numpy((r.random(pairs) > 0.5).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+    pls = [e.plan(2 * pairs, raw_len // 4, True) for e in (a, b)]
+    for step in range(14):
+        if step == 9:
+            a.replay = False        # back to eager steps behind replayed ones
+        for e, pl in zip((a, b), pls):
+            e.train_step_resident(pl, pairs, y, "contrastive" if step % 5 else "bce", raw=raws[step % 4], drop_masks=None, input_ready=True)
+        if step % 3 == 2:
+            torch.cuda.synchronize()
+            _same_state(a, b, step)
+    torch.cuda.synchronize()
+    _same_state(a, b, "end")
+    assert _programs(a) and "x0_free_ev" in pls[0] and "x0_free_ev" not in pls[1]
+
+
+def test_staged_offsets_on_the_tower_stream_are_the_same_steps():
+    """The resident-corpus loop (shards.py; reference: LibriSpeechDataset.__getitem__ crops on the host, voicemap/librispeech.py:103-137):
+    offsets and labels go up on the tower stream in front of the preprocessing that runs there."""
+    a, b = _engines("uniform_euclidean", "f16", 0.0)
+    b.replay = True
+    b.pre_overlap = False
+    r = np.random.default_rng(22)
+    pairs, raw_len = 8, 12000
+    audio = torch.from_numpy((r.normal(0, 0.05, 400000) * 32767).astype(np.int16)).cuda()
+    for step in range(40):          # more steps than staging slots: a slot is refilled
+        o1 = r.integers(0, 400000 - raw_len, pairs).astype(np.int64)
+        o2 = r.integers(0, 400000 - raw_len, pairs).astype(np.int64)
+        y = (r.random(pairs) > 0.5).astype(np.float32)
+        for e in (a, b):
+            e.siamese_train_step_from_offsets(audio, o1, o2, y, raw_len, loss="contrastive", drop_masks=None)
+        if step % 13 == 12:
+            torch.cuda.synchronize()
+            _same_state(a, b, step)
+    torch.cuda.synchronize()
+    _same_state(a, b, "end")

@@ -20,6 +20,6 @@ x = torch.from_numpy(rng.normal(0, 0.05, (2 * pairs, 48000)).astype(np.float32))
 y = torch.cat([torch.zeros(pairs // 2), torch.ones(pairs - pairs // 2)]).cuda()
 pl = eng.plan(2 * pairs, 12000, True)
 for _ in range(steps):
-    eng.train_step_resident(pl, pairs, y, "contrastive", raw=x)
+    eng.train_step_resident(pl, pairs, y, "contrastive", raw=x, input_ready=True)
 torch.cuda.synchronize()
 print("done", name, pairs, steps)

@@ -1291,6 +1291,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt2r_kernel(NtArgs<T> p, int64_t 
 //   N = loads issued after B(kt) = A pieces of kt - 2  +  B(kt + 1)  +  A pieces of kt - 1  +  B(kt + 2)
 // The epilogue is conv_nt2r_kernel's (n2_epilogue).  Same requirements: a_c % 32 == 0, Ktot == 3 * a_c, N % 128 == 0.
 // ------------------------------------------------------------------------------------------------
+// timing experiments of conv_nt3_kernel (WRONG results; tools/build_variant.sh <name> -DVM_NT3_ABL=<bits>): 1 no in-loop weight loads,
+// 2 no in-loop input DMA, 4 no K-loop MFMAs, 8 no epilogue
+#ifndef VM_NT3_ABL
+#define VM_NT3_ABL 0
+#endif
 namespace n3 {
 constexpr int NBLK = 4;
 constexpr int A_BLK = 256 * 64;
@@ -1358,6 +1363,10 @@ static_assert(n3_nwait(0, 4, false) == 12 && n3_nwait(1, 4, false) == 10 && n3_n
 static_assert(n3_nwait(0, 4, true) == 8 && n3_nwait(1, 4, true) == 12 && n3_nwait(2, 4, true) == 12 && n3_nwait(3, 4, true) == 8 &&
               n3_nwait(4, 8, true) == 6 && n3_nwait(11, 4, true) == 0, "conv_nt3_kernel wait schedule (lean prologue)");
 
+// (Round 6, measured and removed: a start offset of half a tile for the workgroup in a CU's second slot in the first round of the grid.
+// The slot timelines of tools/probe/nt3_slots.py show why it cannot pay: the two workgroups of a CU already run half a tile out of
+// phase on their own -- median phase of the second slot's starts 0.48-0.52 on all six launches, profiles/r06_nt3_slots.txt -- and the
+// launches gained nothing at any offset, 0 .. +3 % with the delay itself; round 2 had the same result on conv_nt2r_kernel.)
 // LEAN: the prologue that leaves A(2), A(3) to the first two K tiles (A/B switch nt3_lean)
 template <typename T, int EPI, int CHUNKS, bool LEAN>
 __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n_groups) {
@@ -1491,7 +1500,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
             }
         n2_fill_acc(acc, bias4);
     }
+#if VM_NT3_ABL & 4
+#define VM_MM(A, B, I, J) asm volatile("" : "+v"(acc[I][J]) : "v"(A), "v"(B))
+#else
 #define VM_MM(A, B, I, J) acc[I][J] = Mfma<T>::run(__builtin_bit_cast(V8, B), __builtin_bit_cast(V8, A), acc[I][J])
+#endif
     // KT is a literal in the macros below: every index, every wait count and every branch is a compile-time constant, the loop is
     // straight-line code and no register that a load is still writing ever meets a phi (the rolled form made hipcc copy them)
     // ---- the interleaved loop.  Every memory operation of a K tile sits INSIDE its MFMA stream, one per pair of MFMAs: the
@@ -1512,7 +1525,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     VM_MM(f0[I], bs[cur_][0], I, 0);                                                                                                  \
     VM_MM(f0[I], bs[cur_][2], I, 1);                                                                                                  \
     VM_FRAG_READ(f1[I], aa1_, I)                                                                                                      \
-    if constexpr (kt_ + 2 < NK) {                                                                                                     \
+    if constexpr (kt_ + 2 < NK && !(VM_NT3_ABL & 1)) {                                                                                \
         if constexpr ((I) == 0) VM_GLOAD_FRAG(bs[nxt_][0], bvoff, sb_, 0);                                                            \
         if constexpr ((I) == 1) VM_GLOAD_FRAG(bs[nxt_][1], bvoff, sb_, 1024);                                                         \
         if constexpr ((I) == 2) VM_GLOAD_FRAG(bs[nxt_][2], bvoff, sb_, 2048);                                                         \
@@ -1531,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     VM_MM(f1[I], bs[cur_][1], I, 0);                                                                                                  \
     VM_MM(f1[I], bs[cur_][3], I, 1);                                                                                                  \
     if constexpr (kt_ + 1 < NK) { VM_FRAG_READ(f0[I], an0_, I) }                                                                      \
-    if constexpr ((I) < n3_pieces(kt_, CHUNKS, LEAN).count)                                                                           \
+    if constexpr ((I) < n3_pieces(kt_, CHUNKS, LEAN).count && !(VM_NT3_ABL & 2))                                                      \
         issue_a1(n3_pieces(kt_, CHUNKS, LEAN).block % 4, n3_pieces(kt_, CHUNKS, LEAN).block, n3_pieces(kt_, CHUNKS, LEAN).first + (I)); \
     __builtin_amdgcn_sched_barrier(0);
 #define VM_KTILE_P(KT)                                                                                                                \
@@ -1575,12 +1588,30 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
     }
     VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
+#if VM_NT3_ABL & 8
+    if (acc[0][0][0] == 123.456f && acc[3][1][15] == 1.5f) n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+#else
     n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+#endif
 #if defined(VM_EXPERIMENT_PROFILE)
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const long long pt_end = __builtin_amdgcn_s_memtime();
-#if defined(VM_EXPERIMENT_PROFILE_EPI)
+#if defined(VM_EXPERIMENT_PROFILE_HW)
+        // where and when a workgroup ran (tools/probe/nt3_slots.py): raw stamps + the hardware ids of its CU / workgroup slot
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
+            q[0] = (unsigned int)pt_start;
+            q[1] = (unsigned int)pt_end;
+            q[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13, tg 19:16
+            q[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+            q[4] = (unsigned int)pt_bar;
+            q[5] = (unsigned int)pt_loop;
+            q[6] = (unsigned int)(pt_start >> 32);
+            q[7] = (unsigned int)pt_s3;
+        }
+        (void)pt_first; (void)pt_s2;
+#elif defined(VM_EXPERIMENT_PROFILE_EPI)
         if (lane == 0 && blockIdx.x < 8192) {   // raw stamps: slots 1..6 were written by the epilogue (VM_EPI_MARK)
             unsigned int* q = g_prof + ((int64_t)blockIdx.x * 4 + w) * 8;
             q[0] = (unsigned int)pt_start;

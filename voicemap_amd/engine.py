@@ -276,6 +276,10 @@ class HipEncoderEngine:
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
         self.tower_stream = torch.cuda.Stream(device=self.device)
+        # round 6: a training step whose input does not depend on the main stream (input_ready: a resident corpus + staged offsets, synthetic
+        # data) runs its preprocessing on the tower stream as soon as the PREVIOUS step's block-1 backward has read x0 -- beside that
+        # step's optimizer tail (reduce, norm, Adam, weight copies: six dependent ~5 us launches during which the chip is idle)
+        self.pre_overlap = True
         # round 5: GlobalMaxPool1D finish -> Dense(E) -> head -> loss -> their backward as ONE launch per step (vm_tail_fwd_bwd) + one launch of
         # parameter gradients on the side stream (vm_tail_param_grads) instead of six; bit-identical (tests/test_gpu_kernels.py)
         self.fused_tail = True
@@ -1189,6 +1193,8 @@ class HipEncoderEngine:
                 self._call("vm_conv1_fused_bwd", _p(pl["x0"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
                            _p(b["dp"]), _p(b["scale"]), _p(b["mean"]), _p(b["invstd"]), dm, _p(b["c1"]), _p(b["c2"]), n, wpt, L,
                            c, pool, dt, _p(pl["wgrad_ws"]), _p(self.view("conv1.kernel", G)), _p(self.view("conv1.bias", G)), st)
+                if "x0_free_ev" in pl:
+                    self._record(pl["x0_free_ev"])   # x0's last reader of this step is enqueued: the next step's preprocessing may overwrite it
                 continue
             sparse = (i == last and last > 0)
             if sparse:
@@ -1248,6 +1254,8 @@ class HipEncoderEngine:
             if i == 0:
                 self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(pl["cr_ws"]), st)
                 self._call("vm_conv1_wgrad", _p(pl["x0"]), _p(b["du"]), n, L, c, dt, _p(pl["wgrad_ws"]), gw, st)
+                if "x0_free_ev" in pl:
+                    self._record(pl["x0_free_ev"])
             else:
                 cin = self.blocks[i - 1][1]
 
@@ -1414,9 +1422,10 @@ class HipEncoderEngine:
                 self.overlap_wgrad, self.wgrad_after_dgrad, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
-                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
+                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.pre_overlap, self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
 
-    def _train_step(self, pl: dict, wpt: int, target: torch.Tensor, loss: Optional[str], drop_masks, apply_update: bool, pre):
+    def _train_step(self, pl: dict, wpt: int, target: torch.Tensor, loss: Optional[str], drop_masks, apply_update: bool, pre,
+                    input_ready: bool = False):
         """preprocess (``pre`` = None | ("raw", tensor, downsampling, whitening) | ("offsets", audio, offsets, raw_len, downsampling,
         whitening)) -> forward -> head (``loss`` None: the classifier's) -> backward -> optimizer.  The SECOND time a configuration
         is seen its enqueue sequence is recorded (_Program), from the third on it is replayed: same launches, same arguments, same
@@ -1428,10 +1437,11 @@ class HipEncoderEngine:
             sig = None if pre is None else ((pre[0], pre[1].dtype, tuple(pre[1].shape)) + tuple(pre[-2:]) if pre[0] == "raw"
                                             else (pre[0], pre[1].dtype, pre[3]) + tuple(pre[-2:]))
             masks = None if drop_masks is None else tuple(m is not None for m in drop_masks)
-            key = (id(pl), wpt, loss, apply_update, self.stream(), sig, masks, self._step_flags())
+            key = (id(pl), wpt, loss, apply_update, self.stream(), sig, masks, bool(input_ready), self._step_flags())
             prog = self._programs.get(key)
             if isinstance(prog, _Program):
                 self._programs[key] = self._programs.pop(key)   # most recently used last
+                self._x0_handover(pl, prog)
                 self._replay_step(prog, pl, wpt, target, drop_masks, apply_update, pre)
                 return
             if prog is None:
@@ -1443,12 +1453,28 @@ class HipEncoderEngine:
                     self._destroy_program(self._programs.pop(old))
             else:
                 self._rec = _Program()
+        self._x0_handover(pl, "eager")
         try:
             if pre is not None:
-                if pre[0] == "raw":
-                    self.preprocess(pl, pre[1], pre[2], pre[3], wpt)
-                else:
-                    self.preprocess(pl, pre[1], pre[4], pre[5], wpt, offsets=pre[2], raw_len=pre[3])
+                ahead = bool(input_ready and self.pre_overlap and not self.timed and pl["training"])
+                if ahead:
+                    # on the tower stream, behind the previous step's last reader of x0 only (x0_free_ev: recorded by backward())
+                    cur = torch.cuda.current_stream(self.device)
+                    if "x0_free_ev" not in pl:
+                        pl["x0_free_ev"] = torch.cuda.Event()
+                    pre_cm = self._on(self.tower_stream)
+                    pre_cm.__enter__()
+                    self._wait(self.tower_stream, pl["x0_free_ev"])
+                try:
+                    if pre[0] == "raw":
+                        self.preprocess(pl, pre[1], pre[2], pre[3], wpt)
+                    else:
+                        self.preprocess(pl, pre[1], pre[4], pre[5], wpt, offsets=pre[2], raw_len=pre[3])
+                finally:
+                    if ahead:
+                        pre_cm.__exit__(None, None, None)
+                if ahead:
+                    self._join(cur, self.tower_stream)
             if loss is None:
                 self.forward(pl, wpt, drop_masks)
                 self.classifier_head(pl, target)
@@ -1463,16 +1489,28 @@ class HipEncoderEngine:
         if rec is not None:
             self._programs[key] = self._finish_program(rec)
 
+    def _x0_handover(self, pl: dict, who):
+        """x0_free_ev is a torch event in an eager step and the program's own event in a replayed one: when the step before this one
+        on the same plan was enqueued by somebody else (eager <-> replay, another program) the wait inside this step would see an event
+        that step never recorded -- the tower stream then simply waits for everything the main stream holds (no overlap, once)."""
+        if pl.get("x0_owner") is not who:
+            if pl.get("x0_owner") is not None:
+                self.tower_stream.wait_stream(torch.cuda.current_stream(self.device))
+            pl["x0_owner"] = who
+
     def train_step_resident(self, pl: dict, windows_per_tower: int, target: torch.Tensor, loss: Optional[str] = "contrastive", raw=None,
-                            downsampling: int = 4, whitening: bool = True, drop_masks="auto", apply_update: bool = True):
+                            downsampling: int = 4, whitening: bool = True, drop_masks="auto", apply_update: bool = True,
+                            input_ready: bool = False):
         """One training step on tensors that are already on the device: ``raw`` (n_windows, samples) fp32 / int16 windows (None: the
         plan's input was loaded with load_preprocessed), ``target`` the labels (fp32 (pairs,) for the siamese losses, int32
         (n_windows,) with ``loss=None`` for the classifier).  What siamese_train_step / classifier_train_step run after their
-        host-to-device copies; bench.py times this."""
+        host-to-device copies; bench.py times this.  ``input_ready``: the caller guarantees that ``raw`` is complete in memory
+        whatever the current stream still holds (a resident corpus, synthetic data) -- the preprocessing then runs on the tower stream
+        beside the previous step's optimizer tail (``pre_overlap``) instead of behind it."""
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(pl["n"])
         self._train_step(pl, windows_per_tower, target, loss, drop_masks, apply_update,
-                         None if raw is None else ("raw", raw, downsampling, whitening))
+                         None if raw is None else ("raw", raw, downsampling, whitening), input_ready=input_ready)
         return pl
 
     def _replay_step(self, prog: _Program, pl: dict, wpt: int, target, drop_masks, apply_update: bool, pre):
@@ -1540,30 +1578,36 @@ class HipEncoderEngine:
         host = isinstance(offsets_1, np.ndarray) and isinstance(offsets_2, np.ndarray)
         pairs = int(offsets_1.size) if host else int(offsets_1.numel())
         pl = self.plan(2 * pairs, (raw_len + downsampling - 1) // downsampling, True)
+        staged = ready = False
         if host and not torch.is_tensor(y):
-            offs, yd = self._stage_offsets_and_labels(pl, offsets_1, offsets_2, y, pairs)
+            offs, yd, ready = self._stage_offsets_and_labels(pl, offsets_1, offsets_2, y, pairs)
+            staged = True
         else:
             offs = torch.cat([torch.as_tensor(offsets_1).reshape(-1), torch.as_tensor(offsets_2).reshape(-1)]).to(self.device, torch.int64).contiguous()
             yd = torch.as_tensor(y, dtype=torch.float32).reshape(pairs).to(self.device).contiguous()
         if isinstance(drop_masks, str):
             drop_masks = self.make_drop_masks(2 * pairs)
-        self._train_step(pl, pairs, yd, loss, drop_masks, apply_update, ("offsets", audio, offs, raw_len, downsampling, whitening))
+        self._train_step(pl, pairs, yd, loss, drop_masks, apply_update, ("offsets", audio, offs, raw_len, downsampling, whitening),
+                         input_ready=ready)
+        if staged:
+            self._staged_step_enqueued(pl)
         return pl
 
     def _stage_offsets_and_labels(self, pl: dict, o1: "np.ndarray", o2: "np.ndarray", y, pairs: int):
-        """Host arrays -> the plan's persistent device buffers (2 * pairs int64 offsets, pairs fp32 labels) in ONE asynchronous copy
-        from a ring of pinned staging buffers.  torch's ``.to(device)`` of a pageable array is a blocking copy that is ordered behind
-        everything already enqueued on the stream: three of them per step made the host wait for the GPU to drain, then left the GPU
-        idle while the host prepared the next step (fit_generator at 64 pairs: 1.67 ms per step against 1.45 ms of GPU work).  A slot
-        is reused after 32 steps; its copy's event is waited for first (long done)."""
+        """Host arrays -> device buffers (2 * pairs int64 offsets, pairs fp32 labels) in ONE asynchronous copy from a ring of pinned
+        staging buffers.  torch's ``.to(device)`` of a pageable array is a blocking copy that is ordered behind everything already
+        enqueued on the stream: three of them per step made the host wait for the GPU to drain, then left the GPU idle while the host
+        prepared the next step (fit_generator at 64 pairs: 1.67 ms per step against 1.45 ms of GPU work).  Round 6: the device side is
+        a ring as well (a step reads ITS slot, so the next step's copy needs no ordering against this step's kernels) and, with
+        ``pre_overlap``, the copy goes to the tower stream in front of the preprocessing that runs there ahead of the main stream.
+        A slot is reused after 32 steps; the step that last read it has its end-of-enqueue event waited for first (long done).
+        Returns (offsets, labels, input_ready)."""
         st = pl.get("h2d")
         if st is None:
             nbytes = 2 * pairs * 8 + pairs * 4
-            st = pl["h2d"] = {"dev": torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+            st = pl["h2d"] = {"dev": [torch.empty(nbytes, dtype=torch.uint8, device=self.device) for _ in range(32)],
                               "pin": [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(32)],
                               "ev": [None] * 32, "k": 0}
-            st["offs"] = st["dev"][:2 * pairs * 8].view(torch.int64)
-            st["y"] = st["dev"][2 * pairs * 8:].view(torch.float32)
         k = st["k"] % 32
         st["k"] += 1
         if st["ev"][k] is not None:
@@ -1572,10 +1616,22 @@ class HipEncoderEngine:
         buf[:pairs * 8] = np.ascontiguousarray(o1, dtype=np.int64).reshape(-1).view(np.uint8)
         buf[pairs * 8:2 * pairs * 8] = np.ascontiguousarray(o2, dtype=np.int64).reshape(-1).view(np.uint8)
         buf[2 * pairs * 8:] = np.ascontiguousarray(np.asarray(y, dtype=np.float32).reshape(pairs)).view(np.uint8)
-        st["dev"].copy_(st["pin"][k], non_blocking=True)
+        dev = st["dev"][k]
+        ahead = bool(self.pre_overlap and not self.timed)
+        if ahead:
+            with torch.cuda.stream(self.tower_stream):
+                dev.copy_(st["pin"][k], non_blocking=True)
+        else:
+            dev.copy_(st["pin"][k], non_blocking=True)
+        st["cur"] = k
+        return dev[:2 * pairs * 8].view(torch.int64), dev[2 * pairs * 8:].view(torch.float32), ahead
+
+    def _staged_step_enqueued(self, pl: dict):
+        """The step that reads the staging slot is enqueued: its slot may be refilled once everything enqueued so far has run."""
+        st = pl["h2d"]
+        k = st["cur"]
         ev = st["ev"][k] = st["ev"][k] or torch.cuda.Event()
         ev.record()
-        return st["offs"], st["y"]
 
     def classifier_train_step(self, x, labels, preprocessed: bool = True, downsampling: int = 4, whitening: bool = True,
                               drop_masks="auto", apply_update: bool = True):
