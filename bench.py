@@ -126,7 +126,7 @@ def self_launch(n):
     Fewer than N visible devices is an error unless the transport is the gloo rehearsal (ranks then share devices)."""
     import socket
     import subprocess
-    if os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo":
+    if os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo" and not os.environ.get("VOICEMAP_DIST_SHARE_DEVICE"):
         have = torch.cuda.device_count()
         if have < n:
             fail("bench.py --gpus %d: only %d device(s) visible on this node -- refusing to report a smaller run as n_gpus %d"
@@ -178,9 +178,12 @@ def main():
         fail("bench.py --gpus %d was started with WORLD_SIZE=%d: launch with --nproc-per-node == --gpus (or without torchrun: "
              "bench.py spawns the ranks itself)" % (a.gpus, world))
     n_gpus = world
-    if n_gpus > 1 and os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo" and torch.cuda.device_count() < n_gpus:
+    share = bool(os.environ.get("VOICEMAP_DIST_SHARE_DEVICE"))   # rehearsal of the RCCL path itself on a box with fewer GPUs than ranks:
+    # RCCL refuses two ranks of a communicator on one device -- tests/test_gpu_bench.py asserts that the refusal comes back as an
+    # error line within the watchdog's limit, not as a hang
+    if n_gpus > 1 and os.environ.get("VOICEMAP_DIST_BACKEND") != "gloo" and not share and torch.cuda.device_count() < n_gpus:
         fail("bench.py --gpus %d: only %d device(s) visible on this node" % (n_gpus, torch.cuda.device_count()))
-    if os.environ.get("VOICEMAP_DIST_BACKEND") == "gloo":   # rehearsal: more ranks than GPUs, the replicas share devices
+    if os.environ.get("VOICEMAP_DIST_BACKEND") == "gloo" or share:   # rehearsal: more ranks than GPUs, the replicas share devices
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -294,7 +297,24 @@ def main():
         per_rank = torch.tensor([float(np.median(mine_s)) / a.steps * 1e3, wait_ms], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(per_rank) for _ in range(n_gpus)]
         dist.all_gather(allr, per_rank)
-        out["data_parallel"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+        # what makes the first real N > 1 line self-verifying: the transport's version, WHICH devices the ranks ran on, and whether
+        # the replicas still hold the same parameters after the timed steps (they must: same reduced gradient, same update)
+        props = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "host": os.uname().nodename, "device_index": int(dev.index), "name": props.name,
+                 "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+        idents = [None] * n_gpus
+        dist.all_gather_object(idents, ident)
+        psum = torch.stack([eng.P.double().sum(), eng.P.double().abs().sum(), eng.M.double().sum()])
+        psums = [torch.zeros_like(psum) for _ in range(n_gpus)]
+        dist.all_gather(psums, psum)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception as e:   # noqa: BLE001
+            rccl = "unavailable: %r" % (e,)
+        out["data_parallel"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": rccl,
+                                "rank_devices": idents,
+                                "distinct_devices": len({(i["host"], i["uuid"] or i["pci_bus_id"], i["device_index"]) for i in idents}),
+                                "replicas_bit_identical_after_timed_steps": bool(all(torch.equal(psums[0], q) for q in psums)),
                                 "collectives_per_step": gs.collectives / max(1, a.warmup + a.steps * len(block_s)),
                                 "flat_gradient_bytes": int(eng.n_flat * 4),
                                 "rank_ms_per_step": [round(float(t[0]), 4) for t in allr],

@@ -58,6 +58,8 @@ def test_bench_two_ranks_over_gloo(launch):
     dp = out["data_parallel"]
     assert dp["backend"] == "gloo" and dp["world_size"] == 2 and len(dp["rank_ms_per_step"]) == 2
     assert abs(dp["collectives_per_step"] - 2.0) < 1e-9 and dp["flat_gradient_bytes"] > 4_000_000
+    assert dp["replicas_bit_identical_after_timed_steps"] is True and dp["rccl_version"] is None and len(dp["rank_devices"]) == 2
+    assert dp["distinct_devices"] == 1 and {d["rank"] for d in dp["rank_devices"]} == {0, 1}     # the rehearsal shares the one GPU, and says so
     assert "extras" not in out and "cpu_baseline" not in out     # rank 0 at N = 1 only
     assert r.stdout.count('"metric"') == 1                        # ONE line, from rank 0
 
@@ -72,3 +74,29 @@ def test_bench_refuses_more_ranks_than_devices():
     assert r.returncode != 0
     out = _last_json_line(r.stdout)
     assert out["value"] is None and "device" in out["error"]
+
+
+def test_bench_two_ranks_over_rccl_on_one_device_end_loudly():
+    """VERDICT r5 next #7a: the RCCL transport itself with two ranks on the ONE device of the test box (VOICEMAP_DIST_SHARE_DEVICE).
+    RCCL refuses a communicator with two ranks on one GPU: what must happen then is an error (a non-zero exit with the transport's or
+    the watchdog's message) inside the watchdog's limit -- never a hang.  If a future RCCL accepts the sharing, the line must be a
+    complete N = 2 line over "nccl"."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VOICEMAP_DIST_SHARE_DEVICE="1", VOICEMAP_DIST_WATCHDOG_S="45")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VOICEMAP_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "1", "--pairs", "8"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    log = os.path.join(ROOT, "gpurun_out", "rccl_two_ranks_one_device.log")
+    try:
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, "w") as f:
+            f.write("rc=%d\n--- stdout\n%s\n--- stderr (tail)\n%s\n" % (r.returncode, r.stdout[-4000:], r.stderr[-6000:]))
+    except OSError:
+        pass
+    if r.returncode == 0:
+        out = _last_json_line(r.stdout)
+        assert out["n_gpus"] == 2 and out["data_parallel"]["backend"] == "nccl" and out["data_parallel"]["replicas_bit_identical_after_timed_steps"]
+    else:
+        text = (r.stdout + r.stderr).lower()
+        # the refusal must be RCCL's own (reached through init_process_group("nccl") and the first barrier) or the watchdog's
+        assert "duplicate gpu" in text or "watchdog: no progress" in text, r.stderr[-3000:]

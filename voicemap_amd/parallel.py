@@ -44,6 +44,8 @@ def init_distributed(backend: str | None = None, timeout_s: float | None = None)
         if backend is None:   # VOICEMAP_DIST_BACKEND=gloo: rehearsal of the multi-rank code paths on a box with fewer GPUs than ranks
             backend = os.environ.get("VOICEMAP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            if os.environ.get("VOICEMAP_DIST_SHARE_DEVICE"):   # rehearsal on a box with fewer GPUs than ranks (RCCL is expected to refuse)
+                local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
         kw = {}
         if timeout_s is not None:
