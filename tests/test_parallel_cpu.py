@@ -241,6 +241,7 @@ def test_two_rank_hip_engine_on_one_gpu_over_gloo(tmp_path):
         res = torch.load(str(tmp_path / ("gres%d.pt" % r)))
         assert res["same_P"] and res["same_M"] and res["same_V"] and res["sum_ok"] and res["finite"]
         assert res["collectives_per_step"] == 2
+        assert res["replay_programs"] == 1 and res["replay_same_as_eager"] and res["replay_collectives"] == (14, 14)
         assert res["cache_rows"] == 45 and res["cache_same"]
         assert res["nshot_sharded"] == res["nshot_single"] and res["retrieval_sharded"] == res["retrieval_single"]
 
@@ -363,6 +364,23 @@ def _gpu_worker(rank, world, port, outdir, backend="nccl"):
         dist.all_gather(parts, t)
         res["same_" + name] = bool(all(torch.equal(parts[0], q) for q in parts))
     res["finite"] = bool(torch.isfinite(pl["loss_acc"]).all().item())
+    # round 6: a data-parallel step is recorded and replayed like a single-GPU one (the two collectives are host calls of the program,
+    # engine._host_call): a replaying engine and an eager one, same seed, same batches, hold the same bits after 7 steps
+    from voicemap_amd.engine import _Program
+    ea = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype="f16", seed=9)
+    eb = HipEncoderEngine(blocks, 16, dropout=0.0, head="uniform_euclidean", dtype="f16", seed=9)
+    eb.replay = False
+    for e in (ea, eb):
+        parallel.attach_if_distributed(e)
+    for k in range(7):
+        xa = g.normal(0, 0.05, (pairs, l0, 1)).astype(np.float32)
+        xb = g.normal(0, 0.05, (pairs, l0, 1)).astype(np.float32)
+        for e in (ea, eb):
+            e.siamese_train_step(xa, xb, y, drop_masks=None)
+    torch.cuda.synchronize()
+    res["replay_programs"] = sum(isinstance(p_, _Program) for p_ in ea._programs.values())
+    res["replay_same_as_eager"] = bool(all(torch.equal(getattr(ea, nm_).view(torch.int32), getattr(eb, nm_).view(torch.int32)) for nm_ in ("P", "M", "V", "G")))
+    res["replay_collectives"] = (ea.grad_sync.collectives, eb.grad_sync.collectives)
     # BASELINE.json config 5 sharded: every rank embeds its rows of the corpus, the (N, E) matrix is all-gathered, tasks / query rows
     # are split over ranks and one integer is summed -- every rank must hold the single-process answers
     from voicemap_amd import models as VM, retrieval as R, utils as VU

@@ -454,10 +454,33 @@ class HipEncoderEngine:
             self._rec.cmds.append([1, key, waited.cuda_stream])
             self._rec.cmds.append([2, waiter.cuda_stream, key])
 
+    def _host_call(self, fn):
+        """A step's host-side call that is not a C-ABI entry point (torch.distributed collectives): run now and, in a step being
+        recorded, kept in the program at this position -- a replay calls it again between the same launches."""
+        fn()
+        if self._rec is not None:
+            self._rec.cmds.append([3, fn, None, "host call"])
+
+    def _begin_grad_tail(self, pl: dict):
+        """Data parallelism: every gradient of G[conv2.kernel:] that the main stream writes is enqueued -- hand that range to the
+        gradient hook's early collective (parallel.GradAllReduce.begin_tail), ordered behind the main stream's position and the side
+        stream's weight-gradient GEMMs.  Hooks with ``ordered_begin`` get the ordering from the engine (so a recorded step carries
+        it) and only enqueue the collective."""
+        if "sync_ev" not in pl:
+            pl["sync_ev"] = torch.cuda.Event()
+        gs = self.grad_sync
+        if not hasattr(gs, "ordered_begin"):
+            pl["sync_ev"].record()  # main stream: every gradient of G[conv2.kernel:] that is not on the side stream
+            gs.begin_tail(self, pl["sync_ev"])
+            return
+        self._record(pl["sync_ev"])
+        self._wait(self.side_stream, pl["sync_ev"])
+        self._host_call(lambda: gs.ordered_begin(self))
+
     def _finish_program(self, prog: _Program) -> _Program:
         """Event keys -> events of the program's own (created once; a replay never touches torch's events)."""
         for c in prog.cmds:
-            if c[0] == 0:
+            if c[0] == 0 or c[0] == 3:
                 continue
             slot = 1 if c[0] == 1 else 2
             h = prog.events.get(c[slot])
@@ -505,8 +528,11 @@ class HipEncoderEngine:
                 rc = c[1](*c[2])
             elif k == 1:
                 rc = rec(c[1], c[2])
-            else:
+            elif k == 2:
                 rc = wait(c[1], c[2])
+            else:
+                c[1]()          # a host call of the step (the gradient collectives of data parallelism): _host_call
+                rc = 0
             if rc != 0:
                 msg = self.lib.cdll.vm_last_error()
                 raise _lib.VoicemapHipError("%s failed (%d) in a replayed step: %s" % (c[3] if k == 0 else "stream ordering", rc,
@@ -1266,10 +1292,7 @@ class HipEncoderEngine:
                         # (the bias gradient is nobody's input until the optimizer: off the main stream, with its own workspace)
                         wgrad(self.stream(), pl["cr_ws_side"])
                     if i == 1 and sync_tail:
-                        if "sync_ev" not in pl:
-                            pl["sync_ev"] = torch.cuda.Event()
-                        pl["sync_ev"].record()  # main stream: every gradient of G[conv2.kernel:] that is not on the side stream
-                        self.grad_sync.begin_tail(self, pl["sync_ev"])
+                        self._begin_grad_tail(pl)
 
                 late = self.overlap_wgrad and self.wgrad_after_dgrad and not (i == 1 and sync_tail)
                 if self.overlap_wgrad and not late:
@@ -1277,10 +1300,7 @@ class HipEncoderEngine:
                 elif not self.overlap_wgrad:
                     wgrad(st, pl["cr_ws"])
                     if i == 1 and sync_tail:
-                        if "sync_ev" not in pl:
-                            pl["sync_ev"] = torch.cuda.Event()
-                        pl["sync_ev"].record()
-                        self.grad_sync.begin_tail(self, pl["sync_ev"])
+                        self._begin_grad_tail(pl)
                 lo = pl[i - 1]
                 lo["bnred_now"] = self._bnred_plan(pl, i)
                 if lo["bnred_now"]:
@@ -1369,7 +1389,8 @@ class HipEncoderEngine:
     def optimizer_step(self):
         """Keras Adam(clipnorm) on the flat buffers (after the optional data-parallel gradient sum)."""
         if self.grad_sync is not None:
-            self.grad_sync(self.G)
+            gs, G = self.grad_sync, self.G
+            self._host_call(lambda: gs(G))
         lib, st = self.lib, self.stream()
         skip = self.loss_scaled   # loss-scaled storage: a non-finite gradient norm skips the update on the device
         if (self.clipnorm and self.clipnorm > 0) or skip:
@@ -1422,7 +1443,7 @@ class HipEncoderEngine:
                 self.overlap_wgrad, self.wgrad_after_dgrad, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
-                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.pre_overlap, self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
+                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.pre_overlap, id(self.grad_sync), self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
 
     def _train_step(self, pl: dict, wpt: int, target: torch.Tensor, loss: Optional[str], drop_masks, apply_update: bool, pre,
                     input_ready: bool = False):
@@ -1430,7 +1451,10 @@ class HipEncoderEngine:
         whitening)) -> forward -> head (``loss`` None: the classifier's) -> backward -> optimizer.  The SECOND time a configuration
         is seen its enqueue sequence is recorded (_Program), from the third on it is replayed: same launches, same arguments, same
         stream ordering -- only the input / label / mask pointers and four scalars are patched in."""
-        usable = self.replay and self.grad_sync is None and not self.timed and not self.sync_bn
+        # (a gradient hook that declares itself ``replayable`` -- parallel.GradAllReduce: its two collectives are host calls kept in
+        # the program, its stream ordering goes through the engine -- no longer forces the eager path; SyncBN still does)
+        usable = (self.replay and (self.grad_sync is None or getattr(self.grad_sync, "replayable", False)) and not self.timed
+                  and not self.sync_bn)
         prog = key = None
         if usable:
             # (the offsets path never reads the audio buffer's length: its shape is not part of what a program depends on)

@@ -81,6 +81,8 @@ class GradAllReduce:
     """``engine.grad_sync`` hook (see the module docstring).  ``split_name``: first tensor of the flat buffer that belongs
     to the early collective; everything before it (block 1) is reduced in the hook itself."""
 
+    replayable = True   # engine._train_step may record a step that contains this hook (its collectives are host calls of the program)
+
     def __init__(self, world: int, overlap: bool = True, split_name: str = "conv2.kernel"):
         self.world = world
         self.overlap = overlap
@@ -113,6 +115,26 @@ class GradAllReduce:
             else:
                 side.wait_stream(torch.cuda.current_stream(tail.device))
             with torch.cuda.stream(side):
+                self._work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self._work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+        self._split = split
+        self.collectives += 1
+
+    def ordered_begin(self, engine):
+        """``begin_tail`` for a caller that has already ordered the side stream behind the main stream's last write into the range
+        (engine._begin_grad_tail: through the engine's own event calls, so that a recorded step replays the ordering)."""
+        if self.world <= 1 or not self.overlap or self.split_name not in engine.offsets:
+            return
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        split = engine.offsets[self.split_name][0]
+        if split <= 0 or split >= engine.G.numel():
+            return
+        tail = engine.G[split:]
+        if tail.is_cuda:
+            with torch.cuda.stream(engine.side_stream):
                 self._work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
         else:
             self._work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
