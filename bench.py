@@ -722,7 +722,14 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         ex.update({"pairdist_ms_per_rank_shard_13002x104014x64": t_pd * 1e3,
                    "pairdist_gpairs_per_s": rows8 * n360 / t_pd / 1e9,
                    "pairdist_config": "vm_pairdist_argmin, euclidean, argmin only: one rank's 1/8 row shard of a train-clean-360-sized (104 014 x 64) "
-                                      "embedding matrix against all of it"})
+                                      "embedding matrix against all of it",
+                   # the kernel's bound is fp32 VALU issue: the direct form costs a subtract and an FMA per component pair, a wave-64
+                   # instruction occupies its SIMD for 2 clocks (packed fp32 forms issue at half that rate: no gain on gfx950)
+                   "pairdist_roofline": {"bound": "valu", "unit": "G wave-instructions/s",
+                                         "achieved": 2.0 * rows8 * n360 * E / 64 / t_pd / 1e9, "peak": 1024 * 2.4 / 2.0,
+                                         "frac": (2.0 * rows8 * n360 * E / 64 / t_pd / 1e9) / (1024 * 2.4 / 2.0),
+                                         "note": "2 x M x N x E / 64 wave instructions (subtract + FMA per component pair; addressing, LDS reads "
+                                                 "and the argmin are not counted) against 1024 SIMDs x 2.4 GHz / 2 clocks"}})
         del embm, ws
         torch.cuda.empty_cache()
     except Exception as e:

@@ -89,6 +89,34 @@ def test_pairdist_argmin_vs_numpy(dist, M, N, E, row0):
     assert torch.equal(bi, bi2) and torch.equal(bv, bv2)
 
 
+def test_pairdist_argmin_full_shard_planted_neighbours():
+    """BASELINE.json config 5 at the size bench.py times (one rank's 13 002 x 104 014 x 64 shard of a train-clean-360-sized matrix;
+    experiments/k_way_accuracy.py:52-69 is the loop it replaces): a size-independent property instead of a float64 matrix of 1.35e9
+    entries -- every query has ONE planted reference 1e-2 away (everything else is ~11 away), outside the query rows and different
+    for every query, so the answer is known: argmin = the plant, its distance = the float64 distance to it."""
+    N, M, E, row0 = 104014, 13002, 64, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ref = torch.randn(N, E, device="cuda", generator=g)
+    perm = torch.randperm(N - (row0 + M), device="cuda", generator=g)[:M] + row0 + M     # distinct targets behind the query rows
+    lo = torch.randperm(row0, device="cuda", generator=g)[:M // 4]                         # ... and a quarter of them in front
+    perm[:M // 4] = lo
+    noise = torch.randn(M, E, device="cuda", generator=g) * (1e-2 / 8.0)
+    ref[perm] = ref[row0:row0 + M] + noise
+    q = ref[row0:row0 + M].contiguous()
+    ws = torch.empty(L().query("vm_pairdist_workspace_bytes", M, N) // 4 + 16, device="cuda")
+    bv = torch.empty(M, device="cuda")
+    bi = torch.empty(M, dtype=torch.int32, device="cuda")
+    L().call("vm_pairdist_argmin", p(q), p(ref), M, N, E, DIST["euclidean"], row0, None, p(bv), p(bi), p(ws), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bi.long(), perm)
+    want = (q.double() - ref[perm].double()).pow(2).sum(1).sqrt()
+    assert (bv.double() - want).abs().max().item() < 3e-6 * 1.0 + 1e-7
+    # without the exclusion a query finds itself
+    L().call("vm_pairdist_argmin", p(q), p(ref), M, N, E, DIST["euclidean"], -1, None, p(bv), p(bi), p(ws), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bi.long(), torch.arange(row0, row0 + M, device="cuda")) and bv.abs().max().item() == 0.0
+
+
 def _model_and_data(dtype="f32", speakers=14, files=6):
     from voicemap_amd import models as VM, utils as VU
     from voicemap_amd.librispeech import SyntheticSpeechDataset

@@ -192,12 +192,15 @@ __global__ __launch_bounds__(256) void nshot_indexed_kernel(const float* __restr
 }
 
 // vm_pairdist_argmin: the (M, N) distance matrix between a block of query rows and the whole reference matrix, fp32, with the
-// nearest reference row per query (first minimum; the query's own row can be excluded).  Workgroup = 16 x 16 threads, tile 64
-// queries x 64 references, thread (ty, tx) owns queries 4ty..4ty+3 x references 4tx..4tx+3; the query tile stays in LDS for the
-// whole walk over the references (split over blockIdx.y), reference tiles are staged 64 components at a time.  The euclidean
-// distance is the direct form sqrt(sum (a - b)^2) -- no ||a||^2 + ||b||^2 - 2ab cancellation -- 2 VALU instructions per
-// component pair: VALU-bound, ~5 ms for 13 K x 104 K x 64 (one rank's share of train-clean-360 at cfg-A's E).
-constexpr int PD_T = 64, PD_EC = 64, PD_MAX_E = 256;
+// nearest reference row per query (first minimum; the query's own row can be excluded).  The euclidean distance is the direct form
+// sqrt(sum (a - b)^2) -- no ||a||^2 + ||b||^2 - 2ab cancellation -- 2 VALU instructions per component pair: the kernel's bound is
+// fp32 VALU issue (2 x M x N x E / 64 wave instructions; v_pk_* do not issue faster on gfx950).  Round 6, on the 13 002 x 104 014 x 64
+// shard of BASELINE.json config 5 (profiles/r06_pairdist.txt): the round-5 kernel (16 x 16 threads, 4 x 4 register tiles, both operands
+// from LDS) ran 8.9 ms -- it was LDS-bound: a thread's four ADJACENT reference rows put lanes tx, tx + 4, tx + 8, tx + 12 on the same
+// banks (4-way conflicts on every reference read).  Rows 16 apart + register prefetch of the next stage: 5.5 ms, and the dot product
+// at 3.5 ms showed the LDS still level with the VALU (8 reads per 64 component pairs).  Now the QUERIES are wave-uniform and come through
+// the scalar path (pairdist_qt_kernel lays them out for it), lanes are references: one LDS read per 32 component pairs.
+constexpr int PD_T = 64, PD_RT = 128, PD_EC = 64, PD_MAX_E = 256;   // queries per workgroup, references per stage, components per stage
 
 __global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x, int64_t rows, int E, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -209,125 +212,159 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x,
     if (lane == 0) out[r] = s;
 }
 
-__global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__ q, const float* __restrict__ ref, int64_t M, int64_t N,
-                                                       int E, int dist_kind, int64_t q_row0, const float* __restrict__ qsq,
+// q (M, E) -> qT: per group of 8 queries and per 4 components the 8 x 4 values back to back (128 bytes): what a wave of
+// pairdist_kernel takes per component step through the SCALAR path.  [group][e4][query in group][4]; rows past M / components past E: 0.
+__global__ __launch_bounds__(256) void pairdist_qt_kernel(const float* __restrict__ q, int64_t M, int E, int EP, float* __restrict__ qT) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t groups = (M + 7) / 8;
+    if (i >= groups * 8 * EP) return;
+    const int c = (int)(i & 3), qi = (int)((i >> 2) & 7);
+    const int64_t r = i >> 5;
+    const int e4 = (int)(r % (EP / 4));
+    const int64_t g = r / (EP / 4);
+    const int64_t m = g * 8 + qi;
+    const int e = e4 * 4 + c;
+    qT[i] = (m < M && e < E) ? q[m * E + e] : 0.f;
+}
+
+// Workgroup = 8 waves; wave w owns the 8 queries m0 + 8 w .. + 7 -- WAVE-UNIFORM, so their components arrive through scalar loads
+// (SGPR operands of the subtract / FMA: no LDS read, no vector register) -- and lane l the references n0 + l and n0 + l + 64 of a
+// 128-reference stage, whose 64 components per stage it reads from LDS 16 bytes at a time: ONE LDS read per 32 component pairs.
+template <int DIST>
+__global__ __launch_bounds__(512) void pairdist_kernel(const float* __restrict__ qT, const float* __restrict__ ref, int64_t M, int64_t N,
+                                                       int E, int64_t q_row0, const float* __restrict__ qsq,
                                                        const float* __restrict__ rsq, int tiles_per_split, float* __restrict__ dist,
                                                        float* __restrict__ part_val, int32_t* __restrict__ part_idx) {
-    extern __shared__ __attribute__((aligned(16))) float pd_lds[];
-    const int EP = ((E + 3) / 4) * 4;     // query rows are zero-extended to a multiple of 4 components
-    const int QP = EP + 4;                // row pitch of the query tile (floats)
-    constexpr int RP = PD_EC + 4;         // ... of a reference chunk
-    float* qs = pd_lds;                   // [64][QP]
-    float* rs = qs + PD_T * QP;           // [64][RP]
-    float* red_v = rs + PD_T * RP;        // [64][16]
-    int* red_i = reinterpret_cast<int*>(red_v + PD_T * 16);
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * PD_T;
-    for (int i = tid; i < PD_T * EP; i += 256) {
-        const int r = i / EP, e = i - r * EP;
-        qs[r * QP + e] = (m0 + r < M && e < E) ? q[(m0 + r) * E + e] : 0.f;
-    }
-    float qn[4], bestv[4];
-    int besti[4];
+    constexpr int RT = PD_RT, RP = PD_EC + 4;   // 128 references per stage; row pitch 68 floats = 17 bank quads
+    __shared__ __attribute__((aligned(16))) float rs[RT * RP];
+    const int EP = ((E + 3) / 4) * 4, E4 = EP / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * PD_T + 8 * w;          // this wave's first query
+    const float* qg = qT + (m0 >> 3) * (int64_t)E4 * 32;            // its group's rows of qT (wave-uniform)
+    float qn[8], bestv[8];
+    int besti[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + ty * 4 + i;
-        qn[i] = (dist_kind == VM_DIST_COSINE && m < M) ? sqrtf(qsq[m]) : 1.f;
+    for (int i = 0; i < 8; ++i) {
+        qn[i] = (DIST == VM_DIST_COSINE && m0 + i < M) ? sqrtf(qsq[m0 + i]) : 1.f;
         bestv[i] = INFINITY;
         besti[i] = 0x7fffffff;
     }
-    const int n_tiles = (int)((N + PD_T - 1) / PD_T);
+    const int n_tiles = (int)((N + RT - 1) / RT);
     const int t_lo = blockIdx.y * tiles_per_split;
     const int t_hi = min(n_tiles, t_lo + tiles_per_split);
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int64_t n0 = (int64_t)t * PD_T;
-        float acc[4][4];
+    const int nchunk = (EP + PD_EC - 1) / PD_EC;
+    const int n_stage = (t_hi - t_lo) * nchunk;
+    const bool vec = (E & 3) == 0;
+    // stage s = (tile t_lo + s / nchunk, components (s % nchunk) * 64 ..): this thread's four 16-byte pieces, piece = tid + 512 k
+    auto fetch = [&](int s, f32x4 (&v)[4]) {
+        const int64_t n0 = (int64_t)(t_lo + s / nchunk) * RT;
+        const int ec = (s % nchunk) * PD_EC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k) {
+            const int piece = tid + 512 * k, r = piece >> 4, c = (piece & 15) * 4;
+            const int64_t row = n0 + r;
+            const int col = ec + c;
+            if (vec) {
+                const bool ok = row < N && col < E;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(ref + (ok ? row * E + col : 0));
+                v[k] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-        for (int ec = 0; ec < EP; ec += PD_EC) {
-            const int ew = min(PD_EC, EP - ec);
-            __syncthreads();  // the previous chunk's readers are done (and, the first time, the query tile is complete)
-            for (int i = tid; i < PD_T * PD_EC; i += 256) {
-                const int r = i >> 6, e = i & 63;
-                rs[r * RP + e] = (n0 + r < N && ec + e < E) ? ref[(n0 + r) * E + ec + e] : 0.f;
-            }
-            __syncthreads();
-            for (int e = 0; e < ew; e += 4) {
-                f32x4 qv[4], rv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const f32x4*>(qs + (ty * 4 + i) * QP + ec + e);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(rs + (tx * 4 + j) * RP + e);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (dist_kind == VM_DIST_EUCLIDEAN) {
-                                const float d = qv[i][c] - rv[j][c];
-                                acc[i][j] = fmaf(d, d, acc[i][j]);
-                            } else {
-                                acc[i][j] = fmaf(qv[i][c], rv[j][c], acc[i][j]);
-                            }
-                        }
+                for (int u = 0; u < 4; ++u) v[k][u] = (row < N && col + u < E) ? ref[row * E + col + u] : 0.f;
             }
         }
+    };
+    auto stash = [&](const f32x4 (&v)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + ty * 4 + i;
-            f32x4 o;
+        for (int k = 0; k < 4; ++k) {
+            const int piece = tid + 512 * k, r = piece >> 4, c = (piece & 15) * 4;
+            *reinterpret_cast<f32x4*>(rs + r * RP + c) = v[k];
+        }
+    };
+    f32x4 nxt[4];
+    if (n_stage > 0) fetch(0, nxt);
+    float acc[8][2];
+    for (int s = 0; s < n_stage; ++s) {
+        const int t = t_lo + s / nchunk, ck = s % nchunk;
+        const int ec = ck * PD_EC;
+        const int ew4 = min(PD_EC, EP - ec) / 4;
+        const int64_t n0 = (int64_t)t * RT;
+        __syncthreads();  // the previous stage's readers are done
+        stash(nxt);
+        if (s + 1 < n_stage) fetch(s + 1, nxt);   // in flight while this stage is consumed
+        __syncthreads();
+        if (ck == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t nn = n0 + tx * 4 + j;
+            for (int i = 0; i < 8; ++i) acc[i][0] = acc[i][1] = 0.f;
+        }
+        const float* qe = qg + (ec / 4) * 32;
+#pragma unroll 2
+        for (int e4 = 0; e4 < ew4; ++e4) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rs + lane * RP + e4 * 4);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(rs + (lane + 64) * RP + e4 * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qe + e4 * 32 + i * 4);   // uniform address: a scalar load
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (DIST == VM_DIST_EUCLIDEAN) {
+                        const float d0 = qv[c] - r0[c], d1 = qv[c] - r1[c];
+                        acc[i][0] = fmaf(d0, d0, acc[i][0]);
+                        acc[i][1] = fmaf(d1, d1, acc[i][1]);
+                    } else {
+                        acc[i][0] = fmaf(qv[c], r0[c], acc[i][0]);
+                        acc[i][1] = fmaf(qv[c], r1[c], acc[i][1]);
+                    }
+                }
+            }
+        }
+        if (ck != nchunk - 1) continue;
+        float rn[2] = {1.f, 1.f};
+        if (DIST == VM_DIST_COSINE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rn[j] = sqrtf(n0 + lane + 64 * j < N ? rsq[n0 + lane + 64 * j] : 1.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // ascending reference index within a lane: the first minimum is kept
+            const int64_t nn = n0 + lane + 64 * j;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t m = m0 + i;
                 float d;
-                if (dist_kind == VM_DIST_EUCLIDEAN) {
+                if (DIST == VM_DIST_EUCLIDEAN) {
                     d = sqrtf(acc[i][j]);
-                } else if (dist_kind == VM_DIST_COSINE) {
-                    d = 1.f - acc[i][j] / (qn[i] * sqrtf(nn < N ? rsq[nn] : 1.f));
+                } else if (DIST == VM_DIST_COSINE) {
+                    d = 1.f - acc[i][j] / (qn[i] * rn[j]);
                 } else {
                     d = -acc[i][j];
                 }
-                o[j] = d;
-                if (nn < N && m < M && (q_row0 < 0 || nn != q_row0 + m) && d < bestv[i]) {  // ascending nn: the first minimum is kept
+                if (dist != nullptr && m < M && nn < N) dist[m * N + nn] = d;   // a wave = 256 contiguous bytes of a row
+                if (nn < N && m < M && (q_row0 < 0 || nn != q_row0 + m) && d < bestv[i]) {
                     bestv[i] = d;
                     besti[i] = (int)nn;
                 }
             }
-            if (dist != nullptr && m < M) {
-                const int64_t nn = n0 + tx * 4;
-                if (nn + 3 < N && (N & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(dist + m * N + nn) = o;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (nn + j < N) dist[m * N + nn + j] = o[j];
-                }
-            }
         }
     }
-    __syncthreads();
+    // a lane's minimum is the first in ITS references; across lanes the smaller index wins a tie
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        red_v[(ty * 4 + i) * 16 + tx] = bestv[i];
-        red_i[(ty * 4 + i) * 16 + tx] = besti[i];
-    }
-    __syncthreads();
-    if (tid < PD_T && m0 + tid < M) {
-        float bv = INFINITY;
-        int bi = 0x7fffffff;
-        for (int x = 0; x < 16; ++x) {
-            const float v = red_v[tid * 16 + x];
-            const int ix = red_i[tid * 16 + x];
-            if (v < bv || (v == bv && ix < bi)) {
-                bv = v;
-                bi = ix;
+    for (int i = 0; i < 8; ++i) {
+        float bv = bestv[i];
+        int bi = besti[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov < bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
             }
         }
-        part_val[(int64_t)blockIdx.y * M + m0 + tid] = bv;
-        part_idx[(int64_t)blockIdx.y * M + m0 + tid] = bi;
+        if (lane == 0 && m0 + i < M) {
+            part_val[(int64_t)blockIdx.y * M + m0 + i] = bv;
+            part_idx[(int64_t)blockIdx.y * M + m0 + i] = bi;
+        }
     }
 }
 
@@ -350,7 +387,7 @@ __global__ __launch_bounds__(256) void pairdist_final_kernel(const float* __rest
 }
 
 static int pd_splits(int64_t M, int64_t N) {
-    const int64_t mt = (M + PD_T - 1) / PD_T, nt = (N + PD_T - 1) / PD_T;
+    const int64_t mt = (M + PD_T - 1) / PD_T, nt = (N + PD_RT - 1) / PD_RT;
     int64_t s = (2048 + mt - 1) / mt;  // aim for >= 2048 workgroups (8 per CU)
     if (s > nt) s = nt;
     if (s < 1) s = 1;
@@ -374,7 +411,8 @@ extern "C" int vm_nshot_indexed(const float* emb, int64_t n_rows, const int32_t*
 
 extern "C" int64_t vm_pairdist_workspace_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
-    return (int64_t)vm::pd_splits(M, N) * M * 8 + (M + N) * 4 + 256;
+    // partial minima per split, the two squared-norm vectors, and the scalar-path copy of the queries (8-row groups x up to PD_MAX_E)
+    return (int64_t)vm::pd_splits(M, N) * M * 8 + (M + N) * 4 + 256 + ((M + 7) / 8) * 8 * (int64_t)vm::PD_MAX_E * 4 + 256;
 }
 
 extern "C" int vm_pairdist_argmin(const float* q, const float* ref, int64_t M, int64_t N, int E, int dist_kind, int64_t q_row0,
@@ -396,16 +434,19 @@ extern "C" int vm_pairdist_argmin(const float* q, const float* ref, int64_t M, i
         hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, ref, N, E, rsq);
     }
     const int EP = ((E + 3) / 4) * 4;
-    const size_t lds = (size_t)(PD_T * (EP + 4) + PD_T * (PD_EC + 4) + PD_T * 16 * 2) * 4;
-    const int n_tiles = (int)((N + PD_T - 1) / PD_T);
+    // the scalar-path copy of the queries behind the squared norms (16-byte aligned)
+    float* qT = (float*)(((uintptr_t)(rsq + N) + 255) & ~(uintptr_t)255);
+    const int64_t qt_n = ((M + 7) / 8) * 8 * (int64_t)EP;
+    hipLaunchKernelGGL(pairdist_qt_kernel, dim3((unsigned)((qt_n + 255) / 256)), dim3(256), 0, st, q, M, E, EP, qT);
+    const int n_tiles = (int)((N + PD_RT - 1) / PD_RT);
     const int tps = (n_tiles + splits - 1) / splits;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(pairdist_kernel, dim3((unsigned)((M + PD_T - 1) / PD_T), (unsigned)splits), dim3(256), lds, st, q, ref, M, N, E,
-                       dist_kind, q_row0, qsq, rsq, tps, dist, part_val, part_idx);
+    VM_REQUIRE((E & 3) != 0 || (((uintptr_t)ref) & 15) == 0, "vm_pairdist_argmin: ref must be 16-byte aligned when E %% 4 == 0");
+    const dim3 grid((unsigned)((M + PD_T - 1) / PD_T), (unsigned)splits);
+#define VM_PD(D) hipLaunchKernelGGL(pairdist_kernel<D>, grid, dim3(512), 0, st, qT, ref, M, N, E, q_row0, qsq, rsq, tps, dist, part_val, part_idx)
+    if (dist_kind == VM_DIST_EUCLIDEAN) VM_PD(VM_DIST_EUCLIDEAN);
+    else if (dist_kind == VM_DIST_COSINE) VM_PD(VM_DIST_COSINE);
+    else VM_PD(VM_DIST_DOT);
+#undef VM_PD
     hipLaunchKernelGGL(pairdist_final_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, part_val, part_idx, M, splits, best_val,
                        best_idx);
     return check_launch("vm_pairdist_argmin");
