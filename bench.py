@@ -399,6 +399,35 @@ def main():
                                                   "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                                   "algorithmic_gbs": round(l["gbs"], 1)} for l in f["launches"]]}
                                for nm, f in fam.items()}
+    # the dense 16-bit MFMA rate THIS device sustains from registers, measured here beside the step (vm_mfma_rate_probe: every SIMD
+    # issuing v_mfma_f32_32x32x16 back to back on non-zero operands, ~3 ms per launch, the chip warm from the timed steps): the step
+    # runs on the package power limit (profiles/r06_kernel_power.txt), so `peak` -- the nominal-clock figure the contract asks
+    # for -- is not a rate the part holds; frac_of_sustained prices the dominant launch against what it does hold
+    if rank == 0 and a.dtype in ("f16", "bf16"):
+        try:
+            vm_dt = {"bf16": 1, "f16": 3}[a.dtype]
+            iters = 12000
+            sink = torch.empty(512 * 256, dtype=torch.float32, device=dev)
+            st_ = torch.cuda.current_stream(dev).cuda_stream
+            probe_flops = float(eng.lib.query("vm_mfma_rate_probe_flops", iters))
+            for _ in range(3):
+                eng.lib.call("vm_mfma_rate_probe", vm_dt, iters, sink.data_ptr(), st_)
+            torch.cuda.synchronize()
+            rates = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                eng.lib.call("vm_mfma_rate_probe", vm_dt, iters, sink.data_ptr(), st_)
+                e1.record()
+                torch.cuda.synchronize()
+                rates.append(probe_flops / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+            sustained = float(np.median(rates))
+            roof["mfma_sustained"] = {"tflops": sustained, "frac_of_nominal_peak": sustained / MFMA_16BIT_PEAK_TF,
+                                      "dominant_launch_frac_of_sustained": (nflops / t_avg / 1e12) / sustained,
+                                      "source": "vm_mfma_rate_probe in this run: 512 workgroups x 4 waves x %d x 8 dense v_mfma_f32_32x32x16_%s "
+                                                "from registers, median of 5 launches (HIP events)" % (iters, a.dtype)}
+        except Exception as e:   # noqa: BLE001
+            roof["mfma_sustained"] = {"error": repr(e)}
     roof["step_hbm_frac"] = TRAIN_BYTES_PER_WINDOW * (2 * pairs * a.steps / dt) / (HBM_PEAK_GBS * 1e9)
     roof["step_mfma_frac"] = TRAIN_FLOPS_PER_WINDOW * (2 * pairs * a.steps / dt) / (MFMA_16BIT_PEAK_TF * 1e12)
     out["roofline"] = roof

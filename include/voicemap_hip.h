@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 7.  History: 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 8.  History: 8 = vm_mfma_rate_probe[_flops]; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -71,6 +71,12 @@ int vm_event_create(void** event_out);
 int vm_event_destroy(void* event);
 int vm_event_record(void* event, void* stream);
 int vm_stream_wait_event(void* stream, void* event);
+/* Measurement aid (round 6; not part of the drop-in surface, bench.py only): every SIMD of the device issuing dense
+ * v_mfma_f32_32x32x16 (VM_BF16 / VM_F16 operands, non-zero values) back to back from registers for `iters` x 8 instructions per
+ * wave -- the rate the part SUSTAINS under its power limit, which the step's GEMM launches (they run on that limit) are priced
+ * against beside the nominal 2.5 PFLOP/s.  sink: 512 * 256 floats (never written).  vm_mfma_rate_probe_flops: the FLOPs of one launch. */
+int vm_mfma_rate_probe(int dtype, int iters, float* sink, void* stream);
+int64_t vm_mfma_rate_probe_flops(int iters);
 /* Kernel-selection table for the tests that pin a fallback kernel and for A/B measurements (process-global, see the conventions
  * above; not part of the drop-in surface: voicemap_amd never calls it outside bench.py --tune).  Unknown keys / values out of
  * range return VM_ERR_ARG.  Keys:

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 7  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 8  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -37,6 +37,8 @@ SIGNATURES = {
     "vm_event_record": (I, [P, P]),
     "vm_stream_wait_event": (I, [P, P]),
     "vm_set_tuning": (I, [c_char_p, I]),
+    "vm_mfma_rate_probe": (I, [I, I, P, P]),
+    "vm_mfma_rate_probe_flops": (L, [I]),
     "vm_decimate_whiten_workspace_bytes": (L, [L]),
     "vm_decimate_whiten": (I, [P, I, L, L, I, I, F, L, P, P, P]),
     "vm_crop_decimate_whiten": (I, [P, I, P, L, L, I, I, F, L, P, P, P]),

@@ -2026,6 +2026,57 @@ extern "C" int vm_pack_nt_weights_batch(int n, const void* const* bt, const int*
     return check_launch("vm_pack_nt_weights_batch");
 }
 
+// ---- measurement aid: the dense 16-bit MFMA rate this device SUSTAINS from registers.  The cfg-A step runs at the package power
+// limit (profiles/r06_kernel_power.txt: 1400 W under every GEMM launch, clocks 1.47-1.86 GHz), so the 2.5 PFLOP/s of the 2.4 GHz
+// nominal clock is not a rate the part holds; this launch -- every SIMD of every CU issuing v_mfma_f32_32x32x16 back to back on
+// non-zero operands, nothing else -- is what bench.py times beside the step to say how far the GEMM launches are from THAT.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void mfma_rate_kernel(float* __restrict__ sink, int iters) {
+    using V8 = typename Mfma<T>::Frag;
+    const int lane = threadIdx.x & 63;
+    u32x4 ra, rb;   // dense, lane-dependent operands of ordinary magnitude (zero operands draw less power and clock higher)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = (uint32_t)(lane * 2654435761u + k * 40503u + blockIdx.x * 97u);
+        // two 16-bit values per word, exponent field fixed near 1.0 (0x3C00 / 0x3F80 region), random sign and fraction bits
+        const uint32_t base = std::is_same<T, bf16>::value ? 0x3F003F00u : 0x38003800u;
+        ra[k] = base | (h & 0x80FF80FFu);
+        rb[k] = base | ((h >> 3) & 0x80FF80FFu);
+    }
+    const V8 a = __builtin_bit_cast(V8, ra), b = __builtin_bit_cast(V8, rb);
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = Mfma<T>::run(a, b, acc[k]);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += acc[k][0] + acc[k][7] + acc[k][15];
+    if (t == 123.456f) sink[blockIdx.x * 256 + threadIdx.x] = t;   // never true: keeps the chain alive
+}
+
+constexpr int MFMA_RATE_BLOCKS = 512;   // two 4-wave workgroups per CU: two waves per SIMD, like the GEMM kernels
+
+extern "C" int64_t vm_mfma_rate_probe_flops(int iters) {
+    return (int64_t)MFMA_RATE_BLOCKS * 4 * (int64_t)iters * 8 * (2LL * 32 * 32 * 16);
+}
+
+extern "C" int vm_mfma_rate_probe(int dtype, int iters, float* sink, void* stream) {
+    VM_REQUIRE(sink && iters > 0, "vm_mfma_rate_probe: bad argument (sink: %d floats)", MFMA_RATE_BLOCKS * 256);
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_mfma_rate_probe: VM_BF16 or VM_F16, got dtype %d", dtype);
+    if (dtype == VM_BF16) {
+        hipLaunchKernelGGL((mfma_rate_kernel<bf16>), dim3(MFMA_RATE_BLOCKS), dim3(256), 0, (hipStream_t)stream, sink, iters);
+    } else {
+        hipLaunchKernelGGL((mfma_rate_kernel<f16>), dim3(MFMA_RATE_BLOCKS), dim3(256), 0, (hipStream_t)stream, sink, iters);
+    }
+    return check_launch("vm_mfma_rate_probe");
+}
+
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
