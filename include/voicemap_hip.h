@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 8.  History: 8 = vm_mfma_rate_probe[_flops]; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 8.  History: 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -363,6 +363,12 @@ int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const int32_t* gi
                                const float* mean, const float* invstd, const float* drop, int64_t n_windows,
                                int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_dy,
                                float* part_dyz, void* stream);
+/* vm_bn_pool_bwd_reduce_gmax + vm_bn_bwd_finalize in one launch (round 6; the same sums in fp64, per (tower, channel) by one 32-lane
+ * group): c1 / c2 (towers, C), grad_gamma / grad_beta (C) as vm_bn_bwd_finalize writes them (voicemap/models.py:32-37 backward). */
+int vm_bn_bwd_gmax_finalize(const void* z, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                            int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, double count_per_tower, float* c1,
+                            float* c2, float* grad_gamma, float* grad_beta, void* stream);
 int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
                               const float* mean, const float* invstd, const float* drop, const float* c1, const float* c2,
                               int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, void* du,

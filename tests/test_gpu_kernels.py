@@ -740,6 +740,42 @@ def test_bn_pool_bwd_sparse_gmax_form_equals_dense(dt):
         assert torch.allclose(wa, wb, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,wpt,l,c,pool,with_drop", [(4, 2, 46, 24, 2, False), (70, 35, 30, 40, 2, True), (256, 128, 750, 512, 2, False), (6, 6, 32, 16, 4, True)])
+def test_bn_bwd_gmax_finalize_equals_reduce_then_finalize(dt, n, wpt, l, c, pool, with_drop):
+    """vm_bn_bwd_gmax_finalize (round 6: the last block's sparse BatchNorm-backward sums and their finalize in one launch;
+    voicemap/models.py:32-37 backward) against the two entry points it replaces: c1, c2, grad_gamma, grad_beta agree to the last
+    bit or, where the fp64 summation order shows, to one fp32 rounding."""
+    vm, tdt = DTYPES[dt]
+    r = rng(n + c)
+    lq = l // pool
+    z = quant(np.maximum(r.normal(0.2, 1.0, (n, l, c)), 0.0), dt).to("cuda", tdt).contiguous()
+    towers = n // wpt
+    scale = dev(r.normal(1.0, 0.3, (towers, c)) * np.where(r.random((towers, c)) < 0.3, -1, 1))
+    shift, mean = dev(r.normal(0, 0.3, (towers, c))), dev(r.normal(0.3, 0.1, (towers, c)))
+    invstd = dev(r.uniform(0.5, 2.0, (towers, c)))
+    drop = dev((r.random((n, c)) > 0.2) / 0.8) if with_drop else None
+    dg = dev(r.normal(0, 1, (n, c)))
+    gi = r.integers(0, lq, (n, c))
+    gi[0, :3] = -1                      # "no position" entries contribute nothing
+    gidx = dev(gi, torch.int32)
+    rows = L().query("vm_bn_part_rows")
+    f32 = dict(dtype=torch.float32, device="cuda")
+    pa, pb = torch.zeros(n * rows, c, **f32), torch.zeros(n * rows, c, **f32)
+    ws = torch.empty(L().query("vm_colreduce_workspace_bytes", towers, c) // 4 + 64, **f32)
+    ref = [torch.full((towers, c), float("nan"), **f32), torch.full((towers, c), float("nan"), **f32), torch.full((c,), float("nan"), **f32),
+           torch.full((c,), float("nan"), **f32)]
+    got = [t.clone() for t in ref]
+    head = (p(z), p(dg), p(gidx), p(scale), p(shift), p(mean), p(invstd), p(drop))
+    L().call("vm_bn_pool_bwd_reduce_gmax", *head, n, wpt, l, c, pool, vm, p(pa), p(pb), stream())
+    L().call("vm_bn_bwd_finalize", p(pa), p(pb), n, wpt, c, float(wpt * l), p(ref[0]), p(ref[1]), p(ref[2]), p(ref[3]), p(ws), stream())
+    L().call("vm_bn_bwd_gmax_finalize", *head, n, wpt, l, c, pool, vm, float(wpt * l), p(got[0]), p(got[1]), p(got[2]), p(got[3]), stream())
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b).all()
+        assert torch.allclose(a, b, rtol=3e-7, atol=1e-12), (a - b).abs().max().item()
+
+
 # ----------------------------------------------------------------------------------------------------------
 # cfg-A's own GEMM geometries (experiments/train_siamese.py:20-25: filters 128 -> blocks 2..4 are 128->256 @ L=3000,
 # 256->384 @ L=1500, 384->512 @ L=750) under the DEFAULT dispatch -- no vm_set_tuning call in these tests, so they

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vm_bn_bwd_finalize": (I, [P, P, L, L, I, D, P, P, P, P, P, P]),
     "vm_bn_pool_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_reduce_gmax": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_bn_bwd_gmax_finalize": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, I, D, P, P, P, P, P]),
     "vm_bn_pool_bwd_apply_gmax": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, I, P, P, P]),
     "vm_bn_pool_bwd_apply_pairs": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P, P]),
     "vm_colsum": (I, [P, L, I, P, P, P]),

@@ -1113,6 +1113,61 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_gmax_kernel(const T* _
     }
 }
 
+// The sparse reduce above AND its finalize in one launch (round 6): the sums of the last block run over n_windows x C gathered values
+// -- 128 per (tower, channel) at the bench batch -- which one 32-lane group adds in fp64 by itself: three dependent launches
+// (gather, column reduction, finalize) of the forward -> backward turn-around become one.  Same per-element arithmetic as
+// bn_pool_bwd_reduce_gmax_kernel, fp64 sums of the same fp32 terms (the order differs from the two-stage form; the fp64 sum of a few
+// hundred floats rounds to the same float).
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_gmax_finalize_kernel(const T* __restrict__ z, const float* __restrict__ dg,
+                                                                   const int32_t* __restrict__ gidx, const float* __restrict__ scale,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ drop, int64_t n_windows, int64_t wpt, int64_t L,
+                                                                   FinBnBwd<false> f) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    const int C = f.C;
+    if (c >= C) return;
+    const int64_t Lq = L / POOL;
+    double gg = 0.0, gb = 0.0;
+    for (int tw = 0; tw < f.n_towers; ++tw) {
+        const float sc = scale[tw * C + c], mu = mean[tw * C + c], is = invstd[tw * C + c];
+        double sa = 0.0, sb = 0.0;
+        for (int64_t w = k; w < wpt; w += 32) {
+            const int64_t n = tw * wpt + w, e = n * C + c;
+            const int q = gidx[e];
+            if (q >= 0 && q < Lq) {
+                const float dr = drop ? drop[e] : 1.0f;
+                const bool use_min = sc * dr < 0.f;
+                const T* zp = z + (n * L + (int64_t)q * POOL) * C + c;
+                float ext = Elem<T>::to_f(zp[0]);
+#pragma unroll
+                for (int j = 1; j < POOL; ++j) {
+                    const float zj = Elem<T>::to_f(zp[(int64_t)j * C]);
+                    if (use_min ? (zj < ext) : (zj > ext)) ext = zj;
+                }
+                const float d = Elem<T>::to_f(Elem<T>::from_f(dg[e]));  // same rounding as the dense dp tensor
+                sa += (double)(dr * d);
+                sb += (double)(dr * is * d * (ext - mu));
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+        }
+        if (k == 0) {
+            f.c1[tw * C + c] = (float)(sa / f.count);
+            f.c2[tw * C + c] = (float)(sb / f.count);
+        }
+        gb += sa;
+        gg += sb;
+    }
+    if (k == 0) {
+        f.grad_gamma[c] = (float)gg;
+        f.grad_beta[c] = (float)gb;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, FinBnBwd<false> f) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     if (c >= f.C) return;
@@ -1340,6 +1395,23 @@ extern "C" int vm_bn_pool_bwd_reduce_gmax(const void* z, const float* dg, const 
                            part_dyz);
     }));
     return check_launch("vm_bn_pool_bwd_reduce_gmax");
+}
+
+extern "C" int vm_bn_bwd_gmax_finalize(const void* z, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                                       const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                                       int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, double count_per_tower, float* c1,
+                                       float* c2, float* grad_gamma, float* grad_beta, void* stream) {
+    VM_REQUIRE(z && dg && gidx && scale && shift && mean && invstd && c1 && c2 && grad_gamma && grad_beta,
+               "vm_bn_bwd_gmax_finalize: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && L >= pool && C % 8 == 0,
+               "vm_bn_bwd_gmax_finalize: bad sizes (n_windows a multiple of windows_per_tower, C a multiple of 8)");
+    const int n_towers = (int)(n_windows / windows_per_tower);
+    const FinBnBwd<false> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
+    VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
+        hipLaunchKernelGGL((bn_bwd_gmax_finalize_kernel<T, POOL>), dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)z, dg, gidx, scale, mean, invstd, drop, n_windows, windows_per_tower, L, fin);
+    }));
+    return check_launch("vm_bn_bwd_gmax_finalize");
 }
 
 extern "C" int vm_bn_bwd_from_sums(const float* s0, const float* sa, int64_t rows_per_window, const void* z, const void* dp,

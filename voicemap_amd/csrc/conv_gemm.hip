@@ -1588,6 +1588,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
     }
     VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
+#if defined(VM_NT3_EPI_PRIO)   // experiment build: the epilogue at a raised wave priority (its VALU beside the co-resident wave's MFMAs)
+    __builtin_amdgcn_s_setprio(VM_NT3_EPI_PRIO);
+#endif
 #if VM_NT3_ABL & 8
     if (acc[0][0][0] == 123.456f && acc[3][1][15] == 1.5f) n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
 #else

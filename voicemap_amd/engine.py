@@ -1229,7 +1229,13 @@ class HipEncoderEngine:
             else:
                 common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
             fused_fin = False
-            if sparse:
+            if sparse and self.fused_sums_finalize and not self.sync_bn and c % 8 == 0:
+                # the gather of the sparse sums and their finalize in one launch (three dependent small launches of the forward ->
+                # backward turn-around otherwise)
+                self._call("vm_bn_bwd_gmax_finalize", *common, n, wpt, L, c, pool, dt, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                           _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), st)
+                fused_fin = True
+            elif sparse:
                 self._call("vm_bn_pool_bwd_reduce_gmax", *common, n, wpt, L, c, pool, dt, _p(b["pa"]), _p(b["pb"]), st)
             elif b.get("bnred_now") and self.fused_sums_finalize and not self.sync_bn:
                 self._call("vm_bn_bwd_from_sums_finalize", _p(b["rs0"]), _p(b["rs1"]), b["rs_rows"], None if b.get("pairs_now") else _p(b["z"]),
