@@ -241,7 +241,10 @@ __global__ __launch_bounds__(512) void pairdist_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * PD_T + 8 * w;          // this wave's first query
-    const float* qg = qT + (m0 >> 3) * (int64_t)E4 * 32;            // its group's rows of qT (wave-uniform)
+    // its group's rows of qT (wave-uniform).  A wave past the last query (M not a multiple of 64) computes on the LAST group's rows --
+    // qT holds ceil(M / 8) groups and nothing behind them -- and stores nothing (every use below is guarded by m < M).
+    const int64_t last_group = (M - 1) >> 3;
+    const float* qg = qT + ((m0 >> 3) < last_group ? (m0 >> 3) : last_group) * (int64_t)E4 * 32;
     float qn[8], bestv[8];
     int besti[8];
 #pragma unroll
