@@ -386,8 +386,8 @@ def main():
         return sym
     roof["kernel_symbol"] = symbol(a.dominant, shape)
     roof["source"] = ("bench.py serial attribution pass of this run: HIP events on the launch stream around every GEMM launch, median per "
-                      "launch shape; committed counterparts: profiles/r05_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
-                      "serial step), profiles/r05_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
+                      "launch shape; committed counterparts: profiles/r06_conv_kernels_by_layer.txt (rocprofv3 --kernel-trace of the "
+                      "serial step), profiles/r06_rocprofv3_kernel_stats.csv (default, overlapped step), profiles/pmc_traffic.json (traffic)")
     roof["launch_ms"] = t_avg * 1e3
     roof["launch_shape"] = shape
     # every GEMM launch of the step from the serial pass: ms, TFLOP/s (against the dense 16-bit peak) and algorithmic GB/s
@@ -672,7 +672,8 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
         ex.update({"logmel_2dcnn_train_ms_per_step": t_sp * 1e3, "logmel_2dcnn_audio_s_per_s": 2 * pairs * 3.0 / t_sp,
                    "logmel_frontend_ms_per_256_clips": t_ft * 1e3,
                    "logmel_2dcnn_config": "log-mel 298 x 64 (25 ms / 10 ms frames), Conv2D 3x3 channels 32-64-96-128, embedding 64, "
-                                          "%d pairs, %s storage" % (pairs, a.dtype)})
+                                          "%d pairs, %s storage" % (pairs, a.dtype),
+                   "logmel_2dcnn_precision": config4_precision(a.dtype)})
         del seng, spl
         torch.cuda.empty_cache()
     except Exception as e:  # the side figure must never take the headline line down
@@ -772,21 +773,55 @@ def extras(a, eng, step, pl, xcat, y, pairs, dev, make_engine, make_step, time_b
 
 
 def oracle_referenced_figures(dtype):
-    """Embedding error of storage mode ``dtype`` against the CPU ORACLE in three states, read from the parity report the -m gpu tests
-    wrote (profiles/r05_parity_report.csv, committed; the run that produced it is named there): the bench batch at fresh-init weights
-    (tests/test_gpu_fullsize_oracle.py), the same batch at a trained-like BatchNorm / bias state, and the reference's shipped
-    checkpoint on its own 8 LibriSpeech clips in training mode (tests/test_gpu_golden_step.py).  ``meets_1e-3`` per state."""
+    """Embedding error of storage mode ``dtype`` against the CPU ORACLE, read from the parity report the -m gpu tests wrote
+    (profiles/r06_parity_report.csv, committed: one full run of the suite on an MI355X, NOT this run): the bench batch at fresh-init
+    weights (tests/test_gpu_fullsize_oracle.py), the same batch at a trained-like BatchNorm / bias state, the reference's shipped
+    checkpoint on its own 8 LibriSpeech clips in training mode (tests/test_gpu_golden_step.py) and -- f16, round 6 -- the spread of the
+    guard sweep (tests/test_gpu_f16_guard.py: five seeds of each synthetic state and a state trained for 1 200 steps).
+    ``meets_1e-3`` per entry."""
     want = {"full_size_oracle[%s]" % dtype: ("emb_rel_err_vs_fp64_oracle", "bench_batch_fresh_init"),
             "full_size_oracle_trained_state[%s]" % dtype: ("emb_rel_err_vs_fp32_oracle", "bench_batch_trained_like_batchnorm_and_bias_state"),
             "golden_step_cfgCK_real_clips[%s]" % dtype: ("emb_rel_err", "reference_checkpoint_on_its_8_librispeech_clips_training_mode")}
-    out = {"source": "profiles/r05_parity_report.csv (tests/test_gpu_fullsize_oracle.py, tests/test_gpu_golden_step.py on an MI355X; NOT this run)"}
+    guard = {"f16_guard[fresh_init]": "guard_5_seeds_fresh_init", "f16_guard[trained_like]": "guard_5_seeds_trained_like_state",
+             "f16_guard[trained_1200_steps]": "guard_state_trained_1200_steps_noise_and_unseen_speakers"}
+    out = {"source": "profiles/r06_parity_report.csv (tests/test_gpu_fullsize_oracle.py, tests/test_gpu_golden_step.py, tests/test_gpu_f16_guard.py "
+                     "on an MI355X; NOT this run)"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_parity_report.csv")) as f:
+        spread = {}
+        with open(os.path.join(ROOT, "profiles", "r06_parity_report.csv")) as f:
             for line in f:
                 parts = line.strip().split(",")
-                if len(parts) == 3 and parts[0] in want and parts[1] == want[parts[0]][0]:
+                if len(parts) != 3:
+                    continue
+                if parts[0] in want and parts[1] == want[parts[0]][0]:
                     v = float(parts[2])
                     out[want[parts[0]][1]] = {"embedding_rel_err": v, "meets_1e-3": bool(v < 1e-3)}
+                elif dtype == "f16" and parts[0] in guard and parts[1] in ("emb_rel_err_min", "emb_rel_err_max", "cases"):
+                    spread.setdefault(guard[parts[0]], {})[parts[1]] = float(parts[2])
+        for k, v in spread.items():
+            if "emb_rel_err_max" in v:
+                out[k] = {"embedding_rel_err_min": v.get("emb_rel_err_min"), "embedding_rel_err_max": v["emb_rel_err_max"],
+                          "cases": int(v.get("cases", 0)), "meets_1e-3": bool(v["emb_rel_err_max"] < 1e-3)}
+    except (OSError, ValueError):
+        out["error"] = "parity report not found"
+    return out
+
+
+def config4_precision(dtype):
+    """BASELINE.json config 4 (log-mel + 2-D CNN; NOT in the reference, so its only oracle is this repository's own float64
+    restatement: parity unpinned by construction) at its own size, from the same committed parity report."""
+    key = {"f16": "spectro_step_f16_drop0_298x64_F32", "bf16": "spectro_step_bf16_drop0_298x64_F32", "f32": "spectro_step_f32_drop0_298x64_F32"}.get(dtype)
+    out = {"source": "profiles/r06_parity_report.csv (tests/test_gpu_spectro.py at 298 x 64; NOT this run)", "oracle": "this repository's own float64 "
+           "restatement (oracle/voicemap_oracle.py: the variant does not exist in the reference) -- parity unpinned"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_parity_report.csv")) as f:
+            for line in f:
+                parts = line.strip().split(",")
+                if len(parts) == 3 and parts[0] == key and parts[1] == "emb_rel_err":
+                    v = float(parts[2])
+                    out.update({"embedding_rel_err": v, "meets_1e-3": bool(v < 1e-3)})
+        if out.get("meets_1e-3") is False:
+            out["note"] = "config 4 has no 16-bit storage mode inside the 1e-3 tolerance (its fp32 mode is: 1e-6); the figure stands as measured"
     except (OSError, ValueError):
         out["error"] = "parity report not found"
     return out

@@ -1,7 +1,7 @@
 #!/bin/bash
-# cfg-A evidence of the tree (round 5): bench line, rocprofv3 kernel stats of the default step,
-# serial per-layer trace + timeline, the two PMC traffic passes, one SQ counter pass.   gpurun --timeout 1200 -- 'bash tools/r5_evidence.sh <tag>'
-TAG=${1:-r5p}
+# cfg-A evidence of the tree (round 6): bench line, rocprofv3 kernel stats of the default step,
+# serial per-layer trace + timeline, the two PMC traffic passes, one SQ counter pass.   gpurun --timeout 1200 -- 'bash tools/r6_evidence.sh <tag>'
+TAG=${1:-r6p}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O
@@ -31,3 +31,11 @@ python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc
 python tools/pmc_summary.py $O/pmc_SQ_$TAG > $O/pmc_sq_counters_$TAG.csv 2>&1
 rm -rf $O/trace_$TAG $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc_SQ_$TAG $O/prof_$TAG
 head -3 $O/step_timeline_serial_$TAG.txt; head -6 $O/pmc_sq_counters_$TAG.csv
+# round 6: power / clocks per launch shape, conv_nt3 slot timelines (experiment build, if present), pairdist shard, launch times
+cd $R
+timeout 120 python tools/probe/kernel_power.py 2>&1 | grep -v amdgpu.ids > $O/kernel_power_$TAG.txt; tail -4 $O/kernel_power_$TAG.txt
+timeout 60 python tools/probe/pairdist_time.py 2>&1 | grep -v amdgpu.ids > $O/pairdist_$TAG.txt; cat $O/pairdist_$TAG.txt
+timeout 60 python tools/probe/nt3_launch_times.py 2>&1 | grep -v amdgpu.ids > $O/nt3_launch_times_$TAG.txt
+if [ -f voicemap_amd/lib/libvoicemap_hip_prof.so ]; then
+  VOICEMAP_HIP_LIB=$R/voicemap_amd/lib/libvoicemap_hip_prof.so timeout 100 python tools/probe/nt3_slots.py 2>&1 | grep -v amdgpu.ids > $O/nt3_slots_$TAG.txt; head -2 $O/nt3_slots_$TAG.txt | cut -c1-300
+fi
