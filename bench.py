@@ -435,7 +435,7 @@ def main():
     if a.breakdown and rank == 0 and n_gpus == 1:  # its steps contain collectives: single-process runs only
         names = ["vm_decimate_whiten", "vm_conv1_fused_fwd", "vm_conv1_fused_bwd", "vm_conv1_fwd", "vm_conv_fwd", "vm_bn_finalize", "vm_bn_drop_pool_fwd", "vm_bn_drop_pool_gmax_fwd",
                  "vm_global_maxpool_fwd", "vm_dense_fwd", "vm_siamese_head_loss", "vm_dense_bwd", "vm_global_maxpool_bwd",
-                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_from_sums", "vm_bn_bwd_from_sums_finalize", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
+                 "vm_bn_pool_bwd_reduce", "vm_bn_pool_bwd_reduce_pooled", "vm_bn_pool_bwd_reduce_gmax", "vm_bn_bwd_gmax_finalize", "vm_bn_bwd_from_sums", "vm_bn_bwd_from_sums_finalize", "vm_bn_bwd_finalize", "vm_bn_pool_bwd_apply",
                  "vm_bn_pool_bwd_apply_gmax", "vm_colsum", "vm_du_tower_sums", "vm_fold_bn_weights", "vm_conv_wgrad",
                  "vm_conv_dgrad", "vm_conv1_wgrad", "vm_grad_sqnorm", "vm_adam_clip_step", "vm_prep_conv_weights", "vm_prep_conv_weights_batch",
                  "vm_bn_drop_pool_gmax_partials", "vm_tail_fwd_bwd", "vm_tail_param_grads", "vm_pack_nt_weights_batch", "vm_conv_wgrad_fold_finish"]
