@@ -475,25 +475,28 @@ __device__ inline void n2_load_bias(const NtArgs<T>& p, f32x4 (&b4)[2][4], int c
 }
 // vm_conv_fwd_fold: tile row ``row`` is the first (which = 0) or last (which = 1) position of the window -- take the constant of the
 // tap that falls into the padding off its accumulators (lane r <-> row 32 i + r of the wave's 128, registers <-> channels)
-template <typename T>
+// WIDE (conv_nt3_kernel's 256 x 32 wave tile, round 6 experiment): acc[i][j] is row block i + 4 j of the tile's eight, all of them over
+// the wave's ONE 32-channel block -- every wave holds every row, so every wave takes the constant off ITS channels (h[0] only).
+template <typename T, bool WIDE = false>
 __device__ inline void n2_fold_edge(const NtArgs<T>& p, f32x16 (&acc)[4][2], int row, int which, int wm, int r, int c0) {
-    if ((row >> 7) != wm) return;  // wave-uniform
+    if (!WIDE && (row >> 7) != wm) return;  // wave-uniform
     const float* hb = p.fold_hb + (which ? 2 * p.N : 0) + c0;
     f32x4 h[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) h[j][g] = *reinterpret_cast<const f32x4*>(hb + 32 * j + 8 * g);
-    const int rw = row & 127;
+        for (int g = 0; g < 4; ++g) h[j][g] = *reinterpret_cast<const f32x4*>(hb + (WIDE ? 0 : 32 * j) + 8 * g);
+    const int rw = WIDE ? row : (row & 127);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // every 32-row block with a lane mask: a runtime block index would put acc into scratch
-        const float m = (32 * i + r == rw) ? 1.f : 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const float m = (32 * (WIDE ? i + 4 * j : i) + r == rw) ? 1.f : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] -= m * h[j][g][e];
+        }
     }
 }
 __device__ inline void n2_fill_acc(f32x16 (&acc)[4][2], const f32x4 (&b4)[2][4]) {
@@ -546,7 +549,7 @@ struct N2DrainSync {   // the drain run by the four waves of a 256-thread workgr
     __device__ inline void point() {}
 };
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool WIDE = false>
 __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int t0, int n0, int trows, int lane, int wm, int wn,
                                      const f32x4 (&negc)[2][4]) {
     using namespace n2;
@@ -584,14 +587,16 @@ __device__ inline void n2_tile_write(const NtArgs<T>& p, char* lds, const f32x16
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = wm * 128 + i * 32 + r;
-            const bool partial = wm * 128 + i * 32 + 32 > valid;  // wave-uniform: this 32-row block has rows outside the window
-            const bool zero = (FWD || red) && partial && m >= valid;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                // (WIDE: wn is the wave's 32-channel block 0..3, (i, j) its row block i + 4 j)
+                const int mb = WIDE ? (i + 4 * j) * 32 : wm * 128 + i * 32;
+                const int m = mb + r;
+                const bool partial = mb + 32 > valid;  // wave-uniform: this 32-row block has rows outside the window
+                const bool zero = (FWD || red) && partial && m >= valid;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nl = wn * 64 + j * 32 + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
+                    const int nl = (WIDE ? wn * 32 : wn * 64 + j * 32) + 8 * g + 4 * kh;  // first of this lane's 4 consecutive channels
                     T o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(acc[i][j][4 * g + e]);
@@ -965,7 +970,7 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
 }
 
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool WIDE = false>
 __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (&acc)[4][2], int64_t n, int tl, int t0, int n0, int trows,
                                    int tid, int lane, int w, int wm, int wn) {
     f32x4 negc[2][4];
@@ -975,7 +980,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.fold_ctr + n0 + (WIDE ? wn * 32 : wn * 64 + j * 32) + 8 * g + 4 * (lane >> 5));
                     negc[j][g] = f32x4{-c[0], -c[1], -c[2], -c[3]};
                 }
         }
@@ -983,7 +988,7 @@ __device__ inline void n2_epilogue(const NtArgs<T>& p, char* lds, const f32x16 (
     VM_EPI_MARK(1);
     __syncthreads();  // every wave is done with the operand stages: they become the epilogue tile
     VM_EPI_MARK(2);
-    n2_tile_write<T, EPI>(p, lds, acc, t0, n0, trows, lane, wm, wn, negc);
+    n2_tile_write<T, EPI, WIDE>(p, lds, acc, t0, n0, trows, lane, wm, wn, negc);
     VM_EPI_MARK(3);
     __syncthreads();
     VM_EPI_MARK(4);
@@ -1332,7 +1337,7 @@ constexpr N3Pieces n3_pieces(int i, int chunks, bool lean) {
     if (lean && c == 0) return N3Pieces{0, 0, 0};
     return N3Pieces{(tap < 2 && c + 3 < chunks) ? 2 : 0, c + 3, 2 * tap};
 }
-constexpr int n3_nwait(int kt, int chunks, bool lean) {
+constexpr int n3_nwait(int kt, int chunks, bool lean, int bl = 4) {   // bl: loads per weight set (4; the 256 x 32 wave tile: 2)
     const int nk = 3 * chunks;
     int after = -1;  // operations issued since B(kt) completed its issue; -1: B(kt) not issued yet
     auto issue = [&](int count, bool is_bkt) {
@@ -1343,17 +1348,17 @@ constexpr int n3_nwait(int kt, int chunks, bool lean) {
         }
     };
     issue(4, false);                       // A(0)
-    issue(4, kt == 0);                     // B(0)
+    issue(bl, kt == 0);                    // B(0)
     if (lean) {
-        issue(4, kt == 1);                 // B(1)
+        issue(bl, kt == 1);                // B(1)
         if (chunks > 1) issue(4, false);   // A(1)
     } else {
         if (chunks > 1) issue(4, false);   // A(1)
-        issue(4, kt == 1);                 // B(1)
+        issue(bl, kt == 1);                // B(1)
         if (chunks > 2) issue(4, false);   // A(2)
     }
     for (int i = 0; i < kt; ++i) {         // (the wait of iteration kt opens it)
-        if (i + 2 < nk) issue(4, i + 2 == kt);
+        if (i + 2 < nk) issue(bl, i + 2 == kt);
         issue(n3_pieces(i, chunks, lean).count, false);
     }
     return after;
@@ -1368,7 +1373,10 @@ static_assert(n3_nwait(0, 4, true) == 8 && n3_nwait(1, 4, true) == 12 && n3_nwai
 // phase on their own -- median phase of the second slot's starts 0.48-0.52 on all six launches, profiles/r06_nt3_slots.txt -- and the
 // launches gained nothing at any offset, 0 .. +3 % with the delay itself; round 2 had the same result on conv_nt2r_kernel.)
 // LEAN: the prologue that leaves A(2), A(3) to the first two K tiles (A/B switch nt3_lean)
-template <typename T, int EPI, int CHUNKS, bool LEAN>
+// WIDE (round 6 experiment, vm_set_tuning "nt3_wide"): the wave tile is 256 rows x 32 channels instead of 128 x 64 -- every wave reads
+// ALL of the block's rows from LDS (16 fragment reads per K tile instead of 8) and HALF the weight fragments from L2 (2 instead of
+// 4: the weight stream, 1.77 GB per launch, is the largest movable slice of a launch's energy: profiles/r06_nt3_ablation.txt).
+template <typename T, int EPI, int CHUNKS, bool LEAN, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n_groups) {
     VM_PROF(const long long pt_start = __builtin_amdgcn_s_memtime(); long long pt_first = 0, pt_bar = 0;)
     using namespace n2;
@@ -1376,7 +1384,8 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     constexpr int A_BLK = n3::A_BLK, NK = 3 * CHUNKS;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = WIDE ? 0 : (w >> 1), wn = WIDE ? w : (w & 1);
+    constexpr int WC = WIDE ? 32 : 64;   // channels per wave
 
     unsigned group;
     int tn;
@@ -1409,13 +1418,13 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     // unclobbered and falls back to vector loads (16 of them, and the vmcnt(0) again).
     f32x4 bias_lo[2][4], bias_hi[2][4];
     if constexpr (EPI != EPI_DGRAD) {
-        const float* bp = p.bias + n0 + wn * 64;
+        const float* bp = p.bias + n0 + wn * WC;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bias_lo[j][g] = *reinterpret_cast<const f32x4*>(bp + 32 * j + 8 * g);
-                bias_hi[j][g] = *reinterpret_cast<const f32x4*>(bp + 32 * j + 8 * g + 4);
+            for (int g = 0; g < 4; ++g) {   // (WIDE: j is a row block, both take the wave's one 32-channel block)
+                bias_lo[j][g] = *reinterpret_cast<const f32x4*>(bp + (WIDE ? 0 : 32 * j) + 8 * g);
+                bias_hi[j][g] = *reinterpret_cast<const f32x4*>(bp + (WIDE ? 0 : 32 * j) + 8 * g + 4);
             }
     }
 
@@ -1440,8 +1449,10 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     // ---- weight stream of this wave: (tower, 64-channel block n0 / 64 + wn), NK x 4 KB, base in SGPRs ----
     uint64_t bbase;
     {
+        // (WIDE: the wave's 32 channels are fragment row j = wn & 1 of the 64-channel block (n0 >> 6) + (wn >> 1): 2 KB into each K tile)
         const uint64_t q = (uint64_t)(uintptr_t)p.bt_packed +
-                           ((uint64_t)tw * (unsigned)(p.N >> 6) + (unsigned)((n0 >> 6) + wn)) * (uint64_t)(NK * n3::KT_BYTES);
+                           ((uint64_t)tw * (unsigned)(p.N >> 6) + (unsigned)((n0 >> 6) + (WIDE ? (wn >> 1) : wn))) * (uint64_t)(NK * n3::KT_BYTES) +
+                           (WIDE ? (uint64_t)((wn & 1) * 2048) : 0);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
         bbase = ((uint64_t)hi << 32) | lo;
     }
@@ -1452,8 +1463,10 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         const uint64_t sb_ = bbase + (uint64_t)((KT) * n3::KT_BYTES);             \
         VM_GLOAD_FRAG(bs[(KT) % 3][0], bvoff, sb_, 0);                            \
         VM_GLOAD_FRAG(bs[(KT) % 3][1], bvoff, sb_, 1024);                         \
-        VM_GLOAD_FRAG(bs[(KT) % 3][2], bvoff, sb_, 2048);                         \
-        VM_GLOAD_FRAG(bs[(KT) % 3][3], bvoff, sb_, 3072);                         \
+        if constexpr (!WIDE) {                                                    \
+            VM_GLOAD_FRAG(bs[(KT) % 3][2], bvoff, sb_, 2048);                     \
+            VM_GLOAD_FRAG(bs[(KT) % 3][3], bvoff, sb_, 3072);                     \
+        }                                                                         \
     }
 
     const int r = lane & 31, kh = lane >> 5;
@@ -1514,12 +1527,16 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
     // the one an MFMA pair needs: every wait is lgkmcnt(3) until the last tile drains.  The chunk barrier moves to the middle of
     // tap 2 (before the first read of the next block), behind lgkmcnt(0): all reads of this chunk's block have RETURNED when a wave
     // passes it, so the DMA pieces that recycle the block -- issued at least one tile later -- cannot overtake a read.
-    u32x4 f0[4], f1[4];
+    u32x4 f0[WIDE ? 8 : 4], f1[WIDE ? 8 : 4];
 #define VM_FRAG_READ(dst, base, I)                                                              \
     if constexpr ((I) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(base));          \
     if constexpr ((I) == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dst) : "v"(base)); \
     if constexpr ((I) == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(dst) : "v"(base)); \
-    if constexpr ((I) == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(dst) : "v"(base));
+    if constexpr ((I) == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 4) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 5) asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 6) asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(dst) : "v"(base)); \
+    if constexpr ((I) == 7) asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(dst) : "v"(base));
 #define VM_P_STEP0(I)                                                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f0[I]));                                                                               \
     VM_MM(f0[I], bs[cur_][0], I, 0);                                                                                                  \
@@ -1571,11 +1588,80 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
         VM_P_STEP1(0) VM_P_STEP1(1) VM_P_STEP1(2) VM_P_STEP1(3)                                                                       \
         VM_PROF(if (kt_ == 0) pt_first = __builtin_amdgcn_s_memtime();)                                                               \
     }
+    // ---- the same loop for the 256 x 32 wave tile: ONE MFMA per fragment read (row block I = 0..7 against the wave's one weight
+    // fragment of the k-step), so a read has seven younger reads behind it when its MFMA needs it: every wait is lgkmcnt(7) until the
+    // last tile drains; the weight fragments of tile kt + 2 ride under row blocks 0, 1 of k-step 0, the input DMA pieces under row
+    // blocks 0..3 of k-step 1 as before.  acc[I & 3][I >> 2] is row block I.
+#define VM_W_WAIT(N, R) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(R))
+#define VM_W_STEP0(I)                                                                                                                 \
+    VM_W_WAIT(7, f0[I]);                                                                                                              \
+    VM_MM(f0[I], bs[cur_][0], (I) & 3, (I) >> 2);                                                                                     \
+    VM_FRAG_READ(f1[I], aa1_, I)                                                                                                      \
+    if constexpr (kt_ + 2 < NK && !(VM_NT3_ABL & 1)) {                                                                                \
+        if constexpr ((I) == 0) VM_GLOAD_FRAG(bs[nxt_][0], bvoff, sb_, 0);                                                            \
+        if constexpr ((I) == 1) VM_GLOAD_FRAG(bs[nxt_][1], bvoff, sb_, 1024);                                                         \
+    }                                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define VM_W_STEP1(I)                                                                                                                 \
+    if constexpr (kt_ + 1 < NK) {                                                                                                     \
+        VM_W_WAIT(7, f1[I]);                                                                                                          \
+    } else {                                                                                                                          \
+        if constexpr ((I) == 0) VM_W_WAIT(7, f1[I]);                                                                                  \
+        if constexpr ((I) == 1) VM_W_WAIT(6, f1[I]);                                                                                  \
+        if constexpr ((I) == 2) VM_W_WAIT(5, f1[I]);                                                                                  \
+        if constexpr ((I) == 3) VM_W_WAIT(4, f1[I]);                                                                                  \
+        if constexpr ((I) == 4) VM_W_WAIT(3, f1[I]);                                                                                  \
+        if constexpr ((I) == 5) VM_W_WAIT(2, f1[I]);                                                                                  \
+        if constexpr ((I) == 6) VM_W_WAIT(1, f1[I]);                                                                                  \
+        if constexpr ((I) == 7) VM_W_WAIT(0, f1[I]);                                                                                  \
+    }                                                                                                                                 \
+    VM_MM(f1[I], bs[cur_][1], (I) & 3, (I) >> 2);                                                                                     \
+    if constexpr (kt_ + 1 < NK) { VM_FRAG_READ(f0[I], an0_, I) }                                                                      \
+    if constexpr ((I) < n3_pieces(kt_, CHUNKS, LEAN).count && !(VM_NT3_ABL & 2))                                                      \
+        issue_a1(n3_pieces(kt_, CHUNKS, LEAN).block % 4, n3_pieces(kt_, CHUNKS, LEAN).block, n3_pieces(kt_, CHUNKS, LEAN).first + (I)); \
+    __builtin_amdgcn_sched_barrier(0);
+#define VM_KTILE_W(KT)                                                                                                                \
+    if constexpr ((KT) < NK) {                                                                                                        \
+        constexpr int kt_ = (KT), c_ = kt_ / 3, tap_ = kt_ - 3 * c_, cur_ = kt_ % 3, nxt_ = (kt_ + 2) % 3, ablk_ = c_ % 4;             \
+        constexpr int nc_ = (kt_ + 1) / 3, ntap_ = (kt_ + 1) - 3 * nc_;   /* chunk and tap of the next tile */                          \
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bs[cur_][0]), "+v"(bs[cur_][1]) : "n"(n3_nwait(kt_, CHUNKS, LEAN, 2)) : "memory");  \
+        if constexpr (kt_ == 0) {                                                                                                     \
+            __builtin_amdgcn_s_barrier();                                                                                             \
+            VM_PROF(pt_bar = __builtin_amdgcn_s_memtime();)                                                                           \
+            const uint32_t a00_ = lds0 + a_addr[0][0];                                                                                \
+            VM_FRAG_READ(f0[0], a00_, 0) VM_FRAG_READ(f0[1], a00_, 1) VM_FRAG_READ(f0[2], a00_, 2) VM_FRAG_READ(f0[3], a00_, 3)         \
+            VM_FRAG_READ(f0[4], a00_, 4) VM_FRAG_READ(f0[5], a00_, 5) VM_FRAG_READ(f0[6], a00_, 6) VM_FRAG_READ(f0[7], a00_, 7)         \
+        }                                                                                                                             \
+        const uint32_t aa1_ = lds0 + ablk_ * A_BLK + a_addr[tap_][1];                                                                  \
+        const uint32_t an0_ = lds0 + (nc_ % 4) * A_BLK + a_addr[ntap_][0];                                                             \
+        const uint64_t sb_ = bbase + (uint64_t)((kt_ + 2) * n3::KT_BYTES);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        VM_W_STEP0(0) VM_W_STEP0(1) VM_W_STEP0(2) VM_W_STEP0(3) VM_W_STEP0(4) VM_W_STEP0(5) VM_W_STEP0(6) VM_W_STEP0(7)               \
+        if constexpr (tap_ == 2 && kt_ + 1 < NK) {                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]), "+v"(f1[4]), "+v"(f1[5]),       \
+                         "+v"(f1[6]), "+v"(f1[7]));                                                                                   \
+            __builtin_amdgcn_s_barrier();                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        }                                                                                                                             \
+        VM_W_STEP1(0) VM_W_STEP1(1) VM_W_STEP1(2) VM_W_STEP1(3) VM_W_STEP1(4) VM_W_STEP1(5) VM_W_STEP1(6) VM_W_STEP1(7)               \
+        VM_PROF(if (kt_ == 0) pt_first = __builtin_amdgcn_s_memtime();)                                                               \
+    }
 #define VM_CHUNK(C) VM_KTILE_P(3 * (C)) VM_KTILE_P(3 * (C) + 1) VM_KTILE_P(3 * (C) + 2)
-    VM_CHUNK(0) VM_CHUNK(1) VM_CHUNK(2) VM_CHUNK(3) VM_CHUNK(4) VM_CHUNK(5) VM_CHUNK(6) VM_CHUNK(7)
-    VM_CHUNK(8) VM_CHUNK(9) VM_CHUNK(10) VM_CHUNK(11) VM_CHUNK(12) VM_CHUNK(13) VM_CHUNK(14) VM_CHUNK(15)
+#define VM_CHUNK_W(C) VM_KTILE_W(3 * (C)) VM_KTILE_W(3 * (C) + 1) VM_KTILE_W(3 * (C) + 2)
+    if constexpr (WIDE) {
+        VM_CHUNK_W(0) VM_CHUNK_W(1) VM_CHUNK_W(2) VM_CHUNK_W(3) VM_CHUNK_W(4) VM_CHUNK_W(5) VM_CHUNK_W(6) VM_CHUNK_W(7)
+        VM_CHUNK_W(8) VM_CHUNK_W(9) VM_CHUNK_W(10) VM_CHUNK_W(11) VM_CHUNK_W(12) VM_CHUNK_W(13) VM_CHUNK_W(14) VM_CHUNK_W(15)
+    } else {
+        VM_CHUNK(0) VM_CHUNK(1) VM_CHUNK(2) VM_CHUNK(3) VM_CHUNK(4) VM_CHUNK(5) VM_CHUNK(6) VM_CHUNK(7)
+        VM_CHUNK(8) VM_CHUNK(9) VM_CHUNK(10) VM_CHUNK(11) VM_CHUNK(12) VM_CHUNK(13) VM_CHUNK(14) VM_CHUNK(15)
+    }
     static_assert(CHUNKS <= 16, "conv_nt3_kernel: at most 16 channel chunks are written out");
 #undef VM_CHUNK
+#undef VM_CHUNK_W
+#undef VM_KTILE_W
+#undef VM_W_STEP0
+#undef VM_W_STEP1
+#undef VM_W_WAIT
 #undef VM_KTILE_P
 #undef VM_P_STEP0
 #undef VM_P_STEP1
@@ -1583,18 +1669,18 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(NtArgs<T> p, int64_t n
 #undef VM_MM
 #undef VM_LOAD_SET
     if constexpr (EPI == EPI_FWD_FOLD) {
-        const int c0 = n0 + wn * 64 + 4 * (lane >> 5), rl = p.L - 1 - t0;
-        if (t0 == 0) n2_fold_edge<T>(p, acc, 0, 0, wm, lane & 31, c0);
-        if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T>(p, acc, rl, 1, wm, lane & 31, c0);
+        const int c0 = n0 + wn * WC + 4 * (lane >> 5), rl = p.L - 1 - t0;
+        if (t0 == 0) n2_fold_edge<T, WIDE>(p, acc, 0, 0, wm, lane & 31, c0);
+        if (rl >= 0 && rl < n2r::TROWS) n2_fold_edge<T, WIDE>(p, acc, rl, 1, wm, lane & 31, c0);
     }
     VM_PROF(const long long pt_loop = __builtin_amdgcn_s_memtime();)
 #if defined(VM_NT3_EPI_PRIO)   // experiment build: the epilogue at a raised wave priority (its VALU beside the co-resident wave's MFMAs)
     __builtin_amdgcn_s_setprio(VM_NT3_EPI_PRIO);
 #endif
 #if VM_NT3_ABL & 8
-    if (acc[0][0][0] == 123.456f && acc[3][1][15] == 1.5f) n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+    if (acc[0][0][0] == 123.456f && acc[3][1][15] == 1.5f) n2_epilogue<T, EPI, WIDE>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
 #else
-    n2_epilogue<T, EPI>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
+    n2_epilogue<T, EPI, WIDE>(p, lds, acc, n, tl, t0, n0, n2r::TROWS, tid, lane, w, wm, wn);
 #endif
 #if defined(VM_EXPERIMENT_PROFILE)
     {
@@ -1695,6 +1781,7 @@ extern "C" int64_t vm_conv_stat_rows(int64_t L) { return (L + BM - 1) / BM; }
 namespace vm {
 int g_nt_n2 = 3;       // conv_nt2r_kernel for 16-bit storage: bit 0 forward, bit 1 dgrad; vm_set_tuning("nt_n2", 0..3)
 int g_nt3 = 3;         // conv_nt3_kernel (weights L2 -> registers) where the caller supplies packed weights: bit 0 forward, bit 1 dgrad
+int g_nt3_wide = 0;    // conv_nt3_kernel's 256 x 32 wave tile (half the weight stream, twice the fragment reads): bit 0 forward, bit 1 dgrad
 int g_nt3_lean = 3;    // conv_nt3_kernel's lean prologue (A(2), A(3) requested under the first two K tiles): bit 0 forward, bit 1 dgrad
 int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0, else register staging; vm_set_tuning("nt_glds", 0 | 1)
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
@@ -1730,6 +1817,19 @@ static void launch_n2r(const NtArgs<T>& a, int64_t n_windows, hipStream_t stream
             if (b.bt_packed != nullptr && (g_nt3 & (EPI == EPI_DGRAD ? 2 : 1)) && nt3_chunks(a.a_c)) {
                 const dim3 grid((unsigned)(n_groups * b.tilesN));
 #define VM_NT3(CH, PIPE) hipLaunchKernelGGL((conv_nt3_kernel<T, EPI, CH, PIPE>), grid, dim3(256), 0, stream, b, n_groups)
+                if constexpr (EPI == EPI_FWD_FOLD || EPI == EPI_DGRAD) {   // the 256 x 32 wave tile (experiment; lean prologue only)
+                    if (g_nt3_wide & (EPI == EPI_DGRAD ? 2 : 1)) {
+#define VM_NT3W(CH) hipLaunchKernelGGL((conv_nt3_kernel<T, EPI, CH, true, true>), grid, dim3(256), 0, stream, b, n_groups)
+                        switch (a.a_c / 32) {
+                            case 4: VM_NT3W(4); break;
+                            case 8: VM_NT3W(8); break;
+                            case 12: VM_NT3W(12); break;
+                            default: VM_NT3W(16); break;
+                        }
+#undef VM_NT3W
+                        return;
+                    }
+                }
                 const bool pipe = (g_nt3_lean & (EPI == EPI_DGRAD ? 2 : 1)) != 0;
                 switch (a.a_c / 32) {  // the K loop is written out per channel count: 128, 256, 384, 512 channels on the K side
                     case 4: if (pipe) VM_NT3(4, true); else VM_NT3(4, false); break;
@@ -2083,7 +2183,7 @@ extern "C" int vm_mfma_rate_probe(int dtype, int iters, float* sink, void* strea
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"tn9_stages", &g_tn9_stages, 0, 1}, {"fuse_finalize", &g_fuse_finalize, 0, 31}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt3_wide", &g_nt3_wide, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"tn9_stages", &g_tn9_stages, 0, 1}, {"fuse_finalize", &g_fuse_finalize, 0, 31}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;
