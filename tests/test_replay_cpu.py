@@ -80,3 +80,24 @@ def test_a_failing_call_in_a_replay_raises_with_its_name():
     eng.lib.vm_last_error = lambda: b"boom"
     with pytest.raises(_lib.VoicemapHipError, match="vm_ok.*boom"):
         eng._run_program(prog, {})
+
+
+def test_host_calls_keep_their_place_in_a_recorded_step():
+    """Round 6: a step's host-side calls that are not C-ABI entry points (the two gradient collectives of data parallelism,
+    voicemap_amd/parallel.py) are slots of the program: run when recorded and again, at the same position, in every replay."""
+    eng = _bare_engine()
+    eng._rec = E._Program()
+    seen = []
+    eng._call("vm_before", 1)
+    eng._host_call(lambda: seen.append(len(eng.lib.log)))
+    eng._call("vm_after", 2)
+    rec, eng._rec = eng._rec, None
+    assert seen == [1] and [c[0] for c in rec.cmds] == [0, 3, 0]
+    prog = eng._finish_program(rec)
+    assert prog.events == {}                                   # a host call is not an event key
+    eng.lib.log.clear()
+    eng._run_program(prog, {})
+    assert seen == [1, 1] and eng.lib.log == [("vm_before", 1), ("vm_after", 2)]
+    # outside a recording the call simply runs
+    eng._host_call(lambda: seen.append(-1))
+    assert seen[-1] == -1
