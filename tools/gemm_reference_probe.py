@@ -1,13 +1,14 @@
 """Reality check (not part of the product): what the vendor GEMM library reaches on the plain-GEMM equivalents of the nine
-conv launches (same M, N, K; no im2col, no epilogue), bf16 -> bf16 with fp32 accumulation, via torch.matmul."""
-import time, torch
+conv launches (same M, N, K; no im2col, no epilogue), bf16 -> bf16 (or f16 -> f16: argv[1]) with fp32 accumulation, via torch.matmul."""
+import sys, time, torch
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 dev = torch.device("cuda", 0)
 def bench(M, N, K, trans=False, reps=20):
     if trans:   # wgrad-like: (K x M)^T (K x N): reduction over the long dimension
-        a = torch.randn(K, M, device=dev, dtype=torch.bfloat16); b = torch.randn(K, N, device=dev, dtype=torch.bfloat16)
+        a = torch.randn(K, M, device=dev, dtype=DT); b = torch.randn(K, N, device=dev, dtype=DT)
         f = lambda: torch.matmul(a.t(), b)
     else:
-        a = torch.randn(M, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+        a = torch.randn(M, K, device=dev, dtype=DT); b = torch.randn(N, K, device=dev, dtype=DT)
         f = lambda: torch.matmul(a, b.t())
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()

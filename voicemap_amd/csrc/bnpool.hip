@@ -88,6 +88,12 @@ constexpr int CR_CHUNKS = 32;
 // finalize launch spreads them over C / 8 workgroups reading from L2 -- a launch saved (~5 us) only pays where the layer is narrow.
 // Default: the statistics of narrow, short reductions (the reference's cfg-B at its own batch), nothing else.
 int g_fuse_finalize = 17;
+// Walk of the BatchNorm-backward apply pass over the windows (vm_set_tuning "apply_order"; see bn_pool_bwd_apply_kernel).  The memory-side
+// cache (256 MB) keeps what was touched last: the dgrad that produced dp walked the windows front to back, so its last windows' dp rows
+// (and the rows of the extreme it read beside them for the BatchNorm-backward sums) are still there when this pass starts --
+// tools/probe/mall_recency_probe.py.
+int g_apply_order = 2;   // interleaved A/B, one box: cfg-A 128 pairs 2.633 -> 2.626, 2.630 -> 2.627 ms; cfg-B 128 pairs 1.047 -> 1.041; ascending (1): 2.628 -> 2.640
+
 constexpr int TICKET_WORDS = 16384;
 __device__ unsigned g_tickets[TICKET_WORDS];
 //  the symbol is resolved per device -- a process that drives several GPUs has one g_tickets per device -- and the cursor
@@ -600,15 +606,20 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ c1, const float* __restrict__ c2,
                                                                 int64_t wpt, int64_t L, int C, int P, T* __restrict__ du,
                                                                 float* __restrict__ part_a, const float* __restrict__ sp_dg,
-                                                                const int32_t* __restrict__ sp_idx, const float* __restrict__ e_center = nullptr) {
+                                                                const int32_t* __restrict__ sp_idx, const float* __restrict__ e_center,
+                                                                int order) {
     constexpr int VEC = Elem<T>::kVec;
     __shared__ __attribute__((aligned(16))) float red[256][VEC];
     const int tid = threadIdx.x;
     const int RP = 256 / P;
     const int pl = tid % P, rl = tid / P;
     const int CV = C / VEC;
-    const int64_t n = blockIdx.x;
-    const int seg = blockIdx.y;
+    // order 0: grid (windows, segments) -- the dispatcher walks the segments of ALL windows together; 1 / 2: grid (segments, windows),
+    // window-major, ascending / DESCENDING: the workgroups resident at any time cover a contiguous range of windows, 2 starts with the
+    // windows the producer of dp wrote LAST (g_apply_order).  Same blocks, same sums: bit-identical.
+    const int64_t n = order == 0 ? blockIdx.x : (order == 1 ? blockIdx.y : gridDim.y - 1 - blockIdx.y);
+    const int seg = order == 0 ? blockIdx.y : blockIdx.x;
+    const int nseg = order == 0 ? gridDim.y : gridDim.x;
     const int64_t tw = n / wpt;
     const int64_t Lq = L / POOL;
     const int64_t Q = (L + POOL - 1) / POOL;  // also covers the remainder rows of a floor pool
@@ -726,8 +737,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 for (int j = 0; j < POOL; ++j)
                     if (FULL || j < nrows) store16<T>(op + j * C, ov[j]);
             };
-            int64_t q = seg + (int64_t)rl * gridDim.y;
-            const int64_t qs = (int64_t)RP * gridDim.y;
+            int64_t q = seg + (int64_t)rl * nseg;
+            const int64_t qs = (int64_t)RP * nseg;
             if constexpr (VM_APPLY_TWO_GROUPS && POOL == 2 && !(PAIRS && (SP || sizeof(T) != 2))) {
                 // NG pool groups in flight per thread: 3 NG 16-byte loads before the first is consumed (the pass is a pure stream:
                 // 4.5 TB/s with three).  Same groups in the same order: bit-identical
@@ -768,10 +779,10 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
                 for (int i = 0; i < VEC; ++i) a[i] += t[i];
             }
             storev<VEC>(part_a + row * C + c0, a);
-            if (seg == 0 && gridDim.y < BN_SEG) {   // fewer segments than partial rows: the others are zero
+            if (seg == 0 && nseg < BN_SEG) {   // fewer segments than partial rows: the others are zero
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) a[i] = 0.f;
-                for (int e = gridDim.y; e < BN_SEG; ++e) storev<VEC>(part_a + (row + e) * C + c0, a);
+                for (int e = nseg; e < BN_SEG; ++e) storev<VEC>(part_a + (row + e) * C + c0, a);
             }
         }
         __syncthreads();
@@ -1474,6 +1485,10 @@ extern "C" int vm_bn_bwd_from_sums_finalize(const float* s0, const float* sa, in
     return check_launch("vm_bn_bwd_from_sums_finalize");
 }
 
+static dim3 apply_grid(int64_t n_windows, int segs) {
+    return g_apply_order == 0 ? dim3((unsigned)n_windows, (unsigned)segs) : dim3((unsigned)segs, (unsigned)n_windows);
+}
+
 static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp_dg, const int32_t* sp_idx, const float* scale,
                                   const float* shift, const float* mean, const float* invstd, const float* drop, const float* c1,
                                   const float* c2, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int pool,
@@ -1484,13 +1499,13 @@ static int bn_pool_bwd_apply_impl(const void* z, const void* dp, const float* sp
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         if (sp_idx != nullptr) {
-            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, true>), apply_grid(n_windows, bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                                (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
-                               L, C, P, (T*)du, part_du, sp_dg, sp_idx);
+                               L, C, P, (T*)du, part_du, sp_dg, sp_idx, (const float*)nullptr, g_apply_order);
         } else {
-            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
+            hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, POOL, false>), apply_grid(n_windows, bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
                                (hipStream_t)stream, (const T*)z, (const T*)nullptr, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
-                               L, C, P, (T*)du, part_du, sp_dg, sp_idx);
+                               L, C, P, (T*)du, part_du, sp_dg, sp_idx, (const float*)nullptr, g_apply_order);
         }
     }));
     return check_launch("vm_bn_pool_bwd_apply");
@@ -1514,9 +1529,9 @@ extern "C" int vm_bn_pool_bwd_apply_pairs(const void* e, const void* o, const vo
     VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool_bwd_apply_pairs: 16-bit storage only (VM_BF16 / VM_F16), got dtype %d", dtype);
     VM_DISPATCH_16(dtype, {
         const int P = lanes_for(C / Elem<T>::kVec);
-        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / 2, C, Elem<T>::kVec)), dim3(256), 0,
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, false, true>), apply_grid(n_windows, bn_segs(L / 2, C, Elem<T>::kVec)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)e, (const T*)o, (const T*)dp, scale, mean, invstd, drop, c1, c2, windows_per_tower,
-                           L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr, e_center);
+                           L, C, P, (T*)du, part_du, (const float*)nullptr, (const int32_t*)nullptr, e_center, g_apply_order);
     });
     return check_launch("vm_bn_pool_bwd_apply_pairs");
 }
