@@ -142,6 +142,79 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def live_pmc_traffic(key, a):
+    """HBM bytes per launch of the dominant kernel, counted NOW: two ``rocprofv3 --pmc`` passes (FETCH_SIZE, then WRITE_SIZE: separate
+    passes as MI355X_MICROARCH.md prescribes) over three serial steps of this very script in a child process, folded by
+    tools/pmc_traffic.py (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction).  Returns (bytes or None, how / why not)."""
+    import contextlib
+    import io
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+        return None, "this process runs under a profiler itself"
+    tmp = tempfile.mkdtemp(prefix="vm_pmc_", dir="/tmp")
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    tune = ",".join(t for t in (a.tune, "split_towers=0") if t)
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline", "--no-extras",
+             "--no-overlap-wgrad", "--no-live-pmc", "--tune", tune, "--dtype", a.dtype, "--pairs", str(a.pairs), "--loss", a.loss]
+    t0 = time.perf_counter()
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            r = subprocess.run([exe, "--pmc", c, "--output-format", "csv", "-d", os.path.join(tmp, c), "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s ended with rc %d: %s" % (c, r.returncode, r.stderr.decode(errors="replace")[-200:])
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic
+        with contextlib.redirect_stdout(io.StringIO()):
+            pmc_traffic.main(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), os.path.join(tmp, "traffic.json"))
+        with open(os.path.join(tmp, "traffic.json")) as f:
+            got = json.load(f)["kernels"].get(key)
+        if got is None:
+            return None, "the PMC passes hold no launch of shape %s" % key
+        return got["hbm_bytes"], ("counted in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a child process running three serial "
+                                  "steps of this script on this device, %.0f s; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction "
+                                  "(tools/pmc_traffic.py)" % (time.perf_counter() - t0))
+    except Exception as e:   # noqa: BLE001  (a timeout, a parse error: the committed figure serves, labelled)
+        return None, "live PMC passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def vendor_gemm_ms(kernel, shape, dtype, dev):
+    """What the vendor GEMM library (hipBLASLt / rocBLAS behind torch.matmul) needs for the PLAIN GEMM of the dominant launch -- same
+    M, N, K and storage type, no im2col addressing, no bias / ReLU / statistics / pool-pair epilogue -- on this device, now."""
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    n, L, cin, cout = shape["n_windows"], shape["L"], shape["c_in"], shape["c_out"]
+    if kernel == "vm_conv_wgrad":
+        a_ = torch.randn(n * L, 3 * cin, device=dev, dtype=tdt)
+        b_ = torch.randn(n * L, cout, device=dev, dtype=tdt)
+        f = lambda: torch.matmul(a_.t(), b_)   # noqa: E731
+        mnk = (3 * cin, cout, n * L)
+    else:
+        nn, kk = (cout, 3 * cin) if kernel == "vm_conv_fwd" else (cin, 3 * cout)
+        a_ = torch.randn(n * L, kk, device=dev, dtype=tdt)
+        b_ = torch.randn(nn, kk, device=dev, dtype=tdt)
+        f = lambda: torch.matmul(a_, b_.t())   # noqa: E731
+        mnk = (n * L, nn, kk)
+    for _ in range(3):
+        f()
+    ts = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        f()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), mnk
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +232,8 @@ def main():
                     help="keep the weight-gradient GEMMs on the main stream (default: side stream, concurrent with dgrad)")
     ap.add_argument("--tune", default="", help="extra tuning knobs key=value,key=value (engine switches / vm_set_tuning)")
     ap.add_argument("--breakdown", default="", help="write a per-entry-point time breakdown (extra untimed steps) to this file")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/pmc_traffic.json instead of two "
+                    "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) run by this process on the serial step")
     ap.add_argument("--allow-nonfinite", action="store_true", help="timing experiments with ablated builds (tools/build_variant.sh): results are wrong by design")
     a = ap.parse_args()
 
@@ -169,11 +244,11 @@ def main():
     from voicemap_amd import parallel
     from voicemap_amd.engine import HipEncoderEngine
     # (the rendezvous gets twice the collectives' limit: ranks of a fresh box finish ``import torch`` at different times)
-    watchdog = Watchdog(2 * float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "60")))
+    watchdog = Watchdog(2 * float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "120")))
     watchdog.arm("torch.distributed rendezvous / init_process_group (world %s)" % os.environ.get("WORLD_SIZE", "1"))
     rank, world, local = parallel.init_distributed(timeout_s=watchdog.seconds)
     watchdog.disarm()
-    watchdog.seconds = float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "60"))
+    watchdog.seconds = float(os.environ.get("VOICEMAP_DIST_WATCHDOG_S", "120"))
     if world != a.gpus:
         fail("bench.py --gpus %d was started with WORLD_SIZE=%d: launch with --nproc-per-node == --gpus (or without torchrun: "
              "bench.py spawns the ranks itself)" % (a.gpus, world))
@@ -364,14 +439,24 @@ def main():
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["algorithmic_bytes"] = nbytes
     roof["traffic"] = None
+    key = "%s|%d|%d|%d|%d" % (a.dominant, shape["n_windows"], shape["L"], shape["c_in"], shape["c_out"])
+    committed = None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), if this shape was profiled
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            key = "%s|%d|%d|%d|%d" % (a.dominant, shape["n_windows"], shape["L"], shape["c_in"], shape["c_out"])
-            roof["traffic"] = json.load(f)["kernels"][key]["hbm_bytes"]
-            roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape on another "
-                                      "box (tools/pmc_traffic.py; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- NOT measured in this run")
+            committed = json.load(f)["kernels"][key]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
+    why = "--no-live-pmc" if a.no_live_pmc else ("N > 1 or not rank 0" if n_gpus > 1 or rank else "tools/pmc_traffic.py maps the 256-window launches only")
+    if rank == 0 and n_gpus == 1 and not a.no_live_pmc and 2 * pairs == 256:
+        roof["traffic"], why = live_pmc_traffic(key, a)
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = why
+            roof["traffic_committed"] = committed   # profiles/pmc_traffic.json (another box, another day): the two must agree
+    if roof["traffic"] is None and committed is not None:
+        roof["traffic"] = committed
+        roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape on another "
+                                  "box (tools/pmc_traffic.py; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- NOT measured in this run "
+                                  "(%s)" % why)
     roof["kernel"] = a.dominant
     def symbol(nm, shp=None):   # the folded forward (vm_conv_fwd_fold) is epilogue variant 3 of the same kernel
         sym = KERNEL_SYMBOL[nm].format(T=CTYPE.get(a.dtype, a.dtype))
@@ -428,6 +513,16 @@ def main():
                                                 "from registers, median of 5 launches (HIP events)" % (iters, a.dtype)}
         except Exception as e:   # noqa: BLE001
             roof["mfma_sustained"] = {"error": repr(e)}
+    if rank == 0 and a.dtype in ("f16", "bf16"):
+        try:   # the vendor library on the plain GEMM of the same shape, beside the fused launch it is compared with
+            v_ms, mnk = vendor_gemm_ms(a.dominant, shape, a.dtype, dev)
+            roof["vendor_gemm"] = {"ms": v_ms, "frac": nflops / (v_ms * 1e-3) / 1e12 / MFMA_16BIT_PEAK_TF, "m_n_k": list(mnk),
+                                   "this_launch_ms": t_avg * 1e3,
+                                   "source": "torch.matmul (%s -> %s, fp32 accumulation) on the plain GEMM of the dominant launch's shape in this run, "
+                                             "median of 10 (HIP events): no im2col addressing, no bias / ReLU / statistics / pool-pair epilogue"
+                                             % (a.dtype, a.dtype)}
+        except Exception as e:   # noqa: BLE001
+            roof["vendor_gemm"] = {"error": repr(e)}
     roof["step_hbm_frac"] = TRAIN_BYTES_PER_WINDOW * (2 * pairs * a.steps / dt) / (HBM_PEAK_GBS * 1e9)
     roof["step_mfma_frac"] = TRAIN_FLOPS_PER_WINDOW * (2 * pairs * a.steps / dt) / (MFMA_16BIT_PEAK_TF * 1e12)
     out["roofline"] = roof
@@ -475,6 +570,10 @@ def main():
         out["cpu_baseline"] = {"value": 2 * cpu_pairs * 3.0 / sec, "unit": "audio-s/s", "cores": threads, "kind": "port",
                                "host_cpu_count": os.cpu_count() or 1,
                                "threads_tried_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(trials.items())},
+                               "full_batch_note": "the 128-pair batch of the GPU step is the CPU path's WORSE operating point: 10.0 / 11.3 / 17.8 s "
+                                                  "per step on 32 / 64 / 128 threads of the same 256-cpu host = 77 audio-s/s at best "
+                                                  "(tools/probe/cpu_full_batch.py, round 6) against 150-200 at 8 pairs -- the sample below is "
+                                                  "the batch that favours the CPU",
                                "sample": "<=%d steps of %d pairs, cfg-A, same step definition (fp32 torch-CPU oracle, best of the "
                                          "intra-op thread counts listed in threads_tried on a %d-cpu host: a batch of %d pairs does "
                                          "not scale to every core; %.0f ms/step)"

@@ -37,6 +37,25 @@ def test_bench_single_process_line_contract():
     assert set(roof["families_serial"]) == {"vm_conv_fwd", "vm_conv_dgrad", "vm_conv_wgrad"}
 
 
+def test_bench_counts_the_dominant_launch_traffic_in_the_run():
+    """roofline.traffic is COUNTED by the run that reports it: bench.py, at the headline batch, runs the two
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) on a child process of itself and folds them with tools/pmc_traffic.py; the
+    committed figure of another box rides along and must agree."""
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP_", "ROCPROF"))}
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-extras", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    roof = _last_json_line(r.stdout)["roofline"]
+    assert roof["traffic_source"].startswith("counted in this run"), roof["traffic_source"]
+    assert 0.95 * roof["algorithmic_bytes"] < roof["traffic"] < 1.3 * roof["algorithmic_bytes"]
+    assert roof["traffic_committed"] is None or abs(roof["traffic"] / roof["traffic_committed"] - 1.0) < 0.05
+    v = roof["vendor_gemm"]
+    assert v["ms"] > 0 and v["m_n_k"] == [256 * roof["launch_shape"]["L"], v["m_n_k"][1], v["m_n_k"][2]]
+
+
 @pytest.mark.parametrize("launch", ["self"])
 def test_bench_two_ranks_over_gloo(launch):
     """Plain ``python bench.py --gpus 2`` -- no RANK in the environment: bench.py spawns the two ranks itself by re-executing its own
