@@ -435,13 +435,15 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const float ga = sc * dr, gb0 = sc * (is * k2 * mu - k1), gc = -sc * is * k2;
     const f32x2 bv2 = {bv, bv};
 
-    f32x16 accw, accb;  // accb: the bias gradient sum_rows du[row][c], as one more MFMA with an all-ones A operand -- the
-                        // kernel is VALU-bound and the matrix pipe is mostly idle, so the converts + adds per tile move there
+    f32x16 accw;
+    // the bias gradient sum_rows du[row][c] on the matrix pipe too (the kernel is VALU-bound: the converts + adds per tile move there),
+    // as v_mfma_f32_4x4x4 with an all-ones A operand: D[lane][0] = the sum of the lane's own four K values (round 6: the 32 x 32 x 16
+    // form spent a whole 32 x 32 product -- two of the tile's twelve large MFMAs -- on sixty-four column sums)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    f32x4 accb0 = {0.f, 0.f, 0.f, 0.f}, accb1 = accb0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[r] = accb[r] = 0.f;
-    bf16x8 ones8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones8[e] = (bf16)1.0f;
+    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+    const s16x4 ones4 = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};   // bf16 1.0
 
     const int ch_lo = split * cps;
     int ch_hi = ch_lo + cps;
@@ -622,7 +624,11 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                 }
                 accw = mfma_bf16(ah, bfrag, accw);
                 accw = mfma_bf16(al, bfrag, accw);
-                accb = mfma_bf16(ones8, bfrag, accb);
+                {
+                    const u32x4 bw = __builtin_bit_cast(u32x4, bfrag);
+                    accb0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, u32x2{bw[0], bw[1]}), accb0, 0, 0, 0);
+                    accb1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, u32x2{bw[2], bw[3]}), accb1, 0, 0, 0);
+                }
             }
         }
         if (more) f1_stash(cp[buf ^ 1], nxt, tid);
@@ -632,8 +638,8 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     __shared__ float wred[4][17][64];
 #pragma unroll
     for (int r = 0; r < 16; ++r) wred[wave][r][lane] = role.active ? accw[r] : 0.f;
-    // every accumulator row of accb holds the column sum over ALL K slots (both lane halves): count it once
-    wred[wave][16][lane] = (role.active && hi == 0) ? accb[0] : 0.f;
+    // every lane holds the sum over ITS K slots (half of the channel's rows): the two lane halves are added below
+    wred[wave][16][lane] = role.active ? accb0[0] + accb1[0] : 0.f;
     __syncthreads();
     if (role.active && role.rs == 0) {
         float* slab = ws + (int64_t)blockIdx.x * 33 * F;

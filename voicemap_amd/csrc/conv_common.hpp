@@ -60,6 +60,28 @@ __device__ inline typename Mfma<T>::Frag ones16() {
     return __builtin_bit_cast(typename Mfma<T>::Frag, v);
 }
 
+// v_mfma_f32_4x4x4 (16 independent 4 x 4 x 4 blocks of four lanes): D[lane 4b + j][reg i] = sum_k A[lane 4b + i][k] * B[lane 4b + j][k]
+// (tools/probe/mfma4x4_probe.hip).  Operands: four 16-bit K values per lane, as the two registers of a ds_read_b64_tr_b16.
+template <typename T> struct Mfma4;
+template <> struct Mfma4<f16> {
+    __device__ static inline f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma4<bf16> {
+    __device__ static inline f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        typedef short s4 __attribute__((ext_vector_type(4)));
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+    }
+};
+template <typename T>
+__device__ inline u32x2 ones4() {   // four ones in a 16-bit storage type
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    const uint32_t w = std::is_same<T, bf16>::value ? 0x3F803F80u : 0x3C003C00u;
+    return u32x2{w, w};
+}
+
 // One KB-byte K slice: every wave multiplies its 64 (m) x 64 (n) sub-tile.  lds_a / lds_b: [128][PITCH] bytes.
 // acc[im][in] = B_in . A_im^T, i.e. register r of lane l holds  m = 32*im + (l&31),  n = 32*in + (r&3) + 8*(r>>2) + 4*(l>>5).
 template <typename T, int KB>

@@ -817,16 +817,18 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         // moves a row by 4 banks: consecutive rows overlapped in 12 of their 16 banks -- the 4-way conflicts of the round-3 counters)
         const int li = lane & 15, lg = (lane >> 4) & 1;
         const uint32_t xoff = lds0 + (4 * (li >> 2) + 2 * kh) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
-        const V8 ones = ones16<T>();
+        const u32x2 ones = ones4<T>();
         const int srows = (p.L + 127) / 128;  // vm_conv_stat_rows
-        const int cn = lane & 31;             // the channel (of this wave's 32) whose sums this lane extracts
-        const int rsel = (cn & 3) + 4 * (cn >> 3);
+        const int cn = lane & 31;             // the channel (of this wave's 32) whose sums this lane holds: 16 lg + li
+        // (round 6) The sums ride on v_mfma_f32_4x4x4 (16 blocks of 4 lanes, K = the four rows of a transposing read): with A = B = the
+        // lane's own four values, D[lane][reg lane & 3] is the lane's sum of squares, with A = ones D[lane][0] its sum -- 1024
+        // multiply-adds per instruction where the 32 x 32 x 16 form spent 16384 on a 32 x 32 product of which only the diagonal (or
+        // one row) was wanted.  On the power limit that is what counts: the statistics phase was 13 / 15 / 6 us of the three forward
+        // launches (VM_ABL=8, profiles/r06_nt3_stats_4x4.txt).  The two row halves (kh) of a channel are added across lanes 32 apart.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x16 d1, d2;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) d1[e] = d2[e] = 0.f;
-            u32x2 lo[8], hi[8];   // all 16 transposing reads of the half first, then the 16 MFMAs (one latency, not eight)
+            f32x4 d1a = {0.f, 0.f, 0.f, 0.f}, d1b = d1a, d2a = d1a, d2b = d1a;
+            u32x2 lo[8], hi[8];   // all 16 transposing reads of the half first, then the MFMAs (one latency, not eight)
 #pragma unroll
             for (int rs = 0; rs < 8; ++rs) {
                 const uint32_t a = xoff + (h * 128 + rs * 16) * TP;
@@ -852,21 +854,21 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[7]), "+v"(hi[7]));
                 }
-                const u32x4 xv = {lo[rs][0], lo[rs][1], hi[rs][0], hi[rs][1]};
-                const V8 x = __builtin_bit_cast(V8, xv);
-                d2 = Mfma<T>::run(x, x, d2);
-                d1 = Mfma<T>::run(ones, x, d1);
+                d2a = Mfma4<T>::run(lo[rs], lo[rs], d2a);
+                d2b = Mfma4<T>::run(hi[rs], hi[rs], d2b);
+                d1a = Mfma4<T>::run(ones, lo[rs], d1a);
+                d1b = Mfma4<T>::run(ones, hi[rs], d1b);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // D1[m][n] = sum over the 16 x 8 rows of Z[row][32 w + n] for every m: register 0 of lane n.  D2[m][n] with
-            // m = (r & 3) + 8 (r >> 2) + 4 kh: the diagonal element of channel n is register rsel(n) of the lane with kh == (n >> 2) & 1.
-            float dq = 0.f;
+            float ds = d1a[0] + d1b[0], dq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dq = e == rsel ? d2[e] : dq;
-            if (2 * tl + h < srows) {
+            for (int e = 0; e < 4; ++e) dq = e == (lane & 3) ? d2a[e] + d2b[e] : dq;
+            ds += __shfl_xor(ds, 32, 64);
+            dq += __shfl_xor(dq, 32, 64);
+            if (2 * tl + h < srows && kh == 0) {
                 const int64_t srow = n * srows + 2 * tl + h;
-                if (kh == 0) p.stat_sum[srow * p.N + n0 + 32 * w + cn] = d1[0];
-                if (kh == ((cn >> 2) & 1)) p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
+                p.stat_sum[srow * p.N + n0 + 32 * w + cn] = ds;
+                p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
             }
             bar.point();
         }
@@ -887,13 +889,13 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         // k indices must agree)
         const int li = lane & 15, lg = (lane >> 4) & 1;
         const uint32_t xoff = lds0 + (4 * (li >> 2) + 2 * kh) * TP + (32 * w + 16 * lg + 4 * (li & 3)) * 2;
-        const V8 ones = ones16<T>();
+        const u32x2 ones = ones4<T>();
         u32x2 dlo[16], dhi[16];
-        f32x16 d1[2], d2[2];
+        f32x4 d1[2][2], d2[2][2];   // [half][lo / hi read]: v_mfma_f32_4x4x4 accumulators (see the forward statistics above)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) d1[h][e] = d2[h][e] = 0.f;
+            for (int u = 0; u < 2; ++u) d1[h][u] = d2[h][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const uint32_t a = xoff + (q * 16) * TP;
@@ -928,8 +930,8 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
         VM_RED_MARK(4);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const u32x4 xv = {dlo[q][0], dlo[q][1], dhi[q][0], dhi[q][1]};
-            d1[q >> 3] = Mfma<T>::run(ones, __builtin_bit_cast(V8, xv), d1[q >> 3]);
+            d1[q >> 3][0] = Mfma4<T>::run(ones, dlo[q], d1[q >> 3][0]);
+            d1[q >> 3][1] = Mfma4<T>::run(ones, dhi[q], d1[q >> 3][1]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and loads retire out of order with each other: no counted wait here
         VM_RED_MARK(5);
@@ -950,21 +952,24 @@ __device__ inline void n2_tile_drain(const NtArgs<T>& p, char* lds, int64_t n, i
 #pragma unroll
             for (int rs = 0; rs < 8; ++rs) {
                 const int q = h * 8 + rs;
-                const u32x4 dv = {dlo[q][0], dlo[q][1], dhi[q][0], dhi[q][1]};
-                const u32x4 av = {alo[rs][0], alo[rs][1], ahi[rs][0], ahi[rs][1]};
-                d2[h] = Mfma<T>::run(__builtin_bit_cast(V8, dv), __builtin_bit_cast(V8, av), d2[h]);
+                d2[h][0] = Mfma4<T>::run(dlo[q], alo[rs], d2[h][0]);
+                d2[h][1] = Mfma4<T>::run(dhi[q], ahi[rs], d2[h][1]);
             }
         }
-        const int cn = lane & 31, rsel = (cn & 3) + 4 * (cn >> 3);
+        const int cn = lane & 31;
         const int rows2 = 2 * p.tilesL;  // partial rows per window (vm_conv_dgrad_bnred_rows)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float dq = 0.f;
+            float ds = d1[h][0][0] + d1[h][1][0], dq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dq = e == rsel ? d2[h][e] : dq;
+            for (int e = 0; e < 4; ++e) dq = e == (lane & 3) ? d2[h][0][e] + d2[h][1][e] : dq;
+            ds += __shfl_xor(ds, 32, 64);   // the two row halves (kh) of the channel
+            dq += __shfl_xor(dq, 32, 64);
             const int64_t srow = n * rows2 + 2 * tl + h;
-            if (kh == 0) p.stat_sum[srow * p.N + n0 + 32 * w + cn] = d1[h][0];
-            if (kh == ((cn >> 2) & 1)) p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
+            if (kh == 0) {
+                p.stat_sum[srow * p.N + n0 + 32 * w + cn] = ds;
+                p.stat_sq[srow * p.N + n0 + 32 * w + cn] = dq;
+            }
         }
     }
 }
