@@ -249,6 +249,8 @@ class HipEncoderEngine:
         # on one box -- the weight-gradient GEMM then starts as soon as du exists and the step's tail (block-1 backward, slab sums,
         # optimizer) no longer waits for the last of them
         self.wgrad_after_dgrad = False
+        self.defer_wgrad_tail = 0   # experiment (backward()): where the tap sums / per-tower slab folds behind every weight-gradient GEMM go
+        self.misc_stream = torch.cuda.Stream(device=self.device)
         # training option (bf16): vm_conv_fwd_e -- the conv epilogue also writes the pool-window extreme, the pool pass reads that
         # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
         # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
@@ -1195,6 +1197,7 @@ class HipEncoderEngine:
             self._call("vm_dense_bwd", *dense, _p(self.view("dense.kernel", G)), _p(self.view("dense.bias", G)), _p(pl["dgmax"]), st)
         # GlobalMaxPool1D backward stays sparse (dgmax, gidx): the last block's BN-backward passes consume that form
         last = self.nb - 1
+        wgrad_tails = []   # side stream: the small launches behind every weight-gradient GEMM, deferred behind the last one
         for i in range(self.nb - 1, -1, -1):
             k, c, pool = self.blocks[i]
             b, L = pl[i], pl["L"][i]
@@ -1268,7 +1271,7 @@ class HipEncoderEngine:
             gb = _p(self.view(f"conv{i+1}.bias", G))
             gw = _p(self.view(f"conv{i+1}.kernel", G))
 
-            def wgrad(stream, cr_ws):
+            def wgrad(stream, cr_ws, i=i, b=b, L=L, c=c, gb=gb, gw=gw):
                 # the conv bias gradient = column sums of du (from the apply pass's partials), then the weight gradient
                 cin = self.blocks[i - 1][1]
                 if fold:
@@ -1276,9 +1279,24 @@ class HipEncoderEngine:
                     # the GEMM first (it needs e and du only), the tap sums behind it, then the per-tower slab sums with their factors
                     self._call("vm_conv_wgrad_fold", _p(lo["ep"]), _p(b["du"]), n, wpt, L, cin, c, dt, None, None, None,
                                _p(b["wgrad_ws_fold"]), None, stream)
-                    self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), stream)
-                    self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]),
-                               _p(lo["shift_c" if ((i == 1 and self.fuse_block1) or lo.get("ctr_now")) else "shift"]), _p(b["dsum"]), gw, stream)
+
+                    def finish(st_):
+                        self._call("vm_du_tower_sums", _p(b["pdu"]), _p(b["du"]), n, wpt, L, c, dt, gb, _p(b["dsum"]), _p(cr_ws), st_)
+                        self._call("vm_conv_wgrad_fold_finish", _p(b["wgrad_ws_fold"]), n, wpt, L, cin, c, _p(lo["scale"]),
+                                   _p(lo["shift_c" if ((i == 1 and self.fuse_block1) or lo.get("ctr_now")) else "shift"]), _p(b["dsum"]), gw, st_)
+                    # (round 6 experiments, profiles/r06_wgrad_tail.txt) on the side stream these small launches sit BETWEEN two
+                    # weight-gradient GEMMs; beside the memory-bound apply pass of the main stream their 1024-thread workgroups find
+                    # no compute unit until that pass has drained (85-130 us for a 5 us reduction).  defer_wgrad_tail 1: all of them
+                    # behind the LAST weight-gradient GEMM; 2: on a stream of their own behind their GEMM.
+                    on_side = stream == self.side_stream.cuda_stream
+                    if self.defer_wgrad_tail == 1 and on_side:
+                        wgrad_tails.append(lambda: finish(stream))
+                    elif self.defer_wgrad_tail == 2 and on_side:
+                        self._join(self.misc_stream, self.side_stream)
+                        with self._on(self.misc_stream):
+                            finish(self.stream())
+                    else:
+                        finish(stream)
                 else:
                     self._call("vm_conv_wgrad", _p(pl[i - 1]["act"]), _p(b["du"]), n, L, cin, c, dt, _p(b["wgrad_ws"]), gw, stream)
                     self._call("vm_colsum", _p(b["pdu"]), b["pdu"].shape[0], c, gb, _p(cr_ws), stream)
@@ -1297,6 +1315,12 @@ class HipEncoderEngine:
                         self._wait(self.side_stream, b["ev"])
                         # (the bias gradient is nobody's input until the optimizer: off the main stream, with its own workspace)
                         wgrad(self.stream(), pl["cr_ws_side"])
+                        if i == 1:   # the last weight-gradient GEMM of the step is enqueued: now the deferred sums / slab folds
+                            for fin in wgrad_tails:
+                                fin()
+                            del wgrad_tails[:]
+                            if self.defer_wgrad_tail == 2:   # what waits for the side stream from here on waits for the small launches too
+                                self._join(self.side_stream, self.misc_stream)
                     if i == 1 and sync_tail:
                         self._begin_grad_tail(pl)
 
@@ -1446,10 +1470,10 @@ class HipEncoderEngine:
     # ---- one training step, eager or replayed -----------------------------------------------------------------------------------
     def _step_flags(self):
         return (self.fold_affine, self.fuse_block1, self.fused_bn_reduce, self.fused_sums_finalize, self.split_towers, self.tower_stagger,
-                self.overlap_wgrad, self.wgrad_after_dgrad, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
+                self.overlap_wgrad, self.wgrad_after_dgrad, self.defer_wgrad_tail, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
-                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.pre_overlap, id(self.grad_sync), self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream))
+                self.grad_prescale, self.fused_infer_pool, self.center_blocks, self.pre_overlap, id(self.grad_sync), self.lib.tuning_epoch, id(self.side_stream), id(self.tower_stream), id(self.misc_stream))
 
     def _train_step(self, pl: dict, wpt: int, target: torch.Tensor, loss: Optional[str], drop_masks, apply_update: bool, pre,
                     input_ready: bool = False):
