@@ -362,9 +362,13 @@ def encoder_forward(arch: EncoderArch, p, x: torch.Tensor, training: bool,
     x is (N, L0, 1).  ``collect`` (optional dict) receives per-block batch statistics and
     activations."""
     h = x
+    if storage == "f16":
+        # (round 6) f16 storage emulation only: the HIP block-1 convolution takes the whitened waveform rounded to half -- the precision every
+        # other layer's input has in this mode -- against filters split hi + lo in halves (conv1_fused.hip, f1_products = 2)
+        h = _rnd(h, storage)
     for i, (k, c, pool) in enumerate(arch.blocks):
         kern = p[f"conv{i+1}.kernel"]
-        if storage in _STORE_DT and i > 0:  # GEMM operand copies of the k=3 kernels are 16-bit; block 1 stays fp32
+        if storage in _STORE_DT and i > 0:  # GEMM operand copies of the k=3 kernels are 16-bit; block 1's filters keep 16+ bits (split)
             kern = kern + (_rnd(kern.detach(), storage) - kern.detach())
         # bf16 emulation of block 1: the fused kernels never store z1 (statistics, arg-max and the backward recompute see
         # the fp32 accumulator; only du1 becomes a bf16 MFMA operand); what IS stored is bf16(pooled extreme of z1), and the

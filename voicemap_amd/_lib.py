@@ -161,6 +161,10 @@ class _Lib:
         if self.abi != ABI_VERSION:  # a stale prebuilt library: its entry points take different arguments
             raise VoicemapHipError("%s reports ABI %d, this package binds ABI %d -- rebuild it (python -m voicemap_amd.build --force)"
                                    % (LIB_PATH, self.abi, ABI_VERSION))
+        # experiments: kernel-selection knobs for a whole process (a pytest run under another knob value): VOICEMAP_TUNE="key=value,..."
+        for kv in [t for t in os.environ.get("VOICEMAP_TUNE", "").split(",") if t.strip()]:
+            k, v = kv.split("=")
+            self.call("vm_set_tuning", k.strip().encode(), int(v))
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise with vm_last_error() on failure."""

@@ -81,26 +81,43 @@ __device__ inline F1Fetch f1_fetch(const float* __restrict__ xrow, int64_t t0, i
     return f;
 }
 // ... and stash: hi/lo split + the 8 shifted 2-byte stores per sample
+// PROD (round 6; f16 storage only, vm_set_tuning "f1_products"): how many 16-bit products carry the convolution.
+//   3: the split above on the bf16 pipe, xh*wh + xl*wh + xh*wl (both storage types until round 6; bf16 storage always)
+//   2: the waveform ROUNDED TO HALF (11 significand bits -- what every other layer's input already is in this storage mode), the
+//      filters split hi + lo in halves: xh*wh + xh*wl on the f16 pipe
+//   1: xh*wh alone -- input and filters both at the storage precision, like blocks 2-4
+// With PROD < 3 the xh copies hold halves and the xl copies hold bf16(x): the operand of the backward's weight-gradient MFMA, whose
+// other operand du is a bf16 (gradient range) -- ONE product there too (x at 8 bits beside a du at 8 bits), where the split form
+// took two.  NEED_L: the kernel reads the xl copies at all (PROD 3, or the backward).
+template <int PROD, bool NEED_L>
 __device__ inline void f1_stash_one(F1Copies& sm, float v, int j) {
-    const bf16 h = (bf16)v;
-    const bf16 l = (bf16)(v - (float)h);
+    bf16 h, l;
+    if constexpr (PROD == 3) {
+        h = (bf16)v;
+        l = (bf16)(v - (float)h);
+    } else {
+        h = __builtin_bit_cast(bf16, (_Float16)v);
+        l = (bf16)v;
+    }
     bf16* ph = &sm.xh[0][F1_PAD + j];
     bf16* pl = &sm.xl[0][F1_PAD + j];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         ph[s * (F1_ROW - 1)] = h;  // element F1_PAD + j - s of copy s
-        pl[s * (F1_ROW - 1)] = l;
+        if constexpr (NEED_L) pl[s * (F1_ROW - 1)] = l;
     }
 }
+template <int PROD, bool NEED_L>
 __device__ inline void f1_stash(F1Copies& sm, const F1Fetch& f, int tid) {
-    f1_stash_one(sm, f.va ? f.a : 0.f, tid);
-    if (tid < F1_CPL + 7 - 256) f1_stash_one(sm, f.vb ? f.b : 0.f, 256 + tid);
+    f1_stash_one<PROD, NEED_L>(sm, f.va ? f.a : 0.f, tid);
+    if (tid < F1_CPL + 7 - 256) f1_stash_one<PROD, NEED_L>(sm, f.vb ? f.b : 0.f, 256 + tid);
 }
 
 struct F1Weights {
     bf16x8 h[2], l[2];  // B fragments for k-steps 0,1: element e <-> tap 16*ks + 8*kh + e
 };
 
+template <int PROD>
 __device__ inline void f1_load_weights(F1Weights& w, const float* __restrict__ wk, int F, int c, bool cok, int kh) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -108,16 +125,26 @@ __device__ inline void f1_load_weights(F1Weights& w, const float* __restrict__ w
         for (int e = 0; e < 8; ++e) {
             const int k = 16 * ks + 8 * kh + e;
             const float v = cok ? wk[k * F + c] : 0.f;
-            const bf16 hh = (bf16)v;
-            w.h[ks][e] = hh;
-            w.l[ks][e] = (bf16)(v - (float)hh);
+            if constexpr (PROD == 3) {
+                const bf16 hh = (bf16)v;
+                w.h[ks][e] = hh;
+                w.l[ks][e] = (bf16)(v - (float)hh);
+            } else {   // halves in the 16-bit slots
+                const _Float16 hh = (_Float16)v;
+                w.h[ks][e] = __builtin_bit_cast(bf16, hh);
+                w.l[ks][e] = __builtin_bit_cast(bf16, (_Float16)(v - (float)hh));
+            }
         }
     }
+}
+__device__ inline f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {   // the 16-bit slots hold halves
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // u[p][c] for the 32 positions of row tile rt (local p = 32*rt + row) x the wave's 32 channels
 // (Starting the accumulator at the bias -- the C operand of the first MFMA -- instead of adding it in the epilogue was measured in
 // round 4: 8 v_pk_add_f32 fewer per tile, forward 115 -> 120 us, backward 195 -> 219 us (16 more VGPRs, one wave per SIMD fewer).)
+template <int PROD>
 __device__ inline f32x16 f1_conv_tile(const F1Copies& sm, const F1Weights& w, int rt, int lane) {
     const int i = lane & 31, kh = lane >> 5;
     const int s = i & 7;
@@ -133,10 +160,15 @@ __device__ inline f32x16 f1_conv_tile(const F1Copies& sm, const F1Weights& w, in
     for (int ks = 0; ks < 2; ++ks) {
         const int m0 = F1_PAD + 32 * rt + (i & ~7) + 16 * ks + 8 * kh;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sm.xh[s][m0]);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sm.xl[s][m0]);
-        acc = mfma_bf16(ah, w.h[ks], acc);
-        acc = mfma_bf16(al, w.h[ks], acc);
-        acc = mfma_bf16(ah, w.l[ks], acc);
+        if constexpr (PROD == 3) {
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sm.xl[s][m0]);
+            acc = mfma_bf16(ah, w.h[ks], acc);
+            acc = mfma_bf16(al, w.h[ks], acc);
+            acc = mfma_bf16(ah, w.l[ks], acc);
+        } else {
+            acc = mfma_f16(ah, w.h[ks], acc);
+            if constexpr (PROD == 2) acc = mfma_f16(ah, w.l[ks], acc);
+        }
     }
     return acc;
 }
@@ -179,7 +211,7 @@ __device__ inline void f1_relu4(const f32x16& acc, int g, f32x2 bv2, f32x2& a, f
 //   INFER: act[n][1+q][c] = TS(pooled extreme * scale + shift), sign from scale (moving-statistics affine)
 // z itself is never stored, so it has no storage rounding: statistics, pooling and the backward recompute all see the
 // fp32 accumulator.
-template <typename TS, int POOL, bool INFER>
+template <typename TS, int POOL, bool INFER, int PROD = 3>
 __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                               const float* __restrict__ bias, const float* __restrict__ sgn,
                                                               const float* __restrict__ shift, int64_t L, int F, int chunks,
@@ -206,7 +238,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
     const bool cok = role.active && c < F;
     const int hi = lane >> 5;
     F1Weights w;
-    f1_load_weights(w, wk, F, c, cok, hi);
+    f1_load_weights<PROD>(w, wk, F, c, cok, hi);
     const float bv = cok ? bias[c] : 0.f;
     const float sg = cok ? sgn[c] : 1.f;  // gamma (TRAIN) or scale (INFER): only its sign selects max/min ...
     const float sh = (INFER && cok) ? shift[c] : 0.f;
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
 
     VM_PROF1(long long pq_bar = 0, pq_conv = 0, pq_epi = 0, pq_stash = 0; const long long pq_s1 = __builtin_amdgcn_s_memtime();)
     F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
-    f1_stash(cp[0], nxt, tid);
+    f1_stash<PROD, PROD == 3>(cp[0], nxt, tid);
     VM_PROF1(const long long pq_s2 = __builtin_amdgcn_s_memtime();)
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int buf = (chunk - ch_lo) & 1;
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
         for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
             VM_PROF1(const long long pq_t0 = __builtin_amdgcn_s_memtime();)
-            f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            f32x16 acc = f1_conv_tile<PROD>(sm, w, rt, lane);
             VM_PROF1(asm volatile("" : "+v"(acc)); const long long pq_t1 = __builtin_amdgcn_s_memtime(); pq_conv += pq_t1 - pq_t0;)
             if (cok && t0 + 32 * rt + 32 <= Lq * POOL) {
                 TS* ob = (INFER ? out + (n * (Lq + 2) + 1 + (t0 + 32 * rt) / POOL) * F
@@ -339,7 +371,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
             }
         }
         VM_PROF1(const long long pq_h0 = __builtin_amdgcn_s_memtime();)
-        if (more) f1_stash(cp[buf ^ 1], nxt, tid);
+        if (more) f1_stash<PROD, PROD == 3>(cp[buf ^ 1], nxt, tid);
         VM_PROF1(pq_stash += __builtin_amdgcn_s_memtime() - pq_h0;)
     }
     VM_PROF1(const long long pq_s3 = __builtin_amdgcn_s_memtime();)
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(256) void conv1_fused_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------
 // backward.  grid = (n_windows * splits, ceil(F/128)); a block walks `cps` chunks of one window and keeps its
 // dW (32 taps x 32 channels per wave) and bias-gradient partials in registers; slab layout (33, F) fp32.
-template <typename TS, int POOL>
+template <typename TS, int POOL, int PROD = 3>
 __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                               const float* __restrict__ bias, const TS* __restrict__ dp,
                                                               const float* __restrict__ scale, const float* __restrict__ mean,
@@ -421,7 +453,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     const float* xrow = x + n * (L + F1_K - 1);
 
     F1Weights w;
-    f1_load_weights(w, wk, F, c, cok, hi);
+    f1_load_weights<PROD>(w, wk, F, c, cok, hi);
     const float bv = cok ? bias[c] : 0.f;
     const float sc = cok ? scale[tw * F + c] : 0.f;
     const float mu = cok ? mean[tw * F + c] : 0.f;
@@ -533,7 +565,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
     };
 
     F1Fetch nxt = f1_fetch(xrow, (int64_t)ch_lo * F1_CHUNK, L + F1_K - 1, tid);
-    f1_stash(cp[0], nxt, tid);
+    f1_stash<PROD, true>(cp[0], nxt, tid);
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int buf = (chunk - ch_lo) & 1;
         const int64_t t0 = (int64_t)chunk * F1_CHUNK;
@@ -545,7 +577,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
         const F1Copies& sm = cp[buf];
         for (int rt = role.rs; role.active && rt < 8; rt += role.RS) {
             if (t0 + 32 * rt >= L) break;
-            const f32x16 acc = f1_conv_tile(sm, w, rt, lane);
+            const f32x16 acc = f1_conv_tile<PROD>(sm, w, rt, lane);
             TS dpv[NDP];
 #pragma unroll
             for (int k = 0; k < NDP; ++k) dpv[k] = dpn[k];
@@ -614,16 +646,15 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                 for (int eh = 0; eh < 2; ++eh) {
                     const int S = 32 * rt + 16 * m + 8 * eh + 4 * hi + i;
                     const int m0 = F1_PAD + S - s;
-                    const bf16x4 vh = *reinterpret_cast<const bf16x4*>(&sm.xh[s][m0]);
-                    const bf16x4 vl = *reinterpret_cast<const bf16x4*>(&sm.xl[s][m0]);
+                    // bf16(x): the hi copies of the split form, the xl copies otherwise
+                    const bf16x4 vx = *reinterpret_cast<const bf16x4*>(PROD == 3 ? &sm.xh[s][m0] : &sm.xl[s][m0]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ah[4 * eh + e] = vh[e];
-                        al[4 * eh + e] = vl[e];
-                    }
+                    for (int e = 0; e < 4; ++e) ah[4 * eh + e] = vx[e];
                 }
+                // ONE product: x at 8 significand bits beside a du at 8 -- the residual xl * du the split form added until round 6 is a
+                // zero-mean 2^-9 of terms whose other factor is already rounded at 2^-9, summed over 3 M positions
                 accw = mfma_bf16(ah, bfrag, accw);
-                accw = mfma_bf16(al, bfrag, accw);
+                (void)al;
                 {
                     const u32x4 bw = __builtin_bit_cast(u32x4, bfrag);
                     accb0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, u32x2{bw[0], bw[1]}), accb0, 0, 0, 0);
@@ -631,7 +662,7 @@ __global__ __launch_bounds__(256) void conv1_fused_bwd_kernel(const float* __res
                 }
             }
         }
-        if (more) f1_stash(cp[buf ^ 1], nxt, tid);
+        if (more) f1_stash<PROD, true>(cp[buf ^ 1], nxt, tid);
     }
     // one slab per block.x: (33, F) = 32 tap rows + the bias-gradient row.  Waves that share a column tile
     // (CT < 3: the row tiles are split over several waves) are summed through LDS in a fixed order.
@@ -673,6 +704,7 @@ extern "C" int vm_debug_prof1_read(unsigned int* out, int n_slots) {
 }
 #endif
 
+int g_f1_products = 2;       // f16 storage: 16-bit products of the block-1 convolution (see f1_stash_one); vm_set_tuning("f1_products", 1 | 2 | 3)
 int g_f1_blocks = 1024;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
 int g_f1_fwd_blocks = 4096;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n))
 
@@ -712,17 +744,26 @@ extern "C" int vm_conv1_fused_fwd(const float* x, const float* w, const float* b
     const int64_t gx = n_windows * splits;
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_fwd: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
-#define VM_F1_FWD(POOL, INF)                                                                                              \
-    hipLaunchKernelGGL((conv1_fused_fwd_kernel<T, POOL, INF>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,        \
+#define VM_F1_FWD_P(POOL, INF, PROD)                                                                                      \
+    hipLaunchKernelGGL((conv1_fused_fwd_kernel<T, POOL, INF, PROD>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias,  \
                        gamma_or_scale, shift, L, F, chunks, splits, cps, (T*)out, inference == 2 ? 1 : 0, stat_sum, stat_sq)
+#define VM_F1_FWD(POOL, INF)                                                         \
+    if constexpr (std::is_same<T, f16>::value) {                                     \
+        if (g_f1_products == 1) VM_F1_FWD_P(POOL, INF, 1);                           \
+        else if (g_f1_products == 2) VM_F1_FWD_P(POOL, INF, 2);                      \
+        else VM_F1_FWD_P(POOL, INF, 3);                                              \
+    } else {                                                                         \
+        VM_F1_FWD_P(POOL, INF, 3);                                                   \
+    }
     VM_DISPATCH_16(dtype, {
         if (pool == 2) {
-            if (inference == 1) VM_F1_FWD(2, true); else VM_F1_FWD(2, false);
+            if (inference == 1) { VM_F1_FWD(2, true) } else { VM_F1_FWD(2, false) }
         } else {
-            if (inference == 1) VM_F1_FWD(4, true); else VM_F1_FWD(4, false);
+            if (inference == 1) { VM_F1_FWD(4, true) } else { VM_F1_FWD(4, false) }
         }
     });
 #undef VM_F1_FWD
+#undef VM_F1_FWD_P
     return check_launch("vm_conv1_fused_fwd");
 }
 
@@ -747,15 +788,22 @@ extern "C" int vm_conv1_fused_bwd(const float* x, const float* w, const float* b
     const int64_t gx = n_windows * splits;
     VM_REQUIRE(gx < (1LL << 31), "vm_conv1_fused_bwd: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)((F + 127) / 128));
+#define VM_F1_BWD_P(POOL, PROD)                                                                                                    \
+    hipLaunchKernelGGL((conv1_fused_bwd_kernel<T, POOL, PROD>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const T*)dp, \
+                       scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws)
+#define VM_F1_BWD(POOL)                                                              \
+    if constexpr (std::is_same<T, f16>::value) {                                     \
+        if (g_f1_products == 1) VM_F1_BWD_P(POOL, 1);                                \
+        else if (g_f1_products == 2) VM_F1_BWD_P(POOL, 2);                           \
+        else VM_F1_BWD_P(POOL, 3);                                                   \
+    } else {                                                                         \
+        VM_F1_BWD_P(POOL, 3);                                                        \
+    }
     VM_DISPATCH_16(dtype, {
-        if (pool == 2) {
-            hipLaunchKernelGGL((conv1_fused_bwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const T*)dp,
-                               scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
-        } else {
-            hipLaunchKernelGGL((conv1_fused_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (const T*)dp,
-                               scale, mean, invstd, drop, c1, c2, windows_per_tower, L, F, chunks, splits, cps, (float*)ws);
-        }
+        if (pool == 2) { VM_F1_BWD(2) } else { VM_F1_BWD(4) }
     });
+#undef VM_F1_BWD
+#undef VM_F1_BWD_P
     int rc = check_launch("vm_conv1_fused_bwd");
     if (rc) return rc;
     const int64_t nel = 33LL * F;

@@ -1792,6 +1792,7 @@ int g_nt_glds = 1;     // the LDS-DMA 128^2 kernel where K * sizeof(T) % 64 == 0
 int g_nt_blocks = 512; // persistent grid of the 128^2 kernels (2 workgroups per CU on 256 CUs)
 extern int g_tn_x, g_tn_tile, g_tn9, g_tn9_stages;  // conv_wgrad.hip
 extern int g_fuse_finalize, g_apply_order;          // bnpool.hip
+extern int g_f1_products;            // conv1_fused.hip
 }  // namespace vm
 
 static bool is16(int dtype) { return dtype == VM_BF16 || dtype == VM_F16; }
@@ -2188,7 +2189,7 @@ extern "C" int vm_mfma_rate_probe(int dtype, int iters, float* sink, void* strea
 // Kernel-selection hook for the tests and A/B measurements (not part of the drop-in surface): returns 0 if the key/value is known.
 extern "C" int vm_set_tuning(const char* key, int value) {
     struct Knob { const char* key; int* var; int lo, hi; };
-    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt3_wide", &g_nt3_wide, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"tn9_stages", &g_tn9_stages, 0, 1}, {"fuse_finalize", &g_fuse_finalize, 0, 31}, {"apply_order", &g_apply_order, 0, 2}};
+    static const Knob knobs[] = {{"nt_n2", &g_nt_n2, 0, 3}, {"nt3", &g_nt3, 0, 3}, {"nt3_lean", &g_nt3_lean, 0, 3}, {"nt3_wide", &g_nt3_wide, 0, 3}, {"nt_glds", &g_nt_glds, 0, 1}, {"tn_x", &g_tn_x, 0, 1}, {"tn9", &g_tn9, 0, 2}, {"tn9_stages", &g_tn9_stages, 0, 1}, {"fuse_finalize", &g_fuse_finalize, 0, 31}, {"apply_order", &g_apply_order, 0, 2}, {"f1_products", &g_f1_products, 1, 3}};
     if (key == nullptr) {
         set_error("vm_set_tuning: null key");
         return VM_ERR_ARG;
