@@ -13,7 +13,7 @@ in HBM before the timed region.  value = audio-seconds embedded per second = N *
 Storage mode of the headline (--dtype, default "f16"): IEEE half tensors on the v_mfma_f32_32x32x16_f16 pipe with fp32
 accumulation -- the same bytes and the same matrix-pipe rate as the bf16 that BASELINE.json names for this config, with 11
 instead of 8 significand bits per stored value: it is the 16-bit mode that meets the north star's "embeddings within 1e-3 of the
-reference arithmetic" (7e-4 against the float64 oracle at this very size, tests/test_gpu_fullsize_oracle.py; bf16: 6e-3).  The
+reference arithmetic" (7.4e-4 against the float64 oracle at this very size, tests/test_gpu_fullsize_oracle.py; bf16: 6e-3).  The
 bf16 step is timed the same way and reported under extras.bf16_mode; the line's "precision" object states mode and tolerance.
 
 Timing: ``--blocks`` (default 5) blocks of exactly K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides, the
