@@ -706,7 +706,7 @@ extern "C" int vm_debug_prof1_read(unsigned int* out, int n_slots) {
 
 int g_f1_products = 2;       // f16 storage: 16-bit products of the block-1 convolution (see f1_stash_one); vm_set_tuning("f1_products", 1 | 2 | 3)
 int g_f1_blocks = 1024;      // target workgroup count of the fused block-1 backward (vm_set_tuning("f1_blocks", n))
-int g_f1_fwd_blocks = 4096;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n))
+int g_f1_fwd_blocks = 1024;  // ... and of the forward (vm_set_tuning("f1_fwd_blocks", n)); round 6, with four MFMAs per tile: 4096 -> 1024 is -0.7 % of the cfg-A step, -0.9 % cfg-B (a workgroup walks 6 chunks per tower launch instead of 2: filters and constants loaded once)
 
 static int f1_splits(int64_t n_windows, int chunks, int target) {
     int s = (int)((target + n_windows - 1) / n_windows);  // aim for >= target workgroups
