@@ -20,7 +20,10 @@
 
 namespace vm {
 
-constexpr int BN_SEG = 8;  // partial-sum rows per window (the layout of every part_* tensor)
+#ifndef VM_BN_SEG
+#define VM_BN_SEG 8
+#endif
+constexpr int BN_SEG = VM_BN_SEG;  // partial-sum rows per window (the layout of every part_* tensor)
 // Workgroups per window of the pass kernels = gridDim.y: BN_SEG for the long windows of the 1-D encoder, 1 for short ones (the 2-D
 // variant runs 16 384 windows of 149 pooled rows x 4 channel vectors: eight workgroups per window left 70 % of their threads without a
 // row and the passes at 0.8-1.6 TB/s).  A launch with fewer segments zero-fills the partial rows it does not produce.
