@@ -272,6 +272,7 @@ class HipEncoderEngine:
             self.center_blocks = tuple(int(v) for v in _os.environ["VOICEMAP_CENTER_BLOCKS"].split(",") if v.strip())
         self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
+        self.tower_swap = False  # experiment (forward()): the first tower on the tower stream, the second on the current one
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self._side_priority = 0
@@ -986,11 +987,20 @@ class HipEncoderEngine:
                 pl["tower_ev"] = [torch.cuda.Event() for _ in self.blocks]
             cur = torch.cuda.current_stream(self.device)
             self._join(self.tower_stream, cur)   # the pre-processed windows are ready
-            self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True, fold=fold)
-            if self.tower_stagger and "stagger_ev" in pl:
-                self._wait(self.tower_stream, pl["stagger_ev"])
-            with self._on(self.tower_stream):
+            pl["t2_stream"] = cur if self.tower_swap else self.tower_stream   # the stream the second tower's chain is on
+            if self.tower_swap:
+                # (round 6) the chain that is enqueued SECOND finishes last, and what follows the forward (tail, backward) is on the
+                # current stream: with the first tower on the tower stream and the second on the current one, the hand-over at the
+                # end of the forward waits for a chain that finished long ago instead of crossing queues behind the last kernel
+                with self._on(self.tower_stream):
+                    self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True, fold=fold)
                 self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True, fold=fold)
+            else:
+                self._forward_range(pl, 0, wpt, 0, 1, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], first_of_two=True, fold=fold)
+                if self.tower_stagger and "stagger_ev" in pl:
+                    self._wait(self.tower_stream, pl["stagger_ev"])
+                with self._on(self.tower_stream):
+                    self._forward_range(pl, wpt, wpt, 1, 1, wpt, drop_masks, pl["cr_ws_t2"], pl["gmax_ws_t2"], second_of_two=True, fold=fold)
             self._join(cur, self.tower_stream)
         else:
             self._forward_range(pl, 0, n, 0, n_towers, wpt, drop_masks, pl["cr_ws"], pl["gmax_ws"], fold=fold)
@@ -1031,7 +1041,7 @@ class HipEncoderEngine:
                         m_ = pl["mov_scratch"].data_ptr()   # updates its accumulators
                         v_ = m_ + 4 * c
                 elif second_of_two:         # plain average: the two updates are sequential -- after tower 1's
-                    self._wait(self.tower_stream, pl["tower_ev"][i])
+                    self._wait(pl.get("t2_stream", self.tower_stream), pl["tower_ev"][i])
                 centred = i == 0 and fold and self.fuse_block1   # block 1's extreme is stored as e - max(bias, 0): the offset's constants
                 s_sum, s_sq, s_rows, s_cnt = ssum, ssq, wpt * rows, float(wpt * L)
                 if self.sync_bn:
@@ -1469,7 +1479,7 @@ class HipEncoderEngine:
 
     # ---- one training step, eager or replayed -----------------------------------------------------------------------------------
     def _step_flags(self):
-        return (self.fold_affine, self.fuse_block1, self.fused_bn_reduce, self.fused_sums_finalize, self.split_towers, self.tower_stagger,
+        return (self.fold_affine, self.fuse_block1, self.fused_bn_reduce, self.fused_sums_finalize, self.split_towers, self.tower_stagger, self.tower_swap,
                 self.overlap_wgrad, self.wgrad_after_dgrad, self.defer_wgrad_tail, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
