@@ -97,7 +97,15 @@ int64_t vm_mfma_rate_probe_flops(int iters);
  *                     the reduction is narrow and short (C <= 128, <= 4096 rows per tower).  Default 17: the statistics of small
  *                     layers -- a saved launch pays only there (measurements in bnpool.hip)
  *   "f1_blocks", "f1_fwd_blocks"   target workgroup counts of the fused block-1 kernels (launch geometry; the fp32 partial sums of a
- *                     window are grouped differently, i.e. results change in the last bits). */
+ *                     window are grouped differently, i.e. results change in the last bits; defaults 1024, 1024).
+ *   "f1_products" 1|2|3   (round 6; VM_F16 storage only -- VM_BF16 always takes 3) the 16-bit products that carry the block-1
+ *                     convolution: 3 = waveform and filters split hi + lo in bf16 (xh*wh + xl*wh + xh*wl, ~16 significand bits of
+ *                     both); 2 (default) = the waveform rounded to half, the filters split hi + lo in halves (xh*wh + xh*wl); 1 =
+ *                     xh*wh.  NOT result-preserving: it is the operand precision of block 1 (embeddings against the CPU oracle at the
+ *                     bench batch 6.98e-4 / 7.37e-4 / 7.99e-4, profiles/r06_block1_products.txt).
+ *   "apply_order" 0|1|2   walk of vm_bn_pool_bwd_apply* over the windows: 0 = the segments of all windows together, 1 / 2 =
+ *                     window-major ascending / descending (default 2: it starts on the windows the producer of dp wrote last, which the
+ *                     memory-side cache still holds).  Bit-identical. */
 int vm_set_tuning(const char* key, int value);
 
 /* ---- a6: preprocess_instances / whiten  (voicemap/utils.py:22-34, 88-101) --------------------------

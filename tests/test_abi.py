@@ -52,7 +52,7 @@ def test_tuning_table_is_small_and_rejects_unknown_keys():
     from voicemap_amd import _lib
     lib = _lib.lib()
     for key, good, bad in ((b"nt_n2", 3, 4), (b"nt_glds", 1, 2), (b"tn_x", 1, 2), (b"tn_tile", 256, 64), (b"f1_blocks", 1024, 0),
-                           (b"f1_fwd_blocks", 4096, -1)):
+                           (b"f1_fwd_blocks", 1024, -1), (b"apply_order", 2, 3), (b"f1_products", 2, 0)):   # (good = the defaults)
         assert lib.cdll.vm_set_tuning(key, bad) != 0, key
         assert lib.cdll.vm_set_tuning(key, good) == 0, key
     for gone in (b"nt_ablate", b"nt_ring", b"nt_p8", b"nt_w4", b"nt_n2r", b"gemm_kb", b"no_such_knob"):
