@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 8.  History: 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 9.  History: 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -416,6 +416,23 @@ int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const float* shi
 int vm_bn_drop_pool_gmax_partials(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_windows,
                                   int64_t windows_per_tower, int64_t L, int C, int pool, int dtype, float* part_v, int32_t* part_i,
                                   void* stream);
+/* The LAST block in pair form (round 6; 16-bit storage): vm_conv_fwd_fold leaves (e, o) for it like for the blocks below -- e PADDED
+ * (n_windows, Lq + 2, C), Lq = L / 2 -- and the GlobalMaxPool1D pass reads e alone: BatchNorm is monotone per channel, so
+ * max_j fma(z_j, s, h) == fma(ext_j z, s, h), the values and first-maximum positions are those of vm_bn_drop_pool_gmax_partials on z,
+ * from half the bytes.  voicemap/models.py:31-37.  The backward's sparse sums (vm_bn_bwd_gmax_finalize_e: vm_bn_bwd_gmax_finalize with
+ * e in z's place) and apply pass (vm_bn_pool_bwd_apply_pairs_gmax: vm_bn_pool_bwd_apply_gmax on the (e, o) pair form; du padded
+ * (n_windows, L + 2, C) as there) take the same tensors. */
+int vm_bn_drop_pool_gmax_partials_e(const void* e, const float* scale, const float* shift, const float* drop, int64_t n_windows,
+                                    int64_t windows_per_tower, int64_t Lq, int C, int dtype, float* part_v, int32_t* part_i,
+                                    void* stream);
+int vm_bn_bwd_gmax_finalize_e(const void* e, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* drop, int64_t n_windows, int64_t windows_per_tower,
+                              int64_t Lq, int C, int dtype, double count_per_tower, float* c1, float* c2, float* grad_gamma,
+                              float* grad_beta, void* stream);
+int vm_bn_pool_bwd_apply_pairs_gmax(const void* e, const void* o, const float* dg, const int32_t* gidx, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, const float* drop, const float* c1,
+                                    const float* c2, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C, int dtype, void* du,
+                                    float* part_du, void* stream);
 
 /* ---- a1 tail: GlobalMaxPool1D + Dense(E)  (voicemap/models.py:37-39) ------------------------------------
  * act: padded (n_windows, L+2, C) `dtype`; gmax (n_windows, C) fp32; gidx (n_windows, C) int32 = first argmax. */

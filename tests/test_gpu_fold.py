@@ -478,3 +478,69 @@ def test_conv_fwd_fold_centred_tile(n, Lw, cin, cout):
     assert rel_err(d1[keep], d0[keep]) < 2e-3, (rel_err(d1[keep], d0[keep]), float((bad & keep).mean()), float(keep.mean()),
                                                  [(float(a), float(b)) for a, b in zip(d0[bad & keep][:6], d1[bad & keep][:6])])
     assert ((d1 == 0.0) != (d0 == 0.0))[keep].mean() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("with_drop", [False, True])
+def test_last_block_pair_form_equals_the_z_form(dtype, with_drop):
+    """Round 6: the last block in pair form (voicemap/models.py:31-37 and their backward).  On the (e, o) that encode a z:
+    vm_bn_drop_pool_gmax_partials_e(e) leaves the partial (value, position) rows vm_bn_drop_pool_gmax_partials(z) leaves;
+    vm_bn_bwd_gmax_finalize_e(e) the c1 / c2 / grad_gamma / grad_beta of vm_bn_bwd_gmax_finalize(z); vm_bn_pool_bwd_apply_pairs_gmax(e, o)
+    the du and partial column sums of vm_bn_pool_bwd_apply_gmax(z) -- bit for bit."""
+    vm, tdt = DTYPES[dtype]
+    r = np.random.default_rng(23)
+    n, wpt, Lw, c = 6, 3, 100, 136
+    lq = Lw // 2
+    z = quant(np.maximum(r.normal(0.1, 1, (n, Lw, c)), 0.0), dtype)   # post-ReLU: >= 0, with exact zeros
+    z[:, 10:12] = z[:, 10:11]                                          # a tie inside a pair, in every channel
+    z[:, 40:42] = z[:, 20:22]                                          # ... and two pairs with the same extreme
+    scale = (r.normal(1.0, 0.3, (2, c)) * np.where(r.random((2, c)) < 0.3, -1, 1)).astype(np.float32)
+    shift, mean = r.normal(0, 0.5, (2, c)).astype(np.float32), r.normal(0.4, 0.1, (2, c)).astype(np.float32)
+    invstd = r.uniform(0.5, 2.0, (2, c)).astype(np.float32)
+    c1h, c2h = r.normal(0, 0.01, (2, c)).astype(np.float32), r.normal(0, 0.01, (2, c)).astype(np.float32)
+    drop = dev(((r.random((n, c)) > 0.2) / 0.8).astype(np.float32)) if with_drop else None
+    zt = z.to("cuda", tdt).contiguous()
+    pr = zt.view(n, lq, 2, c)
+    pos = torch.tensor(scale >= 0, device="cuda").repeat_interleave(wpt, 0)[:, None, :]
+    second = torch.where(pos, pr[:, :, 1] > pr[:, :, 0], pr[:, :, 1] < pr[:, :, 0])
+    ext = torch.where(second, pr[:, :, 1], pr[:, :, 0])
+    oth = torch.where(second, pr[:, :, 0], pr[:, :, 1])
+    ep = torch.zeros(n, lq + 2, c, dtype=tdt, device="cuda")
+    ep[:, 1:-1] = ext
+    ep[:, 0] = 7.0      # halo rows must never be read (a finite marker that would win every maximum)
+    ep[:, -1] = 7.0
+    o = (oth.contiguous().view(torch.int16) | (second.to(torch.int16) << 15)).view(tdt).contiguous()
+    sc, sh, mu, isd = dev(scale), dev(shift), dev(mean), dev(invstd)
+    rows = L().query("vm_bn_part_rows")
+    f32 = dict(dtype=torch.float32, device="cuda")
+    # ---- forward: GlobalMaxPool1D partials
+    pv = [torch.full((n * rows, c), float("nan"), **f32) for _ in range(2)]
+    pi = [torch.full((n * rows, c), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
+    L().call("vm_bn_drop_pool_gmax_partials", p(zt), p(sc), p(sh), p(drop), n, wpt, Lw, c, 2, vm, p(pv[0]), p(pi[0]), stream())
+    L().call("vm_bn_drop_pool_gmax_partials_e", p(ep), p(sc), p(sh), p(drop), n, wpt, lq, c, vm, p(pv[1]), p(pi[1]), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(pv[0], pv[1]) and torch.equal(pi[0], pi[1])
+    assert int(pi[1][pi[1] != 0x7fffffff].max()) < lq    # (0x7fffffff: the "empty" partial rows of a window with fewer segments)
+    # ---- backward: sparse sums + finalize, then the apply pass
+    dg = dev(r.normal(0, 1, (n, c)))
+    gi = r.integers(0, lq, (n, c))
+    gi[0, :3] = -1
+    gidx = dev(gi, torch.int32)
+    outs = []
+    for pairs in (False, True):
+        fin = [torch.full((2, c), float("nan"), **f32), torch.full((2, c), float("nan"), **f32), torch.full((c,), float("nan"), **f32),
+               torch.full((c,), float("nan"), **f32)]
+        du = torch.zeros(n, Lw + 2, c, dtype=tdt, device="cuda")
+        pdu = torch.empty(n * rows, c, **f32)
+        tail = (p(dg), p(gidx), p(sc), p(sh), p(mu), p(isd), p(drop))
+        if pairs:
+            L().call("vm_bn_bwd_gmax_finalize_e", p(ep), *tail, n, wpt, lq, c, vm, float(wpt * Lw), p(fin[0]), p(fin[1]), p(fin[2]), p(fin[3]), stream())
+            L().call("vm_bn_pool_bwd_apply_pairs_gmax", p(ep), p(o), *tail, p(dev(c1h)), p(dev(c2h)), n, wpt, Lw, c, vm, p(du), p(pdu), stream())
+        else:
+            L().call("vm_bn_bwd_gmax_finalize", p(zt), *tail, n, wpt, Lw, c, 2, vm, float(wpt * Lw), p(fin[0]), p(fin[1]), p(fin[2]), p(fin[3]), stream())
+            L().call("vm_bn_pool_bwd_apply_gmax", p(zt), *tail, p(dev(c1h)), p(dev(c2h)), n, wpt, Lw, c, 2, vm, p(du), p(pdu), stream())
+        torch.cuda.synchronize()
+        outs.append(fin + [du, pdu])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+    assert outs[1][4].abs().sum() > 0

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 8  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 9  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -97,6 +97,9 @@ SIGNATURES = {
     "vm_bn_drop_pool_gmax_workspace_bytes": (L, [L, I]),
     "vm_bn_drop_pool_gmax_fwd": (I, [P, P, P, P, L, L, L, I, I, I, P, P, P, P]),
     "vm_bn_drop_pool_gmax_partials": (I, [P, P, P, P, L, L, L, I, I, I, P, P, P]),
+    "vm_bn_drop_pool_gmax_partials_e": (I, [P, P, P, P, L, L, L, I, I, P, P, P]),
+    "vm_bn_bwd_gmax_finalize_e": (I, [P, P, P, P, P, P, P, P, L, L, L, I, I, D, P, P, P, P, P]),
+    "vm_bn_pool_bwd_apply_pairs_gmax": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, I, P, P, P]),
     "vm_global_maxpool_fwd": (I, [P, L, L, I, I, P, P, P]),
     "vm_global_maxpool_bwd": (I, [P, P, L, L, I, I, P, P]),
     "vm_dense_fwd": (I, [P, P, P, L, I, I, P, P]),

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
                                                                     const float* __restrict__ shift,
                                                                     const float* __restrict__ drop, int64_t wpt, int64_t L,
                                                                     int C, int P, float* __restrict__ part_v,
-                                                                    int32_t* __restrict__ part_i) {
+                                                                    int32_t* __restrict__ part_i, int64_t win_rows, int row0) {
+    // win_rows / row0: a window holds win_rows rows of which the L read here start at row0 (L, 0: a plain tensor; L + 2, 1: a
+    // padded pool extreme -- vm_bn_drop_pool_gmax_partials_e)
     constexpr int VEC = Elem<T>::kVec;
     __shared__ __attribute__((aligned(16))) float rv[256][VEC];
     __shared__ __attribute__((aligned(16))) int ri[256][VEC];
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void bn_drop_pool_gmax_fwd_kernel(const T* __r
             } else {
                 ones<VEC>(dr);
             }
-            const T* zrow = z + n * L * C + c0;
+            const T* zrow = z + (n * win_rows + row0) * C + c0;
             auto group = [&](int64_t q, const Vec16<T> (&v)[POOL]) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
             };
             int64_t q = seg + (int64_t)rl * nseg;
             const int64_t qs = (int64_t)RP * nseg;
-            if constexpr (VM_APPLY_TWO_GROUPS && POOL == 2 && !(PAIRS && (SP || sizeof(T) != 2))) {
+            if constexpr (VM_APPLY_TWO_GROUPS && POOL == 2 && !(PAIRS && sizeof(T) != 2)) {
                 // NG pool groups in flight per thread: 3 NG 16-byte loads before the first is consumed (the pass is a pure stream:
                 // 4.5 TB/s with three).  Same groups in the same order: bit-identical
                 constexpr int NG = VM_APPLY_TWO_GROUPS == 1 ? 2 : VM_APPLY_TWO_GROUPS;
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(256) void bn_bwd_gmax_finalize_kernel(const T* __re
                                                                    const int32_t* __restrict__ gidx, const float* __restrict__ scale,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ drop, int64_t n_windows, int64_t wpt, int64_t L,
-                                                                   FinBnBwd<false> f) {
+                                                                   FinBnBwd<false> f, int64_t win_rows, int row0) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
     const int C = f.C;
     if (c >= C) return;
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(256) void bn_bwd_gmax_finalize_kernel(const T* __re
             if (q >= 0 && q < Lq) {
                 const float dr = drop ? drop[e] : 1.0f;
                 const bool use_min = sc * dr < 0.f;
-                const T* zp = z + (n * L + (int64_t)q * POOL) * C + c;
+                const T* zp = z + (n * win_rows + row0 + (int64_t)q * POOL) * C + c;
                 float ext = Elem<T>::to_f(zp[0]);
 #pragma unroll
                 for (int j = 1; j < POOL; ++j) {
@@ -1341,7 +1343,7 @@ extern "C" int vm_bn_drop_pool_gmax_fwd(const void* z, const float* scale, const
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i);
+                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i, L, 0);
     }));
     hipLaunchKernelGGL(gmax_segments_kernel, dim3((unsigned)((n_windows * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        part_v, part_i, n_windows, C, gmax, gidx);
@@ -1358,7 +1360,7 @@ extern "C" int vm_bn_drop_pool_gmax_partials(const void* z, const float* scale, 
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         const int P = lanes_for(C / Elem<T>::kVec);
         hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, POOL>), dim3((unsigned)n_windows, (unsigned)bn_segs(L / POOL, C, Elem<T>::kVec)), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i);
+                           (hipStream_t)stream, (const T*)z, scale, shift, drop, windows_per_tower, L, C, P, part_v, part_i, L, 0);
     }));
     return check_launch("vm_bn_drop_pool_gmax_partials");
 }
@@ -1423,7 +1425,7 @@ extern "C" int vm_bn_bwd_gmax_finalize(const void* z, const float* dg, const int
     const FinBnBwd<false> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
     VM_DISPATCH_DTYPE(dtype, VM_DISPATCH_POOL(pool, {
         hipLaunchKernelGGL((bn_bwd_gmax_finalize_kernel<T, POOL>), dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)z, dg, gidx, scale, mean, invstd, drop, n_windows, windows_per_tower, L, fin);
+                           (const T*)z, dg, gidx, scale, mean, invstd, drop, n_windows, windows_per_tower, L, fin, L, 0);
     }));
     return check_launch("vm_bn_bwd_gmax_finalize");
 }
@@ -1546,6 +1548,59 @@ extern "C" int vm_bn_pool_bwd_apply_gmax(const void* z, const float* dg, const i
     VM_REQUIRE(dg && gidx, "vm_bn_pool_bwd_apply_gmax: null pointer");
     return bn_pool_bwd_apply_impl(z, nullptr, dg, gidx, scale, shift, mean, invstd, drop, c1, c2, n_windows, windows_per_tower, L,
                                   C, pool, dtype, du, part_du, stream);
+}
+
+// ---- the LAST block in pair form (round 6): its forward leaves (e, o) like blocks 2..n-1 instead of z, the GlobalMaxPool1D pass reads
+// the padded extreme e alone -- max_j fma(z_j, s, h) == fma(ext_j z, s, h): half the bytes of z on the forward -> backward turn-around --
+// and the backward's sparse sums and apply pass take (e, o).  Same values, same positions as the z forms.
+extern "C" int vm_bn_drop_pool_gmax_partials_e(const void* e, const float* scale, const float* shift, const float* drop, int64_t n_windows,
+                                               int64_t windows_per_tower, int64_t Lq, int C, int dtype, float* part_v, int32_t* part_i,
+                                               void* stream) {
+    VM_REQUIRE(e && scale && shift && part_v && part_i, "vm_bn_drop_pool_gmax_partials_e: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && Lq >= 1 && C % 8 == 0, "vm_bn_drop_pool_gmax_partials_e: bad sizes");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_drop_pool_gmax_partials_e: 16-bit storage only");
+    VM_DISPATCH_16(dtype, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_drop_pool_gmax_fwd_kernel<T, 1>), dim3((unsigned)n_windows, (unsigned)bn_segs(Lq, C, Elem<T>::kVec)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)e, scale, shift, drop, windows_per_tower, Lq, C, P, part_v, part_i, Lq + 2, 1);
+    });
+    return check_launch("vm_bn_drop_pool_gmax_partials_e");
+}
+
+extern "C" int vm_bn_bwd_gmax_finalize_e(const void* e, const float* dg, const int32_t* gidx, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const float* drop, int64_t n_windows,
+                                         int64_t windows_per_tower, int64_t Lq, int C, int dtype, double count_per_tower, float* c1,
+                                         float* c2, float* grad_gamma, float* grad_beta, void* stream) {
+    VM_REQUIRE(e && dg && gidx && scale && shift && mean && invstd && c1 && c2 && grad_gamma && grad_beta,
+               "vm_bn_bwd_gmax_finalize_e: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && n_windows % windows_per_tower == 0 && Lq >= 1 && C % 8 == 0,
+               "vm_bn_bwd_gmax_finalize_e: bad sizes (n_windows a multiple of windows_per_tower, C a multiple of 8)");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_bwd_gmax_finalize_e: 16-bit storage only");
+    const int n_towers = (int)(n_windows / windows_per_tower);
+    const FinBnBwd<false> fin{n_towers, C, count_per_tower, c1, c2, grad_gamma, grad_beta};
+    VM_DISPATCH_16(dtype, {
+        hipLaunchKernelGGL((bn_bwd_gmax_finalize_kernel<T, 1>), dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)e, dg, gidx, scale, mean, invstd, drop, n_windows, windows_per_tower, Lq, fin, Lq + 2, 1);
+    });
+    return check_launch("vm_bn_bwd_gmax_finalize_e");
+}
+
+extern "C" int vm_bn_pool_bwd_apply_pairs_gmax(const void* e, const void* o, const float* dg, const int32_t* gidx, const float* scale,
+                                               const float* shift, const float* mean, const float* invstd, const float* drop,
+                                               const float* c1, const float* c2, int64_t n_windows, int64_t windows_per_tower, int64_t L,
+                                               int C, int dtype, void* du, float* part_du, void* stream) {
+    VM_REQUIRE(e && o && dg && gidx && scale && shift && mean && invstd && c1 && c2 && du && part_du,
+               "vm_bn_pool_bwd_apply_pairs_gmax: null pointer");
+    VM_REQUIRE(n_windows > 0 && windows_per_tower > 0 && L >= 2 && !(L & 1) && C % 8 == 0,
+               "vm_bn_pool_bwd_apply_pairs_gmax: L must be even, C % 8 == 0");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool_bwd_apply_pairs_gmax: 16-bit storage only");
+    VM_DISPATCH_16(dtype, {
+        const int P = lanes_for(C / Elem<T>::kVec);
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, 2, true, true>), apply_grid(n_windows, bn_segs(L / 2, C, Elem<T>::kVec)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)e, (const T*)o, (const T*)nullptr, scale, mean, invstd, drop, c1, c2, windows_per_tower,
+                           L, C, P, (T*)du, part_du, dg, gidx, (const float*)nullptr, g_apply_order);
+    });
+    return check_launch("vm_bn_pool_bwd_apply_pairs_gmax");
 }
 
 extern "C" int vm_du_tower_sums(const float* part_du, const void* du, int64_t n_windows, int64_t windows_per_tower, int64_t L, int C,

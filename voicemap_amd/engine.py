@@ -272,6 +272,11 @@ class HipEncoderEngine:
             self.center_blocks = tuple(int(v) for v in _os.environ["VOICEMAP_CENTER_BLOCKS"].split(",") if v.strip())
         self._fold = {}
         self.fused_infer_pool = self.is16  # inference: vm_conv_fwd_pool where the kernel serves the shape
+        # round 6, measured and left OFF: the last block's forward leaves (e, o) pairs, GlobalMaxPool1D reads e alone (half of z's bytes
+        # on the forward -> backward turn-around) and the sparse backward takes the pair form.  Bit-identical (tests/test_gpu_fold.py), and
+        # an even trade: cfg-A 128 pairs 2.554 -> 2.555, 2.566 -> 2.571 ms -- what the pass over z saves, the pair arithmetic of the
+        # forward epilogue costs (profiles/r06_wgrad_tail.txt)
+        self.last_pairs = False
         self.tower_swap = False  # experiment (forward()): the first tower on the tower stream, the second on the current one
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
         self.side_stream = torch.cuda.Stream(device=self.device)
@@ -927,7 +932,7 @@ class HipEncoderEngine:
         if "fold_ready" in pl:
             return
         n, ls, wpt = pl["n"], pl["L"], pl["wpt"]
-        for i in range(self.nb - 1):
+        for i in range(self.nb - 1 if not (self.last_pairs and self.nb > 1) else self.nb):
             c = self.blocks[i][1]
             pl[i]["ep"] = torch.zeros(n, ls[i + 1] + 2, c, dtype=self.tdt, device=self.device)
             if i > 0:
@@ -1097,7 +1102,11 @@ class HipEncoderEngine:
                     # block's pool extreme and leaves its own; no pass in between
                     lo = pl[i - 1]
                     wfo, hbo, wfp = self._fold_bufs(i)
-                    with_e = i < self.nb - 1
+                    # (round 6) the LAST block in pair form too: its (e, o) feed the GlobalMaxPool1D pass (e alone: half of z's bytes on
+                    # the forward -> backward turn-around) and the backward's sparse sums / apply pass
+                    last_pairs = (i == self.nb - 1 and self.last_pairs and self.fold_pairs and pool == 2 and L % 2 == 0 and c % 8 == 0
+                                  and bool(pl.get("tail_parts")) and self.fused_sums_finalize and not self.sync_bn and "o" in b)
+                    with_e = i < self.nb - 1 or last_pairs
                     use_packed = wfp is not None and self.packed_weights
                     # (a block whose input extreme is stored CENTRED -- block 1's always, a centred tile's below -- folds the shift over
                     # the stored value)
@@ -1112,6 +1121,13 @@ class HipEncoderEngine:
                                nw, wpt, L, cin, c, dt, None if pairs else W(b["z"]), ssum, ssq, W(b["ep"]) if with_e else None,
                                W(b["o"]) if pairs else None, wfp[tw0].data_ptr() if use_packed else None, ctr, st)
                     b["e_now"], b["pairs_now"], b["ctr_now"] = with_e, pairs, ctr is not None
+                    if last_pairs:
+                        finalize()
+                        parts, seg = pl["gmax_ws"], self._seg_rows
+                        self._call("vm_bn_drop_pool_gmax_partials_e", W(b["ep"]), T(b["scale"]), T(b["shift"]), dm, nw, wpt, L // 2, c, dt,
+                                   parts.data_ptr() + w0 * seg * c * 4, parts.data_ptr() + (pl["n"] + w0) * seg * c * 4, st)
+                        fused_tail = True
+                        continue
                     if with_e:
                         finalize()
                         continue
@@ -1242,7 +1258,12 @@ class HipEncoderEngine:
             else:
                 common = (_p(b["z"]), _p(b["dp"]), _p(b["scale"]), _p(b["shift"]), _p(b["mean"]), _p(b["invstd"]), dm)
             fused_fin = False
-            if sparse and self.fused_sums_finalize and not self.sync_bn and c % 8 == 0:
+            if sparse and b.get("pairs_now"):
+                # the last block left (e, o): the sparse sums gather e, the apply pass takes the pair form
+                self._call("vm_bn_bwd_gmax_finalize_e", _p(b["ep"]), *common[1:], n, wpt, L // 2, c, dt, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
+                           _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), st)
+                fused_fin = True
+            elif sparse and self.fused_sums_finalize and not self.sync_bn and c % 8 == 0:
                 # the gather of the sparse sums and their finalize in one launch (three dependent small launches of the forward ->
                 # backward turn-around otherwise)
                 self._call("vm_bn_bwd_gmax_finalize", *common, n, wpt, L, c, pool, dt, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
@@ -1271,7 +1292,10 @@ class HipEncoderEngine:
             if not fused_fin:
                 self._bn_bwd_finalize(("bwd", i), _p(b["pa"]), _p(b["pb"]), n, wpt, c, float(wpt * L), _p(b["c1"]), _p(b["c2"]),
                                       _p(self.view(f"bn{i+1}.gamma", G)), _p(self.view(f"bn{i+1}.beta", G)), _p(pl["cr_ws"]), st)
-            if b.get("pairs_now") and not sparse:
+            if b.get("pairs_now") and sparse:
+                self._call("vm_bn_pool_bwd_apply_pairs_gmax", _p(b["ep"]), _p(b["o"]), *common[1:], _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, dt,
+                           _p(b["du"]), _p(b["pdu"]), st)
+            elif b.get("pairs_now") and not sparse:
                 self._call("vm_bn_pool_bwd_apply_pairs", _p(b["ep"]), _p(b["o"]), *common[1:], _p(b["c1"]), _p(b["c2"]), n, wpt, L, c, dt,
                            _p(b["du"]), _p(b["pdu"]), _p(b["ctr"]) if b.get("ctr_now") else None, st)
             else:
@@ -1479,7 +1503,7 @@ class HipEncoderEngine:
 
     # ---- one training step, eager or replayed -----------------------------------------------------------------------------------
     def _step_flags(self):
-        return (self.fold_affine, self.fuse_block1, self.fused_bn_reduce, self.fused_sums_finalize, self.split_towers, self.tower_stagger, self.tower_swap,
+        return (self.fold_affine, self.fuse_block1, self.fused_bn_reduce, self.fused_sums_finalize, self.split_towers, self.tower_stagger, self.tower_swap, self.last_pairs,
                 self.overlap_wgrad, self.wgrad_after_dgrad, self.defer_wgrad_tail, self.fused_pool_extreme, self.fold_pairs, self.pooled_reduce,
                 self.packed_weights, self.fused_tail, self.defer_head_reduce, self.unbiased, self.clipnorm, self.loss_scaled,
                 self.bn_zero_debias, self.bn_eps, self.bn_momentum, self.beta_1, self.beta_2, self.adam_eps, self._side_priority,
