@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 9.  History: 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 10.  History: 10 = config 4's log-mel image at twice the storage significand (vm_stft_logmel_f16s_split, vm_conv2d_first_fwd_split, vm_bn_pool2d_stack_fwd_split) (round 6); 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -563,6 +563,12 @@ int64_t vm_stft_split_basis_bytes(int win_length);
 int vm_stft_split_basis(const float* basis, int win_length, void* basis16, void* stream);
 int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const void* basis16,
                         const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream);
+/* ... which also leaves what the 16-bit storage type dropped as a second plane of the same layout: out_lo = image - out, rounded to
+ * `dtype` (halo rows not written).  The log-mel image is the one tensor of the variant with a pedestal (mean -1.7, range -10 .. 5 on
+ * speech-like clips) and ONE channel: its 11-bit rounding alone moved config 4's embeddings by 7.7e-4 of the 1e-3 budget
+ * (tools/probe/config4_storage_sites.py); two planes cost 2 bytes per pixel more.  16-bit storage only. */
+int vm_stft_logmel_f16s_split(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop, const void* basis16,
+                              const float* melw, int n_mels, float log_floor, int dtype, void* out, void* out_lo, void* stream);
 /* First Conv2D(3 x 3) of the variant (one input channel) with its own kernels instead of as a band-stacked GEMM with K = 24, N = 32
  * (16-bit storage and C % 32 == 0: one v_mfma_f32_32x32x16 per 32 positions x 32 channels, the nine taps as K, and
  * v_mfma_f32_16x16x32 tiles with the positions as K for the gradient; otherwise on the vector ALUs):
@@ -574,6 +580,15 @@ int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t 
 int vm_conv2d_first_supported(int C, int dtype);
 int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C, int dtype,
                         void* z, float* stat_sum, float* stat_sq, void* stream);
+/* vm_conv2d_first_fwd on the two-plane image (in + in_lo of vm_stft_logmel_f16s_split) with the filters split the same way inside
+ * (w = w_hi + w_lo, both `dtype`): the three significant products in w_hi + in_lo w_hi + in w_lo are 27 of the 32 K slots of TWO
+ * matrix instructions per 32 positions x 32 channels, fp32 accumulation -- image and filters enter at ~2 x the storage significand
+ * (the layer has 9 taps and one input channel: the second instruction is the whole price).  Same z layout, statistics and rounding
+ * of the stored z as vm_conv2d_first_fwd; the weight gradient keeps vm_conv2d_first_wgrad on the high plane.  z_lo (optional): what
+ * the storage type dropped of relu(conv + bias) as a second plane of z's layout -- the statistics are then those of z + z_lo, which is
+ * what vm_bn_pool2d_stack_fwd_split normalises (the backward keeps reading z alone).  16-bit storage and C % 32 == 0 only. */
+int vm_conv2d_first_fwd_split(const void* in, const void* in_lo, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs,
+                              int C, int dtype, void* z, void* z_lo, float* stat_sum, float* stat_sq, void* stream);
 int64_t vm_conv2d_first_wgrad_workspace_bytes(int64_t n_clips, int M, int C);
 int vm_conv2d_first_wgrad(const void* in, const void* du, int64_t n_clips, int M, int64_t L, int Cs, int C, int dtype, void* ws,
                           float* grad_w, void* stream);
@@ -602,6 +617,9 @@ int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M,
  * vm_fold_pool_windows_rows, a_is_act = 1) turns into the BatchNorm-backward constants of the block below without a pass over (z, dq). */
 int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
                            int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);
+/* vm_bn_pool2d_stack_fwd on a z that came as two planes (vm_conv2d_first_fwd_split): the affine is taken of z + z_lo in fp32. */
+int vm_bn_pool2d_stack_fwd_split(const void* z, const void* z_lo, const float* scale, const float* shift, const float* drop, int64_t n_clips,
+                                 int M, int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);
 int64_t vm_fold_pool_windows_rows(int64_t L, int C, int Cs, int dtype);
 int vm_fold_pool_windows_bwd(const void* dxs, const void* q, int64_t n_clips, int M, int64_t L, int C, int Cs, int src_padded, int dtype,
                              void* dq, float* s0, float* sa, void* stream);

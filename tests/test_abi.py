@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in _lib.header_functions():
         assert hasattr(cdll, name), name
     lib = _lib.lib()
-    assert lib.abi == _lib.ABI_VERSION == 9
+    assert lib.abi == _lib.ABI_VERSION == 10
     assert lib.query("vm_bn_part_rows") > 0
     assert lib.query("vm_conv_stat_rows", 3000) == 24
     assert lib.query("vm_conv_wgrad_splits", 256, 3000, 128, 256) >= 1

@@ -431,6 +431,12 @@ def test_full_size_properties_cfgA_bf16():
             # sums of the same bf16 values, in a different fp32 order
             assert eng.fused_bn_reduce
             eng.split_towers = not eng.split_towers
+            # (the reference of this comparison under the same tower launch shape: the block-1 forward's chunking -- hence the fp32 order
+            # of its statistics, hence a few bf16 roundings downstream -- follows the launch size since its workgroups walk six chunks)
+            eng.init_params(1234)
+            eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None, apply_update=False)
+            torch.cuda.synchronize()
+            g1 = eng.G.clone()
             eng.fused_bn_reduce = False
             eng.init_params(1234)
             pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", preprocessed=False, downsampling=4, drop_masks=None,

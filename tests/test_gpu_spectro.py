@@ -151,6 +151,108 @@ def test_conv2d_first_layer_fwd_and_wgrad(dt, n, M, Lw, C):
     assert (gw[:, 3:] == 0).all()
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("n,M,Lw,C", [(2, 5, 298, 32), (1, 3, 130, 96), (2, 4, 37, 64), (1, 2, 256, 128)])
+def test_conv2d_first_layer_split_image(dt, n, M, Lw, C):
+    """vm_conv2d_first_fwd_split: the image as two planes of the storage type (hi + what hi dropped), the filters split the same way
+    inside, three products on two matrix instructions.  Against the float64 convolution of the UN-rounded image and filters: what is
+    left is the rounding of the stored z (2^-12 / 2^-9 relative per element, rms ~0.3 of that) -- and the one-plane entry point on the
+    same data is measurably further away.  Statistics rows of the stored z; the pedestal (-1.7) and range are the log-mel image's."""
+    vm, tdt = DTYPES[dt]
+    r = np.random.default_rng(n * 100 + M + Lw + C)
+    Cs = 8
+    x = (r.normal(-1.7, 1.4, (n * M, Lw, 1))).astype(np.float32).astype(np.float64)
+    w = np.zeros((3, Cs, C), np.float32)
+    w[:, :3] = r.normal(0, 0.3, (3, 3, C))
+    bias = r.normal(0, 0.1, C).astype(np.float32)
+    hi = quant(x, dt).numpy()
+    lo = quant(x - hi, dt).numpy()
+    rows = L().query("vm_conv_stat_rows", Lw)
+    z = torch.empty(n * M, Lw, C, dtype=tdt, device="cuda")
+    z1 = torch.empty_like(z)
+    ssum = torch.empty(n * M * rows, C, dtype=torch.float32, device="cuda")
+    ssq = torch.empty_like(ssum)
+    L().call("vm_conv2d_first_fwd_split", p(padded(hi, tdt)), p(padded(lo, tdt)), p(dev(w)), p(dev(bias)), n, M, Lw, Cs, C, vm, p(z), None,
+             p(ssum), p(ssq), stream())
+    L().call("vm_conv2d_first_fwd", p(padded(hi, tdt)), p(dev(w)), p(dev(bias)), n, M, Lw, Cs, C, vm, p(z1), None, None, stream())
+    torch.cuda.synchronize()
+    img = np.zeros((n, M + 2, Lw + 2))
+    img[:, 1:-1, 1:-1] = x.reshape(n, M, Lw)
+    pre = np.zeros((n, M, Lw, C))
+    for kt in range(3):
+        for km in range(3):
+            pre += img[:, km:km + M, kt:kt + Lw, None] * w[kt, km].astype(np.float64)[None, None, None, :]
+    pre = (pre + bias).reshape(n * M, Lw, C)
+    zr = np.maximum(pre, 0.0)
+    zg = z.to(torch.float64).cpu().numpy()
+    # element-wise: the stored value is the storage rounding of the exact one (a few results sit on a rounding boundary: one ulp there)
+    want = quant(zr, dt).numpy()
+    ulp = np.abs(zr) * (2.0 ** -10 if dt == "f16" else 2.0 ** -7) + 1e-6
+    assert np.all(np.abs(zg - zr) <= 0.5 * ulp * 1.02 + (1e-5 if dt == "f16" else 5e-4))
+    assert np.mean(zg != want) < (2e-3 if dt == "f16" else 2e-2)
+    e_split, e_one = rel_err(zg, zr), rel_err(z1.to(torch.float64).cpu().numpy(), zr)
+    report("conv2d_first_split[%s]" % dt, "rel_err_vs_exact[n%d M%d L%d C%d]" % (n, M, Lw, C), e_split)
+    report("conv2d_first_split[%s]" % dt, "one_plane_rel_err_vs_exact[n%d M%d L%d C%d]" % (n, M, Lw, C), e_one)
+    assert e_split < (2.5e-4 if dt == "f16" else 2e-3) and e_one > 1.5 * e_split
+    pad = np.zeros((n * M, rows * 128, C))
+    pad[:, :Lw] = zg
+    assert np.allclose(ssum.cpu().numpy().reshape(n * M, rows, C), pad.reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    assert np.allclose(ssq.cpu().numpy().reshape(n * M, rows, C), (pad * pad).reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    # ... with the low plane of z: the same high plane, z + z_lo is the exact value to ~2 x the significand, the statistics are those of
+    # the sum; and the boundary pass on the two planes is the one-plane pass on their sum (compared in fp32 storage)
+    zb, zl = torch.empty_like(z), torch.empty_like(z)
+    L().call("vm_conv2d_first_fwd_split", p(padded(hi, tdt)), p(padded(lo, tdt)), p(dev(w)), p(dev(bias)), n, M, Lw, Cs, C, vm, p(zb), p(zl),
+             p(ssum), p(ssq), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(zb, z)
+    z2 = zb.to(torch.float64).cpu().numpy() + zl.to(torch.float64).cpu().numpy()
+    assert rel_err(z2, zr) < (2e-6 if dt == "f16" else 6e-5)
+    pad[:, :Lw] = z2
+    assert np.allclose(ssum.cpu().numpy().reshape(n * M, rows, C), pad.reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    assert np.allclose(ssq.cpu().numpy().reshape(n * M, rows, C), (pad * pad).reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    if M >= 2 and Lw >= 2:
+        Cs2 = 3 * C
+        scale, shift = dev(r.uniform(0.5, 2.0, (1, C)).astype(np.float32)), dev(r.normal(0, 0.5, (1, C)).astype(np.float32))
+        Lq = Lw // 2
+        q2, xs2 = torch.zeros(n * M, Lq + 2, C, dtype=tdt, device="cuda"), torch.zeros(n * (M // 2), Lq + 2, Cs2, dtype=tdt, device="cuda")
+        L().call("vm_bn_pool2d_stack_fwd_split", p(zb), p(zl), p(scale), p(shift), None, n, M, n, Lw, C, Cs2, vm, p(q2), p(xs2), stream())
+        zs = (zb.float() + zl.float()).contiguous()                   # exact in fp32: the two planes do not overlap
+        q1, xs1 = torch.zeros(n * M, Lq + 2, C, dtype=torch.float32, device="cuda"), torch.zeros(n * (M // 2), Lq + 2, Cs2, dtype=torch.float32, device="cuda")
+        L().call("vm_bn_pool2d_stack_fwd", p(zs), p(scale), p(shift), None, n, M, n, Lw, C, Cs2, DTYPES["f32"][0], p(q1), p(xs1), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(q2, q1.to(tdt)) and torch.equal(xs2, xs1.to(tdt))
+
+
+def test_stft_logmel_split_planes():
+    """vm_stft_logmel_f16s_split: out is vm_stft_logmel_f16s's plane bit for bit, out + out_lo is the fp32-storage image to ~2^-21."""
+    n, raw_len, n_mels = 3, 48000, 64
+    r = rng(2)
+    t = np.arange(raw_len) / 16000.0
+    raw = (0.05 * r.normal(0, 1, (n, raw_len)) + 0.2 * np.sin(2 * np.pi * 440.0 * t)[None, :] * r.uniform(0.2, 1.0, (n, 1))).astype(np.float32)
+    rd = dev(raw)
+    T = L().query("vm_stft_frames", raw_len, S.WIN_LENGTH, S.HOP)
+    basis, melw = dev(S.dft_basis()), dev(S.mel_filterbank(n_mels))
+    b16 = torch.empty(L().query("vm_stft_split_basis_bytes", S.WIN_LENGTH) // 2, dtype=torch.float16, device="cuda")
+    L().call("vm_stft_split_basis", p(basis), S.WIN_LENGTH, p(b16), stream())
+    args = (p(rd), 0, n, raw_len, S.WIN_LENGTH, S.HOP, p(b16), p(melw), n_mels, S.LOG_FLOOR)
+    full = torch.zeros(n * n_mels, T + 2, 1, dtype=torch.float32, device="cuda")
+    L().call("vm_stft_logmel_f16s", *args, DTYPES["f32"][0], p(full), stream())
+    for dt in ("f16", "bf16"):
+        vm, tdt = DTYPES[dt]
+        one = torch.zeros(n * n_mels, T + 2, 1, dtype=tdt, device="cuda")
+        hi, lo = torch.zeros_like(one), torch.zeros_like(one)
+        L().call("vm_stft_logmel_f16s", *args, vm, p(one), stream())
+        L().call("vm_stft_logmel_f16s_split", *args, vm, p(hi), p(lo), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(one, hi)
+        assert (lo[:, 0] == 0).all() and (lo[:, -1] == 0).all()
+        err = (hi.double() + lo.double() - full.double()).abs().max().item()
+        assert err < (2e-5 if dt == "f16" else 3e-4), err
+        assert (hi.double() - full.double()).abs().max().item() > 50 * err
+    with pytest.raises(Exception):
+        L().call("vm_stft_logmel_f16s_split", *args, DTYPES["f32"][0], p(full), p(full), stream())
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,M,Lq,C", [(2, 4, 5, 8), (3, 5, 4, 16), (1, 2, 3, 4), (2, 8, 9, 32)])
 def test_pool_windows(dt, n, M, Lq, C):
@@ -311,6 +413,8 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
     emb = pl["emb"].cpu().numpy()
     e_ref = np.concatenate([ref["e1"].numpy(), ref["e2"].numpy()])
     tol = {"f32": 2e-4, "bf16": 6e-2, "f16": 8e-3}[dt]
+    if dt == "f16" and size is CONFIG4:
+        tol = 1e-3   # (round 6) the north star's bar, since the log-mel image enters on two planes (8.5e-4; one plane: 1.27e-3)
     tag = "spectro_step_%s_drop%g_%dx%d_F%d" % (dt, drop, f1.shape[1], f1.shape[2], F_)
     report(tag, "emb_rel_err", rel_err(emb, e_ref))
     assert rel_err(emb, e_ref) < tol
@@ -348,6 +452,34 @@ def test_spectrogram_siamese_step_vs_oracle(dt, drop, size):
         got = eng.get_params()
         for k, v in ref["params"].items():
             assert max_err(got[k], v.numpy()) < 5e-5, k
+
+
+@pytest.mark.parametrize("seed", [11, 23, 37, 41])
+def test_config4_f16_embeddings_within_1e3_over_seeds(seed):
+    """Guard of the config-4 f16 claim (embeddings within 1e-3 of the float64 restatement at 298 x 64, filters 32) over other
+    parameter and clip seeds than the step test's, forward only; and the one-plane image (round 3-5) is outside it on the same data."""
+    from voicemap_amd.spectro_engine import HipSpectrogramEncoderEngine
+    pairs, raw_len, F_, E = CONFIG4
+    arch = O.Encoder2dArch(F_, E, dropout=0.0)
+    pr = O.init_params2d(arch, head="uniform_euclidean", seed=seed)
+    x1, x2 = _clips(pairs, raw_len, seed + 1), _clips(pairs, raw_len, seed + 2)
+    y = np.concatenate([np.zeros(pairs // 2), np.ones(pairs - pairs // 2)])[:, None]
+    f1, f2 = torch.tensor(O.logmel_features(x1.astype(np.float64))), torch.tensor(O.logmel_features(x2.astype(np.float64)))
+    with torch.no_grad():
+        e_ref = np.concatenate([O.encoder2d_forward(arch, pr, f1, True).numpy(), O.encoder2d_forward(arch, pr, f2, True).numpy()])
+    errs = {}
+    for split in (True, False):
+        eng = HipSpectrogramEncoderEngine(F_, E, dropout=0.0, head="uniform_euclidean", dtype="f16")
+        assert eng.split_image
+        eng.split_image = split
+        eng.set_params({k: v.numpy() for k, v in pr.items()})
+        pl = eng.siamese_train_step(x1, x2, y, loss="contrastive", drop_masks=None, apply_update=False)
+        torch.cuda.synchronize()
+        errs[split] = rel_err(pl["emb"].cpu().numpy(), e_ref)
+    report("config4_f16_guard", "emb_rel_err[seed %d]" % seed, errs[True])
+    report("config4_f16_guard", "one_plane_emb_rel_err[seed %d]" % seed, errs[False])
+    assert errs[True] < 1e-3, errs
+    assert errs[False] > errs[True]
 
 
 def test_spectrogram_encoder_api_and_full_size():

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 9  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 10  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -122,13 +122,16 @@ SIGNATURES = {
     "vm_stft_split_basis_bytes": (L, [I]),
     "vm_stft_split_basis": (I, [P, I, P, P]),
     "vm_stft_logmel_f16s": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P]),
+    "vm_stft_logmel_f16s_split": (I, [P, I, L, L, I, I, P, P, I, F, I, P, P, P]),
     "vm_conv2d_first_supported": (I, [I, I]),
     "vm_conv2d_first_fwd": (I, [P, P, P, L, I, L, I, I, I, P, P, P, P]),
+    "vm_conv2d_first_fwd_split": (I, [P, P, P, P, L, I, L, I, I, I, P, P, P, P, P]),
     "vm_conv2d_first_wgrad_workspace_bytes": (L, [L, I, I]),
     "vm_conv2d_first_wgrad": (I, [P, P, L, I, L, I, I, I, P, P, P]),
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),
     "vm_fold_windows": (I, [P, L, I, L, I, I, I, I, P, P]),
     "vm_bn_pool2d_stack_fwd": (I, [P, P, P, P, L, I, L, L, I, I, I, P, P, P]),
+    "vm_bn_pool2d_stack_fwd_split": (I, [P, P, P, P, P, L, I, L, L, I, I, I, P, P, P]),
     "vm_fold_pool_windows_rows": (L, [L, I, I, I]),
     "vm_fold_pool_windows_bwd": (I, [P, P, L, I, L, I, I, I, I, P, P, P, P]),
     "vm_pool_windows_fwd": (I, [P, L, I, L, I, I, P, P]),

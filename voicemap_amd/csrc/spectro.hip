@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(const void* __restrict
 template <typename TOUT, int NMB>
 __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __restrict__ raw, int is_int16, int64_t raw_len, int win, int hop,
                                                                int T, const f16* __restrict__ basis16, int Kp,
-                                                               const float* __restrict__ melw, float log_floor, TOUT* __restrict__ out) {
+                                                               const float* __restrict__ melw, float log_floor, TOUT* __restrict__ out,
+                                                               TOUT* __restrict__ out_lo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pitch = Kp + 8;   // halves: a row is 2 Kp + 16 bytes, the 16-byte operand reads of 32 frames x 2 K-halves are conflict-free
     f16* xh = reinterpret_cast<f16*>(smem);
@@ -276,7 +277,12 @@ __global__ __launch_bounds__(256) void stft_logmel_f16s_kernel(const void* __res
         if (f0 + f < T) {
             const float sum = (red[(0 * n_mels + m) * 32 + f] + red[(1 * n_mels + m) * 32 + f]) +
                               (red[(2 * n_mels + m) * 32 + f] + red[(3 * n_mels + m) * 32 + f]);
-            out[((int64_t)clip * n_mels + m) * (T + 2) + 1 + f0 + f] = Elem<TOUT>::from_f(logf(sum + log_floor));
+            const float lm = logf(sum + log_floor);
+            const int64_t o = ((int64_t)clip * n_mels + m) * (T + 2) + 1 + f0 + f;
+            const TOUT hi = Elem<TOUT>::from_f(lm);
+            out[o] = hi;
+            // (vm_stft_logmel_f16s_split) what the storage type dropped: image = out + out_lo to 2 x the significand
+            if (out_lo != nullptr) out_lo[o] = Elem<TOUT>::from_f(lm - Elem<TOUT>::to_f(hi));
         }
     }
 }
@@ -399,7 +405,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_pool2d_stack_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ drop,
                                                                   int64_t wpt, int M, int L, int C, int Cs, T* __restrict__ q,
-                                                                  T* __restrict__ xs) {
+                                                                  T* __restrict__ xs, const T* __restrict__ z_lo) {
+    // z_lo (optional, vm_bn_pool2d_stack_fwd_split): z comes as two planes of the storage type, the affine sees their fp32 sum
     constexpr int V = Elem<T>::kVec;
     const int CV = C / V, RP = 256 / CV;
     const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
@@ -428,18 +435,38 @@ __global__ __launch_bounds__(256) void bn_pool2d_stack_fwd_kernel(const T* __res
     for (int t = rl; t < Lq; t += RP) {
         const Vec16<T> a0 = load16<T>(z0 + (int64_t)(2 * t) * C), a1 = load16<T>(z0 + (int64_t)(2 * t + 1) * C);
         Vec16<T> o0, o1;
+        if (z_lo != nullptr) {
+            const T* l0 = z_lo + (z0 - z);
+            const Vec16<T> e0 = load16<T>(l0 + (int64_t)(2 * t) * C), e1 = load16<T>(l0 + (int64_t)(2 * t + 1) * C);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float y0 = fmaf(a0.get(i), sc[i], sh[i]) * d0[i], y1 = fmaf(a1.get(i), sc[i], sh[i]) * d0[i];
-            o0.set(i, y1 > y0 ? y1 : y0);
+            for (int i = 0; i < V; ++i) {
+                const float y0 = fmaf(a0.get(i) + e0.get(i), sc[i], sh[i]) * d0[i], y1 = fmaf(a1.get(i) + e1.get(i), sc[i], sh[i]) * d0[i];
+                o0.set(i, y1 > y0 ? y1 : y0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float y0 = fmaf(a0.get(i), sc[i], sh[i]) * d0[i], y1 = fmaf(a1.get(i), sc[i], sh[i]) * d0[i];
+                o0.set(i, y1 > y0 ? y1 : y0);
+            }
         }
         store16<T>(q0 + (int64_t)t * C, o0);
         if (!pair) continue;
         const Vec16<T> b0 = load16<T>(z1 + (int64_t)(2 * t) * C), b1 = load16<T>(z1 + (int64_t)(2 * t + 1) * C);
+        if (z_lo != nullptr) {
+            const T* l1 = z_lo + (z1 - z);
+            const Vec16<T> e0 = load16<T>(l1 + (int64_t)(2 * t) * C), e1 = load16<T>(l1 + (int64_t)(2 * t + 1) * C);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float y0 = fmaf(b0.get(i), sc[i], sh[i]) * d1[i], y1 = fmaf(b1.get(i), sc[i], sh[i]) * d1[i];
-            o1.set(i, y1 > y0 ? y1 : y0);
+            for (int i = 0; i < V; ++i) {
+                const float y0 = fmaf(b0.get(i) + e0.get(i), sc[i], sh[i]) * d1[i], y1 = fmaf(b1.get(i) + e1.get(i), sc[i], sh[i]) * d1[i];
+                o1.set(i, y1 > y0 ? y1 : y0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float y0 = fmaf(b0.get(i), sc[i], sh[i]) * d1[i], y1 = fmaf(b1.get(i), sc[i], sh[i]) * d1[i];
+                o1.set(i, y1 > y0 ? y1 : y0);
+            }
         }
         store16<T>(q1 + (int64_t)t * C, o1);
         Vec16<T> pm;
@@ -773,11 +800,16 @@ template <> struct Mma16<bf16> {
     __device__ static inline f32x4 run16(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T, int CB>   // CB = C / 32
-__global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __restrict__ in, const float* __restrict__ w,
+// SPLIT (vm_conv2d_first_fwd_split): the image comes as two planes in + in_lo (vm_stft_logmel_f16s_split) and the weights are split the same
+// way inside; the three significant products in_hi w_hi + in_lo w_hi + in_hi w_lo are 27 of the 32 K slots of TWO instructions -- a half-wave's
+// slots in order: [hi taps | lo taps] x w_hi, then [hi taps] x w_lo -- so the layer sees image and filters at ~2 x the storage significand.
+template <typename T, int CB, bool SPLIT>   // CB = C / 32
+__global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __restrict__ in, const T* __restrict__ in_lo, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, int64_t n_rows, int M, int L, int Cs,
-                                                                    T* __restrict__ z, float* __restrict__ stat_sum,
+                                                                    T* __restrict__ z, T* __restrict__ z_lo, float* __restrict__ stat_sum,
                                                                     float* __restrict__ stat_sq) {
+    // z_lo (SPLIT only, optional): what the storage type dropped of relu(conv) as a second plane; the statistics are then those of
+    // z + z_lo (what vm_bn_pool2d_stack_fwd_split normalises)
     constexpr int C = 32 * CB;
     using Frag = typename Mma16<T>::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -794,6 +826,7 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
     // this lane's K slots: the lower half-wave carries taps 0 .. 4 in slots 0 .. 4, the upper one taps 5 .. 8 in slots 0 .. 3 (five
     // gather instructions a tile, not eight); the other slots are zero in both operands
     Frag wb[CB];
+    Frag wb2[SPLIT ? CB : 1];
     float bv[CB];
     int off[5];
     unsigned ok = 0;
@@ -805,13 +838,35 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
             off[e] = (km - 1) * (L + 2) + kt;
             if (slot && ms >= 0 && ms < M) ok |= 1u << e;
         }
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-            wb[cb][e] = Elem<T>::from_f(slot ? w[((int64_t)kt * Cs + km) * C + 32 * cb + col] : 0.f);
+            for (int cb = 0; cb < CB; ++cb)
+                wb[cb][e] = Elem<T>::from_f(slot ? w[((int64_t)kt * Cs + km) * C + 32 * cb + col] : 0.f);
+        }
+    }
+    if constexpr (SPLIT) {
+        // slot s of the 16 this half-wave owns (8 per instruction): n = 5 - kh taps; s < n: hi x w_hi, s < 2 n: lo x w_hi, s < 3 n: hi x w_lo
+        const int n = 5 - kh;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) {
+            const int part = sl / n, e = sl - part * n;       // (runtime: once per wave)
+            const int k = 5 * kh + e, kt = k / 3, km = k - 3 * kt;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                T v = Elem<T>::from_f(0.f);
+                if (part < 3) {
+                    const float wf = w[((int64_t)kt * Cs + km) * C + 32 * cb + col];
+                    const T wh = Elem<T>::from_f(wf);
+                    v = part < 2 ? wh : Elem<T>::from_f(wf - Elem<T>::to_f(wh));
+                }
+                if (sl < 8) wb[cb][sl] = v; else wb2[cb][sl - 8] = v;
+            }
+        }
     }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bv[cb] = bias[32 * cb + col];
     const T* base = in + win * (int64_t)(L + 2);
+    const T* base_lo = SPLIT ? in_lo + win * (int64_t)(L + 2) : nullptr;
     float s1[CB], s2[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) s1[cb] = s2[cb] = 0.f;
@@ -821,12 +876,42 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
         if (t0 >= L) break;
         const int t = t0 + col;
         Frag a;
+        Frag a2;
+        T zl[SPLIT ? CB : 1][16];
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            T v = Elem<T>::from_f(0.f);
-            if (e < 5)
-                if (((ok >> e) & 1u) && t < L) v = base[off[e] + t];
-            a[e] = v;
+            for (int e = 0; e < 8; ++e) {
+                T v = Elem<T>::from_f(0.f);
+                if (e < 5)
+                    if (((ok >> e) & 1u) && t < L) v = base[off[e] + t];
+                a[e] = v;
+            }
+        } else {
+            const T zero = Elem<T>::from_f(0.f);
+            T hi[5], lo[5];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                hi[e] = lo[e] = zero;
+                if (((ok >> e) & 1u) && t < L) {
+                    hi[e] = base[off[e] + t];
+                    lo[e] = base_lo[off[e] + t];
+                }
+            }
+            // the 16 slots: kh = 0 (5 taps): hi0-4 lo0-4 hi0-4 0;  kh = 1 (4 taps): hi0-3 lo0-3 hi0-3 0 0 0 0
+            const bool up = kh != 0;
+            a[0] = hi[0]; a[1] = hi[1]; a[2] = hi[2]; a[3] = hi[3];
+            a[4] = up ? lo[0] : hi[4];
+            a[5] = up ? lo[1] : lo[0];
+            a[6] = up ? lo[2] : lo[1];
+            a[7] = up ? lo[3] : lo[2];
+            a2[0] = up ? hi[0] : lo[3];
+            a2[1] = up ? hi[1] : lo[4];
+            a2[2] = up ? hi[2] : hi[0];
+            a2[3] = up ? hi[3] : hi[1];
+            a2[4] = up ? zero : hi[2];
+            a2[5] = up ? zero : hi[3];
+            a2[6] = up ? zero : hi[4];
+            a2[7] = zero;
         }
         const bool whole = t0 + 32 <= L;   // (uniform) every position of the tile counts in the statistics
 #pragma unroll
@@ -835,13 +920,19 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bv[cb];
             acc = Mma16<T>::run32(a, wb[cb], acc);
+            if constexpr (SPLIT) acc = Mma16<T>::run32(a2, wb2[cb], acc);
             float rf[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pl = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const T h = Elem<T>::from_f(fmaxf(acc[r], 0.f));
+                const float v = fmaxf(acc[r], 0.f);
+                const T h = Elem<T>::from_f(v);
                 rf[r] = Elem<T>::to_f(h);
                 tile[pl * C + 32 * cb + col] = h;
+                if constexpr (SPLIT) {
+                    zl[cb][r] = Elem<T>::from_f(v - rf[r]);
+                    if (z_lo != nullptr) rf[r] += Elem<T>::to_f(zl[cb][r]);
+                }
             }
             if (!whole) {
 #pragma unroll
@@ -863,6 +954,22 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
             if (bo < nbytes) *reinterpret_cast<u32x4*>(dst + bo) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + bo);
         }
         asm volatile("" ::: "memory");
+        if constexpr (SPLIT) {
+            if (z_lo != nullptr) {   // the low plane through the same wave-private tile
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * kh) * C + 32 * cb + col] = zl[cb][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                char* dl = reinterpret_cast<char*>(z_lo + (win * L + t0) * (int64_t)C);
+#pragma unroll
+                for (int i = 0; i < 2 * CB; ++i) {
+                    const int bo = (i * 64 + lane) * 16;
+                    if (bo < nbytes) *reinterpret_cast<u32x4*>(dl + bo) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + bo);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
     }
     if (stat_sum != nullptr) {
 #pragma unroll
@@ -946,12 +1053,19 @@ __global__ __launch_bounds__(256) void conv2d_first_wgrad_mfma_kernel(const T* _
 }
 
 template <typename T>
-static void launch_c2f_mfma(const T* in, const float* w, const float* bias, int64_t n_rows, int M, int L, int Cs, int C, T* z, float* stat_sum,
-                            float* stat_sq, hipStream_t stream) {
+static void launch_c2f_mfma(const T* in, const T* in_lo, const float* w, const float* bias, int64_t n_rows, int M, int L, int Cs, int C, T* z,
+                            T* z_lo, float* stat_sum, float* stat_sq, hipStream_t stream) {
     const dim3 grid((unsigned)((n_rows + 3) / 4));
     const size_t lds = (size_t)4 * 32 * C * 2;
-#define VM_LAUNCH_C2F(CB) \
-    hipLaunchKernelGGL((conv2d_first_fwd_mfma_kernel<T, CB>), grid, dim3(256), lds, stream, in, w, bias, n_rows, M, L, Cs, z, stat_sum, stat_sq)
+#define VM_LAUNCH_C2F(CB)                                                                                                                   \
+    do {                                                                                                                                    \
+        if (in_lo != nullptr)                                                                                                               \
+            hipLaunchKernelGGL((conv2d_first_fwd_mfma_kernel<T, CB, true>), grid, dim3(256), lds, stream, in, in_lo, w, bias, n_rows, M, L, Cs, z, \
+                               z_lo, stat_sum, stat_sq);                                                                                         \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((conv2d_first_fwd_mfma_kernel<T, CB, false>), grid, dim3(256), lds, stream, in, in_lo, w, bias, n_rows, M, L, Cs, z, \
+                               z_lo, stat_sum, stat_sq);                                                                                         \
+    } while (0)
     switch (C / 32) {
         case 1: VM_LAUNCH_C2F(1); break;
         case 2: VM_LAUNCH_C2F(2); break;
@@ -1059,8 +1173,8 @@ extern "C" int vm_stft_split_basis(const float* basis, int win_length, void* bas
     return check_launch("vm_stft_split_basis");
 }
 
-extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
-                                   const void* basis16, const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream) {
+static int stft_logmel_f16s(const char* who, const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
+                            const void* basis16, const float* melw, int n_mels, float log_floor, int dtype, void* out, void* out_lo, void* stream) {
     VM_REQUIRE(raw && basis16 && melw && out, "vm_stft_logmel_f16s: null pointer");
     VM_REQUIRE(n_clips > 0 && n_clips < 65536 && win_length >= 2 && win_length <= 512 && hop > 0 && raw_len >= win_length,
                "vm_stft_logmel_f16s: bad sizes (n_fft is 512: win_length <= 512)");
@@ -1074,7 +1188,7 @@ extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clip
     if (red > lds) lds = red;
 #define VM_LAUNCH_SF16(TT, NMB)                                                                                                       \
     hipLaunchKernelGGL((stft_logmel_f16s_kernel<TT, NMB>), grid, dim3(256), lds, (hipStream_t)stream, raw, is_int16, raw_len, win_length, \
-                       hop, n_frames, (const f16*)basis16, Kp, melw, log_floor, (TT*)out)
+                       hop, n_frames, (const f16*)basis16, Kp, melw, log_floor, (TT*)out, (TT*)out_lo)
     VM_DISPATCH_DTYPE(dtype, {
         switch (n_mels / 32) {
             case 1: VM_LAUNCH_SF16(T, 1); break;
@@ -1084,7 +1198,24 @@ extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clip
         }
     });
 #undef VM_LAUNCH_SF16
-    return check_launch("vm_stft_logmel_f16s");
+    return check_launch(who);
+}
+
+extern "C" int vm_stft_logmel_f16s(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
+                                   const void* basis16, const float* melw, int n_mels, float log_floor, int dtype, void* out, void* stream) {
+    return stft_logmel_f16s("vm_stft_logmel_f16s", raw, is_int16, n_clips, raw_len, win_length, hop, basis16, melw, n_mels, log_floor, dtype, out,
+                            nullptr, stream);
+}
+
+// ... and the part of the image the storage type drops as a second plane of the same layout (out_lo = image - out, rounded to `dtype`):
+// the first convolution multiplies both (vm_conv2d_first_fwd_split), so the log-mel image enters the network at 2 x the significand
+extern "C" int vm_stft_logmel_f16s_split(const void* raw, int is_int16, int64_t n_clips, int64_t raw_len, int win_length, int hop,
+                                         const void* basis16, const float* melw, int n_mels, float log_floor, int dtype, void* out,
+                                         void* out_lo, void* stream) {
+    VM_REQUIRE(out_lo, "vm_stft_logmel_f16s_split: null pointer");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_stft_logmel_f16s_split: 16-bit storage only");
+    return stft_logmel_f16s("vm_stft_logmel_f16s_split", raw, is_int16, n_clips, raw_len, win_length, hop, basis16, melw, n_mels, log_floor, dtype,
+                            out, out_lo, stream);
 }
 
 #define VM_DISPATCH_VEC(T, C, ...)                       \
@@ -1119,7 +1250,7 @@ extern "C" int vm_fold_windows(const void* dxs, int64_t n_clips, int M, int64_t 
     return check_launch("vm_fold_windows");
 }
 
-extern "C" int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
+static int bn_pool2d_stack_fwd(const void* z, const void* z_lo, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
                                       int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream) {
     VM_REQUIRE(z && scale && shift && q && xs, "vm_bn_pool2d_stack_fwd: null pointer");
     VM_REQUIRE(n_clips > 0 && M >= 2 && clips_per_tower > 0 && L >= 2 && C > 0 && Cs >= 3 * C, "vm_bn_pool2d_stack_fwd: bad sizes (Cs >= 3 C)");
@@ -1128,9 +1259,23 @@ extern "C" int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const f
         VM_REQUIRE(C % Elem<T>::kVec == 0 && Cs % Elem<T>::kVec == 0 && C / Elem<T>::kVec <= 256,
                    "vm_bn_pool2d_stack_fwd: C and Cs must be multiples of the 16-byte vector, C / vector <= 256");
         hipLaunchKernelGGL((bn_pool2d_stack_fwd_kernel<T>), dim3((unsigned)(n_clips * ((M + 1) / 2))), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)z, scale, shift, drop, clips_per_tower * M, M, (int)L, C, Cs, (T*)q, (T*)xs);
+                           (const T*)z, scale, shift, drop, clips_per_tower * M, M, (int)L, C, Cs, (T*)q, (T*)xs, (const T*)z_lo);
     });
     return check_launch("vm_bn_pool2d_stack_fwd");
+}
+
+extern "C" int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
+                                      int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream) {
+    return bn_pool2d_stack_fwd(z, nullptr, scale, shift, drop, n_clips, M, clips_per_tower, L, C, Cs, dtype, q, xs, stream);
+}
+
+// ... on a z that came as two planes of the storage type (vm_conv2d_first_fwd_split): the affine sees z + z_lo
+extern "C" int vm_bn_pool2d_stack_fwd_split(const void* z, const void* z_lo, const float* scale, const float* shift, const float* drop,
+                                            int64_t n_clips, int M, int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q,
+                                            void* xs, void* stream) {
+    VM_REQUIRE(z_lo, "vm_bn_pool2d_stack_fwd_split: null pointer");
+    VM_REQUIRE(dtype == VM_BF16 || dtype == VM_F16, "vm_bn_pool2d_stack_fwd_split: 16-bit storage only");
+    return bn_pool2d_stack_fwd(z, z_lo, scale, shift, drop, n_clips, M, clips_per_tower, L, C, Cs, dtype, q, xs, stream);
 }
 
 extern "C" int64_t vm_fold_pool_windows_rows(int64_t L, int C, int Cs, int dtype) { return 1; }   // one row of sums per window
@@ -1172,8 +1317,8 @@ extern "C" int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_cl
 
 extern "C" int vm_conv2d_first_supported(int C, int dtype) { return (C % 8 == 0 && C >= 8 && C <= 128) ? 1 : 0; }
 
-extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C,
-                                   int dtype, void* z, float* stat_sum, float* stat_sq, void* stream) {
+static int conv2d_first_fwd(const void* in, const void* in_lo, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C,
+                            int dtype, void* z, void* z_lo, float* stat_sum, float* stat_sq, void* stream) {
     VM_REQUIRE(in && w && bias && z, "vm_conv2d_first_fwd: null pointer");
     VM_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "vm_conv2d_first_fwd: stat_sum / stat_sq must both be set or NULL");
     VM_REQUIRE(n_clips > 0 && M > 0 && L > 0 && Cs >= 3 && vm_conv2d_first_supported(C, dtype), "vm_conv2d_first_fwd: bad sizes (C % 8 == 0, C <= 128, Cs >= 3)");
@@ -1184,14 +1329,26 @@ extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* 
             if (C % 32 == 0) {   // 16-bit storage: the matrix-pipe form, one wave per statistics row
                 const int64_t n_rows = n_clips * M * rows;
                 VM_REQUIRE(n_rows / 4 + 1 < (1LL << 31), "vm_conv2d_first_fwd: too many windows");
-                launch_c2f_mfma<T>((const T*)in, w, bias, n_rows, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq, (hipStream_t)stream);
+                launch_c2f_mfma<T>((const T*)in, (const T*)in_lo, w, bias, n_rows, M, (int)L, Cs, C, (T*)z, (T*)z_lo, stat_sum, stat_sq, (hipStream_t)stream);
                 return check_launch("vm_conv2d_first_fwd");
             }
         }
+        VM_REQUIRE(in_lo == nullptr && z_lo == nullptr, "vm_conv2d_first_fwd_split: 16-bit storage and C % 32 == 0 (the matrix-pipe form) only");
         hipLaunchKernelGGL((conv2d_first_fwd_kernel<T>), dim3((unsigned)(n_clips * M)), dim3(256), 0, (hipStream_t)stream,
                            (const T*)in, w, bias, M, (int)L, Cs, C, (T*)z, stat_sum, stat_sq);
     });
     return check_launch("vm_conv2d_first_fwd");
+}
+
+extern "C" int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs, int C,
+                                   int dtype, void* z, float* stat_sum, float* stat_sq, void* stream) {
+    return conv2d_first_fwd(in, nullptr, w, bias, n_clips, M, L, Cs, C, dtype, z, nullptr, stat_sum, stat_sq, stream);
+}
+
+extern "C" int vm_conv2d_first_fwd_split(const void* in, const void* in_lo, const float* w, const float* bias, int64_t n_clips, int M, int64_t L,
+                                         int Cs, int C, int dtype, void* z, void* z_lo, float* stat_sum, float* stat_sq, void* stream) {
+    VM_REQUIRE(in_lo, "vm_conv2d_first_fwd_split: null pointer");
+    return conv2d_first_fwd(in, in_lo, w, bias, n_clips, M, L, Cs, C, dtype, z, z_lo, stat_sum, stat_sq, stream);
 }
 
 static int64_t c2f_blocks(int64_t n_windows) { return n_windows < 2048 ? n_windows : 2048; }

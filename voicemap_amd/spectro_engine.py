@@ -116,6 +116,11 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.melw = torch.from_numpy(spectro.mel_filterbank(self.n_mels)).to(dev)
         # 16-bit storage: the DFT on the f16 matrix pipe from hi / lo halves of basis and samples (vm_stft_logmel_f16s)
         self.stft_split = self.is16
+        # (round 6) 16-bit storage: the log-mel image as TWO planes of the storage type (hi + what hi dropped), both multiplied by the first
+        # convolution (filters split the same way inside): the one tensor of the variant with a pedestal and a single channel no longer
+        # enters at 11 bits -- its rounding alone was 7.7e-4 of config 4's 1.27e-3 (tools/probe/config4_storage_sites.py)
+        self.split_image = self.is16 and self.first_layer_direct and self.chan[0] % 32 == 0
+        self.split_z = True   # ... and its own output z1 likewise (the largest remaining site: 5.0e-4), read back as z + z_lo by the boundary pass
         self.basis16 = torch.empty(self.lib.query("vm_stft_split_basis_bytes", self.win_length) // 2, dtype=torch.float16, device=dev)
         self._call("vm_stft_split_basis", _p(self.basis), self.win_length, _p(self.basis16), self.stream())
         self.init_params(seed)
@@ -199,6 +204,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         return self.chan[i] % vec == 0 and self.cs[i + 1] % vec == 0
 
     # ---- geometry --------------------------------------------------------------------------------------------------------------
+    def _split_z(self, i: int) -> bool:
+        """block 1's conv output on two planes of the storage type (z + what its rounding dropped; the boundary pass adds them)."""
+        return i == 0 and self.split_image and self.split_z and self.stft_split and self._fused_boundary(0)
+
     def geometry(self, raw_len: int):
         T = spectro.n_frames(raw_len, self.win_length, self.hop)
         Ts, Ms = [T], [self.n_mels]
@@ -221,6 +230,9 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             nw, L = n_clips * Ms[i], Ts[i]
             b = {"nw": nw}
             b["in"] = torch.zeros(nw, L + 2, self.cin[i], dtype=tdt, device=dev)       # block input, halo rows stay zero
+            if i == 0 and self.split_image:
+                b["in_lo"] = torch.zeros_like(b["in"])                                  # ... and what its storage type dropped
+                b["z_lo"] = torch.empty(nw, L, c, dtype=tdt, device=dev)
             b["xs"] = torch.zeros(nw, L + 2, self.cs[i], dtype=tdt, device=dev)        # band-stacked
             b["z"] = torch.empty(nw, L, c, dtype=tdt, device=dev)
             if i < 3:
@@ -281,7 +293,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         if not is16:
             raw = raw.to(torch.float32)
         assert raw.shape[1] == pl["raw_len"]
-        if self.stft_split:
+        if self.stft_split and self.split_image:
+            self._call("vm_stft_logmel_f16s_split", _p(raw), int(is16), pl["n"], pl["raw_len"], self.win_length, self.hop, _p(self.basis16),
+                       _p(self.melw), self.n_mels, self.log_floor, self.dtype, _p(pl[0]["in"]), _p(pl[0]["in_lo"]), self.stream())
+        elif self.stft_split:
             self._call("vm_stft_logmel_f16s", _p(raw), int(is16), pl["n"], pl["raw_len"], self.win_length, self.hop, _p(self.basis16),
                        _p(self.melw), self.n_mels, self.log_floor, self.dtype, _p(pl[0]["in"]), self.stream())
         else:
@@ -316,7 +331,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             ssum = _p(b["ssum"]) if training else None
             ssq = _p(b["ssq"]) if training else None
             stat_rows_per_tower = wpt * b["stat_rows"]
-            if i == 0 and self.first_layer_direct:
+            if i == 0 and self.first_layer_direct and self.split_image and self.stft_split:
+                self._call("vm_conv2d_first_fwd_split", _p(b["in"]), _p(b["in_lo"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n,
+                           Mi, L, self.cs[0], c, dt, _p(b["z"]), _p(b["z_lo"]) if self._split_z(i) else None, ssum, ssq, st)
+            elif i == 0 and self.first_layer_direct:
                 self._call("vm_conv2d_first_fwd", _p(b["in"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n, Mi, L,
                            self.cs[0], c, dt, _p(b["z"]), ssum, ssq, st)
             else:
@@ -372,6 +390,10 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 self._call("vm_bn_drop_pool_gmax_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), nw, wpt, L, c, 2, dt,
                            _p(pl["gmax_w"]), _p(pl["gidx"]), _p(pl["gmax_ws"]), st)
                 self._call("vm_clip_max_fwd", _p(pl["gmax_w"]), n, Mi, 2 * (Mi // 2), c, _p(pl["gmax"]), _p(pl["widx"]), st)
+            elif self._split_z(i):
+                # block 1's z on two planes (round 6): the affine sees their sum
+                self._call("vm_bn_pool2d_stack_fwd_split", _p(b["z"]), _p(b["z_lo"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, Mi, cpt, L, c,
+                           self.cs[i + 1], dt, _p(b["q"]), _p(pl[i + 1]["xs"]), st)
             elif self._fused_boundary(i):
                 # BatchNorm affine + dropout + MaxPool2D(2, 2) + the next block's band stacking in one pass over z
                 self._call("vm_bn_pool2d_stack_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, Mi, cpt, L, c, self.cs[i + 1], dt,
