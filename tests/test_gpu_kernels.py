@@ -576,7 +576,7 @@ def f1_splits(request):
         L().call("vm_set_tuning", b"f1_fwd_blocks", per_window * n)
         L().call("vm_set_tuning", b"f1_blocks", per_window * n)
     yield per_window
-    L().call("vm_set_tuning", b"f1_fwd_blocks", 4096)
+    L().call("vm_set_tuning", b"f1_fwd_blocks", 1024)   # (the defaults)
     L().call("vm_set_tuning", b"f1_blocks", 1024)
 
 
