@@ -120,3 +120,20 @@ def test_bench_two_ranks_over_rccl_on_one_device_end_loudly():
         text = (r.stdout + r.stderr).lower()
         # the refusal must be RCCL's own (reached through init_process_group("nccl") and the first barrier) or the watchdog's
         assert "duplicate gpu" in text or "watchdog: no progress" in text, r.stderr[-3000:]
+
+
+def test_rccl_one_rank_runs_the_data_parallel_step():
+    """RCCL itself under the production data-parallel step, on the one GPU a test box has: a one-rank "nccl" process group with the
+    gradient hook forced on (tools/probe/rccl_one_rank.py).  The early all-reduce rides the side stream behind the weight-gradient GEMMs,
+    the late one sits in the optimizer hook, replayed steps issue both from their host-call slots -- and a sum over one rank being the
+    identity, parameters, Adam slots and gradients must equal an un-hooked engine's bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join("tools", "probe", "rccl_one_rank.py"), "small", "8", "7"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = _last_json_line(r.stdout)
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["same_bits"] and out["finite"]
+    assert out["collectives_per_step"] == 2 and out["replayed_programs"] >= 1
