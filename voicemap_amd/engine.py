@@ -134,6 +134,22 @@ class _DynF(float):
         return o
 
 
+_SHARED_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _shared_stream(device: torch.device, role: str) -> "torch.cuda.Stream":
+    """The process's ONE stream per (device, role) -- every engine's tower / side / misc stream.  The runtime multiplexes streams onto a
+    few hardware queues (four by default): with three private streams per engine, the streams of the fourth and sixth engine of a
+    process landed on shared queues and their three-stream step ran 7.5 % slower than the first engine's (2.80 against 2.60 ms, every
+    launch as fast as before when run serially: tools/probe/placement_spread.py).  Engines of one process enqueue one after the other,
+    so sharing the streams costs them nothing."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SHARED_STREAMS.get((idx, role))
+    if st is None:
+        st = _SHARED_STREAMS[(idx, role)] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _Program:
     """One training step as a flat list of what the host enqueued -- [0, cfunc, args, name] C-ABI calls, [1, event, stream] records,
     [2, stream, event] waits -- plus the (command, argument) slots whose value changes per step (input / label / mask pointers, the
@@ -250,7 +266,7 @@ class HipEncoderEngine:
         # optimizer) no longer waits for the last of them
         self.wgrad_after_dgrad = False
         self.defer_wgrad_tail = 0   # experiment (backward()): where the tap sums / per-tower slab folds behind every weight-gradient GEMM go
-        self.misc_stream = torch.cuda.Stream(device=self.device)
+        self.misc_stream = _shared_stream(self.device, "misc")
         # training option (bf16): vm_conv_fwd_e -- the conv epilogue also writes the pool-window extreme, the pool pass reads that
         # pooled-size tensor (same bits) and the fused BatchNorm-backward sums are taken against the exact extreme.  Off by default:
         # the passes get 0.07 ms shorter and the two epilogues 0.04 ms longer, the step does not move
@@ -279,11 +295,11 @@ class HipEncoderEngine:
         self.last_pairs = False
         self.tower_swap = False  # experiment (forward()): the first tower on the tower stream, the second on the current one
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
-        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = _shared_stream(self.device, "side")
         self._side_priority = 0
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
-        self.tower_stream = torch.cuda.Stream(device=self.device)
+        self.tower_stream = _shared_stream(self.device, "tower")
         # round 6: a training step whose input does not depend on the main stream (input_ready: a resident corpus + staged offsets, synthetic
         # data) runs its preprocessing on the tower stream as soon as the PREVIOUS step's block-1 backward has read x0 -- beside that
         # step's optimizer tail (reduce, norm, Adam, weight copies: six dependent ~5 us launches during which the chip is idle)

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib, spectro
-from .engine import HEADS, LOSSES, FlatState, HipEncoderEngine, _DT, _TORCH_DT, _align, _p
+from .engine import HEADS, LOSSES, FlatState, HipEncoderEngine, _DT, _TORCH_DT, _align, _p, _shared_stream
 
 
 class HipSpectrogramEncoderEngine(HipEncoderEngine):
@@ -105,7 +105,7 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         self.towers_concurrent = True   # forward: the two towers' GEMM launches of the small blocks side by side on two streams
         self.fuse_boundary = True   # BatchNorm + 2 x 2 pooling + band stacking as one pass per block boundary, and its adjoint
         self.fused_bn_sums = True   # ... which also leaves the two BatchNorm-backward sums of the block below (no reduce pass)
-        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = _shared_stream(self.device, "side")
         self.grad_sync = None
         self.grad_prescale = 1.0
         self._plans: Dict[tuple, dict] = {}
