@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 10.  History: 10 = config 4's log-mel image at twice the storage significand (vm_stft_logmel_f16s_split, vm_conv2d_first_fwd_split, vm_bn_pool2d_stack_fwd_split) (round 6); 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 10.  History: 10 = config 4's log-mel image at twice the storage significand (vm_stft_logmel_f16s_split, vm_conv2d_first_fwd_split, vm_conv2d_first_bn_pool_stack, vm_bn_pool2d_stack_fwd_split) (round 6); 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -585,8 +585,9 @@ int vm_conv2d_first_fwd(const void* in, const float* w, const float* bias, int64
  * matrix instructions per 32 positions x 32 channels, fp32 accumulation -- image and filters enter at ~2 x the storage significand
  * (the layer has 9 taps and one input channel: the second instruction is the whole price).  Same z layout, statistics and rounding
  * of the stored z as vm_conv2d_first_fwd; the weight gradient keeps vm_conv2d_first_wgrad on the high plane.  z_lo (optional): what
- * the storage type dropped of relu(conv + bias) as a second plane of z's layout -- the statistics are then those of z + z_lo, which is
- * what vm_bn_pool2d_stack_fwd_split normalises (the backward keeps reading z alone).  16-bit storage and C % 32 == 0 only. */
+ * the storage type dropped of relu(conv + bias) as a second plane of z's layout.  The statistics are those of the two-plane value
+ * (z + z_lo, stored or not): what vm_conv2d_first_bn_pool_stack recomputes and vm_bn_pool2d_stack_fwd_split reads back (the backward
+ * keeps reading z alone).  16-bit storage and C % 32 == 0 only. */
 int vm_conv2d_first_fwd_split(const void* in, const void* in_lo, const float* w, const float* bias, int64_t n_clips, int M, int64_t L, int Cs,
                               int C, int dtype, void* z, void* z_lo, float* stat_sum, float* stat_sq, void* stream);
 int64_t vm_conv2d_first_wgrad_workspace_bytes(int64_t n_clips, int M, int C);
@@ -617,6 +618,16 @@ int vm_pool_windows_bwd(const void* q, const void* dout, int64_t n_clips, int M,
  * vm_fold_pool_windows_rows, a_is_act = 1) turns into the BatchNorm-backward constants of the block below without a pass over (z, dq). */
 int vm_bn_pool2d_stack_fwd(const void* z, const float* scale, const float* shift, const float* drop, int64_t n_clips, int M,
                            int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);
+/* Block 1's boundary without the round trip of z: given the BatchNorm affine (the statistics come from vm_conv2d_first_fwd_split, which
+ * also leaves z for the backward), RECOMPUTE relu(conv + bias) on the two-plane image -- nine taps of a cache-resident one-channel
+ * image: cheaper than reading z back -- apply scale / shift (+ drop) to the fp32 accumulator, pool 2 x 2 and write what
+ * vm_bn_pool2d_stack_fwd writes (q per band, the band-stacked xs from the STORED q values; same layouts, same never-written halo /
+ * out-of-clip / padding entries).  The rounding of block 1's conv output is gone from the forward (5.0e-4 of config 4's f16 embedding
+ * error) and so are its bytes.  in / in_lo / w / bias / Cs as vm_conv2d_first_fwd_split; scale / shift (towers, C); drop (n_clips * M, C)
+ * or NULL; Cs2 = channel pitch of xs (>= 3 C).  16-bit storage, C in {32, 64, 96, 128}. */
+int vm_conv2d_first_bn_pool_stack(const void* in, const void* in_lo, const float* w, const float* bias, const float* scale, const float* shift,
+                                  const float* drop, int64_t n_clips, int M, int64_t clips_per_tower, int64_t L, int Cs, int C, int Cs2,
+                                  int dtype, void* q, void* xs, void* stream);
 /* vm_bn_pool2d_stack_fwd on a z that came as two planes (vm_conv2d_first_fwd_split): the affine is taken of z + z_lo in fp32. */
 int vm_bn_pool2d_stack_fwd_split(const void* z, const void* z_lo, const float* scale, const float* shift, const float* drop, int64_t n_clips,
                                  int M, int64_t clips_per_tower, int64_t L, int C, int Cs, int dtype, void* q, void* xs, void* stream);

@@ -195,9 +195,10 @@ def test_conv2d_first_layer_split_image(dt, n, M, Lw, C):
     report("conv2d_first_split[%s]" % dt, "one_plane_rel_err_vs_exact[n%d M%d L%d C%d]" % (n, M, Lw, C), e_one)
     assert e_split < (2.5e-4 if dt == "f16" else 2e-3) and e_one > 1.5 * e_split
     pad = np.zeros((n * M, rows * 128, C))
-    pad[:, :Lw] = zg
-    assert np.allclose(ssum.cpu().numpy().reshape(n * M, rows, C), pad.reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
-    assert np.allclose(ssq.cpu().numpy().reshape(n * M, rows, C), (pad * pad).reshape(n * M, rows, 128, C).sum(2), rtol=1e-5, atol=1e-4)
+    pad[:, :Lw] = zr   # (the statistics of the split entry point are those of the two-plane value, whether or not its low plane is stored)
+    rt = 1e-5 if dt == "f16" else 1e-4   # (two bf16 planes carry 16 bits)
+    assert np.allclose(ssum.cpu().numpy().reshape(n * M, rows, C), pad.reshape(n * M, rows, 128, C).sum(2), rtol=rt, atol=1e-4)
+    assert np.allclose(ssq.cpu().numpy().reshape(n * M, rows, C), (pad * pad).reshape(n * M, rows, 128, C).sum(2), rtol=rt, atol=1e-4)
     # ... with the low plane of z: the same high plane, z + z_lo is the exact value to ~2 x the significand, the statistics are those of
     # the sum; and the boundary pass on the two planes is the one-plane pass on their sum (compared in fp32 storage)
     zb, zl = torch.empty_like(z), torch.empty_like(z)
@@ -221,6 +222,22 @@ def test_conv2d_first_layer_split_image(dt, n, M, Lw, C):
         L().call("vm_bn_pool2d_stack_fwd", p(zs), p(scale), p(shift), None, n, M, n, Lw, C, Cs2, DTYPES["f32"][0], p(q1), p(xs1), stream())
         torch.cuda.synchronize()
         assert torch.equal(q2, q1.to(tdt)) and torch.equal(xs2, xs1.to(tdt))
+        # ... and the boundary that does not read z at all: the convolution redone from the two-plane image, the affine on the fp32
+        # accumulator.  It sees the exact value where the pass above sees it to two planes: the same stored q / xs but for values on a
+        # rounding boundary (one ulp there); the never-written entries (halo rows, out-of-clip slots, padding channels) stay untouched
+        drop = dev(r.choice([0.0, 1.25], size=(n * M, C), p=[0.2, 0.8]).astype(np.float32))
+        q3, xs3 = torch.full_like(q2, 7.0), torch.full_like(xs2, 7.0)
+        q4, xs4 = torch.full_like(q2, 7.0), torch.full_like(xs2, 7.0)
+        L().call("vm_conv2d_first_bn_pool_stack", p(padded(hi, tdt)), p(padded(lo, tdt)), p(dev(w)), p(dev(bias)), p(scale), p(shift), p(drop), n, M, n,
+                 Lw, Cs, C, Cs2, vm, p(q3), p(xs3), stream())
+        L().call("vm_bn_pool2d_stack_fwd_split", p(zb), p(zl), p(scale), p(shift), p(drop), n, M, n, Lw, C, Cs2, vm, p(q4), p(xs4), stream())
+        torch.cuda.synchronize()
+        for got, want in ((q3, q4), (xs3, xs4)):
+            g64, w64 = got.double().cpu().numpy(), want.double().cpu().numpy()
+            assert np.array_equal(g64 == 7.0, w64 == 7.0)                                 # the same entries written
+            assert np.mean(g64 != w64) < (2e-3 if dt == "f16" else 2e-2)
+            # (one ulp, plus what the two-plane value's 2^-22 / 2^-17 becomes where scale * z and shift cancel)
+            assert np.all(np.abs(g64 - w64) <= np.abs(w64) * (2.0 ** -10 if dt == "f16" else 2.0 ** -7) + (1e-5 if dt == "f16" else 3e-4))
 
 
 def test_stft_logmel_split_planes():

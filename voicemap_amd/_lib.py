@@ -126,6 +126,7 @@ SIGNATURES = {
     "vm_conv2d_first_supported": (I, [I, I]),
     "vm_conv2d_first_fwd": (I, [P, P, P, L, I, L, I, I, I, P, P, P, P]),
     "vm_conv2d_first_fwd_split": (I, [P, P, P, P, L, I, L, I, I, I, P, P, P, P, P]),
+    "vm_conv2d_first_bn_pool_stack": (I, [P, P, P, P, P, P, P, L, I, L, L, I, I, I, I, P, P, P]),
     "vm_conv2d_first_wgrad_workspace_bytes": (L, [L, I, I]),
     "vm_conv2d_first_wgrad": (I, [P, P, L, I, L, I, I, I, P, P, P]),
     "vm_stack_windows": (I, [P, L, I, L, I, I, I, P, P]),

@@ -808,8 +808,8 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
                                                                     const float* __restrict__ bias, int64_t n_rows, int M, int L, int Cs,
                                                                     T* __restrict__ z, T* __restrict__ z_lo, float* __restrict__ stat_sum,
                                                                     float* __restrict__ stat_sq) {
-    // z_lo (SPLIT only, optional): what the storage type dropped of relu(conv) as a second plane; the statistics are then those of
-    // z + z_lo (what vm_bn_pool2d_stack_fwd_split normalises)
+    // SPLIT: the statistics are those of relu(conv + bias) to two planes of the storage type (z + what z's rounding dropped) -- what
+    // vm_conv2d_first_bn_pool_stack recomputes and what vm_bn_pool2d_stack_fwd_split reads back; z_lo (optional) stores the low plane
     constexpr int C = 32 * CB;
     using Frag = typename Mma16<T>::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
                 tile[pl * C + 32 * cb + col] = h;
                 if constexpr (SPLIT) {
                     zl[cb][r] = Elem<T>::from_f(v - rf[r]);
-                    if (z_lo != nullptr) rf[r] += Elem<T>::to_f(zl[cb][r]);
+                    rf[r] += Elem<T>::to_f(zl[cb][r]);   // the statistics of the two-plane value, whether or not its low plane is stored
                 }
             }
             if (!whole) {
@@ -980,6 +980,176 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_mfma_kernel(const T* __r
                 stat_sq[row * C + 32 * cb + col] = b;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block 1's boundary WITHOUT the round trip of z (vm_conv2d_first_bn_pool_stack, round 6): once the statistics are known (they come from
+// vm_conv2d_first_fwd_split, which also leaves z for the backward), the convolution is nine taps of a 10 MB image -- cheaper to redo than
+// to read back -- so this kernel recomputes relu(conv + bias) on the two-plane image (the SPLIT operands above, two matrix instructions
+// per band and 32 x 32 tile), applies the BatchNorm affine (+ dropout) to the fp32 accumulator, pools 2 x 2 and writes what
+// vm_bn_pool2d_stack_fwd writes: q (per band, pooled along T, rounded to the storage type: the backward routes through it) and the
+// band-stacked block-2 input xs = the larger of the two bands' STORED q.  z is neither read nor rounded on the way: the rounding of
+// block 1's conv output (5.0e-4 of config 4's embedding error in f16) is gone and so are 312 MB of reads per 256 clips.
+// D puts a channel in a lane and 16 positions in its registers (r -> position (r & 3) + 8 (r >> 2) + 4 kh): the pool pair (2 t', 2 t' + 1)
+// is registers (r, r + 1) of one lane, the band pair two accumulators of the same lane -- no cross-lane traffic; q0 / q1 / xs tiles
+// (16 pooled positions x C) leave through a wave-private LDS transpose as 16-byte stores.
+// A wave owns 128 positions (64 pooled) of one band pair of one clip.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CB>
+__global__ __launch_bounds__(256) void conv2d_first_bn_pool_stack_kernel(const T* __restrict__ in, const T* __restrict__ in_lo,
+                                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                         const float* __restrict__ drop, int64_t n_items, int64_t wpt, int M,
+                                                                         int L, int Cs, int Cs2, T* __restrict__ q, T* __restrict__ xs) {
+    constexpr int C = 32 * CB;
+    using Frag = typename Mma16<T>::Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int chunks = (L + 127) / 128;
+    const int Mo = M / 2, Mh = (M + 1) / 2, Lq = L / 2;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;   // (clip, band pair, 128-position chunk); no workgroup barrier below
+    if (item >= n_items) return;
+    const int chunk = (int)(item % chunks);
+    const int64_t bp = item / chunks;
+    const int64_t b = bp / Mh;
+    const int mo = (int)(bp - b * Mh);
+    const int64_t n0 = b * M + 2 * mo;                      // the pair's first band as a window
+    const bool pair = 2 * mo + 1 < M;                       // (odd band count: the last band has no partner, the floor pooling drops it)
+    const int64_t tw = n0 / wpt;
+    T* t0s = reinterpret_cast<T*>(smem) + wave * 3 * 16 * C;   // [q0 | q1 | xs][16 pooled positions][C]
+    T* t1s = t0s + 16 * C;
+    T* tps = t1s + 16 * C;
+
+    Frag wb[CB], wb2[CB];
+    {
+        const int n = 5 - kh;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) {
+            const int part = sl / n, e = sl - part * n;
+            const int k = 5 * kh + e, kt = k / 3, km = k - 3 * kt;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                T v = Elem<T>::from_f(0.f);
+                if (part < 3) {
+                    const float wf = w[((int64_t)kt * Cs + km) * C + 32 * cb + col];
+                    const T wh = Elem<T>::from_f(wf);
+                    v = part < 2 ? wh : Elem<T>::from_f(wf - Elem<T>::to_f(wh));
+                }
+                if (sl < 8) wb[cb][sl] = v; else wb2[cb][sl - 8] = v;
+            }
+        }
+    }
+    int off[5];
+    unsigned ok0 = 0, ok1 = 0;   // which taps of band 2 mo / 2 mo + 1 lie inside the clip
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        const int k = 5 * kh + e, kt = k / 3, km = k - 3 * kt;
+        off[e] = (km - 1) * (L + 2) + kt;
+        if (e < 5 - kh) {
+            const int ms0 = 2 * mo + km - 1, ms1 = ms0 + 1;
+            if (ms0 >= 0 && ms0 < M) ok0 |= 1u << e;
+            if (pair && ms1 >= 0 && ms1 < M) ok1 |= 1u << e;
+        }
+    }
+    float bv[CB], sc[CB], sh[CB], d0[CB], d1[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int c = 32 * cb + col;
+        bv[cb] = bias[c];
+        sc[cb] = scale[tw * C + c];
+        sh[cb] = shift[tw * C + c];
+        d0[cb] = drop ? drop[n0 * C + c] : 1.f;
+        d1[cb] = (drop && pair) ? drop[(n0 + 1) * C + c] : 1.f;
+    }
+    const T* base_h = in + n0 * (int64_t)(L + 2);
+    const T* base_l = in_lo + n0 * (int64_t)(L + 2);
+    const T zero = Elem<T>::from_f(0.f);
+    const bool up = kh != 0;
+    auto gather = [&](const T* bh, const T* bl, unsigned ok, int t, Frag& a, Frag& a2) {
+        T hi[5], lo[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            hi[e] = lo[e] = zero;
+            if (((ok >> e) & 1u) && t < L) {
+                hi[e] = bh[off[e] + t];
+                lo[e] = bl[off[e] + t];
+            }
+        }
+        a[0] = hi[0]; a[1] = hi[1]; a[2] = hi[2]; a[3] = hi[3];
+        a[4] = up ? lo[0] : hi[4];
+        a[5] = up ? lo[1] : lo[0];
+        a[6] = up ? lo[2] : lo[1];
+        a[7] = up ? lo[3] : lo[2];
+        a2[0] = up ? hi[0] : lo[3];
+        a2[1] = up ? hi[1] : lo[4];
+        a2[2] = up ? hi[2] : hi[0];
+        a2[3] = up ? hi[3] : hi[1];
+        a2[4] = up ? zero : hi[2];
+        a2[5] = up ? zero : hi[3];
+        a2[6] = up ? zero : hi[4];
+        a2[7] = zero;
+    };
+    T* q0 = q + (n0 * (Lq + 2) + 1) * (int64_t)C;
+    T* q1 = q0 + (int64_t)(Lq + 2) * C;
+    const int64_t xrow = (int64_t)(Lq + 2) * Cs2;
+    T* x1 = xs + ((b * Mo + mo) * (int64_t)(Lq + 2) + 1) * Cs2;
+
+    for (int ti = 0; ti < 4; ++ti) {
+        const int tt0 = chunk * 128 + ti * 32;    // first position of the tile; its pooled positions start at tt0 / 2
+        const int p0 = tt0 / 2;
+        if (p0 >= Lq) break;
+        const int t = tt0 + col;
+        Frag a, a2, c1, c2;
+        gather(base_h, base_l, ok0, t, a, a2);
+        if (pair) gather(base_h + (L + 2), base_l + (L + 2), ok1, t, c1, c2);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv[cb];
+            acc0 = Mma16<T>::run32(a, wb[cb], acc0);
+            acc0 = Mma16<T>::run32(a2, wb2[cb], acc0);
+            if (pair) {
+                acc1 = Mma16<T>::run32(c1, wb[cb], acc1);
+                acc1 = Mma16<T>::run32(c2, wb2[cb], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int pp = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * kh;   // pooled position of registers (r, r + 1) inside the tile
+                const float ya = fmaf(fmaxf(acc0[r], 0.f), sc[cb], sh[cb]) * d0[cb], yb = fmaf(fmaxf(acc0[r + 1], 0.f), sc[cb], sh[cb]) * d0[cb];
+                const T h0 = Elem<T>::from_f(yb > ya ? yb : ya);
+                t0s[pp * C + 32 * cb + col] = h0;
+                if (pair) {
+                    const float yc = fmaf(fmaxf(acc1[r], 0.f), sc[cb], sh[cb]) * d1[cb], yd = fmaf(fmaxf(acc1[r + 1], 0.f), sc[cb], sh[cb]) * d1[cb];
+                    const T h1 = Elem<T>::from_f(yd > yc ? yd : yc);
+                    t1s[pp * C + 32 * cb + col] = h1;
+                    tps[pp * C + 32 * cb + col] = Elem<T>::to_f(h0) >= Elem<T>::to_f(h1) ? h0 : h1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private tiles: the LDS serves a wave's accesses in order)
+        const int np = Lq - p0 < 16 ? Lq - p0 : 16;          // pooled positions of this tile that exist
+        constexpr int VPP = C / 8;                             // 16-byte vectors per position
+#pragma unroll
+        for (int i = 0; i < (16 * VPP + 63) / 64; ++i) {
+            const int idx = i * 64 + lane, pp = idx / VPP, v = idx - pp * VPP;
+            if (pp < np) {
+                const u32x4 v0 = *reinterpret_cast<const u32x4*>(t0s + pp * C + v * 8);
+                *reinterpret_cast<u32x4*>(q0 + (int64_t)(p0 + pp) * C + v * 8) = v0;
+                if (pair) {
+                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(t1s + pp * C + v * 8);
+                    const u32x4 vp = *reinterpret_cast<const u32x4*>(tps + pp * C + v * 8);
+                    *reinterpret_cast<u32x4*>(q1 + (int64_t)(p0 + pp) * C + v * 8) = v1;
+                    T* xr = x1 + (int64_t)(p0 + pp) * Cs2 + v * 8;
+                    *reinterpret_cast<u32x4*>(xr + C) = vp;                                  // this band: the middle slot of its own window
+                    if (mo + 1 < Mo) *reinterpret_cast<u32x4*>(xr + xrow) = vp;              // band mo + 1 sees it as its lower neighbour
+                    if (mo >= 1) *reinterpret_cast<u32x4*>(xr - xrow + 2 * C) = vp;          // band mo - 1 as its upper neighbour
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -1349,6 +1519,33 @@ extern "C" int vm_conv2d_first_fwd_split(const void* in, const void* in_lo, cons
                                          int Cs, int C, int dtype, void* z, void* z_lo, float* stat_sum, float* stat_sq, void* stream) {
     VM_REQUIRE(in_lo, "vm_conv2d_first_fwd_split: null pointer");
     return conv2d_first_fwd(in, in_lo, w, bias, n_clips, M, L, Cs, C, dtype, z, z_lo, stat_sum, stat_sq, stream);
+}
+
+extern "C" int vm_conv2d_first_bn_pool_stack(const void* in, const void* in_lo, const float* w, const float* bias, const float* scale,
+                                             const float* shift, const float* drop, int64_t n_clips, int M, int64_t clips_per_tower, int64_t L,
+                                             int Cs, int C, int Cs2, int dtype, void* q, void* xs, void* stream) {
+    VM_REQUIRE(in && in_lo && w && bias && scale && shift && q && xs, "vm_conv2d_first_bn_pool_stack: null pointer");
+    VM_REQUIRE(n_clips > 0 && M >= 2 && clips_per_tower > 0 && L >= 2 && Cs >= 3 && Cs2 >= 3 * C && Cs2 % 8 == 0,
+               "vm_conv2d_first_bn_pool_stack: bad sizes (M >= 2, L >= 2, Cs >= 3, Cs2 >= 3 C, Cs2 % 8 == 0)");
+    VM_REQUIRE((dtype == VM_BF16 || dtype == VM_F16) && C % 32 == 0 && C >= 32 && C <= 128,
+               "vm_conv2d_first_bn_pool_stack: 16-bit storage and C in {32, 64, 96, 128} (the matrix-pipe form) only");
+    const int64_t n_items = n_clips * ((M + 1) / 2) * ((L + 127) / 128);
+    VM_REQUIRE(n_items / 4 + 1 < (1LL << 31), "vm_conv2d_first_bn_pool_stack: too many windows");
+    const dim3 grid((unsigned)((n_items + 3) / 4));
+    const size_t lds = (size_t)4 * 3 * 16 * C * 2;
+#define VM_LAUNCH_C2P(CB)                                                                                                                     \
+    hipLaunchKernelGGL((conv2d_first_bn_pool_stack_kernel<T, CB>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)in, (const T*)in_lo, w, \
+                       bias, scale, shift, drop, n_items, clips_per_tower * M, M, (int)L, Cs, Cs2, (T*)q, (T*)xs)
+    VM_DISPATCH_16(dtype, {
+        switch (C / 32) {
+            case 1: VM_LAUNCH_C2P(1); break;
+            case 2: VM_LAUNCH_C2P(2); break;
+            case 3: VM_LAUNCH_C2P(3); break;
+            default: VM_LAUNCH_C2P(4); break;
+        }
+    });
+#undef VM_LAUNCH_C2P
+    return check_launch("vm_conv2d_first_bn_pool_stack");
 }
 
 static int64_t c2f_blocks(int64_t n_windows) { return n_windows < 2048 ? n_windows : 2048; }

@@ -121,6 +121,9 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
         # enters at 11 bits -- its rounding alone was 7.7e-4 of config 4's 1.27e-3 (tools/probe/config4_storage_sites.py)
         self.split_image = self.is16 and self.first_layer_direct and self.chan[0] % 32 == 0
         self.split_z = True   # ... and its own output z1 likewise (the largest remaining site: 5.0e-4), read back as z + z_lo by the boundary pass
+        # ... or not read back at all: the boundary pass recomputes the nine-tap convolution from the image (cheaper than 312 MB of z per
+        # 256 clips) and normalises the fp32 accumulator.  False: z_lo is stored and read (vm_bn_pool2d_stack_fwd_split)
+        self.recompute_boundary = True
         self.basis16 = torch.empty(self.lib.query("vm_stft_split_basis_bytes", self.win_length) // 2, dtype=torch.float16, device=dev)
         self._call("vm_stft_split_basis", _p(self.basis), self.win_length, _p(self.basis16), self.stream())
         self.init_params(seed)
@@ -333,7 +336,8 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
             stat_rows_per_tower = wpt * b["stat_rows"]
             if i == 0 and self.first_layer_direct and self.split_image and self.stft_split:
                 self._call("vm_conv2d_first_fwd_split", _p(b["in"]), _p(b["in_lo"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n,
-                           Mi, L, self.cs[0], c, dt, _p(b["z"]), _p(b["z_lo"]) if self._split_z(i) else None, ssum, ssq, st)
+                           Mi, L, self.cs[0], c, dt, _p(b["z"]), _p(b["z_lo"]) if (self._split_z(i) and not self.recompute_boundary) else None,
+                           ssum, ssq, st)
             elif i == 0 and self.first_layer_direct:
                 self._call("vm_conv2d_first_fwd", _p(b["in"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")), n, Mi, L,
                            self.cs[0], c, dt, _p(b["z"]), ssum, ssq, st)
@@ -390,6 +394,12 @@ class HipSpectrogramEncoderEngine(HipEncoderEngine):
                 self._call("vm_bn_drop_pool_gmax_fwd", _p(b["z"]), _p(b["scale"]), _p(b["shift"]), _p(dm), nw, wpt, L, c, 2, dt,
                            _p(pl["gmax_w"]), _p(pl["gidx"]), _p(pl["gmax_ws"]), st)
                 self._call("vm_clip_max_fwd", _p(pl["gmax_w"]), n, Mi, 2 * (Mi // 2), c, _p(pl["gmax"]), _p(pl["widx"]), st)
+            elif self._split_z(i) and self.recompute_boundary:
+                # block 1's boundary without the round trip of z: the convolution redone on the two-plane image, affine + pool + stacking
+                # out of the fp32 accumulator (z, left by the launch above, is the backward's)
+                self._call("vm_conv2d_first_bn_pool_stack", _p(b["in"]), _p(b["in_lo"]), _p(self.view("conv1.kernel")), _p(self.view("conv1.bias")),
+                           _p(b["scale"]), _p(b["shift"]), _p(dm), n, Mi, cpt, L, self.cs[0], c, self.cs[i + 1], dt, _p(b["q"]),
+                           _p(pl[i + 1]["xs"]), st)
             elif self._split_z(i):
                 # block 1's z on two planes (round 6): the affine sees their sum
                 self._call("vm_bn_pool2d_stack_fwd_split", _p(b["z"]), _p(b["z_lo"]), _p(b["scale"]), _p(b["shift"]), _p(dm), n, Mi, cpt, L, c,
