@@ -295,7 +295,12 @@ class HipEncoderEngine:
         self.last_pairs = False
         self.tower_swap = False  # experiment (forward()): the first tower on the tower stream, the second on the current one
         self.tower_stagger = 0  # experiment: tower 2's forward starts after tower 1's block-1 conv (1) / whole block 1 (2)
-        self.side_stream = _shared_stream(self.device, "side")
+        # (round 6, last session) the weight-gradient chain rides the TOWER stream: that stream is idle during the backward, the side
+        # stream was idle during the forward, and one stream beside the main one beats two at every size -- interleaved on one box
+        # (tools/probe/stream_merge_ab.py): cfg-A 128 pairs 2.559 -> 2.549 ms, 64 pairs 1.440 -> 1.427, 32 pairs 0.875 -> 0.860; cfg-B 32
+        # pairs 0.482 -> 0.454 (- 5.8 %), 128 pairs 1.023 -> 1.007: fewer cross-queue hand-overs (the same direction as capping the
+        # runtime at two hardware queues, GPU_MAX_HW_QUEUES=2: 0.474 -> 0.455; one queue: + 12 %).  Same launches, same bits.
+        self.side_stream = _shared_stream(self.device, "tower")
         self._side_priority = 0
         # training forward: the second tower on its own stream (see forward())
         self.split_towers = True
