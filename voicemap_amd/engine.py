@@ -753,9 +753,13 @@ class HipEncoderEngine:
     @side_priority.setter
     def side_priority(self, v):
         """experiment (bench.py --tune side_priority=N): the HIP priority of the side stream the weight-gradient GEMMs run on"""
+        if int(v) == self._side_priority:
+            return
         self._side_priority = int(v)
         self._drop_programs()
-        self.side_stream = torch.cuda.Stream(device=self.device, priority=int(v))
+        # 0: back on the process's shared stream; anything else is a private stream of that priority (an experiment: see _shared_stream
+        # for what private streams cost the later engines of a process)
+        self.side_stream = _shared_stream(self.device, "tower") if int(v) == 0 else torch.cuda.Stream(device=self.device, priority=int(v))
 
     def refresh_weights(self):
         """fp32 master conv kernels -> GEMM-layout copies in the storage dtype (wf: forward, wd: dgrad)."""
