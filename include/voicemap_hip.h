@@ -49,7 +49,7 @@ enum { VM_HEAD_UNIFORM_EUCLIDEAN = 0, VM_HEAD_WEIGHTED_L1 = 1 };
 enum { VM_DIST_EUCLIDEAN = 0, VM_DIST_COSINE = 1, VM_DIST_DOT = 2 };
 
 const char* vm_last_error(void);
-/* 10.  History: 10 = config 4's log-mel image at twice the storage significand (vm_stft_logmel_f16s_split, vm_conv2d_first_fwd_split, vm_conv2d_first_bn_pool_stack, vm_bn_pool2d_stack_fwd_split) (round 6); 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
+/* 11.  History: 11 = vm_program_run / vm_program_table_hash, the native runner of a recorded step (round 6); 10 = config 4's log-mel image at twice the storage significand (vm_stft_logmel_f16s_split, vm_conv2d_first_fwd_split, vm_conv2d_first_bn_pool_stack, vm_bn_pool2d_stack_fwd_split) (round 6); 9 = the last block in pair form (vm_bn_drop_pool_gmax_partials_e, vm_bn_bwd_gmax_finalize_e, vm_bn_pool_bwd_apply_pairs_gmax) (round 6); 8 = vm_mfma_rate_probe[_flops], vm_bn_bwd_gmax_finalize; vm_pairdist_workspace_bytes grew by the scalar-path copy of the queries (round 6); 7 = the fused tail (vm_tail_fwd_bwd, vm_tail_param_grads, vm_bn_drop_pool_gmax_partials), vm_event_* / vm_stream_wait_event, centred tiles (`ctr_out` of vm_fold_bn_weights, `e_center` of vm_conv_fwd_fold / vm_bn_pool_bwd_apply_pairs, `tile_center` of vm_bn_finalize) (round 5); 6 = packed weights (vm_pack_nt_weights[_batch]; the `*_packed` argument of vm_conv_fwd_fold / vm_conv_fwd_pool /
  * vm_conv_dgrad_bnred; `bias`, `wf_packed` and the fourth hb row of vm_fold_bn_weights), the centred block-1 extreme (`center_bias` /
  * `shift_adj` / `mean_adj` of vm_bn_finalize) (round 4).  Earlier: 1 = round 1; 2 = vm_bn_finalize gained the zero-debias arguments (round 2); 3 = VM_F16, `dtype` in vm_conv1_fused_*,
  * `grad_scale` in the loss entry points, `skip_nonfinite` in vm_adam_clip_step, vm_embed_* / vm_pairdist_* (round 3); 4 = the folded-BatchNorm training forward
@@ -71,6 +71,17 @@ int vm_event_create(void** event_out);
 int vm_event_destroy(void* event);
 int vm_event_record(void* event, void* stream);
 int vm_stream_wait_event(void* stream, void* event);
+/* A recorded training step made from C (round 6).  The Python side records the C-ABI calls of one step -- entry point, argument list,
+ * event records / waits between its streams -- and replays that list while the configuration stays the same (voicemap_amd/engine.py
+ * _Program; the reference runs the same train_on_batch 500 times an epoch, experiments/train_siamese.py:65-94).  At the reference's own
+ * batch sizes the step is bound by the host making ~70 calls, and ~1.5 us of each is the binding's argument marshalling: vm_program_run
+ * takes the list as int64 words  [function id, argc, argument words ...]*  (pointers and integers as they are, floats / doubles as their
+ * bits) and makes the calls itself, in order, stopping at the first non-zero return code (its word index in *fail_at).  Function ids are
+ * positions in the name-sorted table of int-returning entry points whose arguments are pointers / int / int64_t / float / double
+ * (csrc/program_run.hip, generated by tools/gen_program_run.py from the binding table); vm_program_table_hash() identifies that table so
+ * that a binding generated from another one refuses to run. */
+int vm_program_run(const int64_t* words, int64_t n_words, int64_t* fail_at);
+int64_t vm_program_table_hash(void);
 /* Measurement aid (round 6; not part of the drop-in surface, bench.py only): every SIMD of the device issuing dense
  * v_mfma_f32_32x32x16 (VM_BF16 / VM_F16 operands, non-zero values) back to back from registers for `iters` x 8 instructions per
  * wave -- the rate the part SUSTAINS under its power limit, which the step's GEMM launches (they run on that limit) are priced

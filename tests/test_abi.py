@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in _lib.header_functions():
         assert hasattr(cdll, name), name
     lib = _lib.lib()
-    assert lib.abi == _lib.ABI_VERSION == 10
+    assert lib.abi == _lib.ABI_VERSION == 11
     assert lib.query("vm_bn_part_rows") > 0
     assert lib.query("vm_conv_stat_rows", 3000) == 24
     assert lib.query("vm_conv_wgrad_splits", 256, 3000, 128, 256) >= 1
@@ -58,3 +58,37 @@ def test_tuning_table_is_small_and_rejects_unknown_keys():
     for gone in (b"nt_ablate", b"nt_ring", b"nt_p8", b"nt_w4", b"nt_n2r", b"gemm_kb", b"no_such_knob"):
         assert lib.cdll.vm_set_tuning(gone, 1) != 0, gone
     assert lib.cdll.vm_set_tuning(None, 1) != 0
+
+
+def test_program_runner_is_generated_from_the_binding_table_and_dispatches():
+    """csrc/program_run.hip is what tools/gen_program_run.py prints for the current binding table; the loaded library reports that
+    table's hash; and vm_program_run walks a word list in order, stopping at the first non-zero return code with its position --
+    checked with entry points that need no GPU (a `_supported` query that answers 0, then vm_bn_part_rows, whose non-zero answer is
+    taken for a failure code)."""
+    import ctypes
+    import importlib.util
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_program_run", os.path.join(root, "tools", "gen_program_run.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(root, "voicemap_amd", "csrc", "program_run.hip")) as f:
+        assert f.read() == gen.render(), "run python tools/gen_program_run.py"
+    tab = _lib.program_table()
+    assert tab is not None, "the library's vm_program_table_hash() is not the binding's"
+    ids, sigs = tab
+    assert sigs["vm_event_record"] == "PP" and sigs["vm_adam_clip_step"].count("F") >= 5
+    lib = _lib.lib()
+    rows = lib.cdll.vm_bn_part_rows()
+    assert rows > 0
+    words = np.array([ids["vm_conv_fwd_fold_supported"], 6, 1, 7, 3, 5, 1, 0,      # an odd shape: not served -> 0 -> the run goes on
+                      ids["vm_bn_part_rows"], 0,
+                      ids["vm_abi_version"], 0], dtype=np.int64)
+    fail = ctypes.c_int64(-1)
+    rc = lib.cdll.vm_program_run(words.ctypes.data, words.size, ctypes.byref(fail))
+    assert rc == rows and fail.value == 8
+    # a wrong argument count and an unknown id are refused at their position
+    bad = np.array([ids["vm_bn_part_rows"], 1, 0], dtype=np.int64)
+    assert lib.cdll.vm_program_run(bad.ctypes.data, bad.size, ctypes.byref(fail)) == -1 and fail.value == 0
+    bad = np.array([10 ** 6, 0], dtype=np.int64)
+    assert lib.cdll.vm_program_run(bad.ctypes.data, bad.size, ctypes.byref(fail)) == -1 and fail.value == 0

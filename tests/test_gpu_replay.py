@@ -57,6 +57,32 @@ def test_replayed_siamese_steps_are_the_eager_steps(dtype, dropout, loss):
     kinds = [c[0] for c in progs[0].cmds]
     assert kinds.count(0) > 30 and kinds.count(1) >= 3 and kinds.count(2) >= 3
     assert {k if not isinstance(k, tuple) else k[0] for _, _, k in progs[0].patches} <= {"raw", "y", "loss_scale", "zc", "lr_t", "gpre", "drop", "dropb"}
+    # ... and (round 6) the same list as int64 words for the library's own runner, which is what replayed it above
+    assert a.native_replay and progs[0].native is not None
+    segs, slots = progs[0].native
+    assert len(segs) == 1 and len(slots) == len(progs[0].patches) and segs[0].dtype == np.int64
+
+
+@pytest.mark.parametrize("dtype,dropout", [("f16", 0.05), ("f32", 0.0)])
+def test_the_native_runner_and_the_python_loop_replay_the_same_steps(dtype, dropout):
+    """vm_program_run (the recorded step as int64 words, called once per step) against the Python loop of ctypes calls it replaces:
+    the same launches with the same arguments -- bit-identical state after every step, float and double slots (lr_t, the zero-debias
+    factor, the loss scale) included."""
+    from voicemap_amd.engine import HipEncoderEngine
+    a = HipEncoderEngine(BLOCKS, 32, dropout=dropout, head="weighted_l1", dtype=dtype, seed=11)
+    b = HipEncoderEngine(BLOCKS, 32, dropout=dropout, head="weighted_l1", dtype=dtype, seed=11)
+    b.native_replay = False
+    r = np.random.default_rng(4)
+    pairs, raw_len = 6, 4800
+    for step in range(8):
+        x1 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        x2 = r.normal(0, 0.05, (pairs, raw_len, 1)).astype(np.float32)
+        y = (r.random((pairs, 1)) > 0.5).astype(np.float32)
+        for eng in (a, b):
+            eng.siamese_train_step(x1, x2, y, loss="bce", preprocessed=False, downsampling=4)
+        torch.cuda.synchronize()
+        _same_state(a, b, step)
+    assert _programs(a)[0].native is not None and len(_programs(b)) == 1
 
 
 def test_replay_follows_the_configuration():

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VOICEMAP_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER_PATH = os.path.join(_HERE, "..", "include", "voicemap_hip.h")
 
 VM_F32, VM_BF16, VM_F32S, VM_F16 = 0, 1, 2, 3
-ABI_VERSION = 10  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
+ABI_VERSION = 11  # include/voicemap_hip.h vm_abi_version(): checked when the library is loaded
 VM_LOSS_CONTRASTIVE, VM_LOSS_BCE = 0, 1
 VM_HEAD_UNIFORM_EUCLIDEAN, VM_HEAD_WEIGHTED_L1 = 0, 1
 VM_DIST_EUCLIDEAN, VM_DIST_COSINE, VM_DIST_DOT = 0, 1, 2
@@ -36,6 +36,8 @@ SIGNATURES = {
     "vm_event_destroy": (I, [P]),
     "vm_event_record": (I, [P, P]),
     "vm_stream_wait_event": (I, [P, P]),
+    "vm_program_run": (I, [P, L, P]),
+    "vm_program_table_hash": (L, []),
     "vm_set_tuning": (I, [c_char_p, I]),
     "vm_mfma_rate_probe": (I, [I, I, P, P]),
     "vm_mfma_rate_probe_flops": (L, [I]),
@@ -187,6 +189,23 @@ class _Lib:
 
 
 _LIB = None
+_PROGRAM_TABLE = False
+
+
+def program_table():
+    """(name -> function id, name -> "PILFD" argument types) of vm_program_run, or None when the loaded library was generated from
+    another table than this binding's (tools/gen_program_run.py: ids are positions in the name-sorted list of int-returning entry
+    points whose arguments are pointers / int / int64 / float / double)."""
+    global _PROGRAM_TABLE
+    if _PROGRAM_TABLE is False:
+        import zlib
+        code = {P: "P", I: "I", L: "L", F: "F", D: "D"}
+        tab = [(n, "".join(code[a] for a in SIGNATURES[n][1])) for n in sorted(SIGNATURES)
+               if SIGNATURES[n][0] is I and n != "vm_program_run" and all(a in code for a in SIGNATURES[n][1])]
+        h = zlib.crc32(";".join("%s:%s" % t for t in tab).encode()) & 0x7FFFFFFF
+        ok = lib().cdll.vm_program_table_hash() == h
+        _PROGRAM_TABLE = ({n: k for k, (n, _) in enumerate(tab)}, dict(tab)) if ok else None
+    return _PROGRAM_TABLE
 
 
 def lib():

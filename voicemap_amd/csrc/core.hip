@@ -28,7 +28,7 @@ int check_launch(const char* what) {
 
 extern "C" const char* vm_last_error(void) { return vm::g_err; }
 
-extern "C" int vm_abi_version(void) { return 10; }
+extern "C" int vm_abi_version(void) { return 11; }
 
 extern "C" int vm_check_device(void) {
     int dev = 0;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import struct
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -159,6 +160,9 @@ class _Program:
 
     def __init__(self):
         self.cmds, self.patches, self.events = [], [], {}
+        # the same list for the library's own runner (vm_program_run): segments -- int64 word arrays, or host calls between them -- and
+        # the (segment, word index, type) of every per-step slot; None: this program replays through the Python loop
+        self.native = None
 
 
 class HipEncoderEngine:
@@ -174,6 +178,9 @@ class HipEncoderEngine:
     _rec = None
     _stream_stack = ()
     replay = False
+    native_replay = True   # a recorded step is replayed by the library's own runner (vm_program_run) instead of a Python loop of ctypes calls
+    _fail_at_v = ctypes.c_int64(0)
+    _fail_at = ctypes.byref(_fail_at_v)
     fused_tail = False
     _packed_weights = False
 
@@ -519,7 +526,61 @@ class HipEncoderEngine:
                 h = prog.events[c[slot]] = out.value
             c[slot] = h
         self._ev_record, self._ev_wait = self.lib.cdll.vm_event_record, self.lib.cdll.vm_stream_wait_event
+        prog.native = self._native_program(prog)   # (used while engine.native_replay is on)
         return prog
+
+    @staticmethod
+    def _word(v, t):
+        """One argument as the int64 word vm_program_run expects: pointers / integers as they are, floats / doubles as their bits."""
+        if t == "F":
+            return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+        if t == "D":
+            return struct.unpack("<q", struct.pack("<d", float(v)))[0]
+        if v is None:
+            return 0
+        if isinstance(v, (ctypes.Array, ctypes.Structure)):   # a host-side argument block (pointer / size tables of the batched entry
+            v = ctypes.addressof(v)                           # points): its address -- the object stays alive in the program's list
+        elif isinstance(v, ctypes._SimpleCData):
+            v = v.value or 0
+        v = int(v)
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def _native_program(self, prog: _Program):
+        """The recorded step as word arrays for vm_program_run (include/voicemap_hip.h): one array per run of C-ABI calls and event
+        records / waits, host calls (the gradient collectives of data parallelism) between them.  None where the library's table is
+        not the binding's or an argument is not a pointer / number."""
+        tab = _lib.program_table()
+        if tab is None:
+            return None
+        ids, sigs = tab
+        segs, cur, where = [], [], {}
+        try:
+            for ci, c in enumerate(prog.cmds):
+                if c[0] == 3:
+                    segs.append(cur)
+                    segs.append(c[1])
+                    cur = []
+                    continue
+                if c[0] == 0:
+                    name, args = c[3], c[2]
+                elif c[0] == 1:
+                    name, args = "vm_event_record", (c[1], c[2])
+                else:
+                    name, args = "vm_stream_wait_event", (c[1], c[2])
+                sig = sigs[name]
+                if len(sig) != len(args):
+                    return None
+                where[ci] = (len(segs), len(cur) + 2)
+                cur += [ids[name], len(args)] + [self._word(v, t) for v, t in zip(args, sig)]
+            segs.append(cur)
+            patches = []
+            for ci, ai, key in prog.patches:
+                si, w0 = where[ci]
+                patches.append((si, w0 + ai, sigs[prog.cmds[ci][3]][ai], key))
+        except (KeyError, TypeError, ValueError, struct.error):
+            return None
+        segs = [np.array(sg, dtype=np.int64) if isinstance(sg, list) else sg for sg in segs]
+        return segs, patches
 
     def _destroy_program(self, prog):
         if isinstance(prog, _Program):
@@ -547,6 +608,23 @@ class HipEncoderEngine:
             pass
 
     def _run_program(self, prog: _Program, dyn: dict):
+        if prog.native is not None and self.native_replay:
+            segs, patches = prog.native
+            word = self._word
+            for si, wi, t, key in patches:
+                segs[si][wi] = word(dyn[key], t)
+            run, fail = self.lib.cdll.vm_program_run, self._fail_at
+            for sg in segs:
+                if isinstance(sg, np.ndarray):
+                    if sg.size:
+                        rc = run(sg.ctypes.data, sg.size, fail)
+                        if rc != 0:
+                            msg = self.lib.cdll.vm_last_error()
+                            raise _lib.VoicemapHipError("a replayed step failed (%d) at word %d of its program: %s"
+                                                        % (rc, self._fail_at_v.value, msg.decode() if msg else ""))
+                else:
+                    sg()          # a host call of the step (the gradient collectives of data parallelism): _host_call
+            return
         cmds = prog.cmds
         for ci, ai, key in prog.patches:
             cmds[ci][2][ai] = dyn[key]
