@@ -287,3 +287,19 @@ def test_staged_offsets_on_the_tower_stream_are_the_same_steps():
             _same_state(a, b, step)
     torch.cuda.synchronize()
     _same_state(a, b, "end")
+
+
+def test_engines_of_a_process_share_their_streams():
+    """One tower stream per device for the whole process, and the weight-gradient chain rides it (round 6): private streams per engine
+    put the 4th and 6th engine of a process on shared hardware queues (+ 7.5 % on their step, profiles/r06_stream_aliasing.txt), and one
+    stream beside the main one beat two at every batch size (profiles/r06_stream_merge.txt).  A priority experiment gets a private
+    stream and 0 returns to the shared one."""
+    from voicemap_amd.engine import HipEncoderEngine
+    a = HipEncoderEngine(BLOCKS, 32, dropout=0.0, head="uniform_euclidean", dtype="f16", seed=1)
+    b = HipEncoderEngine(BLOCKS, 32, dropout=0.0, head=None, dtype="bf16", seed=2)
+    assert a.tower_stream is b.tower_stream and a.misc_stream is b.misc_stream
+    assert a.side_stream is a.tower_stream and b.side_stream is a.tower_stream
+    a.side_priority = -1
+    assert a.side_stream is not a.tower_stream and b.side_stream is b.tower_stream
+    a.side_priority = 0
+    assert a.side_stream is a.tower_stream
